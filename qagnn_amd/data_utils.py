@@ -1,0 +1,223 @@
+"""Host-side producer of the hot path's inputs.
+
+Mirrors, by name and semantics, the two reference entry points that feed `QAGNN.forward`:
+
+* ``load_sparse_adj_data_with_contextnode``  (reference utils/data_utils.py:79-197)
+* ``MultiGPUSparseAdjDataBatchGenerator``    (reference utils/data_utils.py:17-76)
+
+The record -> tensor conversion is re-implemented with vectorised numpy (the reference loops in
+Python and issues one torch op per edge list); the outputs are element-for-element identical to
+the reference's (tests/test_data_utils.py checks that against fixtures produced by the reference's
+own loader).  The batch generator keeps the reference's iteration protocol but moves a batch's
+graph with ONE packed host->device copy instead of 2*bs*nc tiny ones.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+
+def record_to_graph(rec, max_node_num):
+    """One preprocessing record -> loader outputs for that (question, choice) pair.
+
+    Follows reference utils/data_utils.py:101-176.  Returns
+    (adj_len_ori, num_concept, concept_ids[n], node_type_ids[n], node_scores[n], edge_index[2,E], edge_type[E], half_n_rel)
+    as numpy arrays (int64 / float32).
+    """
+    adj, concepts = rec['adj'], np.asarray(rec['concepts'])
+    qm, am = np.asarray(rec['qmask'], dtype=bool), np.asarray(rec['amask'], dtype=bool)
+    cid2score = rec['cid2score']
+    n = int(max_node_num)
+    if len(concepts) != len(set(concepts.tolist())):
+        raise AssertionError('duplicate concept ids in a record')  # reference :107
+    qam = qm | am
+    if not (len(qam) > 0 and qam[0]):
+        raise AssertionError('first concept must be a question/answer concept')  # reference :110
+    # Q/A concepts must form a prefix T..TF..F (reference :111-116)
+    if len(qam) > 1 and np.any(qam[1:] & ~qam[:-1]):
+        raise AssertionError('question/answer concepts must precede all other concepts')
+
+    num_concept = min(len(concepts), n - 1) + 1  # context node included, PAD excluded (:117)
+    concept_ids = np.full(n, 1, dtype=np.int64)
+    concept_ids[0] = 0
+    concept_ids[1:num_concept] = concepts[:num_concept - 1].astype(np.int64) + 1
+    node_scores = np.zeros(n, dtype=np.float32)
+    if cid2score is not None:
+        for j in range(num_concept):  # (:127-131) a missing concept is an error, as in the reference
+            node_scores[j] = np.float32(cid2score[int(concept_ids[j]) - 1])
+    node_type_ids = np.full(n, 2, dtype=np.int64)
+    node_type_ids[0] = 3
+    k_real = num_concept - 1
+    sl = node_type_ids[1:num_concept]
+    sl[qm[:k_real]] = 0
+    sl[am[:k_real]] = 1  # answer flag overrides question flag (:135-136)
+
+    n_node = adj.shape[1]
+    half_n_rel = adj.shape[0] // n_node
+    row = np.asarray(adj.row, dtype=np.int64)
+    col = np.asarray(adj.col, dtype=np.int64)
+    i = row // n_node + 2
+    j = row % n_node + 1
+    k = col + 1
+    # context -> question / answer concept edges, relation ids 0 / 1 (:147-163); the reference scans
+    # coordinates 1..num_concept inclusive, the node-range mask below removes anything >= n
+    lim = min(len(qm), num_concept)
+    qn = np.nonzero(qm[:lim])[0].astype(np.int64) + 1
+    an = np.nonzero(am[:lim])[0].astype(np.int64) + 1
+    half_n_rel += 2
+    i = np.concatenate([i, np.zeros(len(qn), np.int64), np.ones(len(an), np.int64)])
+    j = np.concatenate([j, np.zeros(len(qn) + len(an), np.int64)])
+    k = np.concatenate([k, qn, an])
+    keep = (j < n) & (k < n)
+    i, j, k = i[keep], j[keep], k[keep]
+    edge_type = np.concatenate([i, i + half_n_rel])  # inverse relations (:173)
+    edge_index = np.stack([np.concatenate([j, k]), np.concatenate([k, j])], axis=0)
+    return len(concepts), num_concept, concept_ids, node_type_ids, node_scores, edge_index, edge_type, half_n_rel
+
+
+def records_to_tensors(records, max_node_num, num_choice):
+    """In-memory equivalent of the reference loader (no pickle, no cache)."""
+    n_samples = len(records)
+    assert n_samples % num_choice == 0
+    concept_ids = torch.empty((n_samples, max_node_num), dtype=torch.long)
+    node_type_ids = torch.empty((n_samples, max_node_num), dtype=torch.long)
+    node_scores = torch.empty((n_samples, max_node_num, 1), dtype=torch.float)
+    adj_lengths = torch.empty((n_samples,), dtype=torch.long)
+    adj_lengths_ori = torch.empty((n_samples,), dtype=torch.long)
+    edge_index, edge_type = [], []
+    half_n_rel = 0
+    for idx, rec in enumerate(records):
+        lo, nc, cid, nt, ns, ei, et, half_n_rel = record_to_graph(rec, max_node_num)
+        adj_lengths_ori[idx], adj_lengths[idx] = lo, nc
+        concept_ids[idx] = torch.from_numpy(cid)
+        node_type_ids[idx] = torch.from_numpy(nt)
+        node_scores[idx, :, 0] = torch.from_numpy(ns)
+        edge_index.append(torch.from_numpy(ei))
+        edge_type.append(torch.from_numpy(et))
+    return adj_lengths_ori, concept_ids, node_type_ids, node_scores, adj_lengths, edge_index, edge_type, half_n_rel
+
+
+def load_sparse_adj_data_with_contextnode(adj_pk_path, max_node_num, num_choice, args=None):
+    """Same contract as reference utils/data_utils.py:79-197 (including the `.loaded_cache` side file,
+    written in the reference's own pickle layout so either implementation can read the other's cache)."""
+    cache_path = adj_pk_path + '.loaded_cache'
+    if os.path.exists(cache_path):
+        with open(cache_path, 'rb') as f:
+            (adj_lengths_ori, concept_ids, node_type_ids, node_scores, adj_lengths,
+             edge_index, edge_type, half_n_rel) = pickle.load(f)
+    else:
+        with open(adj_pk_path, 'rb') as fin:
+            records = pickle.load(fin)
+        (adj_lengths_ori, concept_ids, node_type_ids, node_scores, adj_lengths,
+         edge_index, edge_type, half_n_rel) = records_to_tensors(records, max_node_num, num_choice)
+        with open(cache_path, 'wb') as f:
+            pickle.dump([adj_lengths_ori, concept_ids, node_type_ids, node_scores, adj_lengths,
+                         edge_index, edge_type, half_n_rel], f)
+
+    ori = adj_lengths_ori.float()
+    mu = ori.mean().item()
+    sigma = float(np.sqrt(((ori - mu) ** 2).mean().item()))
+    print('| ori_adj_len: mu {:.2f} sigma {:.2f} | adj_len: {:.2f} | prune_rate: {:.2f} | qc_num: {:.2f} | ac_num: {:.2f} |'.format(
+        mu, sigma, adj_lengths.float().mean().item(), (adj_lengths_ori > adj_lengths).float().mean().item(),
+        (node_type_ids == 0).float().sum(1).mean().item(), (node_type_ids == 1).float().sum(1).mean().item()))
+
+    edge_index = [list(edge_index[q:q + num_choice]) for q in range(0, len(edge_index), num_choice)]
+    edge_type = [list(edge_type[q:q + num_choice]) for q in range(0, len(edge_type), num_choice)]
+    concept_ids, node_type_ids, node_scores, adj_lengths = [
+        x.view(-1, num_choice, *x.size()[1:]) for x in (concept_ids, node_type_ids, node_scores, adj_lengths)]
+    return concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type)
+
+
+def batch_graph(edge_index_init, edge_type_init, n_nodes):
+    """LM_QAGNN.batch_graph (reference modeling_qagnn.py:244-251): offset subgraph i by i*n and concatenate.
+
+    One `torch.cat` + one vectorised offset add instead of B tiny adds.
+    """
+    n_examples = len(edge_index_init)
+    counts = torch.tensor([e.size(1) for e in edge_index_init], dtype=torch.long)
+    edge_index = torch.cat(edge_index_init, dim=1)
+    offs = torch.repeat_interleave(torch.arange(n_examples, dtype=torch.long) * n_nodes, counts)
+    edge_index = edge_index + offs.to(edge_index.device).unsqueeze(0)
+    edge_type = torch.cat(edge_type_init, dim=0)
+    return edge_index, edge_type
+
+
+class MultiGPUSparseAdjDataBatchGenerator(object):
+    """Iteration protocol of reference utils/data_utils.py:17-76.
+
+    Yields ``(qids, labels, *tensors0, *lists0, *tensors1, *lists1, edge_index, edge_type)`` per batch with
+    `edge_index` / `edge_type` as nested lists [bs][nc] of device tensors, like the reference.  The graph
+    tensors of a batch are packed into one pinned buffer and moved with a single copy; the per-graph tensors
+    handed out are views into that device buffer.
+    """
+
+    def __init__(self, args, mode, device0, device1, batch_size, indexes, qids, labels,
+                 tensors0=[], lists0=[], tensors1=[], lists1=[], adj_data=None):
+        self.args, self.mode = args, mode
+        self.device0, self.device1 = device0, device1
+        self.batch_size = batch_size
+        self.indexes, self.qids, self.labels = indexes, qids, labels
+        self.tensors0, self.lists0, self.tensors1, self.lists1 = tensors0, lists0, tensors1, lists1
+        self.adj_data = adj_data
+
+    def __len__(self):
+        return (self.indexes.size(0) - 1) // self.batch_size + 1
+
+    def _to_device(self, obj, device):
+        if isinstance(obj, (tuple, list)):
+            return [self._to_device(item, device) for item in obj]
+        return obj.to(device)
+
+    def _graphs_to_device(self, nested_ei, nested_et, device):
+        flat_ei = [t for row in nested_ei for t in row]
+        flat_et = [t for row in nested_et for t in row]
+        counts = [t.size(1) for t in flat_ei]
+        total = sum(counts)
+        packed = torch.empty((3, total), dtype=torch.long)
+        if torch.device(device).type == 'cuda':
+            packed = packed.pin_memory()
+        if total:
+            torch.cat(flat_ei, dim=1, out=packed[:2])
+            torch.cat(flat_et, dim=0, out=packed[2])
+        dev = packed.to(device, non_blocking=True)
+        ei_out, et_out, pos, it = [], [], 0, iter(counts)
+        for row in nested_ei:
+            r_ei, r_et = [], []
+            for _ in row:
+                c = next(it)
+                r_ei.append(dev[:2, pos:pos + c])
+                r_et.append(dev[2, pos:pos + c])
+                pos += c
+            ei_out.append(r_ei)
+            et_out.append(r_et)
+        return ei_out, et_out
+
+    def __iter__(self):
+        bs = self.batch_size
+        n = self.indexes.size(0)
+        if self.mode == 'train' and getattr(self.args, 'drop_partial_batch', False):
+            print('dropping partial batch')
+            n = (n // bs) * bs
+        elif self.mode == 'train' and getattr(self.args, 'fill_partial_batch', False):
+            print('filling partial batch')
+            remain = n % bs
+            if remain > 0:
+                extra = np.random.choice(self.indexes[:-remain], size=(bs - remain), replace=False)
+                self.indexes = torch.cat([self.indexes, torch.tensor(extra)])
+                n = self.indexes.size(0)
+                assert n % bs == 0
+        for a in range(0, n, bs):
+            b = min(n, a + bs)
+            batch_indexes = self.indexes[a:b]
+            batch_qids = [self.qids[idx] for idx in batch_indexes]
+            batch_labels = self._to_device(self.labels[batch_indexes], self.device1)
+            batch_tensors0 = [self._to_device(x[batch_indexes], self.device0) for x in self.tensors0]
+            batch_tensors1 = [self._to_device(x[batch_indexes], self.device1) for x in self.tensors1]
+            batch_lists0 = [self._to_device([x[i] for i in batch_indexes], self.device0) for x in self.lists0]
+            batch_lists1 = [self._to_device([x[i] for i in batch_indexes], self.device1) for x in self.lists1]
+            edge_index_all, edge_type_all = self.adj_data
+            edge_index, edge_type = self._graphs_to_device([edge_index_all[i] for i in batch_indexes],
+                                                           [edge_type_all[i] for i in batch_indexes], self.device1)
+            yield tuple([batch_qids, batch_labels, *batch_tensors0, *batch_lists0, *batch_tensors1,
+                         *batch_lists1, edge_index, edge_type])

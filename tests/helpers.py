@@ -1,0 +1,198 @@
+"""Shared test helpers: deterministic parameter fill, synthetic batches, fixture IO.
+
+Nothing in here touches /root/reference; `tests/golden/make_golden.py` (authoring container only)
+is the one script that does.
+"""
+import os
+import re
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
+
+from qagnn_amd import synthetic  # noqa: E402
+from qagnn_amd import data_utils  # noqa: E402
+
+
+def canonical_key(name):
+    """The shared edge encoder shows up under k+1 prefixes in state_dict(); hash its canonical name."""
+    return re.sub(r'gnn_layers\.\d+\.edge_encoder', 'edge_encoder', name)
+
+
+def det_fill_(module, seed, std):
+    """Fill every parameter/buffer of `module` from a per-name seeded generator.
+
+    Independent of module construction order, so the reference model, the oracle and the HIP-backed
+    mirror get bit-identical weights from (seed, std) alone.  `std` > 0 is a GAIN: 2-D weights are
+    gain * N(0,1) / sqrt(fan_in), which keeps activations O(1) through k layers while leaving the attention
+    logits far from uniform; `std` < 0 means absolute N(0, |std|) (the reference's own init is 0.02).
+    """
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name in sorted(sd.keys()):
+            t = sd[name]
+            if name.endswith('num_batches_tracked'):
+                t.zero_()
+                continue
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(canonical_key(name).encode())) % (2 ** 31))
+            is_bn = bool(re.search(r'(edge_encoder|mlp)\.1\.', name))
+            if name.endswith('running_var'):
+                v = 0.5 + torch.rand(t.shape, generator=g)
+            elif name.endswith('running_mean'):
+                v = 0.1 * torch.randn(t.shape, generator=g)
+            elif is_bn and name.endswith('weight'):
+                v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+            elif name.endswith('bias'):
+                v = 0.1 * torch.randn(t.shape, generator=g)
+            elif name.endswith('emb.weight'):
+                v = torch.randn(t.shape, generator=g)
+            elif std < 0 or t.dim() < 2:
+                v = abs(std) * torch.randn(t.shape, generator=g)
+            else:
+                v = std * torch.randn(t.shape, generator=g) / (t.shape[1] ** 0.5)
+            t.copy_(v.to(t.dtype))
+    return module
+
+
+# ---------------------------------------------------------------------------------------------
+# golden configurations (shared by the generator and by the tests)
+# ---------------------------------------------------------------------------------------------
+def model_cfg(d=200, k=5, n_etype=38, sent_dim=1024, n_concept=2000, concept_in_dim=1024, n_ntype=4):
+    return dict(k=k, n_ntype=n_ntype, n_etype=n_etype, sent_dim=sent_dim, n_concept=n_concept,
+                concept_dim=d, concept_in_dim=concept_in_dim, n_attention_head=2, fc_dim=200,
+                n_fc_layer=0, p_emb=0.0, p_gnn=0.0, p_fc=0.0, freeze_ent_emb=True, init_range=0.02)
+
+
+GOLDEN_CASES = {
+    # name: (shape, n_questions, num_choice, max_node_num, n_rel, model cfg, weight std, train mode, seed)
+    'small_train': dict(shape='tiny', nq=2, nc=3, n=20, n_rel=17, std=1.3, train=True, seed=11,
+                        cfg=model_cfg(d=32, k=2, sent_dim=24, n_concept=300, concept_in_dim=16)),
+    'small_eval': dict(shape='tiny', nq=2, nc=3, n=20, n_rel=17, std=0.8, train=False, seed=12,
+                       cfg=model_cfg(d=32, k=2, sent_dim=24, n_concept=300, concept_in_dim=16)),
+    'config1_train': dict(shape='config1', nq=1, nc=5, n=100, n_rel=17, std=1.3, train=True, seed=13,
+                          cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=1000, concept_in_dim=32)),
+    'config1_refinit': dict(shape='config1', nq=1, nc=5, n=100, n_rel=17, std=-0.02, train=True, seed=14,
+                            cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=1000, concept_in_dim=32)),
+    'csqa_b10': dict(shape='csqa', nq=2, nc=5, n=200, n_rel=17, std=1.3, train=True, seed=15,
+                     cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=2000, concept_in_dim=32)),
+    'medqa_b8': dict(shape='medqa', nq=2, nc=4, n=200, n_rel=15, std=1.3, train=True, seed=16,
+                     cfg=model_cfg(d=200, k=5, n_etype=34, sent_dim=48, n_concept=2000, concept_in_dim=24)),
+    'trunc_eval': dict(shape='csqa', nq=1, nc=4, n=60, n_rel=17, std=0.7, train=False, seed=17,
+                       cfg=model_cfg(d=64, k=3, sent_dim=32, n_concept=2000, concept_in_dim=16)),
+}
+
+
+def make_case_inputs(case):
+    """Records -> loader tensors -> one flattened batch (B = nq*nc subgraphs) + seeded sent_vecs."""
+    c = GOLDEN_CASES[case] if isinstance(case, str) else case
+    B = c['nq'] * c['nc']
+    recs = synthetic.make_records(B, seed=c['seed'], shape=c['shape'], n_rel=c['n_rel'],
+                                  n_concept_vocab=c['cfg']['n_concept'])
+    (_, concept_ids, node_type_ids, node_scores, adj_lengths, edge_index, edge_type, half) = \
+        data_utils.records_to_tensors(recs, c['n'], c['nc'])
+    ei, et = data_utils.batch_graph(edge_index, edge_type, c['n'])
+    g = torch.Generator().manual_seed(c['seed'] + 7)
+    sent_vecs = torch.randn(B, c['cfg']['sent_dim'], generator=g)
+    return dict(records=recs, sent_vecs=sent_vecs, concept_ids=concept_ids, node_type_ids=node_type_ids,
+                node_scores=node_scores, adj_lengths=adj_lengths, edge_index=ei, edge_type=et,
+                edge_index_list=edge_index, edge_type_list=edge_type)
+
+
+def grad_summary(t):
+    """Compact, order-sensitive description of a tensor: norm, signed projection, first elements."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    w = torch.cos(torch.arange(n, dtype=torch.float64) * 0.7311 + 0.3)
+    return np.array([f.norm().item(), (f * w).sum().item(), f.sum().item()] + f[:5].tolist() +
+                    [0.0] * max(0, 5 - n), dtype=np.float64)
+
+
+def mp_inputs(case):
+    """Seeded inputs for the message-passing-stack / single-layer goldens (independent of model weights)."""
+    c = GOLDEN_CASES[case] if isinstance(case, str) else case
+    B, n, d = c['nq'] * c['nc'], c['n'], c['cfg']['concept_dim']
+    g = torch.Generator().manual_seed(c['seed'] + 99)
+    H = torch.randn(B, n, d, generator=g)
+    node_score = torch.randn(B, n, 1, generator=g) * 2.0
+    x = torch.randn(B * n, d, generator=g)
+    extra = torch.randn(B * n, d, generator=g)
+    return H, node_score, x, extra
+
+
+def store(fix, key, t, full):
+    """Full tensor for small cases; summary + leading slice otherwise."""
+    t = t.detach()
+    fix[key + '::sum'] = grad_summary(t)
+    if full or t.numel() <= 8192:
+        fix[key] = t.numpy()
+    else:
+        flat = t.reshape(-1, t.shape[-1])
+        fix[key + '::head'] = flat[:8].numpy()
+        idx = torch.linspace(0, flat.shape[0] - 1, 8).long()
+        fix[key + '::rows'] = flat[idx].numpy()
+
+
+def _close(t, ref, rtol, atol, what):
+    """Elementwise |t - ref| <= atol + rtol * max(|ref| elementwise, max|ref| of the tensor).
+
+    The tensor-level term is the usual backward-error yardstick for fp32 sums of mixed-sign terms: an element
+    that is a near-cancellation of O(max|ref|) contributions cannot be reproduced to a relative 1e-4.
+    """
+    scale = ref.abs().max().item() if ref.numel() else 0.0
+    err = (t - ref).abs()
+    bound = atol + rtol * torch.clamp(ref.abs(), min=scale)
+    bad = err > bound
+    assert not bool(bad.any()), (f'{what}: {int(bad.sum())}/{ref.numel()} elements off, worst |d|={err.max().item():.3e} '
+                                 f'(tensor scale {scale:.3e}, rtol {rtol}, atol {atol})')
+    return err.max().item() if ref.numel() else 0.0
+
+
+def check_stored(fix, key, t, rtol, atol):
+    """Compare tensor `t` with whatever `store` kept under `key`; returns max abs error seen."""
+    t = t.detach().cpu().float()
+    if key in fix:
+        ref = torch.from_numpy(fix[key])
+        worst = _close(t, ref.view_as(t), rtol, atol, key)
+    else:
+        flat = t.reshape(-1, t.shape[-1])
+        idx = torch.linspace(0, flat.shape[0] - 1, 8).long()
+        worst = max(_close(flat[:8], torch.from_numpy(fix[key + '::head']), rtol, atol, key + '::head'),
+                    _close(flat[idx], torch.from_numpy(fix[key + '::rows']), rtol, atol, key + '::rows'))
+    check_summary(fix[key + '::sum'], t, rtol, key)
+    return worst
+
+
+def check_summary(ref_sum, t, rtol, what=''):
+    """Norm / projection comparison: |delta| <= rtol' * norm, with rtol' loosened for the projection sums."""
+    got = grad_summary(t)
+    norm = max(ref_sum[0], 1e-30)
+    assert abs(got[0] - ref_sum[0]) <= 10 * rtol * norm + 1e-12, f'{what}: norm {got[0]} vs {ref_sum[0]}'
+    n = t.numel()
+    tol = 10 * rtol * norm * max(1.0, n ** 0.5) ** 0.5 + 1e-9
+    assert abs(got[1] - ref_sum[1]) <= tol, f'{what}: projection {got[1]} vs {ref_sum[1]} (tol {tol})'
+    assert abs(got[2] - ref_sum[2]) <= tol, f'{what}: sum {got[2]} vs {ref_sum[2]} (tol {tol})'
+
+
+def has_null_gradient(name, train):
+    """Parameters whose exact gradient is identically 0, so autograd returns pure fp32 rounding noise:
+
+    * biases feeding straight into a train-mode BatchNorm (edge_encoder.0.bias, mlp.0.bias): BN removes the mean;
+    * linear_key.bias (always): it shifts every score of a source node's softmax group by the same q_s . b_k.
+    Two correct implementations agree on these only in magnitude, not element by element.
+    """
+    if re.search(r'linear_key\.bias$', name):
+        return True
+    return bool(train and re.search(r'(edge_encoder|mlp)\.0\.bias$', name))
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN_DIR, name + '.npz')
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}

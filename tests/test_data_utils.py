@@ -1,0 +1,130 @@
+"""Host-side loader mirror (qagnn_amd.data_utils) vs fixtures produced by the REFERENCE loader.
+
+Integer outputs must be bit-exact; node scores are fp32 copies and must be bit-exact too.
+"""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+from scipy.sparse import coo_matrix
+
+import helpers
+from qagnn_amd import data_utils, synthetic
+
+CASES = list(helpers.GOLDEN_CASES.keys())
+
+
+def unpack_records(fix):
+    recs = []
+    for i in range(int(fix['n_records'])):
+        shape = tuple(int(v) for v in fix[f'r{i}_shape'])
+        row, col = fix[f'r{i}_row'], fix[f'r{i}_col']
+        adj = coo_matrix((np.ones(len(row), dtype=bool), (row, col)), shape=shape)
+        c2s = None
+        if bool(fix[f'r{i}_has_scores']):
+            c2s = {int(k): float(v) for k, v in zip(fix[f'r{i}_score_keys'], fix[f'r{i}_score_vals'])}
+        recs.append({'adj': adj, 'concepts': fix[f'r{i}_concepts'], 'qmask': fix[f'r{i}_qmask'],
+                     'amask': fix[f'r{i}_amask'], 'cid2score': c2s})
+    return recs
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_synthetic_records_are_reproducible(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    recs = synthetic.make_records(c['nq'] * c['nc'], seed=c['seed'], shape=c['shape'], n_rel=c['n_rel'],
+                                  n_concept_vocab=c['cfg']['n_concept'])
+    stored = unpack_records(fix)
+    assert len(recs) == len(stored)
+    for a, b in zip(recs, stored):
+        assert np.array_equal(a['adj'].row, b['adj'].row) and np.array_equal(a['adj'].col, b['adj'].col)
+        assert np.array_equal(a['concepts'], b['concepts'])
+        assert np.array_equal(a['qmask'], b['qmask']) and np.array_equal(a['amask'], b['amask'])
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_loader_matches_reference_loader(case, tmp_path):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    B, n, nc = c['nq'] * c['nc'], c['n'], c['nc']
+    recs = unpack_records(fix)
+    p = os.path.join(tmp_path, 'syn.graph.adj.pk')
+    with open(p, 'wb') as f:
+        pickle.dump(recs, f)
+    for attempt in range(2):  # second pass reads the `.loaded_cache` side file
+        cids, nt, ns, al, (ei, et) = data_utils.load_sparse_adj_data_with_contextnode(p, n, nc, None)
+        assert cids.shape == (c['nq'], nc, n) and ns.shape == (c['nq'], nc, n, 1) and al.shape == (c['nq'], nc)
+        assert cids.dtype == nt.dtype == al.dtype == torch.long and ns.dtype == torch.float32
+        assert np.array_equal(cids.view(B, n).numpy(), fix['concept_ids'])
+        assert np.array_equal(nt.view(B, n).numpy(), fix['node_type_ids'])
+        assert np.array_equal(ns.view(B, n, 1).numpy(), fix['node_scores'])
+        assert np.array_equal(al.view(B).numpy(), fix['adj_lengths'])
+        assert len(ei) == c['nq'] and all(len(r) == nc for r in ei)
+        flat_ei = [t for r in ei for t in r]
+        flat_et = [t for r in et for t in r]
+        assert all(t.dtype == torch.long and t.dim() == 2 and t.size(0) == 2 for t in flat_ei)
+        assert np.array_equal(np.array([t.size(1) for t in flat_ei]), fix['edge_counts'])
+        assert np.array_equal(torch.cat(flat_ei, 1).numpy(), fix['edge_index_cat'])
+        assert np.array_equal(torch.cat(flat_et, 0).numpy(), fix['edge_type_cat'])
+        bei, bet = data_utils.batch_graph(flat_ei, flat_et, n)
+        assert np.array_equal(bei.numpy(), fix['batched_edge_index'])
+        assert bei.dtype == torch.long and bet.dtype == torch.long
+    assert os.path.exists(p + '.loaded_cache')
+
+
+def test_loader_invariants():
+    """symmetric edge multiset, no edge touches a PAD node, node 0 is the context node."""
+    recs = synthetic.make_records(8, seed=3, shape='csqa')
+    _, cids, nt, ns, al, ei, et, half = data_utils.records_to_tensors(recs, 200, 4)
+    assert half == 19
+    for g in range(8):
+        e, t = ei[g].numpy(), et[g].numpy()
+        assert e.max(initial=0) < al[g].item()
+        fwd = set(zip(e[0], e[1], t))
+        assert all((b, a, (r + half) % (2 * half)) in fwd for a, b, r in fwd)
+        assert nt[g, 0] == 3 and cids[g, 0] == 0
+        assert (nt[g, al[g]:] == 2).all() and (cids[g, al[g]:] == 1).all() and (ns[g, al[g]:] == 0).all()
+
+
+def test_loader_rejects_bad_records():
+    rec = synthetic.make_records(1, seed=5, shape='tiny')[0]
+    bad = dict(rec)
+    bad['concepts'] = np.concatenate([rec['concepts'][:1], rec['concepts'][:1], rec['concepts'][2:]]) \
+        if len(rec['concepts']) > 1 else rec['concepts']
+    if len(rec['concepts']) > 1:
+        with pytest.raises(AssertionError):
+            data_utils.record_to_graph(bad, 20)
+    bad2 = dict(rec)
+    bad2['qmask'] = np.zeros_like(rec['qmask'])
+    bad2['amask'] = np.zeros_like(rec['amask'])
+    with pytest.raises(AssertionError):
+        data_utils.record_to_graph(bad2, 20)
+    if rec['cid2score'] is not None:
+        bad3 = dict(rec)
+        bad3['cid2score'] = {-1: 0.0}
+        with pytest.raises(KeyError):
+            data_utils.record_to_graph(bad3, 20)
+
+
+def test_batch_generator_protocol():
+    recs = synthetic.make_records(12, seed=9, shape='tiny')
+    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, 20, 3)
+    nq = 4
+    nested_ei = [ei[q * 3:(q + 1) * 3] for q in range(nq)]
+    nested_et = [et[q * 3:(q + 1) * 3] for q in range(nq)]
+    t1 = [x.view(nq, 3, *x.shape[1:]) for x in (cids, nt, ns, al)]
+    labels = torch.arange(nq)
+    gen = data_utils.MultiGPUSparseAdjDataBatchGenerator(None, 'eval', 'cpu', 'cpu', 3, torch.arange(nq),
+                                                         [f'q{i}' for i in range(nq)], labels,
+                                                         tensors0=[torch.zeros(nq, 3, 5)], tensors1=t1,
+                                                         adj_data=(nested_ei, nested_et))
+    assert len(gen) == 2
+    batches = list(gen)
+    assert [len(b[0]) for b in batches] == [3, 1]
+    qids, lab, lm0, c_, n_, s_, a_, bei, bet = batches[0]
+    assert qids == ['q0', 'q1', 'q2'] and torch.equal(lab, labels[:3]) and lm0.shape == (3, 3, 5)
+    for q in range(3):
+        for ch in range(3):
+            assert torch.equal(bei[q][ch], nested_ei[q][ch]) and torch.equal(bet[q][ch], nested_et[q][ch])

@@ -1,0 +1,117 @@
+"""Pin the CPU oracle against fixtures produced by the reference's own code (tests/golden/make_golden.py).
+
+fp32 tolerances: the oracle runs the same ATen CPU kernels in the same order as the reference + stand-ins,
+so agreement is expected at the 1e-6 level; the asserted bound is rtol 1e-5 / atol 1e-6 on forward values
+and rtol 1e-4 on gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import qagnn_oracle as O
+
+CASES = list(helpers.GOLDEN_CASES.keys())
+
+
+def build_oracle(case):
+    c = helpers.GOLDEN_CASES[case]
+    torch.manual_seed(0)
+    model = O.build_qagnn(c['cfg'])
+    helpers.det_fill_(model, c['seed'], c['std'])
+    model.pooler.dropout.p = 0.0
+    model.pooler.attention.dropout.p = 0.0
+    model.train(c['train'])
+    return model
+
+
+def golden_inputs(case, fix):
+    c = helpers.GOLDEN_CASES[case]
+    B, n = c['nq'] * c['nc'], c['n']
+    cids = torch.from_numpy(fix['concept_ids']).view(B, n)
+    nt = torch.from_numpy(fix['node_type_ids']).view(B, n)
+    ns = torch.from_numpy(fix['node_scores']).view(B, n, 1)
+    al = torch.from_numpy(fix['adj_lengths']).view(B)
+    ei = torch.from_numpy(fix['batched_edge_index'].astype(np.int64))
+    et = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
+    sv = torch.from_numpy(fix['sent_vecs'])
+    return sv, cids, nt, ns, al, ei, et
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_state_dict_keys_match_reference_contract(case):
+    """the shared edge encoder appears under gnn.edge_encoder AND every gnn.gnn_layers.{l}.edge_encoder."""
+    model = build_oracle(case)
+    keys = set(model.state_dict().keys())
+    k = helpers.GOLDEN_CASES[case]['cfg']['k']
+    for l in range(k):
+        for suffix in ('0.weight', '0.bias', '1.weight', '1.bias', '1.running_mean', '1.running_var',
+                       '1.num_batches_tracked', '3.weight', '3.bias'):
+            assert f'gnn.gnn_layers.{l}.edge_encoder.{suffix}' in keys
+            assert f'gnn.edge_encoder.{suffix}' in keys
+        for nm in ('linear_key', 'linear_msg', 'linear_query'):
+            assert f'gnn.gnn_layers.{l}.{nm}.weight' in keys
+    assert 'fc.layers.0-Linear.weight' in keys and 'concept_emb.cpt_transform.weight' in keys
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_qagnn_forward_backward_matches_reference(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    B = c['nq'] * c['nc']
+    model = build_oracle(case)
+    sv, cids, nt, ns, al, ei, et = golden_inputs(case, fix)
+    logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
+    torch.testing.assert_close(logits, torch.from_numpy(fix['logits']), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pool_attn, torch.from_numpy(fix['pool_attn']), rtol=1e-5, atol=1e-6)
+    w = torch.linspace(0.5, 1.5, B).view(B, 1)
+    (logits * w).sum().backward()
+    n_checked = 0
+    for pname, p in model.named_parameters():
+        if p.grad is None or helpers.has_null_gradient(pname, c['train']):
+            continue
+        helpers.check_stored(fix, 'grad::' + pname, p.grad, rtol=1e-4, atol=1e-5)
+        n_checked += 1
+    assert n_checked > 20
+    for bname, b in model.named_buffers():
+        np.testing.assert_allclose(b.numpy(), fix['buf::' + bname], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_message_passing_stack_matches_reference(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    B, n = c['nq'] * c['nc'], c['n']
+    model = build_oracle(case)
+    _, _, nt, _, al, ei, et = golden_inputs(case, fix)
+    H, ns, x, extra = helpers.mp_inputs(case)
+    ns = ns * (torch.arange(n) < al.unsqueeze(1)).float().unsqueeze(2)
+    Hg = H.clone().requires_grad_(True)
+    out = model.gnn(Hg, (ei, et), nt, ns)
+    helpers.check_stored(fix, 'mp_out', out, rtol=1e-5, atol=1e-5)
+    wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out)
+    (out * wg).sum().backward()
+    helpers.check_stored(fix, 'mp_dH', Hg.grad, rtol=1e-4, atol=1e-5)
+    for pname, p in model.gnn.named_parameters():
+        if p.grad is not None and not helpers.has_null_gradient(pname, c['train']):
+            helpers.check_stored(fix, 'mpgrad::' + pname, p.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_single_gatconve_layer_matches_reference(case):
+    fix = helpers.load_golden(case)
+    model = build_oracle(case)
+    _, _, nt, _, al, ei, et = golden_inputs(case, fix)
+    H, ns, x, extra = helpers.mp_inputs(case)
+    layer = model.gnn.gnn_layers[0]
+    xg = x.clone().requires_grad_(True)
+    out, (ei_loops, alpha) = layer(xg, ei, et, nt.view(-1), extra, return_attention_weights=True)
+    assert ei_loops.size(1) == ei.size(1) + x.size(0)
+    helpers.check_stored(fix, 'layer_out', out, rtol=1e-5, atol=1e-5)
+    helpers.check_stored(fix, 'layer_alpha', alpha, rtol=1e-5, atol=1e-7)
+    wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out)
+    (out * wl).sum().backward()
+    helpers.check_stored(fix, 'layer_dx', xg.grad, rtol=1e-4, atol=1e-5)
+    for pname, p in layer.named_parameters():
+        if p.grad is not None and not helpers.has_null_gradient(pname, helpers.GOLDEN_CASES[case]['train']):
+            helpers.check_stored(fix, 'layergrad::' + pname, p.grad, rtol=1e-4, atol=1e-5)
