@@ -1,0 +1,166 @@
+/*
+ * qagnn_hip.h -- C ABI of libqagnn_hip.so: the MI355X (gfx950) kernels behind QA-GNN's GNN hot path.
+ *
+ * The reference (michiyasunaga/qagnn @ v1) has no FFI: its boundary for this path is the Python nn.Module
+ * contract  QAGNN.forward(sent_vecs, concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type))
+ * (modeling/modeling_qagnn.py:141) and every native kernel it runs comes from third-party wheels (torch-geometric
+ * 1.7.0, torch-scatter 2.0.7, ATen/cuBLAS).  Each entry point below therefore cites the reference call site(s)
+ * whose native kernels it replaces.  qagnn_amd/ (Python) mirrors the reference's module interface on top of this
+ * ABI; INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, all pointers are DEVICE pointers unless named h_*; no allocation inside the library;
+ *     every call enqueues on `stream` and returns immediately (graph-capture safe, re-entrant per stream).
+ *   - return value: QAGNN_OK or a QAGNN_E* code; qagnn_last_error() gives a message for the calling thread.
+ *   - fp32 everywhere ("dtype f32"), int32 graph arrays, int64 only where the reference hands us int64 tensors.
+ *   - "head-padded" node rows: a feature row of d = H*dh floats is stored as H groups of HP = roundup4(dh) floats
+ *     (pads are zero), DP = H*HP floats per row (d=200,H=4: HP=52, DP=208 -> 832-byte rows, 16-byte aligned heads).
+ *     H must be 4 (the reference hard-codes head_count=4, modeling_qagnn.py:387) and dh <= 64.
+ */
+#ifndef QAGNN_HIP_H
+#define QAGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QAGNN_OK 0
+#define QAGNN_EINVAL 1       /* bad argument (null pointer, misaligned, size constraint violated) */
+#define QAGNN_EUNSUPPORTED 2 /* shape outside what the kernels were written for */
+#define QAGNN_EHIP 3         /* a HIP runtime call failed; see qagnn_last_error() */
+
+typedef void* qagnn_stream_t; /* hipStream_t */
+
+const char* qagnn_last_error(void);
+int qagnn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Graph preparation (integer).  Replaces, once per batch instead of once per layer:
+ *   modeling_qagnn.py:419-438  make_one_hot x4, node_type[edge_index[0/1]], self-loop append
+ *   modeling_qagnn.py:476-479  torch_scatter out-degree
+ *   PyG softmax / scatter      the implicit grouping by edge_index[0] (softmax) and edge_index[1] (aggregation)
+ * Edge ids: 0..E-1 are the caller's edges, E+v is the self loop of node row v (appended for ALL N rows, :436-438).
+ * Edge class  c = etype*T*T + ntype[src]*T + ntype[tgt]  for real edges,  R*T*T + ntype[v]  for self loops;
+ * the edge encoder's input one-hot (:419-433) is a function of c alone, C = R*T*T + T classes.
+ * All three orders are sorted by (group key, edge id), i.e. deterministic and equal to the reference's CPU
+ * summation order inside every group.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct qagnn_graph {
+  int32_t N, E, Ep, R, T, C;   /* Ep = E + N */
+  /* grouped by SOURCE (softmax segments), position p in [0,Ep) */
+  int32_t* rowptr_s;           /* [N+1] */
+  int32_t* tgt_s;              /* [Ep] target node of position p */
+  int32_t* src_s;              /* [Ep] source node of position p (segment owner, for edge-parallel kernels) */
+  int32_t* cls_s;              /* [Ep] edge class */
+  int32_t* eid_s;              /* [Ep] edge id (caller order) at position p */
+  /* grouped by TARGET (aggregation segments) */
+  int32_t* rowptr_t;           /* [N+1] */
+  int32_t* src_t;              /* [Ep] */
+  int32_t* cls_t;              /* [Ep] */
+  int32_t* pos_t;              /* [Ep] position of the same edge in the source order */
+  /* grouped by CLASS, cut into chunks of <= QAGNN_CLS_CHUNK edges that never straddle a class */
+  int32_t* clsptr;             /* [C+1] */
+  int32_t* cls_count;          /* [C]   edges per class (the count-weighted BatchNorm of the edge encoder needs it) */
+  int32_t* src_c;              /* [Ep] */
+  int32_t* tgt_c;              /* [Ep] */
+  int32_t* pos_c;              /* [Ep] position in the source order */
+  int32_t* chunk_cls;          /* [max_chunks] */
+  int32_t* chunk_beg;          /* [max_chunks] */
+  int32_t* chunk_len;          /* [max_chunks] */
+  int32_t* n_chunks;           /* [1] device scalar */
+  int32_t* chunkptr;           /* [C+1] first chunk of each class */
+  int32_t max_chunks;          /* Ep / QAGNN_CLS_CHUNK + C + 1 */
+  int32_t* err;                /* [1] device flag: 1 = an index was out of range (it was clamped) */
+} qagnn_graph;
+
+#define QAGNN_CLS_CHUNK 64
+
+/* int32 elements of device storage needed for all arrays of a qagnn_graph plus scratch. */
+int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T);
+/* Carve `storage` (int32, qagnn_graph_storage_elems elements, 16-byte aligned) into *g and build everything. */
+int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t* edge_index /* [2][E] */, const int64_t* edge_type /* [E] */,
+                     const int64_t* node_type /* [N] */, int32_t N, int32_t E, int32_t R, int32_t T, qagnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32).  Replace the cuBLAS SGEMMs of
+ *   modeling_qagnn.py:464-466 (linear_key/msg/query, after the project-then-gather rewrite: N rows, not E'),
+ *   modeling_qagnn.py:443,408 (GATConvE.mlp), :92 (Vh, Vx), :73 (emb_score) and their autograd backward.
+ * NN:  C[M][ldc] (+)= [A1 | A2][M][K1+K2] * [B1 ; B2][K1+K2][No]  + bias[No] + rowtab[rowidx[m]][No]
+ *      optional A prologue  a <- max(0, a*a_scale[k] + a_shift[k])   (BatchNorm+ReLU folded into the operand load)
+ * TN:  C[Ka][ldc] (+)= A[R][Ka]^T * B[R][No]      (weight gradients; split over rows, deterministic two-stage sum)
+ * Constraints: K1, K2, Ka multiples of 16... see each function; all row pitches multiples of 4 floats, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct qagnn_gemm_nn_args {
+  const float* A1; int32_t lda1; int32_t K1; const float* B1; int32_t ldb1;
+  const float* A2; int32_t lda2; int32_t K2; const float* B2; int32_t ldb2; /* A2 may be NULL (K2 = 0) */
+  float* C; int32_t ldc; int32_t M; int32_t No;
+  const float* bias;                 /* [No] or NULL */
+  const float* rowtab; int32_t ldt;  /* [G][ldt] or NULL */
+  const int64_t* rowidx;             /* [M] row -> table row (node_type ids are int64 in the reference) */
+  const float* a_scale; const float* a_shift; /* [K1] or NULL; applies to A1 only */
+  int32_t accumulate;                /* 1: C += result */
+} qagnn_gemm_nn_args;
+int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
+
+/* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) */
+int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);
+int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t Ka,
+                      int32_t No, const float* a_scale, const float* a_shift /* BN+ReLU prologue on A, or NULL */,
+                      int32_t accumulate, float* workspace, qagnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Column reductions over rows (bias / BatchNorm gradients, batch statistics).  Replace ATen sum / BatchNorm1d
+ * statistics kernels (modeling_qagnn.py:408 BatchNorm1d over all N rows, PAD rows included).
+ *   mode 0: out[g][c] = sum_r [grp(r)==g] X[r][c]                 (grp = rowidx or a single group)
+ *   mode 1: out[c]    = sum_r (X[r][c] - mean[c])^2               (two-pass variance)
+ *   mode 2: out[0][c] = sum_r dY[r][c],  out[1][c] = sum_r dY[r][c] * (H[r][c]-mean[c])*invstd[c]
+ *           with dY = dR * [H*scale+shift > 0]   (BatchNorm+ReLU backward reductions; X = dR, X2 = H)
+ * workspace: qagnn_colreduce_workspace_elems floats.
+ * ------------------------------------------------------------------------------------------------------------ */
+int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_t groups);
+int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
+                        const int64_t* rowidx, int32_t groups, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, float* out, float* workspace, qagnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Elementwise kernels.
+ *   bn_relu_bwd:  dH = gscale[c] * (dY - c1[c] - hhat*c2[c]),  dY = dR*[H*scale+shift>0], hhat=(H-mean)*invstd
+ *                 (train: c1 = mean(dY), c2 = mean(dY*hhat); eval: c1 = c2 = 0)       -- BatchNorm1d backward, :408
+ *   gelu_dropout: Y = gelu_tanh(X) * keep/(1-p)     (utils/layers.py:10-14 + F.dropout, modeling_qagnn.py:48-49,92-93)
+ *                 keep is a counter-based hash of (seed, element index); backward regenerates it.
+ *   sin_basis:    out[r][j] = sin(js[j] * score[r])  for j < J, 0 for J <= j < ldo   (modeling_qagnn.py:70-72)
+ * ------------------------------------------------------------------------------------------------------------ */
+int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
+                          const float* invstd, const float* scale, const float* shift, const float* gscale, const float* c1,
+                          const float* c2, qagnn_stream_t stream);
+int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
+int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
+int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The edge kernels: relation-aware multi-head graph attention over the batched subgraphs.  Replace
+ *   PyG propagate/__lift__ gathers (modeling_qagnn.py:442), the concat + per-edge SGEMMs (:464-466), the score
+ *   reduction (:469-470), PyG softmax grouped by SOURCE (:472), out-degree scaling (:476-481), msg*alpha (:483)
+ *   and the torch_scatter scatter-add by TARGET (:388,442), plus all of their autograd backward.
+ * Inputs are the per-NODE projections (head-padded, row pitch ldk = 3*DP: K | M | Q) and the per-CLASS tables
+ * (row pitch lde = 2*DP: Ek | Em):
+ *   key_e = K[tgt] + Ek[c],  msg_e = M[src] + Em[c],  score_eh = qscale * <Q[src], key_e>_h
+ *   a_eh = softmax over the out-edges of src (eps 1e-16),  alpha_eh = deg(src) * a_eh
+ *   aggr[tgt] += alpha_eh * msg_e
+ * forward writes a[Ep][4], alpha[Ep][4] (source order) and aggr[N][DP]; `score` is scratch [Ep][4].
+ * backward takes G = d aggr [N][DP] and writes dKMQ [N][3*DP], dEkEm [C][2*DP]; scratch: ga[Ep][4] (becomes gs),
+ * rs[N][4], cls_part[max_chunks][2*DP].
+ * ------------------------------------------------------------------------------------------------------------ */
+int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
+                            float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
+                            qagnn_stream_t stream);
+int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
+                            float qscale, const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ,
+                            float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QAGNN_HIP_H */

@@ -161,7 +161,7 @@ class CustomizedEmbedding(nn.Module):
 # --------------------------------------------------------------------------------------
 def make_one_hot(labels, C):
     """modeling_qagnn.py:352-367: int64 [M] -> fp32 [M, C]."""
-    out = torch.zeros(labels.size(0), C, dtype=torch.float32, device=labels.device)
+    out = torch.zeros(labels.size(0), C, dtype=torch.get_default_dtype(), device=labels.device)
     return out.scatter_(1, labels.unsqueeze(1), 1)
 
 
@@ -242,8 +242,8 @@ class GATConvE(nn.Module):
         n_groups = int(src.max()) + 1
         alpha = segment_softmax(scores, src, n_groups)  # grouped by SOURCE node
         self._alpha = alpha
-        ones = torch.ones(src.size(0), dtype=torch.float32)
-        cnt = torch.zeros(n_groups, dtype=torch.float32).index_add_(0, src, ones)[src]  # :476-479
+        ones = torch.ones(src.size(0), dtype=scores.dtype)
+        cnt = torch.zeros(n_groups, dtype=scores.dtype).index_add_(0, src, ones)[src]  # :476-479
         alpha = alpha * cnt.unsqueeze(1)
         return (msg * alpha.view(-1, H, 1)).view(-1, H * dh)
 

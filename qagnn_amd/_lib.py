@@ -1,0 +1,269 @@
+"""ctypes binding of libqagnn_hip.so (include/qagnn_hip.h) + a thin tensor-level wrapper.
+
+PyTorch is used here for exactly three things: device memory (torch.empty), the current HIP stream handle and
+raw data pointers.  All compute goes through the C ABI.  There is no fallback: if the shared library is missing
+or no MI355X is visible, `HipKernels()` raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libqagnn_hip.so')
+
+EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32',
+           'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_relu_bwd_f32',
+           'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
+           'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
+
+_i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
+
+
+class qagnn_graph(C.Structure):
+    _fields_ = ([(n, _i32) for n in ('N', 'E', 'Ep', 'R', 'T', 'C')] +
+                [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'cls_t', 'pos_t',
+                                    'clsptr', 'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
+                                    'chunk_len', 'n_chunks', 'chunkptr')] +
+                [('max_chunks', _i32), ('err', _vp)])
+
+
+class qagnn_gemm_nn_args(C.Structure):
+    _fields_ = [('A1', _vp), ('lda1', _i32), ('K1', _i32), ('B1', _vp), ('ldb1', _i32),
+                ('A2', _vp), ('lda2', _i32), ('K2', _i32), ('B2', _vp), ('ldb2', _i32),
+                ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
+                ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
+                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32)]
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library and declare prototypes.  Raises OSError if it has not been built."""
+    if not os.path.exists(path):
+        raise OSError(f'{path} not found: build it with `python -m qagnn_amd.build` (hipcc, gfx950)')
+    lib = C.CDLL(path)
+    lib.qagnn_last_error.restype = C.c_char_p
+    lib.qagnn_abi_version.restype = _i32
+    lib.qagnn_graph_storage_elems.restype = _i64
+    lib.qagnn_graph_storage_elems.argtypes = [_i32, _i32, _i32, _i32]
+    lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
+    lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
+    lib.qagnn_gemm_tn_workspace_elems.restype = _i64
+    lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]
+    lib.qagnn_colreduce_workspace_elems.restype = _i64
+    lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
+    lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
+    lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
+    lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ('qagnn_abi_version',):
+            fn.restype = _i32
+    return lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t, name, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.is_contiguous(), \
+        f'{name}: need a contiguous 2-D {dtype} device tensor, got {tuple(t.shape)} {t.dtype} {t.device}'
+    return t
+
+
+class HipGraph:
+    """Device-side prepared graph (see qagnn_graph in include/qagnn_hip.h)."""
+
+    def __init__(self, storage, cstruct, N, E, R, T):
+        self.storage, self.c = storage, cstruct
+        self.N, self.E, self.Ep, self.R, self.T = N, E, E + N, R, T
+        self.C = R * T * T + T
+        self.max_chunks = cstruct.max_chunks
+
+    def array(self, name, length):
+        """int32 view of one of the struct's arrays (for tests and attention-weight export)."""
+        off = (getattr(self.c, name) - self.storage.data_ptr()) // 4
+        return self.storage[off:off + length]
+
+    @property
+    def cls_count(self):
+        return self.array('cls_count', self.C)
+
+    @property
+    def eid_s(self):
+        return self.array('eid_s', self.Ep)
+
+
+class HipKernels:
+    """Tensor-level calls into libqagnn_hip.so on the current HIP stream."""
+    name = 'hip'
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError('qagnn_amd needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback')
+        self.lib = load_library()
+        if self.lib.qagnn_abi_version() != 1:
+            raise RuntimeError('libqagnn_hip.so ABI version mismatch')
+
+    # -- helpers -----------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f'{what} failed (code {rc}): {self.lib.qagnn_last_error().decode()}')
+
+    # -- graph -------------------------------------------------------------------------------------------------
+    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype):
+        assert edge_index.dtype == torch.long and edge_type.dtype == torch.long and node_type.dtype == torch.long
+        assert edge_index.dim() == 2 and edge_index.size(0) == 2
+        edge_index, edge_type, node_type = edge_index.contiguous(), edge_type.contiguous(), node_type.contiguous()
+        N, E = node_type.numel(), edge_index.size(1)
+        elems = self.lib.qagnn_graph_storage_elems(N, E, n_etype, n_ntype)
+        storage = torch.empty(elems, dtype=torch.int32, device=node_type.device)
+        g = qagnn_graph()
+        rc = self.lib.qagnn_graph_prep(C.byref(g), storage.data_ptr(), _ptr(edge_index) if E else None,
+                                       _ptr(edge_type) if E else None, node_type.data_ptr(), N, E, n_etype, n_ntype,
+                                       self._stream())
+        self._check(rc, 'qagnn_graph_prep')
+        return HipGraph(storage, g, N, E, n_etype, n_ntype)
+
+    # -- GEMMs ---------------------------------------------------------------------------------------------------
+    def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
+                out=None, accumulate=False):
+        _chk2d(A1, 'A1'), _chk2d(B1, 'B1')
+        M, K1 = A1.shape
+        No = B1.size(1)
+        assert B1.size(0) == K1
+        a = qagnn_gemm_nn_args()
+        a.A1, a.lda1, a.K1, a.B1, a.ldb1 = A1.data_ptr(), K1, K1, B1.data_ptr(), No
+        if A2 is not None:
+            _chk2d(A2, 'A2'), _chk2d(B2, 'B2')
+            assert A2.size(0) == M and B2.shape == (A2.size(1), No)
+            a.A2, a.lda2, a.K2, a.B2, a.ldb2 = A2.data_ptr(), A2.size(1), A2.size(1), B2.data_ptr(), No
+        if out is None:
+            assert not accumulate
+            out = torch.empty((M, No), dtype=torch.float32, device=A1.device)
+        else:
+            _chk2d(out, 'out')
+            assert out.shape == (M, No)
+        a.C, a.ldc, a.M, a.No = out.data_ptr(), No, M, No
+        if bias is not None:
+            assert bias.is_contiguous() and bias.numel() == No and bias.dtype == torch.float32
+            a.bias = bias.data_ptr()
+        if rowtab is not None:
+            _chk2d(rowtab, 'rowtab')
+            assert rowtab.size(1) == No and rowidx.dtype == torch.long and rowidx.numel() == M and rowidx.is_contiguous()
+            a.rowtab, a.ldt, a.rowidx = rowtab.data_ptr(), No, rowidx.data_ptr()
+        if a_scale is not None:
+            assert a_scale.numel() == K1 and a_shift.numel() == K1 and a_scale.is_contiguous() and a_shift.is_contiguous()
+            a.a_scale, a.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
+        a.accumulate = 1 if accumulate else 0
+        self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')
+        return out
+
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False):
+        _chk2d(A, 'A'), _chk2d(B, 'B')
+        R, Ka = A.shape
+        No = B.size(1)
+        assert B.size(0) == R
+        if out is None:
+            assert not accumulate
+            out = torch.empty((Ka, No), dtype=torch.float32, device=A.device)
+        ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka, No), dtype=torch.float32, device=A.device)
+        rc = self.lib.qagnn_gemm_tn_f32(A.data_ptr(), Ka, B.data_ptr(), No, out.data_ptr(), No, R, Ka, No, _ptr(a_scale),
+                                        _ptr(a_shift), 1 if accumulate else 0, ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_gemm_tn_f32')
+        return out
+
+    # -- reductions / elementwise ----------------------------------------------------------------------------------
+    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout):
+        _chk2d(X, 'X')
+        R, Cc = X.shape
+        out = torch.empty((nout, Cc), dtype=torch.float32, device=X.device)
+        ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, groups), dtype=torch.float32, device=X.device)
+        rc = self.lib.qagnn_colreduce_f32(mode, X.data_ptr(), Cc, _ptr(X2), Cc, R, Cc, _ptr(rowidx), groups, _ptr(mean),
+                                          _ptr(invstd), _ptr(scale), _ptr(shift), out.data_ptr(), ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_colreduce_f32')
+        return out
+
+    def colsum(self, X, rowidx=None, groups=1):
+        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups)
+
+    def colvar_sum(self, X, mean):
+        return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1)[0]
+
+    def bn_bwd_reduce(self, dR, H, mean, invstd, scale, shift):
+        _chk2d(H, 'H')
+        return self._colreduce(2, dR, H, None, 1, mean, invstd, scale, shift, 2)
+
+    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gscale, c1, c2):
+        _chk2d(dR, 'dR'), _chk2d(H, 'H')
+        R, Cc = H.shape
+        dH = torch.empty_like(H)
+        rc = self.lib.qagnn_bn_relu_bwd_f32(dR.data_ptr(), H.data_ptr(), dH.data_ptr(), Cc, R, Cc, mean.data_ptr(),
+                                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gscale.data_ptr(),
+                                            c1.data_ptr(), c2.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_bn_relu_bwd_f32')
+        return dH
+
+    def gelu_dropout_fwd(self, X, p, seed):
+        assert X.is_contiguous() and X.dtype == torch.float32
+        Y = torch.empty_like(X)
+        self._check(self.lib.qagnn_gelu_dropout_fwd_f32(X.data_ptr(), Y.data_ptr(), X.numel(), float(p), int(seed),
+                                                        self._stream()), 'qagnn_gelu_dropout_fwd_f32')
+        return Y
+
+    def gelu_dropout_bwd(self, X, dY, p, seed):
+        assert X.is_contiguous() and dY.is_contiguous()
+        dX = torch.empty_like(X)
+        self._check(self.lib.qagnn_gelu_dropout_bwd_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), X.numel(), float(p),
+                                                        int(seed), self._stream()), 'qagnn_gelu_dropout_bwd_f32')
+        return dX
+
+    def sin_basis(self, score, js, ldo):
+        assert score.is_contiguous() and js.is_contiguous() and score.dtype == js.dtype == torch.float32
+        R, J = score.numel(), js.numel()
+        out = torch.empty((R, ldo), dtype=torch.float32, device=score.device)
+        self._check(self.lib.qagnn_sin_basis_f32(score.data_ptr(), js.data_ptr(), out.data_ptr(), ldo, R, J, self._stream()),
+                    'qagnn_sin_basis_f32')
+        return out
+
+    # -- edge kernels -------------------------------------------------------------------------------------------------
+    def edge_attn_fwd(self, graph, KMQ, EkEm, HP, qscale):
+        _chk2d(KMQ, 'KMQ'), _chk2d(EkEm, 'EkEm')
+        DP = 4 * HP
+        assert KMQ.shape == (graph.N, 3 * DP) and EkEm.shape == (graph.C, 2 * DP)
+        dev = KMQ.device
+        score = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
+        a = torch.empty_like(score)
+        alpha = torch.empty_like(score)
+        aggr = torch.empty((graph.N, DP), dtype=torch.float32, device=dev)
+        rc = self.lib.qagnn_edge_attn_fwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP,
+                                              float(qscale), score.data_ptr(), a.data_ptr(), alpha.data_ptr(),
+                                              aggr.data_ptr(), DP, self._stream())
+        self._check(rc, 'qagnn_edge_attn_fwd_f32')
+        return aggr, a, alpha
+
+    def edge_attn_bwd(self, graph, KMQ, EkEm, HP, qscale, a, alpha, G):
+        _chk2d(KMQ, 'KMQ'), _chk2d(EkEm, 'EkEm'), _chk2d(G, 'G')
+        DP = 4 * HP
+        dev = KMQ.device
+        dKMQ = torch.empty_like(KMQ)
+        dEkEm = torch.empty_like(EkEm)
+        ga = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
+        rs = torch.empty((graph.N, 4), dtype=torch.float32, device=dev)
+        cls_part = torch.empty((graph.max_chunks, 2 * DP), dtype=torch.float32, device=dev)
+        rc = self.lib.qagnn_edge_attn_bwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP,
+                                              float(qscale), a.data_ptr(), alpha.data_ptr(), G.data_ptr(), DP,
+                                              dKMQ.data_ptr(), dEkEm.data_ptr(), ga.data_ptr(), rs.data_ptr(),
+                                              cls_part.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_edge_attn_bwd_f32')
+        return dKMQ, dEkEm

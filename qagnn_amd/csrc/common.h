@@ -1,0 +1,67 @@
+// Shared helpers for the gfx950 kernels of libqagnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/qagnn_hip.h"
+
+namespace qagnn {
+
+void set_error(const char* fmt, ...);
+
+#define QAGNN_REQUIRE(cond, code, ...) \
+  do {                                 \
+    if (!(cond)) {                     \
+      qagnn::set_error(__VA_ARGS__);   \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define QAGNN_LAUNCH_CHECK(name)                                               \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      qagnn::set_error("%s launch failed: %s", name, hipGetErrorString(e__));  \
+      return QAGNN_EHIP;                                                       \
+    }                                                                          \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// MI355X: 8 XCDs, workgroup b is observed to run on XCD b % 8 (speed only, never correctness).
+// Remap so that each XCD walks a contiguous range of logical work items: neighbouring node rows (one
+// subgraph = n consecutive rows, all its edges stay inside) then share one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = b & 7, slot = b >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane ends up with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64));
+  v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64));
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
+  return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
+}
+
+}  // namespace qagnn

@@ -1,0 +1,231 @@
+// Column reductions and elementwise kernels around the dense part of a GATConvE layer (HBM-bound, float4 lanes).
+//
+// Reference ops replaced: BatchNorm1d statistics / backward inside GATConvE.mlp (modeling_qagnn.py:408,443; over ALL
+// N rows, PAD rows included), tanh-GELU (utils/layers.py:10-14) + F.dropout (modeling_qagnn.py:48-49, 92-93),
+// the sin basis of the node-score embedding (modeling_qagnn.py:70-72), and bias / type-table gradient sums.
+#include "common.h"
+
+namespace qagnn {
+
+constexpr int CR_ROWS = 256;  // rows per block (4 waves x 64 rows)
+
+// MODE 0: grouped column sums   MODE 1: sum (x-mean)^2   MODE 2: BN+ReLU backward reductions (2 outputs)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, int ldx, const float* __restrict__ X2, int ldx2,
+                                                   int R, int Cc, const int64_t* __restrict__ rowidx, int groups,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   float* __restrict__ part) {
+  constexpr int NOUT = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);
+  __shared__ __attribute__((aligned(16))) float red[4][NOUT][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const bool act = col < Cc;
+  const int r0 = blockIdx.y * CR_ROWS + w * 64;
+  float4 acc[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, sc = mu, sh = mu;
+  if (act && MODE >= 1) mu = ld4(mean + col);
+  if (act && MODE == 2) { is = ld4(invstd + col); sc = ld4(scale + col); sh = ld4(shift + col); }
+  if (act) {
+    const int rend = min(R, r0 + 64);
+    for (int r = r0; r < rend; ++r) {
+      const float4 x = ld4(X + (int64_t)r * ldx + col);
+      if (MODE == 0) {
+        const int g = rowidx ? (int)rowidx[r] : 0;
+        // wave-uniform branch: every lane of the wave is on the same row
+        if (g == 0) acc[0] = add4(acc[0], x);
+        else if (g == 1) acc[1] = add4(acc[1], x);
+        else if (g == 2) acc[2] = add4(acc[2], x);
+        else acc[3] = add4(acc[3], x);
+      } else if (MODE == 1) {
+        const float4 d = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
+        acc[0] = make_float4(fmaf(d.x, d.x, acc[0].x), fmaf(d.y, d.y, acc[0].y), fmaf(d.z, d.z, acc[0].z), fmaf(d.w, d.w, acc[0].w));
+      } else {
+        const float4 h = ld4(X2 + (int64_t)r * ldx2 + col);
+        float4 dy;
+        dy.x = fmaf(h.x, sc.x, sh.x) > 0.f ? x.x : 0.f;
+        dy.y = fmaf(h.y, sc.y, sh.y) > 0.f ? x.y : 0.f;
+        dy.z = fmaf(h.z, sc.z, sh.z) > 0.f ? x.z : 0.f;
+        dy.w = fmaf(h.w, sc.w, sh.w) > 0.f ? x.w : 0.f;
+        acc[0] = add4(acc[0], dy);
+        acc[1].x = fmaf(dy.x, (h.x - mu.x) * is.x, acc[1].x);
+        acc[1].y = fmaf(dy.y, (h.y - mu.y) * is.y, acc[1].y);
+        acc[1].z = fmaf(dy.z, (h.z - mu.z) * is.z, acc[1].z);
+        acc[1].w = fmaf(dy.w, (h.w - mu.w) * is.w, acc[1].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) st4(&red[w][o][lane * 4], acc[o]);
+  __syncthreads();
+  const int nout = MODE == 0 ? groups : NOUT;
+  for (int i = threadIdx.x; i < nout * 256; i += 256) {
+    const int o = i >> 8, c = i & 255;
+    if (blockIdx.x * 256 + c < Cc) {
+      const float s = (red[0][o][c] + red[1][o][c]) + (red[2][o][c] + red[3][o][c]);
+      part[((int64_t)blockIdx.y * nout + o) * Cc + blockIdx.x * 256 + c] = s;
+    }
+  }
+}
+
+__global__ void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * tot + i];
+  out[i] = s;
+}
+
+__global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH, int ld, int R,
+                              int Cc, const float* __restrict__ mean, const float* __restrict__ invstd,
+                              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ gscale,
+                              const float* __restrict__ c1, const float* __restrict__ c2) {
+  const int c4n = Cc >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)R * c4n) return;
+  const int r = (int)(i / c4n), col = (int)(i % c4n) * 4;
+  const int64_t off = (int64_t)r * ld + col;
+  const float4 g = ld4(dR + off), h = ld4(Hh + off);
+  const float4 mu = ld4(mean + col), is = ld4(invstd + col), sc = ld4(scale + col), sh = ld4(shift + col);
+  const float4 gs = ld4(gscale + col), k1 = ld4(c1 + col), k2 = ld4(c2 + col);
+  float4 o;
+#define ONE(f)                                              \
+  {                                                         \
+    const float dy = fmaf(h.f, sc.f, sh.f) > 0.f ? g.f : 0.f; \
+    const float hh = (h.f - mu.f) * is.f;                   \
+    o.f = gs.f * (dy - k1.f - hh * k2.f);                   \
+  }
+  ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+  st4(dH + off, o);
+}
+
+// ---- GELU (tanh form) + dropout -----------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float x2 = x * x;
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+  const float t = tanhf(u);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
+}
+// counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index); same value in fwd and bwd
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <bool BWD>
+__global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
+                               float p, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = ld4(X + i * 4);
+  float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (BWD) g = ld4(dY + i * 4);
+  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float4 o;
+#define ONE(f, k)                                                                  \
+  {                                                                                \
+    const float keep = (p > 0.f && uniform01(seed, (uint64_t)i * 4 + k) < p) ? 0.f : inv; \
+    o.f = BWD ? g.f * keep * gelu_grad_f(x.f) : keep * gelu_f(x.f);                \
+  }
+  ONE(x, 0) ONE(y, 1) ONE(z, 2) ONE(w, 3)
+#undef ONE
+  st4(out + i * 4, o);
+}
+
+__global__ void k_sin_basis(const float* __restrict__ score, const float* __restrict__ js, float* __restrict__ out, int ldo, int R,
+                            int J) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)R * ldo) return;
+  const int r = (int)(i / ldo), j = (int)(i % ldo);
+  out[i] = j < J ? sinf(js[j] * score[r]) : 0.f;
+}
+
+}  // namespace qagnn
+
+using namespace qagnn;
+
+extern "C" int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_t groups) {
+  return (int64_t)cdiv(R, CR_ROWS) * (groups < 2 ? 2 : groups) * Cc;
+}
+
+extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
+                                   const int64_t* rowidx, int32_t groups, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, float* out, float* workspace, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(X && out && workspace, QAGNN_EINVAL, "colreduce: null pointer");
+  QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ldx % 4 == 0 && aligned16(X), QAGNN_EINVAL, "colreduce: bad sizes/alignment");
+  QAGNN_REQUIRE(mode >= 0 && mode <= 2, QAGNN_EINVAL, "colreduce: bad mode %d", mode);
+  dim3 grid(cdiv(Cc, 256), cdiv(R, CR_ROWS));
+  int nout;
+  if (mode == 0) {
+    QAGNN_REQUIRE(groups >= 1 && groups <= 4 && (groups == 1 || rowidx), QAGNN_EINVAL, "colreduce: groups=%d (1..4)", groups);
+    nout = groups;
+    k_colreduce<0><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+  } else if (mode == 1) {
+    QAGNN_REQUIRE(mean && aligned16(mean), QAGNN_EINVAL, "colreduce: mode 1 needs mean");
+    nout = 1;
+    k_colreduce<1><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+  } else {
+    QAGNN_REQUIRE(X2 && mean && invstd && scale && shift && ldx2 % 4 == 0 && aligned16(X2), QAGNN_EINVAL,
+                  "colreduce: mode 2 needs X2, mean, invstd, scale, shift");
+    nout = 2;
+    k_colreduce<2><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+  }
+  QAGNN_LAUNCH_CHECK("k_colreduce");
+  const int tot = nout * Cc;
+  k_colreduce_final<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, out, grid.y, tot);
+  QAGNN_LAUNCH_CHECK("k_colreduce_final");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc,
+                                     const float* mean, const float* invstd, const float* scale, const float* shift,
+                                     const float* gscale, const float* c1, const float* c2, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gscale && c1 && c2, QAGNN_EINVAL, "bn_relu_bwd: null pointer");
+  QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd: bad sizes");
+  const int64_t tot = (int64_t)R * (Cc / 4);
+  k_bn_relu_bwd<<<cdiv(tot, 256), 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gscale, c1, c2);
+  QAGNN_LAUNCH_CHECK("k_bn_relu_bwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(X && Y && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(Y), QAGNN_EINVAL, "gelu_dropout_fwd: bad args");
+  QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_fwd: p=%f", p);
+  k_gelu_dropout<false><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, nullptr, Y, n / 4, p, seed);
+  QAGNN_LAUNCH_CHECK("k_gelu_dropout_fwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed,
+                                          qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(X && dY && dX && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX), QAGNN_EINVAL,
+                "gelu_dropout_bwd: bad args");
+  QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd: p=%f", p);
+  k_gelu_dropout<true><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, dY, dX, n / 4, p, seed);
+  QAGNN_LAUNCH_CHECK("k_gelu_dropout_bwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J,
+                                   qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(score && js && out && R > 0 && J > 0 && ldo >= J, QAGNN_EINVAL, "sin_basis: bad args");
+  const int64_t tot = (int64_t)R * ldo;
+  k_sin_basis<<<cdiv(tot, 256), 256, 0, stream>>>(score, js, out, ldo, R, J);
+  QAGNN_LAUNCH_CHECK("k_sin_basis");
+  return QAGNN_OK;
+}

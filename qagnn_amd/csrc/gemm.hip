@@ -1,0 +1,344 @@
+// Dense fp32 GEMMs on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// These replace the cuBLAS SGEMMs the reference launches per EDGE (modeling_qagnn.py:464-466) by per-NODE
+// projections (project-then-gather), plus GATConvE.mlp (:443), Vh/Vx (:92) and emb_score (:73),
+// and the autograd backward of all of them.
+//
+// MFMA 16x16x4 f32 operand layout (wave64), from the CDNA4 ISA:
+//   A: lane l holds A[i = l & 15][k = l >> 4]       B: lane l holds B[k = l >> 4][j = l & 15]
+//   D: lane l, reg r holds D[row = (l >> 4) * 4 + r][col = l & 15]
+#include "common.h"
+
+namespace qagnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;        // k-tile
+constexpr int NN_BM = 128;    // rows per block (4 waves x 2 row tiles of 16)
+constexpr int PA_NN = BK + 1; // LDS pitch of the row-major A tile: odd -> conflict-free column reads
+
+__host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn : bn + 16; }  // rows k, k+1 land 16 banks apart
+
+// ------------------------------------------------------------------------------------------------------------
+// NN:  C[M][No] (+)= [A1|A2] * [B1;B2] + bias + rowtab[rowidx]
+// block = 256 threads; tile 128 x (NT*16); wave w owns row tiles 2w, 2w+1 and all NT column tiles.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, bool AFFINE>
+__global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
+  constexpr int BN = NT * 16;
+  constexpr int PB = pitch_b(BN);
+  constexpr int B_F4 = BK * BN / 4;                 // float4 per B tile
+  constexpr int B_IT = (B_F4 + 255) / 256;
+  __shared__ float As[NN_BM * PA_NN];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * PB];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // column blocks of one row block are adjacent in blockIdx -> they share the A rows through one XCD's L2 when
+  // gridDim.x (column blocks) is small; rows vary with blockIdx.y.
+  const int m0 = blockIdx.y * NN_BM, n0 = blockIdx.x * BN;
+  const int nk1 = a.K1 / BK, nkt = nk1 + a.K2 / BK;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2];
+  float4 rb[B_IT];
+  const int ar = tid >> 2, ac4 = tid & 3;  // A tile: 64 rows x 4 float4 per pass, 2 passes
+
+  auto gload = [&](int kt) {
+    const bool first = kt < nk1;
+    const float* A = first ? a.A1 : a.A2;
+    const int lda = first ? a.lda1 : a.lda2;
+    const float* B = first ? a.B1 : a.B2;
+    const int ldb = first ? a.ldb1 : a.ldb2;
+    const int k0 = (first ? kt : kt - nk1) * BK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = m0 + ar + p * 64;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < a.M) {
+        v = ld4(A + (int64_t)row * lda + k0 + ac4 * 4);
+        if (AFFINE && first) {
+          const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
+          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        }
+      }
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int col = n0 + c4 * 4;
+        if (col < a.No) v = ld4(B + (int64_t)(k0 + kr) * ldb + col);
+      }
+      rb[it] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float* d = As + (ar + p * 64) * PA_NN + ac4 * 4;
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        st4(Bs + kr * PB + c4 * 4, rb[it]);
+      }
+    }
+  };
+
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);  // next tile's HBM/L2 latency hides under this tile's MFMAs
+    const float* Aw = As + (w * 32 + (lane & 15)) * PA_NN + (lane >> 4);
+    const float* Bw = Bs + (lane >> 4) * PB + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const float a0 = Aw[kk * 4], a1 = Aw[16 * PA_NN + kk * 4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float b = Bw[kk * 4 * PB + j * 16];
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column (lane & 15) of 4 consecutive rows per accumulator
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + w * 32 + i * 16 + (lane >> 4) * 4 + r;
+      if (row >= a.M) continue;
+      const float* trow = a.rowtab ? a.rowtab + (int64_t)a.rowidx[row] * a.ldt : nullptr;
+      float* crow = a.C + (int64_t)row * a.ldc;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + j * 16 + (lane & 15);
+        if (col >= a.No) continue;
+        float v = acc[i][j][r];
+        if (a.bias) v += a.bias[col];
+        if (trow) v += trow[col];
+        if (a.accumulate) v += crow[col];
+        crow[col] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// TN:  P[chunk][Ka][No] = sum over the chunk's rows of A[r][ka] * B[r][no]; a second kernel sums the chunks in order.
+// block tile 64 (ka) x NT*16 (no); wave w owns ka rows 16w..16w+15; k-tiles of 16 rows.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TN_BM = 64;
+constexpr int PA_TN = 80;   // 64 + 16: rows k, k+1 of the k-major A tile land 16 banks apart
+constexpr int TN_RC = 1024; // rows per chunk
+
+template <int NT, bool AFFINE>
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                 float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
+                                                 const float* __restrict__ a_shift) {
+  constexpr int BN = NT * 16;
+  constexpr int PB = pitch_b(BN);
+  constexpr int B_F4 = BK * BN / 4;
+  constexpr int B_IT = (B_F4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[BK * PA_TN];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * PB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * TN_BM, chunk = blockIdx.z;
+  const int r_beg = chunk * TN_RC, r_end = min(R, r_beg + TN_RC);
+  const int nkt = (r_end - r_beg + BK - 1) / BK;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ra, rb[B_IT];
+  const int akr = tid >> 4, ac4 = tid & 15;  // A tile: 16 rows x 16 float4
+
+  auto gload = [&](int kt) {
+    const int r0 = r_beg + kt * BK;
+    {
+      const int row = r0 + akr, col = m0 + ac4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < r_end && col < Ka) {
+        v = ld4(A + (int64_t)row * lda + col);
+        if (AFFINE) {
+          const float4 sc = ld4(a_scale + col), sh = ld4(a_shift + col);
+          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        }
+      }
+      ra = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int row = r0 + kr, col = n0 + c4 * 4;
+        if (row < r_end && col < No) v = ld4(B + (int64_t)row * ldb + col);
+      }
+      rb[it] = v;
+    }
+  };
+  auto lstore = [&]() {
+    st4(As + akr * PA_TN + ac4 * 4, ra);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        st4(Bs + kr * PB + c4 * 4, rb[it]);
+      }
+    }
+  };
+
+  if (nkt > 0) gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+    const float* Aw = As + (lane >> 4) * PA_TN + w * 16 + (lane & 15);
+    const float* Bw = Bs + (lane >> 4) * PB + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const float av = Aw[kk * 4 * PA_TN];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bw[kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* Pc = P + (int64_t)chunk * Ka * No;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + w * 16 + (lane >> 4) * 4 + r;
+    if (row >= Ka) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 16 + (lane & 15);
+      if (col < No) Pc[(int64_t)row * No + col] = acc[j][r];
+    }
+  }
+}
+
+__global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C, int ldc, int Ka, int No, int nchunks,
+                             int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Ka * No) return;
+  const int row = (int)(i / No), col = (int)(i % No);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += P[(int64_t)c * Ka * No + i];
+  float* d = C + (int64_t)row * ldc + col;
+  *d = accumulate ? *d + s : s;
+}
+
+template <int NT>
+static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
+  dim3 grid(cdiv(a.No, NT * 16), cdiv(a.M, NN_BM));
+  if (a.a_scale) k_gemm_nn<NT, true><<<grid, 256, 0, stream>>>(a);
+  else k_gemm_nn<NT, false><<<grid, 256, 0, stream>>>(a);
+  QAGNN_LAUNCH_CHECK("k_gemm_nn");
+  return QAGNN_OK;
+}
+
+template <int NT>
+static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
+                     const float* sh, int nchunks, hipStream_t stream) {
+  dim3 grid(cdiv(No, NT * 16), cdiv(Ka, TN_BM), nchunks);
+  if (sc) k_gemm_tn<NT, true><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh);
+  else k_gemm_tn<NT, false><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh);
+  QAGNN_LAUNCH_CHECK("k_gemm_tn");
+  return QAGNN_OK;
+}
+
+// column-tile count per block: the widest instantiation that divides No, else the one wasting the least
+static int pick_nt(int No) {
+  const int cands[5] = {13, 7, 8, 4, 2};
+  for (int c : cands)
+    if (No % (c * 16) == 0) return c;
+  int best = 4;
+  int64_t best_cost = INT64_MAX;
+  for (int c : cands) {
+    const int64_t cost = (int64_t)cdiv(No, c * 16) * c * 16;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+}  // namespace qagnn
+
+using namespace qagnn;
+
+extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(a && a->A1 && a->B1 && a->C, QAGNN_EINVAL, "gemm_nn: null pointer");
+  QAGNN_REQUIRE(a->M > 0 && a->No > 0 && a->K1 > 0, QAGNN_EINVAL, "gemm_nn: bad sizes M=%d No=%d K1=%d", a->M, a->No, a->K1);
+  QAGNN_REQUIRE(a->K1 % BK == 0 && a->K2 % BK == 0 && a->K2 >= 0, QAGNN_EINVAL, "gemm_nn: K1=%d K2=%d must be multiples of %d",
+                a->K1, a->K2, BK);
+  QAGNN_REQUIRE(a->No % 4 == 0, QAGNN_EINVAL, "gemm_nn: No=%d must be a multiple of 4", a->No);
+  QAGNN_REQUIRE(a->lda1 % 4 == 0 && a->ldb1 % 4 == 0 && aligned16(a->A1) && aligned16(a->B1), QAGNN_EINVAL,
+                "gemm_nn: operand 1 must be 16-byte aligned with pitches multiple of 4");
+  QAGNN_REQUIRE(a->K2 == 0 || (a->A2 && a->B2 && a->lda2 % 4 == 0 && a->ldb2 % 4 == 0 && aligned16(a->A2) && aligned16(a->B2)),
+                QAGNN_EINVAL, "gemm_nn: operand 2 must be 16-byte aligned with pitches multiple of 4");
+  QAGNN_REQUIRE(!a->rowtab || a->rowidx, QAGNN_EINVAL, "gemm_nn: rowtab without rowidx");
+  QAGNN_REQUIRE(!a->a_scale || (a->a_shift && aligned16(a->a_scale) && aligned16(a->a_shift)), QAGNN_EINVAL,
+                "gemm_nn: a_scale/a_shift must both be given and 16-byte aligned");
+  switch (pick_nt(a->No)) {
+    case 13: return launch_nn<13>(*a, stream);
+    case 8: return launch_nn<8>(*a, stream);
+    case 7: return launch_nn<7>(*a, stream);
+    case 4: return launch_nn<4>(*a, stream);
+    default: return launch_nn<2>(*a, stream);
+  }
+}
+
+extern "C" int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No) {
+  return (int64_t)cdiv(R, TN_RC) * Ka * No;
+}
+
+extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
+                                 int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, int32_t accumulate,
+                                 float* workspace, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(A && B && C && workspace, QAGNN_EINVAL, "gemm_tn: null pointer");
+  QAGNN_REQUIRE(R > 0 && Ka > 0 && No > 0 && Ka % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
+                "gemm_tn: bad sizes R=%d Ka=%d No=%d (Ka, No multiples of 4)", R, Ka, No);
+  QAGNN_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && aligned16(A) && aligned16(B), QAGNN_EINVAL,
+                "gemm_tn: operands must be 16-byte aligned with pitches multiple of 4");
+  QAGNN_REQUIRE(!a_scale || (a_shift && aligned16(a_scale) && aligned16(a_shift)), QAGNN_EINVAL,
+                "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
+  const int nchunks = cdiv(R, TN_RC);
+  int rc;
+  switch (pick_nt(No)) {
+    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+  }
+  if (rc != QAGNN_OK) return rc;
+  const int64_t tot = (int64_t)Ka * No;
+  k_sum_chunks<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, accumulate);
+  QAGNN_LAUNCH_CHECK("k_sum_chunks");
+  return QAGNN_OK;
+}

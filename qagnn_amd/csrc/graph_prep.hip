@@ -1,0 +1,305 @@
+// Graph preparation for the batched QA subgraphs (integer work, once per batch).
+//
+// Builds three deterministic orderings of the E' = E + N edges (caller edges + one self loop per node row):
+// grouped by source (softmax segments), by target (aggregation segments) and by edge class (gradients of the
+// per-class tables).  Inside every group edges are sorted by edge id, so all floating-point reductions done
+// by the edge kernels run in a fixed order that matches the reference's CPU order (index_add_ in edge order).
+//
+// Reference semantics being replaced: modeling/modeling_qagnn.py:419-438 (one-hots, head/tail type lookup,
+// self loops) and :476-479 (out-degree); PyG's implicit grouping in softmax()/scatter().
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace qagnn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- decode + histogram ---------------------------------------------------------------------------------
+__global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
+                               const int64_t* __restrict__ node_type, int N, int E, int R, int T, int* __restrict__ es,
+                               int* __restrict__ et, int* __restrict__ ec, int* __restrict__ cnt_s, int* __restrict__ cnt_t,
+                               int* __restrict__ cls_count, int* __restrict__ err) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ep = E + N;
+  if (e >= Ep) return;
+  int s, t, c;
+  bool bad = false;
+  if (e < E) {
+    int64_t s64 = edge_index[e], t64 = edge_index[(int64_t)E + e], r64 = edge_type[e];
+    bad = s64 < 0 || s64 >= N || t64 < 0 || t64 >= N || r64 < 0 || r64 >= R;
+    s = (int)min(max(s64, (int64_t)0), (int64_t)N - 1);
+    t = (int)min(max(t64, (int64_t)0), (int64_t)N - 1);
+    int r = (int)min(max(r64, (int64_t)0), (int64_t)R - 1);
+    int64_t hs = node_type[s], ht = node_type[t];
+    bad = bad || hs < 0 || hs >= T || ht < 0 || ht >= T;
+    int h = (int)min(max(hs, (int64_t)0), (int64_t)T - 1), tl = (int)min(max(ht, (int64_t)0), (int64_t)T - 1);
+    c = r * T * T + h * T + tl;
+  } else {
+    s = t = e - E;
+    int64_t hs = node_type[s];
+    bad = hs < 0 || hs >= T;
+    c = R * T * T + (int)min(max(hs, (int64_t)0), (int64_t)T - 1);
+  }
+  if (bad) *err = 1;
+  es[e] = s;
+  et[e] = t;
+  ec[e] = c;
+  atomicAdd(&cnt_s[s], 1);
+  atomicAdd(&cnt_t[t], 1);
+  atomicAdd(&cls_count[c], 1);
+}
+
+// ---- exclusive scan of up to 3 independent arrays, one 1024-thread block each ---------------------------------
+__device__ void block_exclusive_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int wtot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? in[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+      int w = lane < 16 ? wtot[lane] : 0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        int u = __shfl_up(w, o, 64);
+        if (lane >= o) w += u;
+      }
+      if (lane < 16) wtot[lane] = w;  // inclusive over waves
+    }
+    __syncthreads();
+    const int carry = carry_s;
+    const int woff = wid ? wtot[wid - 1] : 0;
+    if (i < n) out[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + wtot[15];
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+__global__ __launch_bounds__(1024) void k_scan3(const int* a0, int* o0, int n0, const int* a1, int* o1, int n1, const int* a2,
+                                                int* o2, int n2) {
+  if (blockIdx.x == 0) block_exclusive_scan(a0, o0, n0);
+  else if (blockIdx.x == 1) block_exclusive_scan(a1, o1, n1);
+  else block_exclusive_scan(a2, o2, n2);
+}
+
+// ---- bucket fill (unordered inside a bucket; fixed up by k_sort_segments) --------------------------------------
+__global__ void k_fill(const int* __restrict__ es, const int* __restrict__ et, const int* __restrict__ rowptr_s,
+                       const int* __restrict__ rowptr_t, int* __restrict__ cnt_s, int* __restrict__ cnt_t,
+                       int* __restrict__ tmp_s, int* __restrict__ tmp_t, int Ep) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Ep) return;
+  const int s = es[e], t = et[e];
+  tmp_s[rowptr_s[s] + atomicSub(&cnt_s[s], 1) - 1] = e;
+  tmp_t[rowptr_t[t] + atomicSub(&cnt_t[t], 1) - 1] = e;
+}
+
+// one wave per (node, direction): rank-by-counting sort of the bucket by edge id
+__global__ __launch_bounds__(256) void k_sort_segments(const int* __restrict__ rowptr_s, const int* __restrict__ rowptr_t,
+                                                       const int* __restrict__ tmp_s, const int* __restrict__ tmp_t,
+                                                       int* __restrict__ eid_s, int* __restrict__ eid_t,
+                                                       int* __restrict__ srcpos, int N) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= 2 * N) return;
+  const bool by_src = w < N;
+  const int v = by_src ? w : w - N;
+  const int* rowptr = by_src ? rowptr_s : rowptr_t;
+  const int* tmp = by_src ? tmp_s : tmp_t;
+  int* out = by_src ? eid_s : eid_t;
+  const int beg = rowptr[v], L = rowptr[v + 1] - beg;
+  for (int i = lane; i < L; i += 64) {
+    const int id = tmp[beg + i];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) rank += tmp[beg + j] < id;
+    out[beg + rank] = id;
+    if (by_src) srcpos[id] = beg + rank;
+  }
+}
+
+__global__ void k_payload(const int* __restrict__ es, const int* __restrict__ et, const int* __restrict__ ec,
+                          const int* __restrict__ eid_s, const int* __restrict__ eid_t, const int* __restrict__ srcpos,
+                          int* __restrict__ tgt_s, int* __restrict__ src_s, int* __restrict__ cls_s, int* __restrict__ src_t,
+                          int* __restrict__ cls_t, int* __restrict__ pos_t, int Ep) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Ep) return;
+  const int e = eid_s[p];
+  tgt_s[p] = et[e];
+  src_s[p] = es[e];
+  cls_s[p] = ec[e];
+  const int e2 = eid_t[p];
+  src_t[p] = es[e2];
+  cls_t[p] = ec[e2];
+  pos_t[p] = srcpos[e2];
+}
+
+// ---- stable counting sort of the source-ordered positions by class -------------------------------------------
+#define CLS_BLK 1024
+__global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s, int* __restrict__ hist, int Ep, int C) {
+  extern __shared__ int lh[];
+  for (int c = threadIdx.x; c < C; c += 256) lh[c] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * CLS_BLK;
+  for (int i = threadIdx.x; i < CLS_BLK; i += 256)
+    if (base + i < Ep) atomicAdd(&lh[cls_s[base + i]], 1);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) hist[(int64_t)blockIdx.x * C + c] = lh[c];
+}
+
+__global__ void k_cls_base(int* __restrict__ hist, const int* __restrict__ clsptr, int nblk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int run = clsptr[c];
+  for (int b = 0; b < nblk; ++b) {
+    const int t = hist[(int64_t)b * C + c];
+    hist[(int64_t)b * C + c] = run;
+    run += t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cls_scatter(const int* __restrict__ cls_s, const int* __restrict__ src_s,
+                                                     const int* __restrict__ tgt_s, const int* __restrict__ hist,
+                                                     int* __restrict__ src_c, int* __restrict__ tgt_c, int* __restrict__ pos_c,
+                                                     int Ep, int C) {
+  __shared__ int lc[CLS_BLK];
+  const int base = blockIdx.x * CLS_BLK;
+  for (int i = threadIdx.x; i < CLS_BLK; i += 256) lc[i] = base + i < Ep ? cls_s[base + i] : -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < CLS_BLK; i += 256) {
+    const int p = base + i;
+    if (p >= Ep) continue;
+    const int c = lc[i];
+    int rank = 0;
+    for (int j = 0; j < i; ++j) rank += lc[j] == c;
+    const int dst = hist[(int64_t)blockIdx.x * C + c] + rank;
+    pos_c[dst] = p;
+    src_c[dst] = src_s[p];
+    tgt_c[dst] = tgt_s[p];
+  }
+}
+
+// chunk table: class c owns chunks [chunkptr[c], chunkptr[c+1]), each <= QAGNN_CLS_CHUNK consecutive class-order slots
+__global__ __launch_bounds__(1024) void k_chunk_counts(const int* __restrict__ cls_count, int* __restrict__ nch, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) nch[c] = (cls_count[c] + QAGNN_CLS_CHUNK - 1) / QAGNN_CLS_CHUNK;
+}
+__global__ __launch_bounds__(1024) void k_chunk_scan(const int* nch, int* chunkptr, int C) { block_exclusive_scan(nch, chunkptr, C); }
+__global__ void k_chunk_fill(const int* __restrict__ clsptr, const int* __restrict__ chunkptr, int* __restrict__ chunk_cls,
+                             int* __restrict__ chunk_beg, int* __restrict__ chunk_len, int* __restrict__ n_chunks, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) *n_chunks = chunkptr[C];
+  if (c >= C) return;
+  const int b = clsptr[c], e = clsptr[c + 1];
+  int k = chunkptr[c];
+  for (int p = b; p < e; p += QAGNN_CLS_CHUNK, ++k) {
+    chunk_cls[k] = c;
+    chunk_beg[k] = p;
+    chunk_len[k] = min(QAGNN_CLS_CHUNK, e - p);
+  }
+}
+
+static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+
+}  // namespace qagnn
+
+using namespace qagnn;
+
+extern "C" const char* qagnn_last_error(void) { return g_err; }
+extern "C" int qagnn_abi_version(void) { return 1; }
+
+extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
+  const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;
+  const int64_t maxch = Ep / QAGNN_CLS_CHUNK + C + 1;
+  const int64_t nblk = (Ep + CLS_BLK - 1) / CLS_BLK;
+  int64_t tot = 0;
+  tot += 2 * up4(N + 1);      // rowptr_s, rowptr_t
+  tot += 11 * up4(Ep);        // tgt_s src_s cls_s eid_s src_t cls_t pos_t src_c tgt_c pos_c + eid_t
+  tot += 3 * up4(C + 1);      // clsptr, chunkptr, nch scratch
+  tot += up4(C);              // cls_count
+  tot += 3 * up4(maxch);      // chunk tables
+  tot += 2 * up4(4);          // n_chunks, err
+  tot += 2 * up4(N);          // cnt_s, cnt_t
+  tot += 6 * up4(Ep);         // es et ec tmp_s tmp_t srcpos
+  tot += up4(nblk * C);       // per-block class histograms
+  return tot;
+}
+
+extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t* edge_index, const int64_t* edge_type,
+                                const int64_t* node_type, int32_t N, int32_t E, int32_t R, int32_t T, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(g && storage && node_type, QAGNN_EINVAL, "graph_prep: null pointer");
+  QAGNN_REQUIRE(N > 0 && E >= 0 && R > 0 && T > 0, QAGNN_EINVAL, "graph_prep: bad sizes N=%d E=%d R=%d T=%d", N, E, R, T);
+  QAGNN_REQUIRE(E == 0 || (edge_index && edge_type), QAGNN_EINVAL, "graph_prep: null edge arrays with E=%d", E);
+  QAGNN_REQUIRE(aligned16(storage), QAGNN_EINVAL, "graph_prep: storage must be 16-byte aligned");
+  const int64_t Ep64 = (int64_t)E + N, C64 = (int64_t)R * T * T + T;
+  QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_prep: E+N=%lld too large", (long long)Ep64);
+  QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_prep: %lld edge classes > 8192", (long long)C64);
+  const int Ep = (int)Ep64, C = (int)C64;
+  const int maxch = Ep / QAGNN_CLS_CHUNK + C + 1;
+  const int nblk = cdiv(Ep, CLS_BLK);
+  int32_t* p = storage;
+  auto take = [&](int64_t n) { int32_t* r = p; p += up4(n); return r; };
+  g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch;
+  g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
+  g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
+  g->src_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
+  g->src_c = take(Ep); g->tgt_c = take(Ep); g->pos_c = take(Ep);
+  int32_t* eid_t = take(Ep);
+  g->clsptr = take(C + 1); g->chunkptr = take(C + 1);
+  int32_t* nch = take(C + 1);
+  g->cls_count = take(C);
+  g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
+  g->n_chunks = take(4); g->err = take(4);
+  // ---- scratch; zero-initialised region first (cls_count must be zero too, it sits just before) ----
+  int32_t* cnt_s = take(N); int32_t* cnt_t = take(N);
+  int32_t* es = take(Ep); int32_t* et = take(Ep); int32_t* ec = take(Ep);
+  int32_t* tmp_s = take(Ep); int32_t* tmp_t = take(Ep); int32_t* srcpos = take(Ep);
+  int32_t* hist = take((int64_t)nblk * C);
+
+  hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)es - (char*)g->cls_count), stream);
+  if (he != hipSuccess) { set_error("graph_prep: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  const int TB = 256;
+  k_decode_count<<<cdiv(Ep, TB), TB, 0, stream>>>(edge_index, edge_type, node_type, N, E, R, T, es, et, ec, cnt_s, cnt_t,
+                                                   g->cls_count, g->err);
+  QAGNN_LAUNCH_CHECK("k_decode_count");
+  k_scan3<<<3, 1024, 0, stream>>>(cnt_s, g->rowptr_s, N, cnt_t, g->rowptr_t, N, g->cls_count, g->clsptr, C);
+  QAGNN_LAUNCH_CHECK("k_scan3");
+  k_fill<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, g->rowptr_s, g->rowptr_t, cnt_s, cnt_t, tmp_s, tmp_t, Ep);
+  QAGNN_LAUNCH_CHECK("k_fill");
+  k_sort_segments<<<cdiv(2 * (int64_t)N, 4), 256, 0, stream>>>(g->rowptr_s, g->rowptr_t, tmp_s, tmp_t, g->eid_s, eid_t, srcpos, N);
+  QAGNN_LAUNCH_CHECK("k_sort_segments");
+  k_payload<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, ec, g->eid_s, eid_t, srcpos, g->tgt_s, g->src_s, g->cls_s, g->src_t,
+                                              g->cls_t, g->pos_t, Ep);
+  QAGNN_LAUNCH_CHECK("k_payload");
+  k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, Ep, C);
+  QAGNN_LAUNCH_CHECK("k_cls_hist");
+  k_cls_base<<<cdiv(C, 256), 256, 0, stream>>>(hist, g->clsptr, nblk, C);
+  QAGNN_LAUNCH_CHECK("k_cls_base");
+  k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
+  QAGNN_LAUNCH_CHECK("k_cls_scatter");
+  k_chunk_counts<<<cdiv(C, 1024), 1024, 0, stream>>>(g->cls_count, nch, C);
+  QAGNN_LAUNCH_CHECK("k_chunk_counts");
+  k_chunk_scan<<<1, 1024, 0, stream>>>(nch, g->chunkptr, C);
+  QAGNN_LAUNCH_CHECK("k_chunk_scan");
+  k_chunk_fill<<<cdiv(C, 256), 256, 0, stream>>>(g->clsptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C);
+  QAGNN_LAUNCH_CHECK("k_chunk_fill");
+  return QAGNN_OK;
+}

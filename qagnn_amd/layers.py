@@ -1,0 +1,134 @@
+"""Boundary glue around the GNN stack, kept on stock PyTorch-ROCm ops for now ("can stay stock
+PyTorch first"; fusing them is rows f2/f3 of section 8).  Same class names, constructor arguments, parameter
+names (state-dict keys) and numerics as the reference's utils/layers.py; written from the reference's behaviour:
+
+  GELU / gelu                              utils/layers.py:10-22   tanh-form GELU
+  MLP                                      utils/layers.py:47-87   the `fc` head (one Linear at fc_layer_num=0)
+  MatrixVectorScaledDotProductAttention    utils/layers.py:276-299
+  MultiheadAttPoolLayer                    utils/layers.py:324-371 masked multi-head attention pooling over nodes
+  CustomizedEmbedding                      utils/layers.py:571-607 frozen entity table + cpt_transform + GELU
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def gelu(x):
+    # identical to the reference's 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3))) up to fp32 rounding (3e-8)
+    return F.gelu(x, approximate='tanh')
+
+
+class GELU(nn.Module):
+    def forward(self, x):
+        return gelu(x)
+
+
+class MLP(nn.Module):
+    activation_classes = {'gelu': GELU, 'relu': nn.ReLU, 'tanh': nn.Tanh}
+
+    def __init__(self, input_size, hidden_size, output_size, num_layers, dropout, batch_norm=False,
+                 init_last_layer_bias_to_zero=False, layer_norm=False, activation='gelu'):
+        super().__init__()
+        if batch_norm and layer_norm:
+            raise AssertionError('batch_norm and layer_norm are mutually exclusive')
+        self.input_size, self.hidden_size, self.output_size = input_size, hidden_size, output_size
+        self.num_layers, self.dropout = num_layers, dropout
+        self.batch_norm, self.layer_norm = batch_norm, layer_norm
+        self.layers = nn.Sequential()
+        sizes = [input_size] + [hidden_size] * num_layers + [output_size]
+        for i in range(num_layers + 1):
+            self.layers.add_module(f'{i}-Linear', nn.Linear(sizes[i], sizes[i + 1]))
+            if i == num_layers:
+                break
+            self.layers.add_module(f'{i}-Dropout', nn.Dropout(dropout))
+            if batch_norm:
+                self.layers.add_module(f'{i}-BatchNorm1d', nn.BatchNorm1d(hidden_size))
+            if layer_norm:
+                self.layers.add_module(f'{i}-LayerNorm', nn.LayerNorm(hidden_size))
+            self.layers.add_module(f'{i}-{activation}', self.activation_classes[activation.lower()]())
+        if init_last_layer_bias_to_zero:
+            self.layers[-1].bias.data.fill_(0)
+
+    def forward(self, input):
+        return self.layers(input)
+
+
+class MatrixVectorScaledDotProductAttention(nn.Module):
+    def __init__(self, temperature, attn_dropout=0.1):
+        super().__init__()
+        self.temperature = temperature
+        self.dropout = nn.Dropout(attn_dropout)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, q, k, v, mask=None):
+        """q [m, dk], k [m, l, dk], v [m, l, dv], mask [m, l] (True = ignore) -> ([m, dv], [m, l])."""
+        attn = torch.einsum('md,mld->ml', q, k) / self.temperature
+        if mask is not None:
+            attn = attn.masked_fill(mask, -np.inf)
+        attn = self.dropout(self.softmax(attn))
+        return torch.einsum('ml,mld->md', attn, v), attn
+
+
+class MultiheadAttPoolLayer(nn.Module):
+    def __init__(self, n_head, d_q_original, d_k_original, dropout=0.1):
+        super().__init__()
+        if d_k_original % n_head != 0:
+            raise AssertionError('d_k_original must be divisible by n_head')
+        self.n_head = n_head
+        self.d_k = self.d_v = d_k_original // n_head
+        self.w_qs = nn.Linear(d_q_original, n_head * self.d_k)
+        self.w_ks = nn.Linear(d_k_original, n_head * self.d_k)
+        self.w_vs = nn.Linear(d_k_original, n_head * self.d_v)
+        for lin, fan in ((self.w_qs, d_q_original), (self.w_ks, d_k_original), (self.w_vs, d_k_original)):
+            nn.init.normal_(lin.weight, mean=0, std=math.sqrt(2.0 / (fan + self.d_k)))
+        self.attention = MatrixVectorScaledDotProductAttention(temperature=math.sqrt(self.d_k))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, q, k, mask=None):
+        """q [b, d_q], k [b, l, d_k], mask [b, l] -> (pooled [b, n_head*d_v], attn [n_head*b, l] head-major)."""
+        nh, dk, dv = self.n_head, self.d_k, self.d_v
+        b, l = k.size(0), k.size(1)
+        qs = self.w_qs(q).view(b, nh, dk).transpose(0, 1).reshape(nh * b, dk)
+        ks = self.w_ks(k).view(b, l, nh, dk).permute(2, 0, 1, 3).reshape(nh * b, l, dk)
+        vs = self.w_vs(k).view(b, l, nh, dv).permute(2, 0, 1, 3).reshape(nh * b, l, dv)
+        if mask is not None:
+            mask = mask.repeat(nh, 1)
+        out, attn = self.attention(qs, ks, vs, mask=mask)
+        out = out.view(nh, b, dv).transpose(0, 1).reshape(b, nh * dv)
+        return self.dropout(out), attn
+
+
+class CustomizedEmbedding(nn.Module):
+    def __init__(self, concept_num, concept_in_dim, concept_out_dim, use_contextualized=False,
+                 pretrained_concept_emb=None, freeze_ent_emb=True, scale=1.0, init_range=0.02):
+        super().__init__()
+        self.scale = scale
+        self.use_contextualized = use_contextualized
+        if not use_contextualized:
+            self.emb = nn.Embedding(concept_num, concept_in_dim)
+            if pretrained_concept_emb is not None:
+                self.emb.weight.data.copy_(pretrained_concept_emb)
+            else:
+                self.emb.weight.data.normal_(mean=0.0, std=init_range)
+            if freeze_ent_emb:
+                for p in self.emb.parameters():
+                    p.requires_grad = False
+        if concept_in_dim != concept_out_dim:
+            self.cpt_transform = nn.Linear(concept_in_dim, concept_out_dim)
+            self.activation = GELU()
+
+    def forward(self, index, contextualized_emb=None):
+        if contextualized_emb is not None:
+            if index.size(0) != contextualized_emb.size(0):
+                raise AssertionError('index / contextualized_emb batch mismatch')
+            e = contextualized_emb * self.scale
+            if hasattr(self, 'cpt_transform'):
+                e = self.activation(self.cpt_transform(e))
+            return e.gather(1, index.unsqueeze(-1).expand(-1, -1, e.size(-1)))
+        e = self.emb(index) * self.scale
+        if hasattr(self, 'cpt_transform'):
+            e = self.activation(self.cpt_transform(e))
+        return e

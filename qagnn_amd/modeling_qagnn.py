@@ -1,0 +1,323 @@
+"""MI355X-native QA-GNN decoder: drop-in mirror of the reference's module interface for the GNN hot path.
+
+Same class names, constructor signatures, forward signatures, state-dict keys and train/eval semantics as
+reference modeling/modeling_qagnn.py (QAGNN :99-189, QAGNN_Message_Passing :7-95, GATConvE :380-484,
+make_one_hot :352-367, LM_QAGNN.batch_graph :244-251), but the math is re-derived for the hardware
+(SURVEY.md 7.2 / 9): per-NODE K|M|Q projections on the fp32 matrix cores instead of per-edge GEMMs, a per-CLASS
+edge-encoder table (<= R*T^2+T distinct rows, count-weighted BatchNorm) instead of E' encoder rows, and hand-written
+gather / segmented-softmax / aggregate kernels over graph orderings that are built once per batch.
+
+nn.Linear / nn.BatchNorm1d sub-modules are kept as PARAMETER CONTAINERS only (so checkpoints load with
+strict=True); their forward() is never called on the GNN path.  All heavy compute goes through qagnn_amd.ops
+(C-ABI kernels of libqagnn_hip.so); the tiny table math (4-row type table, <=~600-row edge table) and the
+pooling/fc head are stock PyTorch-ROCm ops on the GPU.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .layers import GELU, MLP, CustomizedEmbedding, MultiheadAttPoolLayer, gelu
+
+
+def make_one_hot(labels, C):
+    """int64 [M] -> fp32 [M, C] one-hot (reference modeling_qagnn.py:352-367).  Kept for API parity; the kernels
+    consume integer class ids directly and never materialise one-hots."""
+    return F.one_hot(labels, C).to(torch.float32)
+
+
+_LAYOUTS = {}
+
+
+def head_layout(d, device):
+    key = (d, str(device))
+    if key not in _LAYOUTS:
+        _LAYOUTS[key] = ops.HeadLayout(d, device)
+    return _LAYOUTS[key]
+
+
+def _pad2(W, L):
+    """dense [out, in] weight -> (W^T padded [DP_in, DP_out], W padded [DP_out, DP_in]), both contiguous."""
+    Wt = L.pad(L.pad(W).t())          # [DP_in, DP_out]
+    return Wt, Wt.t().contiguous()
+
+
+def edge_class_features(n_etype, n_ntype, device):
+    """Input rows of the edge encoder for every edge class (the one-hot concat of modeling_qagnn.py:419-433).
+
+    class c = etype*T*T + head*T + tail for real edges; R*T*T + type for the self loop of a node of that type
+    (self loops use one-hot index R and head = tail = own type, :420-421,428-429)."""
+    R, T = n_etype, n_ntype
+    C = R * T * T + T
+    c = torch.arange(C, device=device)
+    is_self = c >= R * T * T
+    et = torch.where(is_self, torch.full_like(c, R), c // (T * T))
+    hd = torch.where(is_self, c - R * T * T, (c // T) % T)
+    tl = torch.where(is_self, c - R * T * T, c % T)
+    feat = torch.zeros(C, R + 1 + 2 * T, device=device)
+    ar = torch.arange(C, device=device)
+    feat[ar, et] = 1
+    feat[ar, R + 1 + hd] = 1
+    feat[ar, R + 1 + T + tl] = 1
+    return feat
+
+
+def edge_class_table(edge_encoder, graph, training, n_updates=1):
+    """tab[c] = edge_encoder(one-hot features of class c)  -> [C, d].
+
+    The reference runs the shared encoder on all E' edge rows every layer (modeling_qagnn.py:433); its rows only
+    take C distinct values, and train-mode BatchNorm statistics over the E' rows equal count-weighted statistics
+    over the C distinct rows.  Running statistics are updated `n_updates` times (the reference
+    calls the shared module once per layer, i.e. k times per forward of the stack).
+    """
+    lin1, bn, lin2 = edge_encoder[0], edge_encoder[1], edge_encoder[3]
+    feat = edge_class_features(graph.R, graph.T, lin1.weight.device)
+    h = F.linear(feat, lin1.weight, lin1.bias)
+    if training or not bn.track_running_stats:
+        Ep = float(graph.Ep)
+        w = (graph.cls_count.to(h.dtype) / Ep).unsqueeze(1)
+        mu = (w * h).sum(0)
+        var = (w * (h - mu) ** 2).sum(0)
+        if training and bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 0.1
+                unbiased = var * (Ep / max(Ep - 1.0, 1.0))
+                for _ in range(n_updates):
+                    bn.running_mean.mul_(1 - m).add_(m * mu)
+                    bn.running_var.mul_(1 - m).add_(m * unbiased)
+                bn.num_batches_tracked += n_updates
+    else:
+        mu, var = bn.running_mean, bn.running_var
+    hn = (h - mu) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+    return F.linear(F.relu(hn), lin2.weight, lin2.bias)
+
+
+class GATConvE(nn.Module):
+    """One relation-aware graph-attention hop (reference modeling_qagnn.py:380-484).
+
+    Args:
+        emb_dim (int): dimensionality of GNN hidden states
+        n_ntype (int): number of node types (e.g. 4)
+        n_etype (int): number of edge relation types (e.g. 38)
+    """
+
+    def __init__(self, args, emb_dim, n_ntype, n_etype, edge_encoder, head_count=4, aggr="add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError('only aggr="add" (the reference default) is implemented')
+        if head_count != ops.H_HEADS:
+            raise NotImplementedError('the edge kernels are written for head_count=4 (the reference value)')
+        self.args = args
+        assert emb_dim % 2 == 0
+        self.emb_dim = emb_dim
+        self.n_ntype, self.n_etype = n_ntype, n_etype
+        self.edge_encoder = edge_encoder
+        self.head_count = head_count
+        assert emb_dim % head_count == 0
+        self.dim_per_head = emb_dim // head_count
+        self.linear_key = nn.Linear(3 * emb_dim, head_count * self.dim_per_head)
+        self.linear_msg = nn.Linear(3 * emb_dim, head_count * self.dim_per_head)
+        self.linear_query = nn.Linear(2 * emb_dim, head_count * self.dim_per_head)
+        self._alpha = None
+        self.mlp = nn.Sequential(nn.Linear(emb_dim, emb_dim), nn.BatchNorm1d(emb_dim), nn.ReLU(), nn.Linear(emb_dim, emb_dim))
+
+    # ---- parameter packing into the kernels' head-padded operand layout (differentiable torch gathers) ----------
+    def packed_projection(self, L):
+        d, DP = self.emb_dim, L.DP
+        Wcat = torch.cat([self.linear_key.weight[:, :2 * d], self.linear_msg.weight[:, :2 * d], self.linear_query.weight], 0)
+        t = L.pad(Wcat.t().reshape(2 * d, 3, d)).reshape(2, d, 3 * DP)  # [x|extra half, in, (K|M|Q) padded out]
+        W_nt = L.pad(t.transpose(1, 2)).contiguous()                     # [2, 3DP, DP]
+        W_t = W_nt.transpose(1, 2).contiguous()                          # [2, DP, 3DP]
+        bias = torch.cat([W_t.new_zeros(2 * DP), L.pad(self.linear_query.bias)])
+        return W_t, W_nt, bias
+
+    def packed_edge_tables(self, tab, L):
+        """[C, d] class table -> [C, 2*DP]:  Ek = Wk[:, 2d:] tab + bk | Em = Wm[:, 2d:] tab + bm (head-padded)."""
+        d = self.emb_dim
+        We = torch.cat([self.linear_key.weight[:, 2 * d:], self.linear_msg.weight[:, 2 * d:]], 0)
+        be = torch.cat([self.linear_key.bias, self.linear_msg.bias])
+        ekem = F.linear(tab, We, be)  # [C, 2d]
+        return L.pad(ekem.view(-1, 2, d)).reshape(-1, 2 * L.DP).contiguous()
+
+    def packed_mlp(self, L):
+        lin1, bn, lin2 = self.mlp[0], self.mlp[1], self.mlp[3]
+        W1t, W1 = _pad2(lin1.weight, L)
+        W2t, W2 = _pad2(lin2.weight, L)
+        return (W1t, W1, L.pad(lin1.bias), L.pad(bn.weight), L.pad(bn.bias), W2t, W2, L.pad(lin2.bias),
+                L.pad(bn.running_mean), L.pad(bn.running_var))
+
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop):
+        """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order)."""
+        W_t, W_nt, bias = self.packed_projection(L)
+        KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)
+        aggr, a = ops.edge_attention(KMQ, self.packed_edge_tables(tab, L), graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
+        bn = self.mlp[1]
+        use_batch_stats = self.training or not bn.track_running_stats
+        y, mean_p, var_p = ops.gat_mlp(aggr, *self.packed_mlp(L), use_batch_stats, bn.eps, p_drop if self.training else 0.0,
+                                       apply_act)
+        if self.training and bn.track_running_stats:
+            with torch.no_grad():
+                R = float(Xp.size(0))
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(m * L.unpad(mean_p))
+                bn.running_var.mul_(1 - m).add_(m * L.unpad(var_p) * (R / max(R - 1.0, 1.0)))
+                bn.num_batches_tracked += 1
+        return y, a
+
+    def forward(self, x, edge_index, edge_type, node_type, node_feature_extra, return_attention_weights=False, graph=None):
+        # x: [N, emb_dim]; edge_index: [2, E]; edge_type: [E]; node_type: [N]; node_feature_extra: [N, emb_dim]
+        L = head_layout(self.emb_dim, x.device)
+        if graph is None:
+            graph = ops.kernels().graph_prep(edge_index, edge_type, node_type, self.n_etype, self.n_ntype)
+        tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=1)
+        y, a = self.hop(L.pad(x), L.pad(node_feature_extra), graph, tab, L, apply_act=False, p_drop=0.0)
+        out = L.unpad(y)
+        if return_attention_weights:
+            N = x.size(0)
+            loop = torch.arange(N, dtype=torch.long, device=x.device).unsqueeze(0).repeat(2, 1)
+            alpha = torch.empty_like(a)
+            alpha[graph.eid_s.long()] = a  # back to caller edge order, self loops last (:436-438)
+            return out, (torch.cat([edge_index, loop], dim=1), alpha)
+        return out
+
+
+class QAGNN_Message_Passing(nn.Module):
+    """k GATConvE hops + node-type / node-score embeddings (reference modeling_qagnn.py:7-95)."""
+
+    def __init__(self, args, k, n_ntype, n_etype, input_size, hidden_size, output_size, dropout=0.1):
+        super().__init__()
+        assert input_size == output_size
+        self.args = args
+        self.n_ntype, self.n_etype = n_ntype, n_etype
+        assert input_size == hidden_size
+        self.hidden_size = hidden_size
+        self.emb_node_type = nn.Linear(self.n_ntype, hidden_size // 2)
+        self.basis_f = 'sin'  # the only basis the reference uses (:20)
+        self.emb_score = nn.Linear(hidden_size // 2, hidden_size // 2)
+        self.edge_encoder = nn.Sequential(nn.Linear(n_etype + 1 + n_ntype * 2, hidden_size), nn.BatchNorm1d(hidden_size),
+                                          nn.ReLU(), nn.Linear(hidden_size, hidden_size))
+        self.k = k
+        self.gnn_layers = nn.ModuleList([GATConvE(args, hidden_size, n_ntype, n_etype, self.edge_encoder) for _ in range(k)])
+        self.Vh = nn.Linear(input_size, output_size)
+        self.Vx = nn.Linear(hidden_size, output_size)
+        self.activation = GELU()
+        self.dropout = nn.Dropout(dropout)
+        self.dropout_rate = dropout
+        self._js = {}
+
+    def _js_table(self, device):
+        """1.1**j in fp32, computed on the HOST exactly like the oracle: sin arguments reach ~1e4, so a 1-ulp
+        difference in this table would move sin() by ~1e-3."""
+        key = str(device)
+        if key not in self._js:
+            self._js[key] = torch.pow(1.1, torch.arange(self.hidden_size // 2).float()).to(device)
+        return self._js[key]
+
+    def node_feature_extra(self, node_type_flat, node_score_flat, L):
+        """[N, DP] head-padded cat(node_type_emb, node_score_emb)  (:65-73, 86)."""
+        h = self.hidden_size // 2
+        dev = node_type_flat.device
+        temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)  # Linear applied to the T one-hots
+        type_emb = temb.index_select(0, node_type_flat)
+        JP = ops.roundup(h, 16)
+        sinB = ops.kernels().sin_basis(node_score_flat.contiguous(), self._js_table(dev), JP)
+        Wes_t = F.pad(self.emb_score.weight.t(), (0, JP - h, 0, JP - h)).contiguous()  # [JP in, JP out]
+        Wes = Wes_t.t().contiguous()
+        pre = ops.linear_nn(sinB, Wes_t, Wes, bias=F.pad(self.emb_score.bias, (0, JP - h)))
+        score_emb = ops.gelu_dropout(pre, 0.0, False)[:, :h]
+        return L.pad(torch.cat([type_emb, score_emb], dim=1))
+
+    def forward(self, H, A, node_type, node_score, cache_output=False, graph=None):
+        """
+        H: (batch_size, n_node, d_node) node features;  A: (edge_index [2, E], edge_type [E]) of the batched graph
+        node_type: long (batch_size, n_node): 0 question entity, 1 answer entity, 2 other, 3 context node
+        node_score: (batch_size, n_node, 1)
+        """
+        bs, n = node_type.size()
+        d = self.hidden_size
+        L = head_layout(d, H.device)
+        edge_index, edge_type = A
+        ntype = node_type.reshape(-1).contiguous()
+        if graph is None:
+            graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype)
+        extra_p = self.node_feature_extra(ntype, node_score.reshape(-1), L)
+        Hp = L.pad(H.reshape(bs * n, d))
+        tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=self.k)
+        Xp = Hp
+        for layer in self.gnn_layers:  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
+            Xp, _ = layer.hop(Xp, extra_p, graph, tab, L, apply_act=True, p_drop=self.dropout_rate)
+        Vh_t, Vh = _pad2(self.Vh.weight, L)
+        Vx_t, Vx = _pad2(self.Vx.weight, L)
+        Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=L.pad(self.Vh.bias + self.Vx.bias))
+        out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
+        return L.unpad(out).view(bs, n, d)
+
+
+class QAGNN(nn.Module):
+    """The drop-in boundary (reference modeling_qagnn.py:99-189): same constructor, same forward signature,
+    returns (logits [B, 1], pool_attn [n_head*B, n])."""
+
+    def __init__(self, args, k, n_ntype, n_etype, sent_dim, n_concept, concept_dim, concept_in_dim, n_attention_head,
+                 fc_dim, n_fc_layer, p_emb, p_gnn, p_fc, pretrained_concept_emb=None, freeze_ent_emb=True, init_range=0.02):
+        super().__init__()
+        self.init_range = init_range
+        self.concept_emb = CustomizedEmbedding(concept_num=n_concept, concept_out_dim=concept_dim, use_contextualized=False,
+                                               concept_in_dim=concept_in_dim, pretrained_concept_emb=pretrained_concept_emb,
+                                               freeze_ent_emb=freeze_ent_emb)
+        self.svec2nvec = nn.Linear(sent_dim, concept_dim)
+        self.concept_dim = concept_dim
+        self.activation = GELU()
+        self.gnn = QAGNN_Message_Passing(args, k=k, n_ntype=n_ntype, n_etype=n_etype, input_size=concept_dim,
+                                         hidden_size=concept_dim, output_size=concept_dim, dropout=p_gnn)
+        self.pooler = MultiheadAttPoolLayer(n_attention_head, sent_dim, concept_dim)
+        self.fc = MLP(concept_dim + sent_dim + concept_dim, fc_dim, 1, n_fc_layer, p_fc, layer_norm=True)
+        self.dropout_e = nn.Dropout(p_emb)
+        self.dropout_fc = nn.Dropout(p_fc)
+        if init_range > 0:
+            self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.init_range)
+            if hasattr(module, 'bias') and module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def forward(self, sent_vecs, concept_ids, node_type_ids, node_scores, adj_lengths, adj, emb_data=None, cache_output=False):
+        """
+        sent_vecs (B, dim_sent); concept_ids (B, n); node_type_ids (B, n); node_scores (B, n, 1); adj_lengths (B,)
+        adj = (edge_index [2, E] with global node ids g*n + local, edge_type [E]);  returns (B, 1), (n_head*B, n)
+        """
+        dev = node_type_ids.device
+        n = node_type_ids.size(1)
+        gnn_input0 = self.activation(self.svec2nvec(sent_vecs)).unsqueeze(1)
+        gnn_input1 = self.concept_emb(concept_ids[:, 1:] - 1, emb_data).to(dev)
+        gnn_input = self.dropout_e(torch.cat([gnn_input0, gnn_input1], dim=1))
+
+        # node-score normalisation (:160-167): negate, subtract the context node's score, mask PAD, / mean |.|
+        ar = torch.arange(n, device=dev)
+        _mask = (ar < adj_lengths.unsqueeze(1)).float()
+        node_scores = -node_scores
+        node_scores = (node_scores - node_scores[:, 0:1, :]).squeeze(2) * _mask
+        mean_norm = node_scores.abs().sum(dim=1) / adj_lengths
+        node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
+
+        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores)
+        Z_vecs = gnn_output[:, 0]
+        mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
+        mask[mask.all(1), 0] = 0  # never mask every node (:177)
+        graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask)
+        if cache_output:
+            self.concept_ids, self.adj, self.pool_attn = concept_ids, adj, pool_attn
+        concat = self.dropout_fc(torch.cat((graph_vecs, sent_vecs, Z_vecs), 1))
+        return self.fc(concat), pool_attn
+
+
+def batch_graph(edge_index_init, edge_type_init, n_nodes):
+    """LM_QAGNN.batch_graph (reference modeling_qagnn.py:244-251); see qagnn_amd.data_utils.batch_graph."""
+    from .data_utils import batch_graph as _bg
+    return _bg(edge_index_init, edge_type_init, n_nodes)

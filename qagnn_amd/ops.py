@@ -1,0 +1,217 @@
+"""Autograd operators of the hot path, each a thin differentiable wrapper over C-ABI kernels.
+
+The kernel provider is `qagnn_amd._lib.HipKernels` (libqagnn_hip.so on the current HIP stream).  There is no
+CPU implementation in this package: `kernels()` raises if the library or the GPU is missing.  Tests may install a
+torch emulation of the same kernel interface with `set_kernels()` to exercise the HOST logic (packing, autograd
+wiring, the hand-derived backward formulas) on a machine without a GPU; that emulation lives under tests/.
+
+Internal layout ("head-padded"): a feature row of d = H*dh floats is stored as H groups of HP = roundup4(dh)
+floats, DP = H*HP per row, pads are zero.  All matrices handed to the kernels are contiguous 2-D fp32.
+"""
+import math
+
+import torch
+
+_K = None
+
+
+def kernels():
+    global _K
+    if _K is None:
+        from ._lib import HipKernels
+        _K = HipKernels()
+    return _K
+
+
+def set_kernels(k):
+    """Install a kernel provider (tests only); returns the previous one."""
+    global _K
+    old, _K = _K, k
+    return old
+
+
+H_HEADS = 4  # GATConvE hard-codes head_count=4 (reference modeling_qagnn.py:387)
+
+
+def roundup(x, m):
+    return (x + m - 1) // m * m
+
+
+class HeadLayout:
+    """Index maps between the reference's dense feature axis (d) and the head-padded axis (DP)."""
+
+    def __init__(self, d, device):
+        assert d % H_HEADS == 0, 'emb_dim must be divisible by the 4 attention heads'
+        self.d, self.dh = d, d // H_HEADS
+        self.HP = roundup(self.dh, 4)
+        if self.HP > 64:
+            raise NotImplementedError(f'dim_per_head={self.dh} > 64 is outside what the edge kernels support')
+        self.DP = H_HEADS * self.HP
+        j = torch.arange(self.DP)
+        h, i = j // self.HP, j % self.HP
+        src = torch.where(i < self.dh, h * self.dh + i, torch.full_like(j, -1))
+        self.pad_src = src.to(device)                      # [DP] dense index or -1
+        self.valid = (src >= 0).to(device)
+        self.dense_pos = torch.nonzero(src >= 0).flatten().to(device)  # [d] padded position of dense index k (ascending)
+
+    def pad(self, x):
+        """[*, d] -> [*, DP] (zeros in the pads).  Differentiable torch gather."""
+        xe = torch.nn.functional.pad(x, (0, 1))
+        idx = torch.where(self.pad_src >= 0, self.pad_src, torch.full_like(self.pad_src, self.d))
+        return xe.index_select(-1, idx).contiguous()
+
+    def unpad(self, xp):
+        return xp.index_select(-1, self.dense_pos)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class LinearNNFn(torch.autograd.Function):
+    """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
+
+    @staticmethod
+    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx):
+        K = kernels()
+        C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx)
+        ctx.save_for_backward(A1, B1, A2, B2, rowidx)
+        ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        K = kernels()
+        A1, B1, A2, B2, rowidx = ctx.saved_tensors
+        dC = dC.contiguous()
+        need = ctx.needs_input_grad
+        dA1 = K.gemm_nn(dC, B1) if need[0] else None
+        dB1t = K.gemm_tn(A1, dC) if need[1] else None
+        dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
+        dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
+        has_bias, has_tab, G = ctx.has
+        dbias = drowtab = None
+        if has_tab and need[7]:
+            drowtab = K.colsum(dC, rowidx, G)
+            if has_bias and need[6]:
+                dbias = drowtab.sum(0)
+        elif has_bias and need[6]:
+            dbias = K.colsum(dC)[0]
+        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
+
+
+def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None):
+    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class GeluDropoutFn(torch.autograd.Function):
+    """Y = dropout(gelu_tanh(X), p)   (utils/layers.py:10-14 + F.dropout); the keep mask is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, X, p, seed):
+        ctx.save_for_backward(X)
+        ctx.p, ctx.seed = p, seed
+        return kernels().gelu_dropout_fwd(X, p, seed)
+
+    @staticmethod
+    def backward(ctx, dY):
+        (X,) = ctx.saved_tensors
+        return kernels().gelu_dropout_bwd(X, dY.contiguous(), ctx.p, ctx.seed), None, None
+
+
+_seed_counter = [0]
+
+
+def next_seed():
+    """Per-call dropout seed drawn from torch's CPU generator state (so torch.manual_seed controls it)."""
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0] * 0x85EBCA77) % (2 ** 63)
+
+
+def gelu_dropout(X, p, training):
+    p = float(p) if training else 0.0
+    return GeluDropoutFn.apply(X, p, next_seed() if p > 0 else 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class EdgeAttnFn(torch.autograd.Function):
+    """aggr = edge attention + aggregation (see qagnn_edge_attn_fwd_f32); also returns the un-scaled attention a."""
+
+    @staticmethod
+    def forward(ctx, KMQ, EkEm, graph, HP, qscale):
+        aggr, a, alpha = kernels().edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
+        ctx.save_for_backward(KMQ, EkEm, a, alpha)
+        ctx.graph, ctx.HP, ctx.qscale = graph, HP, qscale
+        ctx.mark_non_differentiable(a)
+        return aggr, a
+
+    @staticmethod
+    def backward(ctx, G, _da):
+        KMQ, EkEm, a, alpha = ctx.saved_tensors
+        dKMQ, dEkEm = kernels().edge_attn_bwd(ctx.graph, KMQ, EkEm, ctx.HP, ctx.qscale, a, alpha, G.contiguous())
+        return dKMQ, dEkEm, None, None, None
+
+
+def edge_attention(KMQ, EkEm, graph, HP, qscale):
+    return EdgeAttnFn.apply(KMQ, EkEm, graph, HP, qscale)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class GatMlpFn(torch.autograd.Function):
+    """GATConvE.mlp + activation of one hop, fused:  X' = dropout(gelu(Lin2(relu(BN(Lin1(aggr))))))
+
+    reference: modeling_qagnn.py:443 (mlp, def :408), :48-49 (GELU, dropout).  BatchNorm1d runs over ALL N rows
+    (PAD rows included); in training mode it uses biased batch statistics and updates the running buffers with the
+    unbiased variance (momentum 0.1), exactly like torch.nn.BatchNorm1d.  BN + ReLU are folded into the operand load
+    of the second GEMM (and of its weight-gradient GEMM), so relu(bn(h1)) is never materialised.
+    """
+
+    @staticmethod
+    def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act):
+        K = kernels()
+        R = aggr.size(0)
+        h1 = K.gemm_nn(aggr, W1t, bias=b1)
+        if training:
+            mean = K.colsum(h1)[0] / R
+            var = K.colvar_sum(h1, mean) / R  # biased
+        else:
+            mean, var = run_mean, run_var
+        invstd = torch.rsqrt(var + eps)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
+        y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
+        ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma)
+        ctx.cfg = (training, p, seed, R, apply_act)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        K = kernels()
+        aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma = ctx.saved_tensors
+        training, p, seed, R, apply_act = ctx.cfg
+        dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
+        dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)  # relu(bn(h1))^T @ dout
+        db2 = K.colsum(dout)[0]
+        dr = K.gemm_nn(dout, W2)
+        red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
+        dbeta, dgamma = red[0], red[1]
+        if training:
+            c1, c2 = red[0] / R, red[1] / R
+        else:
+            c1 = c2 = torch.zeros_like(red[0])
+        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma * invstd, c1.contiguous(), c2.contiguous())
+        dW1t = K.gemm_tn(aggr, dh1)
+        db1 = K.colsum(dh1)[0]
+        daggr = K.gemm_nn(dh1, W1)
+        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None
+
+
+def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True):
+    """`batch_stats`: BatchNorm uses batch statistics (train mode); `p`: dropout rate (0 disables); `apply_act`: GELU+dropout
+    fused after the second Linear (False returns the raw GATConvE output)."""
+    p = float(p) if apply_act else 0.0
+    return GatMlpFn.apply(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p,
+                          next_seed() if p > 0 else 0, apply_act)
+
+
+QSCALE = lambda dh: 1.0 / math.sqrt(dh)  # noqa: E731  (query / sqrt(dim_per_head), modeling_qagnn.py:469)

@@ -1,0 +1,186 @@
+"""Torch emulation of the kernel interface of qagnn_amd._lib.HipKernels.  TEST INFRASTRUCTURE ONLY.
+
+Purpose: (1) run the package's HOST logic (parameter packing, autograd wiring, hand-derived backward formulas,
+BatchNorm bookkeeping) on a machine without a GPU, against the golden fixtures; (2) serve as the per-kernel
+expected value in the `-m gpu` tests, where every HIP kernel is compared with the method of the same name here.
+It is installed with qagnn_amd.ops.set_kernels() by tests and never imported by the package.
+"""
+import numpy as np
+import torch
+
+CLS_CHUNK = 64
+
+
+class EmuGraph:
+    """Same arrays, same canonical order (group key, then edge id) as qagnn_graph_prep."""
+
+    def __init__(self, edge_index, edge_type, node_type, R, T):
+        dev = node_type.device
+        N, E = node_type.numel(), edge_index.size(1)
+        self.N, self.E, self.Ep, self.R, self.T = N, E, E + N, R, T
+        self.C = R * T * T + T
+        loops = torch.arange(N, device=dev)
+        es = torch.cat([edge_index[0], loops])
+        et = torch.cat([edge_index[1], loops])
+        ec = torch.cat([edge_type * T * T + node_type[edge_index[0]] * T + node_type[edge_index[1]],
+                        R * T * T + node_type])
+        self.es, self.et, self.ec = es, et, ec
+        eid_s = torch.sort(es, stable=True).indices
+        eid_t = torch.sort(et, stable=True).indices
+        self.eid_s = eid_s.int()
+        self.rowptr_s = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(es, minlength=N).cumsum(0)]).int()
+        self.rowptr_t = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(et, minlength=N).cumsum(0)]).int()
+        self.tgt_s, self.src_s, self.cls_s = et[eid_s].int(), es[eid_s].int(), ec[eid_s].int()
+        srcpos = torch.empty_like(eid_s)
+        srcpos[eid_s] = torch.arange(self.Ep, device=dev)
+        self.src_t, self.cls_t, self.pos_t = es[eid_t].int(), ec[eid_t].int(), srcpos[eid_t].int()
+        pos_c = torch.sort(self.cls_s.long(), stable=True).indices
+        self.pos_c = pos_c.int()
+        self.src_c, self.tgt_c = self.src_s[pos_c], self.tgt_s[pos_c]
+        self.cls_count = torch.bincount(ec, minlength=self.C).int()
+        self.clsptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), self.cls_count.long().cumsum(0)]).int()
+        nch = (self.cls_count.long() + CLS_CHUNK - 1) // CLS_CHUNK
+        self.chunkptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), nch.cumsum(0)]).int()
+        self.n_chunks = int(nch.sum())
+        self.max_chunks = self.Ep // CLS_CHUNK + self.C + 1
+        cc, cb, cl = [], [], []
+        for c in range(self.C):
+            b, e = int(self.clsptr[c]), int(self.clsptr[c + 1])
+            for p in range(b, e, CLS_CHUNK):
+                cc.append(c), cb.append(p), cl.append(min(CLS_CHUNK, e - p))
+        self.chunk_cls = torch.tensor(cc, dtype=torch.int32)
+        self.chunk_beg = torch.tensor(cb, dtype=torch.int32)
+        self.chunk_len = torch.tensor(cl, dtype=torch.int32)
+
+
+def _uniform01(seed, idx):
+    """numpy twin of uniform01() in csrc/elementwise.hip (splitmix64 finaliser)."""
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) + (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+def _gelu_grad(x):
+    u = 0.7978845608028654 * (x + 0.044715 * x ** 3)
+    t = torch.tanh(u)
+    return 0.5 * (1 + t) + 0.5 * x * (1 - t * t) * 0.7978845608028654 * (1 + 3 * 0.044715 * x * x)
+
+
+class EmuKernels:
+    name = 'emu'
+
+    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype):
+        return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype)
+
+    def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
+                out=None, accumulate=False):
+        if a_scale is not None:
+            A1 = torch.relu(A1 * a_scale + a_shift)
+        C = A1 @ B1
+        if A2 is not None:
+            C = C + A2 @ B2
+        if bias is not None:
+            C = C + bias
+        if rowtab is not None:
+            C = C + rowtab[rowidx]
+        if out is not None:
+            if accumulate:
+                out += C
+            else:
+                out.copy_(C)
+            return out
+        return C
+
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False):
+        if a_scale is not None:
+            A = torch.relu(A * a_scale + a_shift)
+        C = A.t() @ B
+        if out is not None:
+            if accumulate:
+                out += C
+            else:
+                out.copy_(C)
+            return out
+        return C
+
+    def colsum(self, X, rowidx=None, groups=1):
+        if rowidx is None:
+            return X.sum(0, keepdim=True)
+        return torch.zeros(groups, X.size(1), dtype=X.dtype, device=X.device).index_add_(0, rowidx, X)
+
+    def colvar_sum(self, X, mean):
+        return ((X - mean) ** 2).sum(0)
+
+    def bn_bwd_reduce(self, dR, H, mean, invstd, scale, shift):
+        dy = dR * ((H * scale + shift) > 0)
+        return torch.stack([dy.sum(0), (dy * (H - mean) * invstd).sum(0)])
+
+    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gscale, c1, c2):
+        dy = dR * ((H * scale + shift) > 0)
+        return gscale * (dy - c1 - (H - mean) * invstd * c2)
+
+    def _keep(self, X, p, seed):
+        if p <= 0:
+            return torch.ones_like(X)
+        u = _uniform01(seed, np.arange(X.numel(), dtype=np.uint64))
+        keep = torch.from_numpy((u >= np.float32(p)).astype(np.float32)).view_as(X).to(X.device, X.dtype)
+        return keep / (1.0 - p)
+
+    def gelu_dropout_fwd(self, X, p, seed):
+        return _gelu(X) * self._keep(X, p, seed)
+
+    def gelu_dropout_bwd(self, X, dY, p, seed):
+        return dY * self._keep(X, p, seed) * _gelu_grad(X)
+
+    def sin_basis(self, score, js, ldo):
+        out = torch.zeros(score.numel(), ldo, dtype=score.dtype, device=score.device)
+        out[:, :js.numel()] = torch.sin(js.unsqueeze(0) * score.reshape(-1, 1))
+        return out
+
+    # ---- edge kernels (formulas of SURVEY.md 9.1 / 9.2, vectorised over the source-ordered edge list) ----------
+    def edge_attn_fwd(self, g, KMQ, EkEm, HP, qscale):
+        DP = 4 * HP
+        K, M, Q = KMQ[:, :DP], KMQ[:, DP:2 * DP], KMQ[:, 2 * DP:]
+        Ek, Em = EkEm[:, :DP], EkEm[:, DP:]
+        s, t, c = g.src_s.long(), g.tgt_s.long(), g.cls_s.long()
+        key = K[t] + Ek[c]
+        score = qscale * (Q[s] * key).view(-1, 4, HP).sum(-1)
+        idx = s.view(-1, 1).expand_as(score)
+        m = torch.full((g.N, 4), float('-inf'), dtype=score.dtype, device=score.device).scatter_reduce(0, idx, score, 'amax')
+        ex = (score - m[s]).exp()
+        den = torch.zeros(g.N, 4, dtype=score.dtype, device=score.device).index_add_(0, s, ex)
+        a = ex / (den[s] + 1e-16)
+        deg = (g.rowptr_s[1:] - g.rowptr_s[:-1]).to(score.dtype)
+        alpha = a * deg[s].unsqueeze(1)
+        msg = (M[s] + Em[c]).view(-1, 4, HP) * alpha.unsqueeze(2)
+        aggr = torch.zeros(g.N, DP, dtype=KMQ.dtype, device=KMQ.device).index_add_(0, t, msg.view(-1, DP))
+        return aggr, a, alpha
+
+    def edge_attn_bwd(self, g, KMQ, EkEm, HP, qscale, a, alpha, G):
+        DP = 4 * HP
+        K, M, Q = KMQ[:, :DP], KMQ[:, DP:2 * DP], KMQ[:, 2 * DP:]
+        Ek, Em = EkEm[:, :DP], EkEm[:, DP:]
+        s, t, c = g.src_s.long(), g.tgt_s.long(), g.cls_s.long()
+        Gt = G[t].view(-1, 4, HP)
+        msg = (M[s] + Em[c]).view(-1, 4, HP)
+        key = (K[t] + Ek[c]).view(-1, 4, HP)
+        dmsg = (alpha.unsqueeze(2) * Gt).view(-1, DP)
+        z = lambda n: torch.zeros(n, DP, dtype=KMQ.dtype, device=KMQ.device)  # noqa: E731
+        dM = z(g.N).index_add_(0, s, dmsg)
+        dEm = z(g.C).index_add_(0, c, dmsg)
+        deg = (g.rowptr_s[1:] - g.rowptr_s[:-1]).to(KMQ.dtype)[s].unsqueeze(1)
+        ga = deg * (msg * Gt).sum(-1)
+        r = torch.zeros(g.N, 4, dtype=KMQ.dtype, device=KMQ.device).index_add_(0, s, a * ga)
+        gs = qscale * a * (ga - r[s])
+        dQ = z(g.N).index_add_(0, s, (gs.unsqueeze(2) * key).view(-1, DP))
+        dkey = (gs.unsqueeze(2) * Q[s].view(-1, 4, HP)).view(-1, DP)
+        dK = z(g.N).index_add_(0, t, dkey)
+        dEk = z(g.C).index_add_(0, c, dkey)
+        return torch.cat([dK, dM, dQ], 1), torch.cat([dEk, dEm], 1)

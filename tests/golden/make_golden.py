@@ -145,6 +145,75 @@ def run_reference_loader(ref_du, recs, n, nc):
     return cids, ntypes, nscores, alens, ei, et
 
 
+def run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens, edge_index, edge_type):
+    """Everything measured on the reference model for one case; returns a dict of fixture entries."""
+    import helpers
+    fix = {}
+    B, n = c['nq'] * c['nc'], c['n']
+    torch.manual_seed(0)
+    model = ref_mq.QAGNN(None, cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['sent_dim'], cfg['n_concept'],
+                         cfg['concept_dim'], cfg['concept_in_dim'], cfg['n_attention_head'], cfg['fc_dim'],
+                         cfg['n_fc_layer'], cfg['p_emb'], cfg['p_gnn'], cfg['p_fc'],
+                         pretrained_concept_emb=None, freeze_ent_emb=True, init_range=cfg['init_range'])
+    helpers.det_fill_(model, c['seed'], c['std'])
+    # pooler dropout is hard-wired to 0.1 in the reference (layers.py:326); parity needs it off
+    model.pooler.dropout.p = 0.0
+    model.pooler.attention.dropout.p = 0.0
+    model.train(c['train'])
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}  # pristine weights + buffers
+    model_eval_state = model.training
+    sent_vecs = inp['sent_vecs'].clone()
+    logits, pool_attn = model(sent_vecs, cids.view(B, n), ntypes.view(B, n), nscores.view(B, n, 1),
+                              alens.view(B), (edge_index, edge_type))
+    fix['sent_vecs'] = sent_vecs.numpy()
+    fix['logits'] = logits.detach().numpy()
+    fix['pool_attn'] = pool_attn.detach().numpy()
+    # loss = sum(logits * w) with fixed w, so every output element matters
+    w = torch.linspace(0.5, 1.5, B).view(B, 1)
+    loss = (logits * w).sum()
+    loss.backward()
+    full = name.startswith('small')
+    for pname, p in model.named_parameters():
+        if p.grad is not None:
+            helpers.store(fix, 'grad::' + pname, p.grad, full)
+    # BN buffers after this forward (train mode updates them: k times for the shared edge encoder)
+    for bname, b in model.named_buffers():
+        fix['buf::' + bname] = b.detach().clone().numpy()
+    # ---- message-passing stack alone, on seeded inputs that do not depend on the weights --------
+    H, ns, x, extra = helpers.mp_inputs(name)
+    ns = ns * (torch.arange(n) < alens.view(B).unsqueeze(1)).float().unsqueeze(2)
+    model.load_state_dict(sd_before)
+    model.train(model_eval_state)
+    Hg = H.clone().requires_grad_(True)
+    gnn_out = model.gnn(Hg, (edge_index, edge_type), ntypes.view(B, n), ns)
+    helpers.store(fix, 'mp_out', gnn_out, full)
+    wg = torch.cos(torch.arange(gnn_out.numel(), dtype=torch.float32) * 0.37).view_as(gnn_out)
+    model.zero_grad()
+    (gnn_out * wg).sum().backward()
+    helpers.store(fix, 'mp_dH', Hg.grad, full)
+    for pname, p in model.gnn.named_parameters():
+        if p.grad is not None:
+            helpers.store(fix, 'mpgrad::' + pname, p.grad, full)
+    for bname, b in model.gnn.named_buffers():
+        fix['mpbuf::' + bname] = b.detach().clone().numpy()
+    # ---- one GATConvE layer alone, with attention weights ------------------------------------------
+    model.load_state_dict(sd_before)
+    model.train(model_eval_state)
+    layer = model.gnn.gnn_layers[0]
+    xg = x.clone().requires_grad_(True)
+    out, (ei_loops, alpha) = layer(xg, edge_index, edge_type, ntypes.view(-1), extra, return_attention_weights=True)
+    helpers.store(fix, 'layer_out', out, full)
+    helpers.store(fix, 'layer_alpha', alpha, full)
+    wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out)
+    model.zero_grad()
+    (out * wl).sum().backward()
+    helpers.store(fix, 'layer_dx', xg.grad, full)
+    for pname, p in layer.named_parameters():
+        if p.grad is not None:
+            helpers.store(fix, 'layergrad::' + pname, p.grad, full)
+    return fix
+
+
 def main():
     import helpers
     ref_du, ref_mq = import_reference()
@@ -169,73 +238,22 @@ def main():
         # ---- reference batch_graph (unbound method; `self` unused) ---------------------------
         edge_index, edge_type = ref_mq.LM_QAGNN.batch_graph(None, ei_flat, et_flat, n)
         fix['batched_edge_index'] = edge_index.numpy().astype(np.int32)
-        # ---- reference model -----------------------------------------------------------------
-        torch.manual_seed(0)
-        model = ref_mq.QAGNN(None, cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['sent_dim'], cfg['n_concept'],
-                             cfg['concept_dim'], cfg['concept_in_dim'], cfg['n_attention_head'], cfg['fc_dim'],
-                             cfg['n_fc_layer'], cfg['p_emb'], cfg['p_gnn'], cfg['p_fc'],
-                             pretrained_concept_emb=None, freeze_ent_emb=True, init_range=cfg['init_range'])
-        helpers.det_fill_(model, c['seed'], c['std'])
-        # pooler dropout is hard-wired to 0.1 in the reference (layers.py:326); parity needs it off
-        model.pooler.dropout.p = 0.0
-        model.pooler.attention.dropout.p = 0.0
-        model.train(c['train'])
-        sent_vecs = inp['sent_vecs'].clone()
-        logits, pool_attn = model(sent_vecs, cids.view(B, n), ntypes.view(B, n), nscores.view(B, n, 1),
-                                  alens.view(B), (edge_index, edge_type))
-        fix['sent_vecs'] = sent_vecs.numpy()
-        fix['logits'] = logits.detach().numpy()
-        fix['pool_attn'] = pool_attn.detach().numpy()
-        # intermediate: re-run the pieces the way QAGNN.forward does, to expose gnn_output / graph_vecs
-        with torch.no_grad():
-            model_eval_state = model.training
-            sd_before = {k: v.clone() for k, v in model.state_dict().items()}
-        # loss = sum(logits * w) with fixed w, so every output element matters
-        w = torch.linspace(0.5, 1.5, B).view(B, 1)
-        loss = (logits * w).sum()
-        loss.backward()
-        full = name.startswith('small')
-        for pname, p in model.named_parameters():
-            if p.grad is not None:
-                helpers.store(fix, 'grad::' + pname, p.grad, full)
-        # BN buffers after this forward (train mode updates them: k times for the shared edge encoder)
-        for bname, b in model.named_buffers():
-            fix['buf::' + bname] = b.detach().clone().numpy()
-        # ---- message-passing stack alone, on seeded inputs that do not depend on the weights --------
-        H, ns, x, extra = helpers.mp_inputs(name)
-        ns = ns * (torch.arange(n) < alens.view(B).unsqueeze(1)).float().unsqueeze(2)
-        model.load_state_dict(sd_before)
-        model.train(model_eval_state)
-        Hg = H.clone().requires_grad_(True)
-        gnn_out = model.gnn(Hg, (edge_index, edge_type), ntypes.view(B, n), ns)
-        helpers.store(fix, 'mp_out', gnn_out, full)
-        wg = torch.cos(torch.arange(gnn_out.numel(), dtype=torch.float32) * 0.37).view_as(gnn_out)
-        model.zero_grad()
-        (gnn_out * wg).sum().backward()
-        helpers.store(fix, 'mp_dH', Hg.grad, full)
-        for pname, p in model.gnn.named_parameters():
-            if p.grad is not None:
-                helpers.store(fix, 'mpgrad::' + pname, p.grad, full)
-        for bname, b in model.gnn.named_buffers():
-            fix['mpbuf::' + bname] = b.detach().clone().numpy()
-        # ---- one GATConvE layer alone, with attention weights ------------------------------------------
-        model.load_state_dict(sd_before)
-        model.train(model_eval_state)
-        layer = model.gnn.gnn_layers[0]
-        xg = x.clone().requires_grad_(True)
-        out, (ei_loops, alpha) = layer(xg, edge_index, edge_type, ntypes.view(-1), extra, return_attention_weights=True)
-        helpers.store(fix, 'layer_out', out, full)
-        helpers.store(fix, 'layer_alpha', alpha, full)
-        wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out)
-        model.zero_grad()
-        (out * wl).sum().backward()
-        helpers.store(fix, 'layer_dx', xg.grad, full)
-        for pname, p in layer.named_parameters():
-            if p.grad is not None:
-                helpers.store(fix, 'layergrad::' + pname, p.grad, full)
+        # ---- reference model: run 1 = caller edge order (the fixtures); run 2 = permuted edge order, only used to
+        #      record the reference's own fp32 re-ordering noise per tensor ('noise::<key>') ----------------------
+        fix.update(run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens, edge_index, edge_type))
+        perm = torch.randperm(edge_index.size(1), generator=torch.Generator().manual_seed(c['seed'] + 5))
+        alt = run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens, edge_index[:, perm], edge_type[perm])
+        for key in list(fix.keys()):
+            if key.endswith('::sum') or key.startswith('noise::') or key not in alt:
+                continue
+            base = key[:-len('::head')] if key.endswith('::head') else (key[:-len('::rows')] if key.endswith('::rows') else key)
+            if base == 'layer_alpha' or not isinstance(fix[key], np.ndarray) or fix[key].dtype != np.float32:
+                continue
+            dn = float(np.abs(fix[key].astype(np.float64) - alt[key].astype(np.float64)).max()) if fix[key].size else 0.0
+            fix['noise::' + base] = np.array(max(dn, float(fix.get('noise::' + base, 0.0))))
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **fix)
-        print(f'{name}: B={B} n={n} E={edge_index.size(1)} logits={logits.detach().view(-1)[:3].tolist()} '
+        print(f'{name}: B={B} n={n} E={edge_index.size(1)} logits={fix["logits"].reshape(-1)[:3].tolist()} '
               f'-> {os.path.getsize(path) / 1024:.0f} KiB')
 
 

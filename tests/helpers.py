@@ -72,17 +72,17 @@ def model_cfg(d=200, k=5, n_etype=38, sent_dim=1024, n_concept=2000, concept_in_
 
 GOLDEN_CASES = {
     # name: (shape, n_questions, num_choice, max_node_num, n_rel, model cfg, weight std, train mode, seed)
-    'small_train': dict(shape='tiny', nq=2, nc=3, n=20, n_rel=17, std=1.3, train=True, seed=11,
+    'small_train': dict(shape='tiny', nq=2, nc=3, n=20, n_rel=17, std=1.0, train=True, seed=11,
                         cfg=model_cfg(d=32, k=2, sent_dim=24, n_concept=300, concept_in_dim=16)),
     'small_eval': dict(shape='tiny', nq=2, nc=3, n=20, n_rel=17, std=0.8, train=False, seed=12,
                        cfg=model_cfg(d=32, k=2, sent_dim=24, n_concept=300, concept_in_dim=16)),
-    'config1_train': dict(shape='config1', nq=1, nc=5, n=100, n_rel=17, std=1.3, train=True, seed=13,
+    'config1_train': dict(shape='config1', nq=1, nc=5, n=100, n_rel=17, std=0.6, train=True, seed=13,
                           cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=1000, concept_in_dim=32)),
     'config1_refinit': dict(shape='config1', nq=1, nc=5, n=100, n_rel=17, std=-0.02, train=True, seed=14,
                             cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=1000, concept_in_dim=32)),
-    'csqa_b10': dict(shape='csqa', nq=2, nc=5, n=200, n_rel=17, std=1.3, train=True, seed=15,
+    'csqa_b10': dict(shape='csqa', nq=2, nc=5, n=200, n_rel=17, std=0.6, train=True, seed=15,
                      cfg=model_cfg(d=200, k=5, sent_dim=64, n_concept=2000, concept_in_dim=32)),
-    'medqa_b8': dict(shape='medqa', nq=2, nc=4, n=200, n_rel=15, std=1.3, train=True, seed=16,
+    'medqa_b8': dict(shape='medqa', nq=2, nc=4, n=200, n_rel=15, std=0.6, train=True, seed=16,
                      cfg=model_cfg(d=200, k=5, n_etype=34, sent_dim=48, n_concept=2000, concept_in_dim=24)),
     'trunc_eval': dict(shape='csqa', nq=1, nc=4, n=60, n_rel=17, std=0.7, train=False, seed=17,
                        cfg=model_cfg(d=64, k=3, sent_dim=32, n_concept=2000, concept_in_dim=16)),
@@ -139,43 +139,86 @@ def store(fix, key, t, full):
         fix[key + '::rows'] = flat[idx].numpy()
 
 
-def _close(t, ref, rtol, atol, what):
-    """Elementwise |t - ref| <= atol + rtol * max(|ref| elementwise, max|ref| of the tensor).
+NOISE_MULT = 6.0
+
+
+def _close(t, ref, rtol, atol, what, noise=0.0):
+    """Elementwise |t - ref| <= atol + rtol * max(|ref| elementwise, max|ref| of the tensor) + NOISE_MULT * noise.
+
+    `noise` is the reference's OWN fp32 re-ordering noise for this tensor: make_golden.py runs the reference twice,
+    the second time with the edge list permuted (a mathematically neutral change that only re-orders its float
+    sums), and stores max|run1 - run2| per tensor.  The train-mode cases are visibly ill-conditioned in fp32 (the
+    reference moves its own gradients by up to 1e-3..3e-2 of their scale under that permutation), so the bar for
+    "identical within fp32" is stated relative to that floor.
 
     The tensor-level term is the usual backward-error yardstick for fp32 sums of mixed-sign terms: an element
     that is a near-cancellation of O(max|ref|) contributions cannot be reproduced to a relative 1e-4.
     """
     scale = ref.abs().max().item() if ref.numel() else 0.0
     err = (t - ref).abs()
-    bound = atol + rtol * torch.clamp(ref.abs(), min=scale)
+    bound = atol + rtol * torch.clamp(ref.abs(), min=scale) + NOISE_MULT * float(noise)
     bad = err > bound
     assert not bool(bad.any()), (f'{what}: {int(bad.sum())}/{ref.numel()} elements off, worst |d|={err.max().item():.3e} '
-                                 f'(tensor scale {scale:.3e}, rtol {rtol}, atol {atol})')
+                                 f'(tensor scale {scale:.3e}, rtol {rtol}, atol {atol}, ref noise {float(noise):.3e})')
     return err.max().item() if ref.numel() else 0.0
+
+
+def _stored_scale(fix, base):
+    arrs = [fix[k] for k in (base, base + '::head', base + '::rows') if k in fix]
+    return max((float(np.abs(a).max()) for a in arrs if a.size), default=0.0)
+
+
+def section_rel_noise(fix, section):
+    """max over the tensors of a gradient section ('grad', 'mpgrad', 'layergrad') of reference-noise / tensor scale.
+
+    A single permuted re-run is a noisy estimate of one tensor's noise, but all gradients of one backward pass share
+    the same conditioning, so the section-wide maximum is the robust floor (most sections: 1e-6..3e-5; two chaotic
+    ones, config1_refinit/grad and csqa_b10/mpgrad, reach 6e-3 in the reference itself)."""
+    cache = fix.setdefault('_relnoise', {})
+    if section not in cache:
+        worst = 0.0
+        pre = 'noise::' + section + '::'
+        for k in list(fix.keys()):
+            if isinstance(k, str) and k.startswith(pre) and not re.search(r'(linear_key|pooler\.w_ks)\.bias$|(edge_encoder|mlp)\.0\.bias$', k):
+                worst = max(worst, float(fix[k]) / (_stored_scale(fix, k[len('noise::'):]) + 1e-30))
+        cache[section] = worst
+    return cache[section]
 
 
 def check_stored(fix, key, t, rtol, atol):
     """Compare tensor `t` with whatever `store` kept under `key`; returns max abs error seen."""
     t = t.detach().cpu().float()
+    noise = float(fix['noise::' + key]) if ('noise::' + key) in fix else 0.0
+    section = key.split('::')[0]
+    if section in ('grad', 'mpgrad', 'layergrad'):
+        noise = max(noise, section_rel_noise(fix, section) * _stored_scale(fix, key))
     if key in fix:
         ref = torch.from_numpy(fix[key])
-        worst = _close(t, ref.view_as(t), rtol, atol, key)
+        worst = _close(t, ref.view_as(t), rtol, atol, key, noise)
     else:
         flat = t.reshape(-1, t.shape[-1])
         idx = torch.linspace(0, flat.shape[0] - 1, 8).long()
-        worst = max(_close(flat[:8], torch.from_numpy(fix[key + '::head']), rtol, atol, key + '::head'),
-                    _close(flat[idx], torch.from_numpy(fix[key + '::rows']), rtol, atol, key + '::rows'))
-    check_summary(fix[key + '::sum'], t, rtol, key)
+        worst = max(_close(flat[:8], torch.from_numpy(fix[key + '::head']), rtol, atol, key + '::head', noise),
+                    _close(flat[idx], torch.from_numpy(fix[key + '::rows']), rtol, atol, key + '::rows', noise))
+    check_summary(fix[key + '::sum'], t, rtol, key, noise)
     return worst
 
 
-def check_summary(ref_sum, t, rtol, what=''):
+def check_plain(fix, key, t, rtol, atol):
+    """Like check_stored for entries stored as one plain array (logits, pool_attn, buffers)."""
+    noise = float(fix['noise::' + key]) if ('noise::' + key) in fix else 0.0
+    ref = torch.from_numpy(np.asarray(fix[key])).float()
+    return _close(t.detach().cpu().float().reshape(ref.shape), ref, rtol, atol, key, noise)
+
+
+def check_summary(ref_sum, t, rtol, what='', noise=0.0):
     """Norm / projection comparison: |delta| <= rtol' * norm, with rtol' loosened for the projection sums."""
     got = grad_summary(t)
     norm = max(ref_sum[0], 1e-30)
-    assert abs(got[0] - ref_sum[0]) <= 10 * rtol * norm + 1e-12, f'{what}: norm {got[0]} vs {ref_sum[0]}'
     n = t.numel()
-    tol = 10 * rtol * norm * max(1.0, n ** 0.5) ** 0.5 + 1e-9
+    nz = NOISE_MULT * float(noise) * n ** 0.5
+    assert abs(got[0] - ref_sum[0]) <= 10 * rtol * norm + nz + 1e-12, f'{what}: norm {got[0]} vs {ref_sum[0]}'
+    tol = 10 * rtol * norm * max(1.0, n ** 0.5) ** 0.5 + nz + 1e-9
     assert abs(got[1] - ref_sum[1]) <= tol, f'{what}: projection {got[1]} vs {ref_sum[1]} (tol {tol})'
     assert abs(got[2] - ref_sum[2]) <= tol, f'{what}: sum {got[2]} vs {ref_sum[2]} (tol {tol})'
 
@@ -187,7 +230,7 @@ def has_null_gradient(name, train):
     * linear_key.bias (always): it shifts every score of a source node's softmax group by the same q_s . b_k.
     Two correct implementations agree on these only in magnitude, not element by element.
     """
-    if re.search(r'linear_key\.bias$', name):
+    if re.search(r'(linear_key|pooler\.w_ks)\.bias$', name):  # pooler keys: same shift-invariance in the pooling softmax
         return True
     return bool(train and re.search(r'(edge_encoder|mlp)\.0\.bias$', name))
 

@@ -1,0 +1,163 @@
+"""Host logic of qagnn_amd (packing, autograd wiring, hand-derived backward, BN bookkeeping) on CPU.
+
+The C-ABI kernels are replaced by tests/emu_kernels.py (torch), everything else is the shipped package code.
+Expected values are the fixtures produced by the REFERENCE's own code.  Tolerances (fp32, relative to the tensor's
+max magnitude plus 6x the reference's own fp32 re-ordering noise, see helpers._close): forward 1e-4, gradients 2e-3.  The reformulation (project-then-gather, class
+table, weighted BatchNorm) and every hand-derived backward formula are mathematically EXACT: in float64 this
+package and the oracle agree to 1e-13 on logits and 5e-13 on every gradient (test_float64_exactness below); the
+fp32 budget is rounding only, amplified by 5 train-mode BatchNorm layers in backward.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from emu_kernels import EmuKernels
+from qagnn_amd import modeling_qagnn as MQ
+from qagnn_amd import ops
+
+CASES = list(helpers.GOLDEN_CASES.keys())
+FWD = dict(rtol=1e-4, atol=1e-5)
+BWD = dict(rtol=2e-3, atol=1e-5)
+
+
+@pytest.fixture(autouse=True)
+def _emu():
+    old = ops.set_kernels(EmuKernels())
+    yield
+    ops.set_kernels(old)
+
+
+def build(case):
+    c = helpers.GOLDEN_CASES[case]
+    cfg = c['cfg']
+    torch.manual_seed(0)
+    model = MQ.QAGNN(None, cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['sent_dim'], cfg['n_concept'], cfg['concept_dim'],
+                     cfg['concept_in_dim'], cfg['n_attention_head'], cfg['fc_dim'], cfg['n_fc_layer'], cfg['p_emb'],
+                     cfg['p_gnn'], cfg['p_fc'], pretrained_concept_emb=None, freeze_ent_emb=True, init_range=cfg['init_range'])
+    helpers.det_fill_(model, c['seed'], c['std'])
+    model.pooler.dropout.p = 0.0
+    model.pooler.attention.dropout.p = 0.0
+    model.train(c['train'])
+    return model
+
+
+def golden_inputs(case, fix):
+    from test_oracle_golden import golden_inputs as gi
+    return gi(case, fix)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_state_dict_keys_equal_oracle(case):
+    from oracle import qagnn_oracle as O
+    a = set(build(case).state_dict().keys())
+    b = set(O.build_qagnn(helpers.GOLDEN_CASES[case]['cfg']).state_dict().keys())
+    assert a == b
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_qagnn_matches_reference(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    B = c['nq'] * c['nc']
+    model = build(case)
+    sv, cids, nt, ns, al, ei, et = golden_inputs(case, fix)
+    logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
+    helpers.check_plain(fix, 'logits', logits, **FWD)
+    helpers.check_plain(fix, 'pool_attn', pool_attn, **FWD)
+    w = torch.linspace(0.5, 1.5, B).view(B, 1)
+    (logits * w).sum().backward()
+    n_checked = 0
+    for pname, p in model.named_parameters():
+        if p.grad is None or helpers.has_null_gradient(pname, c['train']):
+            continue
+        helpers.check_stored(fix, 'grad::' + pname, p.grad, **BWD)
+        n_checked += 1
+    assert n_checked > 20
+    for bname, b in model.named_buffers():
+        helpers.check_plain(fix, 'buf::' + bname, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_message_passing_stack_matches_reference(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    n = c['n']
+    model = build(case)
+    _, _, nt, _, al, ei, et = golden_inputs(case, fix)
+    H, ns, x, extra = helpers.mp_inputs(case)
+    ns = ns * (torch.arange(n) < al.unsqueeze(1)).float().unsqueeze(2)
+    Hg = H.clone().requires_grad_(True)
+    out = model.gnn(Hg, (ei, et), nt, ns)
+    helpers.check_stored(fix, 'mp_out', out, **FWD)
+    wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out)
+    (out * wg).sum().backward()
+    helpers.check_stored(fix, 'mp_dH', Hg.grad, **BWD)
+    for pname, p in model.gnn.named_parameters():
+        if p.grad is not None and not helpers.has_null_gradient(pname, c['train']):
+            helpers.check_stored(fix, 'mpgrad::' + pname, p.grad, **BWD)
+    for bname, b in model.gnn.named_buffers():
+        helpers.check_plain(fix, 'mpbuf::' + bname, b, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_single_gatconve_layer_matches_reference(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    model = build(case)
+    _, _, nt, _, al, ei, et = golden_inputs(case, fix)
+    H, ns, x, extra = helpers.mp_inputs(case)
+    layer = model.gnn.gnn_layers[0]
+    xg = x.clone().requires_grad_(True)
+    out, (ei_loops, alpha) = layer(xg, ei, et, nt.view(-1), extra, return_attention_weights=True)
+    assert ei_loops.size(1) == ei.size(1) + x.size(0)
+    helpers.check_stored(fix, 'layer_out', out, **FWD)
+    helpers.check_stored(fix, 'layer_alpha', alpha, rtol=1e-4, atol=1e-7)
+    wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out)
+    (out * wl).sum().backward()
+    helpers.check_stored(fix, 'layer_dx', xg.grad, **BWD)
+    for pname, p in layer.named_parameters():
+        if p.grad is not None and not helpers.has_null_gradient(pname, c['train']):
+            helpers.check_stored(fix, 'layergrad::' + pname, p.grad, **BWD)
+
+
+@pytest.mark.parametrize('case', ['config1_train', 'small_eval', 'medqa_b8'])
+def test_float64_exactness(case):
+    """In float64 the reformulated path equals the reference formulation to ~1e-12: the algebra is exact."""
+    from test_oracle_golden import build_oracle
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    B = c['nq'] * c['nc']
+    sv, cids, nt, ns, al, ei, et = golden_inputs(case, fix)
+    torch.set_default_dtype(torch.float64)
+    try:
+        res = []
+        for model in (build(case).double(), build_oracle(case).double()):
+            logits, _ = model(sv.double(), cids, nt, ns.double(), al, (ei, et))
+            (logits * torch.linspace(0.5, 1.5, B).view(B, 1)).sum().backward()
+            res.append((logits.detach(), {n: p.grad for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    (l1, g1), (l2, g2) = res
+    assert (l1 - l2).abs().max().item() < 1e-10
+    assert set(g1) == set(g2)
+    for n in g1:
+        if helpers.has_null_gradient(n, c['train']):
+            continue
+        scale = g2[n].abs().max().item() + 1e-300
+        assert (g1[n] - g2[n]).abs().max().item() / scale < 1e-9, n
+
+
+def test_no_kernel_provider_without_gpu():
+    """The package has no CPU fallback: without the emulation installed, asking for kernels must raise."""
+    ops.set_kernels(None)
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, OSError)):
+            ops.kernels()
+
+
+def test_unsupported_shapes_raise():
+    with pytest.raises(NotImplementedError):
+        MQ.GATConvE(None, 200, 4, 38, None, head_count=8)
+    with pytest.raises(NotImplementedError):
+        ops.HeadLayout(4 * 68, 'cpu')
