@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- QA-subgraphs/sec (batch x num_choice) of one fwd+bwd of the QA-GNN decoder path on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
+with torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], synthetic stand-in of SURVEY.md 8(d)): CommonsenseQA-shaped batch of 64 questions
+x 5 choices = 320 subgraphs per GPU, n = 200 node slots, 40..199 concepts and 400..2000 directed edges per subgraph,
+38 relation types, 5 GAT layers, d = 200, 4 heads, sent_dim = concept_in_dim = 1024, frozen 100 000 x 1024 entity
+table, dropout 0.2 everywhere (the reference's run-script values), train-mode BatchNorm, fp32.  The LM encoder is
+outside the metric (north_star): `sent_vecs` is a random [B, 1024] tensor.  All inputs are resident in HBM before
+the timed region.  One step = zero_grad + QAGNN.forward + cross-entropy over the 5 choices + backward; with N > 1
+every rank runs its own 64 questions (weak scaling) and the step additionally all-reduces the decoder gradients and
+all-gathers the logits over RCCL.
+
+Extra objects on the JSON line:
+  roofline     the edge stage of GATConvE forward (qagnn_edge_attn_fwd_f32: scores + segment softmax + aggregate),
+               ALGORITHMIC bytes E'*2410 + N*800 per layer call / its average duration, measured here
+               with HIP events on the launch stream around every call inside the timed steps.
+  cpu_baseline the CPU oracle (reference formulation, torch CPU, all host cores) on a bounded sample of the same
+               workload (B = 10 subgraphs = the reference's own mini-batch of 2 questions), fwd+bwd.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from qagnn_amd import data_utils, ops, synthetic  # noqa: E402
+from qagnn_amd import modeling_qagnn as MQ  # noqa: E402
+
+D, K_LAYERS, N_ETYPE, N_NTYPE, SENT_DIM, CONCEPT_IN, N_NODE, NC = 200, 5, 38, 4, 1024, 1024, 200, 5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_batch(n_questions, seed, n_concept):
+    recs = synthetic.make_records(n_questions * NC, seed=seed, shape='csqa', n_concept_vocab=n_concept)
+    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, N_NODE, NC)
+    bei, bet = data_utils.batch_graph(ei, et, N_NODE)
+    g = torch.Generator().manual_seed(seed + 1)
+    sent = torch.randn(n_questions * NC, SENT_DIM, generator=g)
+    labels = torch.randint(0, NC, (n_questions,), generator=g)
+    return dict(sent=sent, cids=cids, nt=nt, ns=ns, al=al, ei=bei, et=bet, labels=labels)
+
+
+def build_model(cls_module, n_concept, p=0.2, seed=0):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(1234)
+    table = torch.randn(n_concept, CONCEPT_IN, generator=g) * 0.1
+    model = cls_module.QAGNN(None, K_LAYERS, N_NTYPE, N_ETYPE, SENT_DIM, n_concept, D, CONCEPT_IN, 2, 200, 0, p, p, p,
+                             pretrained_concept_emb=table, freeze_ent_emb=True, init_range=0.02)
+    # init_range=0.02 re-initialises the embedding too (reference _init_weights quirk); restore the "pretrained" table
+    model.concept_emb.emb.weight.data.copy_(table)
+    return model
+
+
+class TimedKernels:
+    """Proxy around the kernel provider that brackets selected calls with HIP events on the launch stream."""
+
+    def __init__(self, inner, names):
+        self._inner, self._names = inner, set(names)
+        self.name = inner.name
+        self.events = {n: [] for n in names}
+        self.enabled = False
+
+    def __getattr__(self, attr):
+        fn = getattr(self._inner, attr)
+        if attr not in self._names:
+            return fn
+
+        def wrapped(*a, **kw):
+            if not self.enabled:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            self.events[attr].append((e0, e1))
+            return out
+        return wrapped
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
+
+
+def step(model, b, world, flat_grad_params):
+    for p in flat_grad_params:
+        p.grad = None
+    logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], (b['ei'], b['et']))
+    logits = logits.view(-1, NC)
+    loss = torch.nn.functional.cross_entropy(logits, b['labels'])
+    loss.backward()
+    if world > 1:
+        import torch.distributed as dist
+        flat = torch.cat([p.grad.reshape(-1) for p in flat_grad_params])
+        dist.all_reduce(flat)  # RCCL all-reduce(sum) of the ~2.85 M decoder gradients, one bucket
+        off = 0
+        for p in flat_grad_params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+        gathered = [torch.empty_like(logits) for _ in range(world)]
+        dist.all_gather(gathered, logits.detach())  # per-batch logits for accuracy / reporting
+    return logits
+
+
+def cpu_baseline(budget_s=12.0):
+    """CPU oracle (reference formulation) on the host cores, B = 10 subgraphs of the same distribution."""
+    from oracle import qagnn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_concept = 5000  # table size does not matter on CPU (pure gather of 1990 rows); keeps RAM small
+    b = make_batch(2, seed=123, n_concept=n_concept)
+    model = build_model(O, n_concept)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def one():
+        for p in params:
+            p.grad = None
+        logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], (b['ei'], b['et']))
+        torch.nn.functional.cross_entropy(logits.view(-1, NC), b['labels']).backward()
+    one()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        if time.perf_counter() - t0 > budget_s and reps >= 3:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=round(10 / dt, 2), unit='QA-subgraphs/s', cores=cores, kind='port',
+                sample=f'oracle (reference formulation, torch CPU fp32) fwd+bwd, B=10 subgraphs (2 questions x 5), n=200, '
+                       f'{reps} reps, {dt * 1e3:.0f} ms each, E={b["ei"].size(1)} edges')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--questions', type=int, default=64, help='questions per GPU (x5 choices = subgraphs per GPU)')
+    ap.add_argument('--n-concept', type=int, default=100000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dropout', type=float, default=0.2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    b = {k: v.to(dev) for k, v in make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept).items()}
+    model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep'])
+    ops.set_kernels(timed)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(model, b, world, params)
+    sync()
+    timed.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(model, b, world, params)
+    sync()
+    dt = time.perf_counter() - t0
+    timed.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        B = args.questions * NC
+        N = B * N_NODE
+        E = b['ei'].size(1)
+        Ep = E + N
+        fwd_ms, n_fwd = timed.mean_ms('edge_attn_fwd')
+        bwd_ms, n_bwd = timed.mean_ms('edge_attn_bwd')
+        prep_ms, _ = timed.mean_ms('graph_prep')
+        alg_fwd = Ep * 2410 + N * 800
+        alg_bwd = Ep * 5610 + N * 800
+        achieved = alg_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        out = {
+            'metric': 'QA-subgraphs/sec (batch x num_choice) fwd+bwd', 'value': round(B * world * args.steps / dt, 1),
+            'unit': 'QA-subgraphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: CSQA-shaped batch 64 questions x 5 choices = 320 subgraphs per GPU, n=200 node slots, '
+                                   '400..2000 edges/subgraph, 5-layer GAT d=200 H=4, 38 relations, QAGNN decoder fwd+bwd '
+                                   '(LM encoder excluded: random sent_vecs), dropout 0.2, train-mode BN',
+                       'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
+                       'parallelism': f'dp{world}' if world > 1 else 'single'},
+            'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores + k_edge_softmax + k_edge_aggregate), per GAT layer',
+                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': None, 'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+                         'launches_timed': n_fwd,
+                         'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
+                                      'achieved': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0}},
+            'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
+                                      'graph_prep': round(prep_ms, 3)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+            out['speedup_vs_cpu_baseline'] = round(out['value'] / out['cpu_baseline']['value'], 1)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,280 @@
+"""Per-kernel parity: every C-ABI kernel of libqagnn_hip.so against the torch emulation of the same name
+(tests/emu_kernels.py) on the same seeded inputs.  Integer outputs must be bit-exact; fp32 outputs are checked
+against a float64 evaluation with a backward-error bound (|d| <= c * eps32 * sum|terms|).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from emu_kernels import EmuGraph, EmuKernels
+
+EMU = EmuKernels()
+EPS = 1.2e-7
+
+
+def test_library_exports_every_declared_symbol():
+    """`-m "not gpu"`: the C-ABI library loads and exports every symbol include/qagnn_hip.h declares."""
+    import re
+    from qagnn_amd import _lib
+    from qagnn_amd.build import build
+    build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    hdr = open(os.path.join(helpers.ROOT, 'include', 'qagnn_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(qagnn_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in qagnn_hip.h but not exported'
+    assert sorted(_lib.EXPORTS) == declared
+    _lib.load_library()  # prototypes resolve
+    assert lib.qagnn_abi_version() == 1
+
+
+def hip():
+    from qagnn_amd import ops
+    ops.set_kernels(None)
+    return ops.kernels()
+
+
+def rand_graph(seed, N, E, R=38, T=4, hub=False):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, N, (E,), generator=g)
+    tgt = torch.randint(0, N, (E,), generator=g)
+    if hub and E:
+        src[: E // 3] = 0  # a hub source with a long softmax segment
+        tgt[E // 3: E // 2] = 1
+    et = torch.randint(0, R, (E,), generator=g)
+    nt = torch.randint(0, T, (N,), generator=g)
+    return torch.stack([src, tgt]), et, nt, R, T
+
+
+GRAPH_CASES = [('rand_small', lambda: rand_graph(1, 50, 300)), ('rand_hub', lambda: rand_graph(2, 700, 9000, hub=True)),
+               ('no_edges', lambda: rand_graph(3, 40, 0)), ('one_node', lambda: rand_graph(4, 1, 5)),
+               ('medqa_classes', lambda: rand_graph(5, 3000, 40000, R=34)), ('big', lambda: rand_graph(6, 64000, 400000))]
+
+
+def golden_graph(case):
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    ei = torch.from_numpy(fix['batched_edge_index'].astype(np.int64))
+    et = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
+    nt = torch.from_numpy(fix['node_type_ids']).reshape(-1)
+    return ei, et, nt, c['cfg']['n_etype'], c['cfg']['n_ntype']
+
+
+GRAPH_ARRAYS = [('rowptr_s', 'N+1'), ('tgt_s', 'Ep'), ('src_s', 'Ep'), ('cls_s', 'Ep'), ('eid_s', 'Ep'), ('rowptr_t', 'N+1'),
+                ('src_t', 'Ep'), ('cls_t', 'Ep'), ('pos_t', 'Ep'), ('clsptr', 'C+1'), ('cls_count', 'C'), ('src_c', 'Ep'),
+                ('tgt_c', 'Ep'), ('pos_c', 'Ep'), ('chunkptr', 'C+1')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n, _ in GRAPH_CASES] + ['g:csqa_b10', 'g:medqa_b8', 'g:small_train'])
+def test_graph_prep_bit_exact(name):
+    ei, et, nt, R, T = golden_graph(name[2:]) if name.startswith('g:') else dict(GRAPH_CASES)[name]()
+    K = hip()
+    g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    torch.cuda.synchronize()
+    e = EmuGraph(ei, et, nt, R, T)
+    assert (g.N, g.E, g.Ep, g.C, g.max_chunks) == (e.N, e.E, e.Ep, e.C, e.max_chunks)
+    sizes = {'N+1': e.N + 1, 'Ep': e.Ep, 'C+1': e.C + 1, 'C': e.C}
+    for arr, sz in GRAPH_ARRAYS:
+        got = g.array(arr, sizes[sz]).cpu()
+        assert torch.equal(got, getattr(e, arr).int()), f'{arr} differs'
+    nch = int(g.array('n_chunks', 1).item())
+    assert nch == e.n_chunks
+    for arr in ('chunk_cls', 'chunk_beg', 'chunk_len'):
+        assert torch.equal(g.array(arr, nch).cpu(), getattr(e, arr)), f'{arr} differs'
+    assert int(g.array('err', 1).item()) == 0
+
+
+@pytest.mark.gpu
+def test_graph_prep_flags_out_of_range_indices():
+    ei, et, nt, R, T = rand_graph(7, 30, 100)
+    ei[0, 5] = 1000
+    g = hip().graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    assert int(g.array('err', 1).item()) == 1
+
+
+def _bound(absA, absB, extra=0.0):
+    return 8 * EPS * (absA @ absB) + 1e-6 + extra
+
+
+GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (130, 112, 0, 112), (513, 32, 32, 96),
+               (64, 64, 0, 64), (3, 16, 0, 4), (20000, 208, 208, 624)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K1,K2,No', GEMM_SHAPES)
+@pytest.mark.parametrize('variant', ['plain', 'bias_tab', 'affine', 'accumulate'])
+def test_gemm_nn(M, K1, K2, No, variant):
+    g = torch.Generator().manual_seed(M + K1 + No)
+    A1, B1 = torch.randn(M, K1, generator=g), torch.randn(K1, No, generator=g)
+    A2 = torch.randn(M, K2, generator=g) if K2 else None
+    B2 = torch.randn(K2, No, generator=g) if K2 else None
+    kw, kw64 = {}, {}
+    if variant == 'bias_tab':
+        kw = dict(bias=torch.randn(No, generator=g), rowtab=torch.randn(4, No, generator=g), rowidx=torch.randint(0, 4, (M,), generator=g))
+    if variant == 'affine':
+        kw = dict(a_scale=torch.randn(K1, generator=g), a_shift=torch.randn(K1, generator=g))
+    out0 = torch.randn(M, No, generator=g) if variant == 'accumulate' else None
+    K = hip()
+    cu = lambda t: None if t is None else t.cuda()  # noqa: E731
+    got = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), out=cu(out0), accumulate=out0 is not None, **{k: cu(v) for k, v in kw.items()}).cpu()
+    d = lambda t: None if t is None else (t.double() if t.is_floating_point() else t)  # noqa: E731
+    ref = EMU.gemm_nn(d(A1), d(B1), d(A2), d(B2), **{k: d(v) for k, v in kw.items()})
+    if out0 is not None:
+        ref = ref + out0.double()
+    A1e = torch.relu(A1 * kw['a_scale'] + kw['a_shift']) if variant == 'affine' else A1
+    bound = _bound(A1e.abs().double(), B1.abs().double())
+    if K2:
+        bound = bound + 8 * EPS * (A2.abs().double() @ B2.abs().double())
+    bound = bound + 4 * EPS * ref.abs()
+    err = (got.double() - ref).abs()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Ka,No', [(5000, 208, 208), (1030, 624, 208), (2049, 208, 624), (100, 112, 112), (64000, 208, 208), (7, 32, 96)])
+@pytest.mark.parametrize('affine', [False, True])
+def test_gemm_tn(R, Ka, No, affine):
+    g = torch.Generator().manual_seed(R + Ka)
+    A, B = torch.randn(R, Ka, generator=g), torch.randn(R, No, generator=g)
+    kw = dict(a_scale=torch.randn(Ka, generator=g), a_shift=torch.randn(Ka, generator=g)) if affine else {}
+    got = hip().gemm_tn(A.cuda(), B.cuda(), **{k: v.cuda() for k, v in kw.items()}).cpu()
+    ref = EMU.gemm_tn(A.double(), B.double(), **{k: v.double() for k, v in kw.items()})
+    Ae = torch.relu(A * kw['a_scale'] + kw['a_shift']) if affine else A
+    bound = 16 * EPS * (Ae.abs().double().t() @ B.abs().double()) + 1e-6
+    err = (got.double() - ref).abs()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,C', [(1000, 208), (64000, 208), (257, 624), (5, 32)])
+def test_column_reductions_and_bn_backward(R, C):
+    g = torch.Generator().manual_seed(R * 7 + C)
+    X, H = torch.randn(R, C, generator=g), torch.randn(R, C, generator=g) * 2 + 0.3
+    idx = torch.randint(0, 4, (R,), generator=g)
+    K = hip()
+    for rowidx, groups in ((None, 1), (idx, 4)):
+        got = K.colsum(X.cuda(), None if rowidx is None else rowidx.cuda(), groups).cpu()
+        ref = EMU.colsum(X.double(), rowidx, groups)
+        assert (got.double() - ref).abs().max().item() <= 4 * EPS * X.abs().sum(0).max().item() + 1e-6
+    mean = H.mean(0)
+    got = K.colvar_sum(H.cuda(), mean.cuda()).cpu()
+    ref = EMU.colvar_sum(H.double(), mean.double())
+    assert ((got.double() - ref).abs() <= 8 * EPS * ref + 1e-6).all()
+    var = ref.float() / R
+    invstd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    args = (X, H, mean, invstd, scale, shift)
+    got = K.bn_bwd_reduce(*[t.cuda() for t in args]).cpu()
+    ref = EMU.bn_bwd_reduce(*[t.double() for t in args])
+    # mask flips at |y| ~ 1e-7 are legal; give the bound the size of a few elements
+    tol = 8 * EPS * (X.abs() * (1 + ((H - mean) * invstd).abs())).sum(0).max().item() + 3 * X.abs().max().item() * 4
+    assert (got.double() - ref).abs().max().item() <= tol
+    c1, c2 = ref[0].float() / R, ref[1].float() / R
+    args2 = args + (gamma * invstd, c1, c2)
+    got = K.bn_relu_bwd(*[t.cuda() for t in args2]).cpu()
+    ref = EMU.bn_relu_bwd(*[t.double() for t in args2])
+    err = (got.double() - ref).abs()
+    flips = (err > 1e-4 * (1 + ref.abs())).sum().item()
+    assert flips <= 2, f'{flips} elements differ beyond fp32 rounding'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', [0.0, 0.2, 0.5])
+def test_gelu_dropout_forward_backward_and_mask(p):
+    g = torch.Generator().manual_seed(11)
+    X, dY = torch.randn(3000, 208, generator=g) * 2, torch.randn(3000, 208, generator=g)
+    K = hip()
+    seed = 0x1234567ABCDEF
+    y = K.gelu_dropout_fwd(X.cuda(), p, seed).cpu()
+    dx = K.gelu_dropout_bwd(X.cuda(), dY.cuda(), p, seed).cpu()
+    yr = EMU.gelu_dropout_fwd(X.double(), p, seed)
+    dxr = EMU.gelu_dropout_bwd(X.double(), dY.double(), p, seed)
+    assert torch.equal(y == 0, (yr == 0) | (X == 0)), 'keep mask differs from the counter-based hash'
+    assert (y.double() - yr).abs().max().item() < 2e-6 * (1 + yr.abs().max().item())
+    assert (dx.double() - dxr).abs().max().item() < 2e-6 * (1 + dxr.abs().max().item())
+    if p > 0:
+        keep_rate = (y != 0).float().mean().item()
+        assert abs(keep_rate - (1 - p)) < 0.01
+        y2 = K.gelu_dropout_fwd(X.cuda(), p, seed + 1).cpu()
+        assert not torch.equal(y2 == 0, y == 0)
+    # tanh-GELU equals torch's approximate='tanh'
+    if p == 0:
+        assert (y - torch.nn.functional.gelu(X, approximate='tanh')).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_sin_basis_matches_host_libm():
+    g = torch.Generator().manual_seed(5)
+    score = torch.randn(5000, generator=g) * 3
+    js = torch.pow(1.1, torch.arange(100).float())
+    got = hip().sin_basis(score.cuda(), js.cuda(), 112).cpu()
+    ref = EMU.sin_basis(score, js, 112)  # fp32 product js*score, then sin: same argument bits as the oracle
+    assert got.shape == (5000, 112) and (got[:, 100:] == 0).all()
+    assert (got - ref).abs().max().item() < 5e-7
+
+
+def edge_inputs(case_or_name, HP, seed):
+    if case_or_name in dict(GRAPH_CASES):
+        ei, et, nt, R, T = dict(GRAPH_CASES)[case_or_name]()
+    else:
+        ei, et, nt, R, T = golden_graph(case_or_name)
+    g = torch.Generator().manual_seed(seed)
+    N, C, DP = nt.numel(), R * T * T + T, 4 * HP
+    dh = {52: 50, 8: 8, 28: 25, 16: 16}[HP]
+    mask = (torch.arange(DP) % HP < dh).float()
+    KMQ = torch.randn(N, 3 * DP, generator=g) * mask.repeat(3)
+    EkEm = torch.randn(C, 2 * DP, generator=g) * mask.repeat(2)
+    G = torch.randn(N, DP, generator=g) * mask
+    return (ei, et, nt, R, T), KMQ, EkEm, G, 1.0 / dh ** 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,HP', [('csqa_b10', 52), ('medqa_b8', 52), ('small_train', 8), ('rand_hub', 52), ('rand_small', 28),
+                                     ('no_edges', 16), ('one_node', 52), ('big', 52)])
+def test_edge_attention_forward_backward(name, HP):
+    (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs(name, HP, 21)
+    K = hip()
+    g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    aggr, a, alpha = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
+    dKMQ, dEkEm = K.edge_attn_bwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs, a, alpha, G.cuda())
+    torch.cuda.synchronize()
+    e = EmuGraph(ei, et, nt, R, T)
+    aggr_r, a_r, alpha_r = EMU.edge_attn_fwd(e, KMQ.double(), EkEm.double(), HP, qs)
+    dKMQ_r, dEkEm_r = EMU.edge_attn_bwd(e, KMQ.double(), EkEm.double(), HP, qs, a_r, alpha_r, G.double())
+    for nm, got, ref, tol in (('a', a, a_r, 2e-6), ('alpha', alpha, alpha_r, 2e-6), ('aggr', aggr, aggr_r, 5e-6),
+                              ('dKMQ', dKMQ, dKMQ_r, 2e-5), ('dEkEm', dEkEm, dEkEm_r, 2e-5)):
+        got = got.cpu().double()
+        scale = ref.abs().max().item() + 1e-30
+        err = (got - ref).abs().max().item()
+        assert err <= tol * scale, f'{nm}: max err {err:.3e} vs scale {scale:.3e}'
+        assert torch.isfinite(got).all()
+    # pads stay exactly zero
+    DP = 4 * HP
+    dh = {52: 50, 8: 8, 28: 25, 16: 16}[HP]
+    padmask = (torch.arange(DP) % HP >= dh)
+    assert (aggr.cpu()[:, padmask] == 0).all() and (dKMQ.cpu()[:, padmask.repeat(3)] == 0).all()
+    # softmax rows: sum over each source segment of a == 1 (size-independent property)
+    seg = torch.zeros(e.N, 4, dtype=torch.float64).index_add_(0, e.src_s.long(), a.cpu().double())
+    assert (seg - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_edge_attention_is_deterministic():
+    (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs('rand_hub', 52, 3)
+    K = hip()
+    outs = []
+    for _ in range(3):
+        g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+        aggr, a, alpha = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), 52, qs)
+        dKMQ, dEkEm = K.edge_attn_bwd(g, KMQ.cuda(), EkEm.cuda(), 52, qs, a, alpha, G.cuda())
+        outs.append([t.cpu() for t in (aggr, a, dKMQ, dEkEm)])
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert torch.equal(x, y), 'run-to-run bit difference: a reduction order is not fixed'
