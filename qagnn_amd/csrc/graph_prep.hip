@@ -164,14 +164,23 @@ __global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s,
   for (int c = threadIdx.x; c < C; c += 256) hist[(int64_t)blockIdx.x * C + c] = lh[c];
 }
 
-__global__ void k_cls_base(int* __restrict__ hist, const int* __restrict__ clsptr, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// exclusive scan over the blocks of one class (column c of hist), one wave per class, 64 blocks per step
+__global__ __launch_bounds__(256) void k_cls_base(int* __restrict__ hist, const int* __restrict__ clsptr, int nblk, int C) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
   int run = clsptr[c];
-  for (int b = 0; b < nblk; ++b) {
-    const int t = hist[(int64_t)b * C + c];
-    hist[(int64_t)b * C + c] = run;
-    run += t;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = b < nblk ? hist[(int64_t)b * C + c] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (b < nblk) hist[(int64_t)b * C + c] = run + incl - v;
+    run += __shfl(incl, 63, 64);
   }
 }
 
@@ -291,7 +300,7 @@ extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t*
   QAGNN_LAUNCH_CHECK("k_payload");
   k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_hist");
-  k_cls_base<<<cdiv(C, 256), 256, 0, stream>>>(hist, g->clsptr, nblk, C);
+  k_cls_base<<<cdiv(C, 4), 256, 0, stream>>>(hist, g->clsptr, nblk, C);
   QAGNN_LAUNCH_CHECK("k_cls_base");
   k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_scatter");

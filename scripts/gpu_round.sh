@@ -1,23 +1,36 @@
 #!/bin/bash
-# One GPU-box visit: kernel tests, parity tests, smoke, bench, rocprof.  Everything lands in gpurun_out/.
+# One GPU-box visit: kernel tests, parity tests, smoke, bench, rocprof.  Small logs land in gpurun_out/ (<64 MiB!).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out
+REPO="$PWD"
+rm -rf gpurun_out; mkdir -p gpurun_out
 export TMPDIR=/tmp
-rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
-nproc >> gpurun_out/gpu.txt
+( rocm-smi --showproductname 2>/dev/null | head -8; nproc; free -g | head -2 ) > gpurun_out/gpu.txt
 ( time python __graft_entry__.py ) > gpurun_out/build.log 2>&1
-timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short --timeout 180 -p no:cacheprovider > gpurun_out/test_kernels.log 2>&1
-echo "kernels exit $?" >> gpurun_out/summary.txt
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q --tb=short --timeout 300 -p no:cacheprovider > gpurun_out/test_parity.log 2>&1
-echo "parity exit $?" >> gpurun_out/summary.txt
-timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
-echo "smoke exit $?" >> gpurun_out/summary.txt
-timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
-echo "bench exit $?" >> gpurun_out/summary.txt
-if [ "$1" == "prof" ]; then
-  cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r1 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1
-  cd "$OLDPWD"; echo "prof exit $?" >> gpurun_out/summary.txt
-  find gpurun_out/prof -name "*stats*" | head >> gpurun_out/summary.txt
+if [[ "$*" == *kernels* ]]; then
+  timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
+  echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
-tail -5 gpurun_out/test_kernels.log gpurun_out/test_parity.log gpurun_out/smoke.log gpurun_out/bench.log
+if [[ "$*" == *parity* ]]; then
+  timeout 1200 python -X faulthandler -m pytest tests/test_hip_parity.py -m gpu -q --tb=short -rf --timeout 300 -p no:cacheprovider > /tmp/parity_full.log 2>&1; ( head -c 40000 /tmp/parity_full.log; echo; echo "......"; tail -c 20000 /tmp/parity_full.log ) > gpurun_out/test_parity.log
+  echo "parity exit $?" >> gpurun_out/summary.txt
+fi
+if [[ "$*" == *smoke* ]]; then
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -n 50 > gpurun_out/smoke.log
+  echo "smoke exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+fi
+if [[ "$*" == *bench* ]]; then
+  timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -n 50 > gpurun_out/bench.log
+  echo "bench exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+fi
+if [[ "$*" == *prof* ]]; then
+  rm -rf /tmp/prof; mkdir -p /tmp/prof
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r1 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
+  echo "prof exit $?" >> gpurun_out/summary.txt
+  mkdir -p gpurun_out/prof
+  find /tmp/prof -name "*kernel_stats*" -exec cp {} gpurun_out/prof/ \;
+  find /tmp/prof -name "*domain_stats*" -exec cp {} gpurun_out/prof/ \;
+  ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
+fi
+for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
 cat gpurun_out/summary.txt
+du -sh gpurun_out

@@ -196,14 +196,15 @@ def test_gelu_dropout_forward_backward_and_mask(p):
     dx = K.gelu_dropout_bwd(X.cuda(), dY.cuda(), p, seed).cpu()
     yr = EMU.gelu_dropout_fwd(X.double(), p, seed)
     dxr = EMU.gelu_dropout_bwd(X.double(), dY.double(), p, seed)
-    assert torch.equal(y == 0, (yr == 0) | (X == 0)), 'keep mask differs from the counter-based hash'
+    live = X.abs() < 3  # away from the fp32 underflow of gelu(x) for very negative x
+    assert torch.equal((y == 0)[live], ((yr == 0) | (X == 0))[live]), 'keep mask differs from the counter-based hash'
     assert (y.double() - yr).abs().max().item() < 2e-6 * (1 + yr.abs().max().item())
     assert (dx.double() - dxr).abs().max().item() < 2e-6 * (1 + dxr.abs().max().item())
     if p > 0:
-        keep_rate = (y != 0).float().mean().item()
+        keep_rate = (y != 0)[live].float().mean().item()
         assert abs(keep_rate - (1 - p)) < 0.01
         y2 = K.gelu_dropout_fwd(X.cuda(), p, seed + 1).cpu()
-        assert not torch.equal(y2 == 0, y == 0)
+        assert not torch.equal((y2 == 0)[live], (y == 0)[live])
     # tanh-GELU equals torch's approximate='tanh'
     if p == 0:
         assert (y - torch.nn.functional.gelu(X, approximate='tanh')).abs().max().item() < 2e-6

@@ -143,7 +143,7 @@ def test_oracle_parity_odd_shapes(train):
 
 
 def _full_size_batch(B=320, n=200, seed=77):
-    recs = synthetic.make_records(B, seed=seed, shape='csqa')
+    recs = synthetic.make_records(B, seed=seed, shape='csqa', n_concept_vocab=2000)  # ids must fit the model's table
     _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, 5)
     bei, bet = data_utils.batch_graph(ei, et, n)
     g = torch.Generator().manual_seed(seed)
@@ -158,7 +158,7 @@ def test_full_size_batch_properties():
     train mode: (3) fwd+bwd is finite, gradients reach every trainable tensor, BN buffers moved.
     """
     from qagnn_amd import modeling_qagnn as MQ
-    cfg = helpers.model_cfg(d=200, k=5, sent_dim=64, n_concept=100000 // 50, concept_in_dim=32)
+    cfg = helpers.model_cfg(d=200, k=5, sent_dim=64, n_concept=2000, concept_in_dim=32)
     torch.manual_seed(0)
     model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
     helpers.det_fill_(model, 5, 0.6)

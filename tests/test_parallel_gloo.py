@@ -1,0 +1,105 @@
+"""World-size-2 `gloo` test (CPU) of the question-sharded data-parallel path: sharding + flat-bucket gradient
+all-reduce + logits all-gather reproduce the reference's gradient-accumulation semantics (qagnn.py:252-266)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+
+CASE = dict(shape='tiny', nq=5, nc=3, n=20, n_rel=17, std=0.8, train=True, seed=41,
+            cfg=helpers.model_cfg(d=32, k=2, sent_dim=24, n_concept=300, concept_in_dim=16))
+
+
+def _build():
+    from test_host_logic_emu import build
+    helpers.GOLDEN_CASES['_par'] = CASE
+    try:
+        return build('_par')
+    finally:
+        del helpers.GOLDEN_CASES['_par']
+
+
+def _run_questions(model, inp, a, b, n_global):
+    """fwd+bwd on questions [a, b) with the reference's mini-batch loss weight; returns logits [b-a, nc]."""
+    from qagnn_amd import data_utils, parallel
+    nc, n = CASE['nc'], CASE['n']
+    sl = slice(a * nc, b * nc)
+    ei, et = data_utils.batch_graph(inp['edge_index_list'][sl], inp['edge_type_list'][sl], n)
+    logits, _ = model(inp['sent_vecs'][sl], inp['concept_ids'][sl], inp['node_type_ids'][sl], inp['node_scores'][sl],
+                      inp['adj_lengths'][sl], (ei, et))
+    logits = logits.view(b - a, nc)
+    labels = (torch.arange(a, b) % nc)
+    loss = torch.nn.functional.cross_entropy(logits, labels) * parallel.shard_loss_weight(b - a, n_global)
+    loss.backward()
+    return logits.detach()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(helpers.ROOT, 'tests'))
+    from emu_kernels import EmuKernels
+    from qagnn_amd import ops, parallel
+    ops.set_kernels(EmuKernels())
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    inp = helpers.make_case_inputs(CASE)
+    model = _build()
+    a, b = parallel.shard_questions(CASE['nq'], rank, world)
+    logits = _run_questions(model, inp, a, b, CASE['nq'])
+    params = [p for p in model.parameters() if p.requires_grad]
+    n = parallel.allreduce_gradients(params)
+    allz = parallel.allgather_logits(logits)
+    if rank == 0:
+        q.put((n, allz.numpy(), {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_questions_covers_everything():
+    from qagnn_amd import parallel
+    for nq in (1, 5, 64, 67):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_questions(nq, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == nq
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_gradient_accumulation():
+    from emu_kernels import EmuKernels
+    from qagnn_amd import ops, parallel
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, allz, grads = q.get(timeout=240)
+    allz, grads = torch.from_numpy(allz), {k: torch.from_numpy(v) for k, v in grads.items()}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # serial reference: the same two shards as gradient-accumulation mini-batches on one model copy
+    old = ops.set_kernels(EmuKernels())
+    try:
+        inp = helpers.make_case_inputs(CASE)
+        model = _build()
+        zs = []
+        for r in range(2):
+            a, b = parallel.shard_questions(CASE['nq'], r, 2)
+            zs.append(_run_questions(model, inp, a, b, CASE['nq']))
+    finally:
+        ops.set_kernels(old)
+    assert allz.shape == (CASE['nq'], CASE['nc'])
+    assert torch.allclose(allz, torch.cat(zs), rtol=1e-5, atol=1e-6)
+    ref = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) == set(grads) and n == sum(v.numel() for v in ref.values())
+    for k in ref:
+        if helpers.has_null_gradient(k, True):
+            continue
+        assert torch.allclose(grads[k], ref[k], rtol=1e-4, atol=1e-6 + 1e-4 * ref[k].abs().max().item()), k
