@@ -22,10 +22,12 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- decode + histogram ---------------------------------------------------------------------------------
+// class ids of tens of thousands of self loops collide on a handful of counters: the class histogram is taken from
+// the per-block LDS histograms of k_cls_hist instead of one global atomic per edge.
 __global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
                                const int64_t* __restrict__ node_type, int N, int E, int R, int T, int* __restrict__ es,
                                int* __restrict__ et, int* __restrict__ ec, int* __restrict__ cnt_s, int* __restrict__ cnt_t,
-                               int* __restrict__ cls_count, int* __restrict__ err) {
+                               int* __restrict__ err) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int Ep = E + N;
   if (e >= Ep) return;
@@ -53,7 +55,6 @@ __global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int
   ec[e] = c;
   atomicAdd(&cnt_s[s], 1);
   atomicAdd(&cnt_t[t], 1);
-  atomicAdd(&cls_count[c], 1);
 }
 
 // ---- exclusive scan of up to 3 independent arrays, one 1024-thread block each ---------------------------------
@@ -153,7 +154,8 @@ __global__ void k_payload(const int* __restrict__ es, const int* __restrict__ et
 
 // ---- stable counting sort of the source-ordered positions by class -------------------------------------------
 #define CLS_BLK 1024
-__global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s, int* __restrict__ hist, int Ep, int C) {
+__global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s, int* __restrict__ hist,
+                                                  int* __restrict__ cls_count, int Ep, int C) {
   extern __shared__ int lh[];
   for (int c = threadIdx.x; c < C; c += 256) lh[c] = 0;
   __syncthreads();
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s,
   for (int i = threadIdx.x; i < CLS_BLK; i += 256)
     if (base + i < Ep) atomicAdd(&lh[cls_s[base + i]], 1);
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) hist[(int64_t)blockIdx.x * C + c] = lh[c];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    hist[(int64_t)blockIdx.x * C + c] = lh[c];
+    if (lh[c]) atomicAdd(&cls_count[c], lh[c]);
+  }
 }
 
 // exclusive scan over the blocks of one class (column c of hist), one wave per class, 64 blocks per step
@@ -287,9 +292,9 @@ extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t*
   if (he != hipSuccess) { set_error("graph_prep: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   const int TB = 256;
   k_decode_count<<<cdiv(Ep, TB), TB, 0, stream>>>(edge_index, edge_type, node_type, N, E, R, T, es, et, ec, cnt_s, cnt_t,
-                                                   g->cls_count, g->err);
+                                                   g->err);
   QAGNN_LAUNCH_CHECK("k_decode_count");
-  k_scan3<<<3, 1024, 0, stream>>>(cnt_s, g->rowptr_s, N, cnt_t, g->rowptr_t, N, g->cls_count, g->clsptr, C);
+  k_scan3<<<2, 1024, 0, stream>>>(cnt_s, g->rowptr_s, N, cnt_t, g->rowptr_t, N, nullptr, nullptr, 0);
   QAGNN_LAUNCH_CHECK("k_scan3");
   k_fill<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, g->rowptr_s, g->rowptr_t, cnt_s, cnt_t, tmp_s, tmp_t, Ep);
   QAGNN_LAUNCH_CHECK("k_fill");
@@ -298,8 +303,10 @@ extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t*
   k_payload<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, ec, g->eid_s, eid_t, srcpos, g->tgt_s, g->src_s, g->cls_s, g->src_t,
                                               g->cls_t, g->pos_t, Ep);
   QAGNN_LAUNCH_CHECK("k_payload");
-  k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, Ep, C);
+  k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_hist");
+  k_chunk_scan<<<1, 1024, 0, stream>>>(g->cls_count, g->clsptr, C);  // clsptr = exclusive scan of the class counts
+  QAGNN_LAUNCH_CHECK("k_cls_scan");
   k_cls_base<<<cdiv(C, 4), 256, 0, stream>>>(hist, g->clsptr, nblk, C);
   QAGNN_LAUNCH_CHECK("k_cls_base");
   k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);

@@ -133,6 +133,20 @@ class GATConvE(nn.Module):
         bias = torch.cat([W_t.new_zeros(2 * DP), L.pad(self.linear_query.bias)])
         return W_t, W_nt, bias
 
+    def packed_projection_typed(self, L, temb, SP):
+        """Operands of the K|M|Q projection when node_feature_extra = cat(type_emb[node_type], score_emb) (the only
+        form QAGNN_Message_Passing produces, modeling_qagnn.py:86): the type half collapses to a T-row table that the
+        GEMM epilogue adds by node type, and only the score half (d/2 wide) stays a GEMM operand: K = DP + SP instead
+        of 2*DP.  Returns Wx_t [DP, 3DP], Wx [3DP, DP], Ws_t [SP, 3DP], Ws [3DP, SP], TT [T, 3DP] (bq folded in)."""
+        d, h, DP = self.emb_dim, self.emb_dim // 2, L.DP
+        Wcat = torch.cat([self.linear_key.weight[:, :2 * d], self.linear_msg.weight[:, :2 * d], self.linear_query.weight], 0)  # [3d, 2d]
+        out_p = L.pad(Wcat.t().reshape(2 * d, 3, d)).reshape(2 * d, 3 * DP)            # [in (2d), padded out]
+        Wx = L.pad(out_p[:d].t()).contiguous()                                          # [3DP, DP]
+        Ws = F.pad(out_p[d + h:].t(), (0, SP - h)).contiguous()                         # [3DP, SP]
+        bias = torch.cat([out_p.new_zeros(2 * DP), L.pad(self.linear_query.bias)])
+        TT = (temb @ out_p[d:d + h] + bias).contiguous()                                # [T, 3DP]
+        return Wx.t().contiguous(), Wx, Ws.t().contiguous(), Ws, TT
+
     def packed_edge_tables(self, tab, L):
         """[C, d] class table -> [C, 2*DP]:  Ek = Wk[:, 2d:] tab + bk | Em = Wm[:, 2d:] tab + bm (head-padded)."""
         d = self.emb_dim
@@ -148,10 +162,18 @@ class GATConvE(nn.Module):
         return (W1t, W1, L.pad(lin1.bias), L.pad(bn.weight), L.pad(bn.bias), W2t, W2, L.pad(lin2.bias),
                 L.pad(bn.running_mean), L.pad(bn.running_var))
 
-    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop):
-        """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order)."""
-        W_t, W_nt, bias = self.packed_projection(L)
-        KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None):
+        """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
+
+        `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
+        decomposed form is used instead (see packed_projection_typed)."""
+        if typed is None:
+            W_t, W_nt, bias = self.packed_projection(L)
+            KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)
+        else:
+            temb, ntype, S = typed
+            Wx_t, Wx, Ws_t, Ws, TT = self.packed_projection_typed(L, temb, S.size(1))
+            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype)
         aggr, a = ops.edge_attention(KMQ, self.packed_edge_tables(tab, L), graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
         use_batch_stats = self.training or not bn.track_running_stats
@@ -215,19 +237,19 @@ class QAGNN_Message_Passing(nn.Module):
             self._js[key] = torch.pow(1.1, torch.arange(self.hidden_size // 2).float()).to(device)
         return self._js[key]
 
-    def node_feature_extra(self, node_type_flat, node_score_flat, L):
-        """[N, DP] head-padded cat(node_type_emb, node_score_emb)  (:65-73, 86)."""
+    def node_feature_extra(self, node_type_flat, node_score_flat):
+        """The two halves of node_feature_extra (:65-73, 86), kept apart: the T-row type-embedding table
+        temb [T, d/2] (= GELU(Linear) of the T one-hots) and the per-node score embedding S [N, SP] (SP = d/2 rounded
+        up to 16, pad columns are exactly 0)."""
         h = self.hidden_size // 2
         dev = node_type_flat.device
-        temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)  # Linear applied to the T one-hots
-        type_emb = temb.index_select(0, node_type_flat)
+        temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)
         JP = ops.roundup(h, 16)
         sinB = ops.kernels().sin_basis(node_score_flat.contiguous(), self._js_table(dev), JP)
         Wes_t = F.pad(self.emb_score.weight.t(), (0, JP - h, 0, JP - h)).contiguous()  # [JP in, JP out]
         Wes = Wes_t.t().contiguous()
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=F.pad(self.emb_score.bias, (0, JP - h)))
-        score_emb = ops.gelu_dropout(pre, 0.0, False)[:, :h]
-        return L.pad(torch.cat([type_emb, score_emb], dim=1))
+        return temb, ops.gelu_dropout(pre, 0.0, False)
 
     def forward(self, H, A, node_type, node_score, cache_output=False, graph=None):
         """
@@ -242,12 +264,12 @@ class QAGNN_Message_Passing(nn.Module):
         ntype = node_type.reshape(-1).contiguous()
         if graph is None:
             graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype)
-        extra_p = self.node_feature_extra(ntype, node_score.reshape(-1), L)
+        temb, S = self.node_feature_extra(ntype, node_score.reshape(-1))
         Hp = L.pad(H.reshape(bs * n, d))
         tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=self.k)
         Xp = Hp
         for layer in self.gnn_layers:  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
-            Xp, _ = layer.hop(Xp, extra_p, graph, tab, L, apply_act=True, p_drop=self.dropout_rate)
+            Xp, _ = layer.hop(Xp, None, graph, tab, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S))
         Vh_t, Vh = _pad2(self.Vh.weight, L)
         Vx_t, Vx = _pad2(self.Vx.weight, L)
         Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=L.pad(self.Vh.bias + self.Vx.bias))

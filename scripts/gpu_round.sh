@@ -24,11 +24,10 @@ if [[ "$*" == *bench* ]]; then
 fi
 if [[ "$*" == *prof* ]]; then
   rm -rf /tmp/prof; mkdir -p /tmp/prof
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r1 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
   echo "prof exit $?" >> gpurun_out/summary.txt
   mkdir -p gpurun_out/prof
-  find /tmp/prof -name "*kernel_stats*" -exec cp {} gpurun_out/prof/ \;
-  find /tmp/prof -name "*domain_stats*" -exec cp {} gpurun_out/prof/ \;
+  find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
   ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
 fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
