@@ -70,12 +70,16 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   }
 }
 
-__global__ void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= tot) return;
+// ordered sum of the chunk partials: 64 outputs x 4 chunk partitions per block, partitions combined in fixed order
+__global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot) {
+  __shared__ float red[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * tot + i];
-  out[i] = s;
+  if (o < tot)
+    for (int c = q; c < nchunks; c += 4) s += part[(int64_t)c * tot + o];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && o < tot) out[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH, int ld, int R,
@@ -183,7 +187,7 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
   }
   QAGNN_LAUNCH_CHECK("k_colreduce");
   const int tot = nout * Cc;
-  k_colreduce_final<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, out, grid.y, tot);
+  k_colreduce_final<<<cdiv(tot, 64), 256, 0, stream>>>(workspace, out, grid.y, tot);
   QAGNN_LAUNCH_CHECK("k_colreduce_final");
   return QAGNN_OK;
 }

@@ -44,7 +44,17 @@ def _pad2(W, L):
     return Wt, Wt.t().contiguous()
 
 
+_CLASS_FEATS = {}
+
+
 def edge_class_features(n_etype, n_ntype, device):
+    key = (n_etype, n_ntype, str(device))
+    if key not in _CLASS_FEATS:
+        _CLASS_FEATS[key] = _edge_class_features(n_etype, n_ntype, device)
+    return _CLASS_FEATS[key]
+
+
+def _edge_class_features(n_etype, n_ntype, device):
     """Input rows of the edge encoder for every edge class (the one-hot concat of modeling_qagnn.py:419-433).
 
     class c = etype*T*T + head*T + tail for real edges; R*T*T + type for the self loop of a node of that type
@@ -133,20 +143,6 @@ class GATConvE(nn.Module):
         bias = torch.cat([W_t.new_zeros(2 * DP), L.pad(self.linear_query.bias)])
         return W_t, W_nt, bias
 
-    def packed_projection_typed(self, L, temb, SP):
-        """Operands of the K|M|Q projection when node_feature_extra = cat(type_emb[node_type], score_emb) (the only
-        form QAGNN_Message_Passing produces, modeling_qagnn.py:86): the type half collapses to a T-row table that the
-        GEMM epilogue adds by node type, and only the score half (d/2 wide) stays a GEMM operand: K = DP + SP instead
-        of 2*DP.  Returns Wx_t [DP, 3DP], Wx [3DP, DP], Ws_t [SP, 3DP], Ws [3DP, SP], TT [T, 3DP] (bq folded in)."""
-        d, h, DP = self.emb_dim, self.emb_dim // 2, L.DP
-        Wcat = torch.cat([self.linear_key.weight[:, :2 * d], self.linear_msg.weight[:, :2 * d], self.linear_query.weight], 0)  # [3d, 2d]
-        out_p = L.pad(Wcat.t().reshape(2 * d, 3, d)).reshape(2 * d, 3 * DP)            # [in (2d), padded out]
-        Wx = L.pad(out_p[:d].t()).contiguous()                                          # [3DP, DP]
-        Ws = F.pad(out_p[d + h:].t(), (0, SP - h)).contiguous()                         # [3DP, SP]
-        bias = torch.cat([out_p.new_zeros(2 * DP), L.pad(self.linear_query.bias)])
-        TT = (temb @ out_p[d:d + h] + bias).contiguous()                                # [T, 3DP]
-        return Wx.t().contiguous(), Wx, Ws.t().contiguous(), Ws, TT
-
     def packed_edge_tables(self, tab, L):
         """[C, d] class table -> [C, 2*DP]:  Ek = Wk[:, 2d:] tab + bk | Em = Wm[:, 2d:] tab + bm (head-padded)."""
         d = self.emb_dim
@@ -162,22 +158,61 @@ class GATConvE(nn.Module):
         return (W1t, W1, L.pad(lin1.bias), L.pad(bn.weight), L.pad(bn.bias), W2t, W2, L.pad(lin2.bias),
                 L.pad(bn.running_mean), L.pad(bn.running_var))
 
-    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None):
+    # the same packings as pure functions of the parameter tensors (run once on element ids by ops.GatherPlan)
+    N_SOURCES = 14
+
+    def pack_sources(self):
+        lin1, bn, lin2 = self.mlp[0], self.mlp[1], self.mlp[3]
+        return [self.linear_key.weight, self.linear_key.bias, self.linear_msg.weight, self.linear_msg.bias,
+                self.linear_query.weight, self.linear_query.bias, lin1.weight, lin1.bias, bn.weight, bn.bias,
+                bn.running_mean, bn.running_var, lin2.weight, lin2.bias]
+
+    @staticmethod
+    def pack_build(src, L, SP):
+        """sources (pack_sources order) -> [Wx_t, Wx, Ws_t, Ws, Wtype, bias_kmq, We_p, be_p, W1t, W1, b1, gamma, beta, W2t, W2,
+        b2, run_mean, run_var] in operand layout (selection-only ops)."""
+        Wk, bk, Wm, bm, Wq, bq, W1, b1, gam, bet, rm, rv, W2, b2 = src
+        d, h, DP = L.d, L.d // 2, L.DP
+        Wcat = torch.cat([Wk[:, :2 * d], Wm[:, :2 * d], Wq], 0)                         # [3d, 2d]
+        out_p = L.pad(Wcat.t().reshape(2 * d, 3, d)).reshape(2 * d, 3 * DP)            # [in (2d), padded out]
+        Wx = L.pad(out_p[:d].t()).contiguous()                                          # [3DP, DP]
+        Ws = F.pad(out_p[d + h:].t(), (0, SP - h)).contiguous()                         # [3DP, SP]
+        Wtype = out_p[d:d + h].contiguous()                                             # [h, 3DP]
+        bias = torch.cat([out_p.new_zeros(2 * DP), L.pad(bq)])
+        We = L.pad(torch.cat([Wk[:, 2 * d:], Wm[:, 2 * d:]], 0).reshape(2, d, d).transpose(1, 2)).transpose(1, 2)  # [2, DP, d]
+        We_p = We.reshape(2 * DP, d).contiguous()
+        be_p = L.pad(torch.stack([bk, bm])).reshape(2 * DP)
+        W1t, W1p = _pad2(W1, L)
+        W2t, W2p = _pad2(W2, L)
+        return [Wx.t().contiguous(), Wx, Ws.t().contiguous(), Ws, Wtype, bias, We_p, be_p, W1t, W1p, L.pad(b1), L.pad(gam),
+                L.pad(bet), W2t, W2p, L.pad(b2), L.pad(rm), L.pad(rv)]
+
+    N_PACKED = 18
+
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None):
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
-        decomposed form is used instead (see packed_projection_typed)."""
+        decomposed form is used instead (see packed_projection_typed).  `packed` = this layer's pack_build() outputs
+        when the caller packed all layers with one gather."""
         if typed is None:
             W_t, W_nt, bias = self.packed_projection(L)
             KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)
+            ekem = self.packed_edge_tables(tab, L)
+            mlp_ops = self.packed_mlp(L)
         else:
             temb, ntype, S = typed
-            Wx_t, Wx, Ws_t, Ws, TT = self.packed_projection_typed(L, temb, S.size(1))
+            if packed is None:
+                packed = self.pack_build(self.pack_sources(), L, S.size(1))
+            Wx_t, Wx, Ws_t, Ws, Wtype, bias, We_p, be_p = packed[:8]
+            TT = torch.addmm(bias, temb, Wtype)                      # [T, 3DP] type-embedding half of the projection + bq
             KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype)
-        aggr, a = ops.edge_attention(KMQ, self.packed_edge_tables(tab, L), graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
+            ekem = torch.addmm(be_p, tab, We_p.t())                  # [C, 2DP]: Ek | Em, pads exactly 0
+            mlp_ops = packed[8:]
+        aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
         use_batch_stats = self.training or not bn.track_running_stats
-        y, mean_p, var_p = ops.gat_mlp(aggr, *self.packed_mlp(L), use_batch_stats, bn.eps, p_drop if self.training else 0.0,
+        y, mean_p, var_p = ops.gat_mlp(aggr, *mlp_ops, use_batch_stats, bn.eps, p_drop if self.training else 0.0,
                                        apply_act)
         if self.training and bn.track_running_stats:
             with torch.no_grad():
@@ -228,6 +263,7 @@ class QAGNN_Message_Passing(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.dropout_rate = dropout
         self._js = {}
+        self._plan = ops.GatherPlan()
 
     def _js_table(self, device):
         """1.1**j in fp32, computed on the HOST exactly like the oracle: sin arguments reach ~1e4, so a 1-ulp
@@ -237,18 +273,35 @@ class QAGNN_Message_Passing(nn.Module):
             self._js[key] = torch.pow(1.1, torch.arange(self.hidden_size // 2).float()).to(device)
         return self._js[key]
 
-    def node_feature_extra(self, node_type_flat, node_score_flat):
+    def pack_all(self, L):
+        """All operand packings of the stack with one gather: (per-layer lists, [Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes])."""
+        h = self.hidden_size // 2
+        JP = ops.roundup(h, 16)
+        nsrc = GATConvE.N_SOURCES
+        sources = [t for layer in self.gnn_layers for t in layer.pack_sources()] + \
+                  [self.Vh.weight, self.Vh.bias, self.Vx.weight, self.Vx.bias, self.emb_score.weight, self.emb_score.bias]
+
+        def build(src):
+            outs = []
+            for l in range(self.k):
+                outs += GATConvE.pack_build(src[l * nsrc:(l + 1) * nsrc], L, JP)
+            Vhw, Vhb, Vxw, Vxb, Wes, bes = src[self.k * nsrc:]
+            Vh_t, Vh = _pad2(Vhw, L)
+            Vx_t, Vx = _pad2(Vxw, L)
+            Wes_t = F.pad(Wes.t(), (0, JP - h, 0, JP - h)).contiguous()
+            return outs + [Vh_t, Vh, Vx_t, Vx, L.pad(Vhb), L.pad(Vxb), Wes_t, Wes_t.t().contiguous(), F.pad(bes, (0, JP - h))]
+        packed = self._plan(sources, build)
+        npk = GATConvE.N_PACKED
+        return [packed[l * npk:(l + 1) * npk] for l in range(self.k)], packed[self.k * npk:]
+
+    def node_feature_extra(self, node_type_flat, node_score_flat, Wes_t, Wes, bes):
         """The two halves of node_feature_extra (:65-73, 86), kept apart: the T-row type-embedding table
         temb [T, d/2] (= GELU(Linear) of the T one-hots) and the per-node score embedding S [N, SP] (SP = d/2 rounded
         up to 16, pad columns are exactly 0)."""
-        h = self.hidden_size // 2
         dev = node_type_flat.device
         temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)
-        JP = ops.roundup(h, 16)
-        sinB = ops.kernels().sin_basis(node_score_flat.contiguous(), self._js_table(dev), JP)
-        Wes_t = F.pad(self.emb_score.weight.t(), (0, JP - h, 0, JP - h)).contiguous()  # [JP in, JP out]
-        Wes = Wes_t.t().contiguous()
-        pre = ops.linear_nn(sinB, Wes_t, Wes, bias=F.pad(self.emb_score.bias, (0, JP - h)))
+        sinB = ops.kernels().sin_basis(node_score_flat.contiguous(), self._js_table(dev), Wes_t.size(0))
+        pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
         return temb, ops.gelu_dropout(pre, 0.0, False)
 
     def forward(self, H, A, node_type, node_score, cache_output=False, graph=None):
@@ -264,15 +317,14 @@ class QAGNN_Message_Passing(nn.Module):
         ntype = node_type.reshape(-1).contiguous()
         if graph is None:
             graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype)
-        temb, S = self.node_feature_extra(ntype, node_score.reshape(-1))
+        per_layer, (Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes) = self.pack_all(L)
+        temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
         Hp = L.pad(H.reshape(bs * n, d))
         tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=self.k)
         Xp = Hp
-        for layer in self.gnn_layers:  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
-            Xp, _ = layer.hop(Xp, None, graph, tab, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S))
-        Vh_t, Vh = _pad2(self.Vh.weight, L)
-        Vx_t, Vx = _pad2(self.Vx.weight, L)
-        Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=L.pad(self.Vh.bias + self.Vx.bias))
+        for layer, pk in zip(self.gnn_layers, per_layer):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
+            Xp, _ = layer.hop(Xp, None, graph, tab, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S), packed=pk)
+        Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
         return L.unpad(out).view(bs, n, d)
 

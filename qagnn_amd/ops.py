@@ -53,15 +53,53 @@ class HeadLayout:
         self.pad_src = src.to(device)                      # [DP] dense index or -1
         self.valid = (src >= 0).to(device)
         self.dense_pos = torch.nonzero(src >= 0).flatten().to(device)  # [d] padded position of dense index k (ascending)
+        self.pad_idx = torch.where(src >= 0, src, torch.full_like(src, self.d)).to(device)  # pads read an appended zero column
 
     def pad(self, x):
         """[*, d] -> [*, DP] (zeros in the pads).  Differentiable torch gather."""
-        xe = torch.nn.functional.pad(x, (0, 1))
-        idx = torch.where(self.pad_src >= 0, self.pad_src, torch.full_like(self.pad_src, self.d))
-        return xe.index_select(-1, idx).contiguous()
+        return torch.nn.functional.pad(x, (0, 1)).index_select(-1, self.pad_idx).contiguous()
 
     def unpad(self, xp):
         return xp.index_select(-1, self.dense_pos)
+
+
+class GatherPlan:
+    """Pack many parameters into the kernels' operand layouts with ONE gather (and one index_add in backward).
+
+    The packing of a weight (slice, transpose, head-pad, concatenate) only moves elements.  The readable torch
+    packing code is therefore run ONCE on tensors holding element ids; the ids that come out are the gather index.
+    Afterwards a forward costs `torch.cat(sources)` + `index_select` instead of ~10 tiny kernels per weight.
+    """
+
+    def __init__(self):
+        self.sig = None
+
+    def __call__(self, sources, build):
+        sig = tuple((tuple(t.shape), str(t.device), t.dtype) for t in sources)
+        if sig != self.sig:
+            dev = sources[0].device
+            ids, off = [], 1
+            for t in sources:
+                ids.append((torch.arange(t.numel(), dtype=torch.float64, device=dev) + off).view(t.shape))
+                off += t.numel()
+            outs = build(ids)
+            total = off - 1  # index of the appended zero element
+            idx, self.slices, pos = [], [], 0
+            for o in outs:
+                i = o.reshape(-1).round().long() - 1
+                i = torch.where(i < 0, torch.full_like(i, total), i)
+                n = i.numel()
+                n4 = roundup(n, 4)  # keep every packed operand 16-byte aligned
+                if n4 != n:
+                    i = torch.cat([i, torch.full((n4 - n,), total, dtype=torch.long, device=dev)])
+                idx.append(i)
+                self.slices.append((pos, n, tuple(o.shape)))
+                pos += n4
+            self.idx = torch.cat(idx)
+            self.sig = sig
+        flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
+        packed = flat.index_select(0, self.idx)
+        return [packed[a:a + n].view(shape) for a, n, shape in self.slices]
 
 
 # ------------------------------------------------------------------------------------------------------------------
