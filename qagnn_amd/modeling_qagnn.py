@@ -47,10 +47,10 @@ def _pad2(W, L):
 _CLASS_FEATS = {}
 
 
-def edge_class_features(n_etype, n_ntype, device):
-    key = (n_etype, n_ntype, str(device))
+def edge_class_features(n_etype, n_ntype, device, dtype=torch.float32):
+    key = (n_etype, n_ntype, str(device), dtype)
     if key not in _CLASS_FEATS:
-        _CLASS_FEATS[key] = _edge_class_features(n_etype, n_ntype, device)
+        _CLASS_FEATS[key] = _edge_class_features(n_etype, n_ntype, device).to(dtype)
     return _CLASS_FEATS[key]
 
 
@@ -83,7 +83,7 @@ def edge_class_table(edge_encoder, graph, training, n_updates=1):
     calls the shared module once per layer, i.e. k times per forward of the stack).
     """
     lin1, bn, lin2 = edge_encoder[0], edge_encoder[1], edge_encoder[3]
-    feat = edge_class_features(graph.R, graph.T, lin1.weight.device)
+    feat = edge_class_features(graph.R, graph.T, lin1.weight.device, lin1.weight.dtype)
     h = F.linear(feat, lin1.weight, lin1.bias)
     if training or not bn.track_running_stats:
         Ep = float(graph.Ep)
