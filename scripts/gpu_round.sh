@@ -28,6 +28,7 @@ if [[ "$*" == *prof* ]]; then
   echo "prof exit $?" >> gpurun_out/summary.txt
   mkdir -p gpurun_out/prof
   find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
+  python scripts/trace_by_shape.py /tmp/prof/r1_kernel_trace.csv > gpurun_out/prof/by_shape.txt 2>&1
   ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
 fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
