@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   if (act && MODE == 2) { is = ld4(invstd + col); sc = ld4(scale + col); sh = ld4(shift + col); }
   if (act) {
     const int rend = min(R, r0 + 64);
+#pragma unroll 8
     for (int r = r0; r < rend; ++r) {
       const float4 x = ld4(X + (int64_t)r * ldx + col);
       if (MODE == 0) {
@@ -75,8 +76,10 @@ __global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict
   __shared__ float red[4][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
-  if (o < tot)
+  if (o < tot) {
+#pragma unroll 8
     for (int c = q; c < nchunks; c += 4) s += part[(int64_t)c * tot + o];
+  }
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
   if (q == 0 && o < tot) out[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TN_BM = 64;
 constexpr int PA_TN = 80;   // 64 + 16: rows k, k+1 of the k-major A tile land 16 banks apart
-constexpr int TN_RC = 1024; // rows per chunk
+constexpr int TN_RC = 512;  // rows per chunk (more, smaller chunks: 2+ blocks per CU for the 208x208 gradients)
 
 template <int NT, bool AFFINE>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 ra, rb[B_IT];
   const int akr = tid >> 4, ac4 = tid & 15;  // A tile: 16 rows x 16 float4
+  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;  // this thread's A columns never change: load the BN affine once
+  if (AFFINE && m0 + ac4 * 4 < Ka) { a_sc = ld4(a_scale + m0 + ac4 * 4); a_sh = ld4(a_shift + m0 + ac4 * 4); }
 
   auto gload = [&](int kt) {
     const int r0 = r_beg + kt * BK;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
       if (row < r_end && col < Ka) {
         v = ld4(A + (int64_t)row * lda + col);
         if (AFFINE) {
-          const float4 sc = ld4(a_scale + col), sh = ld4(a_shift + col);
+          const float4 sc = a_sc, sh = a_sh;
           v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
           v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
           v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);

@@ -63,43 +63,91 @@ class HeadLayout:
         return xp.index_select(-1, self.dense_pos)
 
 
+class _PlanGatherFn(torch.autograd.Function):
+    """outputs = split(cat(sources, 0)[idx]);  backward = K inverse gathers (no atomics, fixed order)."""
+
+    @staticmethod
+    def forward(ctx, plan, *sources):
+        flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
+        packed = flat.index_select(0, plan.idx)
+        ctx.plan = plan
+        ctx.src_shapes = [t.shape for t in sources]
+        return tuple(packed[a:a + n].view(shape) for a, n, shape in plan.slices)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        parts = []
+        for g, (a, n, shape), n4 in zip(grads, plan.slices, plan.padded):
+            parts.append(g.reshape(-1) if g is not None else plan.idx.new_zeros(n, dtype=plan.dtype))
+            if n4 != n:
+                parts.append(plan.idx.new_zeros(n4 - n, dtype=plan.dtype))
+        parts.append(plan.idx.new_zeros(1, dtype=plan.dtype))  # the slot missing multiplicities point to
+        gflat = torch.cat(parts)
+        gsrc = gflat.index_select(0, plan.inv[0])
+        for k in range(1, len(plan.inv)):
+            gsrc = gsrc + gflat.index_select(0, plan.inv[k])
+        out, off = [], 0
+        for shape in ctx.src_shapes:
+            n = 1
+            for v in shape:
+                n *= v
+            out.append(gsrc[off:off + n].view(shape))
+            off += n
+        return (None,) + tuple(out)
+
+
 class GatherPlan:
-    """Pack many parameters into the kernels' operand layouts with ONE gather (and one index_add in backward).
+    """Pack many parameters into the kernels' operand layouts with ONE gather (and a few inverse gathers in backward).
 
     The packing of a weight (slice, transpose, head-pad, concatenate) only moves elements.  The readable torch
     packing code is therefore run ONCE on tensors holding element ids; the ids that come out are the gather index.
-    Afterwards a forward costs `torch.cat(sources)` + `index_select` instead of ~10 tiny kernels per weight.
+    Afterwards a forward costs `torch.cat(sources)` + `index_select` instead of ~10 tiny kernels per weight, and the
+    backward gathers, for every source element, the gradients of the (at most K) packed positions it was copied to --
+    no atomics, fixed summation order.
     """
 
     def __init__(self):
         self.sig = None
 
+    def _build(self, sources, build):
+        dev = sources[0].device
+        ids, off = [], 1
+        for t in sources:
+            ids.append((torch.arange(t.numel(), dtype=torch.float64, device=dev) + off).view(t.shape))
+            off += t.numel()
+        outs = build(ids)
+        total = off - 1  # index of the appended zero element
+        idx, self.slices, self.padded, pos = [], [], [], 0
+        for o in outs:
+            i = o.reshape(-1).round().long() - 1
+            i = torch.where(i < 0, torch.full_like(i, total), i)
+            n = i.numel()
+            n4 = roundup(n, 4)  # keep every packed operand 16-byte aligned
+            if n4 != n:
+                i = torch.cat([i, torch.full((n4 - n,), total, dtype=torch.long, device=dev)])
+            idx.append(i)
+            self.slices.append((pos, n, tuple(o.shape)))
+            self.padded.append(n4)
+            pos += n4
+        self.idx = torch.cat(idx)
+        self.dtype = sources[0].dtype
+        # inverse map: for source element s, the packed positions holding a copy of it (missing -> position `pos`)
+        order = torch.sort(self.idx, stable=True).indices
+        counts = torch.bincount(self.idx, minlength=total + 1)[:total]
+        starts = torch.cumsum(counts, 0) - counts
+        K = int(counts.max().item()) if total > 0 else 1
+        self.inv = []
+        for k in range(max(K, 1)):
+            take = order[torch.clamp(starts + k, max=order.numel() - 1)]
+            self.inv.append(torch.where(counts > k, take, torch.full_like(take, pos)))
+
     def __call__(self, sources, build):
         sig = tuple((tuple(t.shape), str(t.device), t.dtype) for t in sources)
         if sig != self.sig:
-            dev = sources[0].device
-            ids, off = [], 1
-            for t in sources:
-                ids.append((torch.arange(t.numel(), dtype=torch.float64, device=dev) + off).view(t.shape))
-                off += t.numel()
-            outs = build(ids)
-            total = off - 1  # index of the appended zero element
-            idx, self.slices, pos = [], [], 0
-            for o in outs:
-                i = o.reshape(-1).round().long() - 1
-                i = torch.where(i < 0, torch.full_like(i, total), i)
-                n = i.numel()
-                n4 = roundup(n, 4)  # keep every packed operand 16-byte aligned
-                if n4 != n:
-                    i = torch.cat([i, torch.full((n4 - n,), total, dtype=torch.long, device=dev)])
-                idx.append(i)
-                self.slices.append((pos, n, tuple(o.shape)))
-                pos += n4
-            self.idx = torch.cat(idx)
+            self._build(sources, build)
             self.sig = sig
-        flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
-        packed = flat.index_select(0, self.idx)
-        return [packed[a:a + n].view(shape) for a, n, shape in self.slices]
+        return list(_PlanGatherFn.apply(self, *sources))
 
 
 # ------------------------------------------------------------------------------------------------------------------
