@@ -7,7 +7,8 @@
 
 namespace qagnn {
 
-constexpr int CR_ROWS = 256;  // rows per block (4 waves x 64 rows)
+constexpr int CR_ROWS = 128;  // rows per block (4 waves x 32 rows): >= 2 blocks per CU at N = 64 000
+constexpr int CR_WR = CR_ROWS / 4;
 
 // MODE 0: grouped column sums   MODE 1: sum (x-mean)^2   MODE 2: BN+ReLU backward reductions (2 outputs)
 template <int MODE>
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 256 + lane * 4;
   const bool act = col < Cc;
-  const int r0 = blockIdx.y * CR_ROWS + w * 64;
+  const int r0 = blockIdx.y * CR_ROWS + w * CR_WR;
   float4 acc[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -29,32 +30,44 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   if (act && MODE >= 1) mu = ld4(mean + col);
   if (act && MODE == 2) { is = ld4(invstd + col); sc = ld4(scale + col); sh = ld4(shift + col); }
   if (act) {
-    const int rend = min(R, r0 + 64);
-#pragma unroll 8
-    for (int r = r0; r < rend; ++r) {
-      const float4 x = ld4(X + (int64_t)r * ldx + col);
-      if (MODE == 0) {
-        const int g = rowidx ? (int)rowidx[r] : 0;
-        // wave-uniform branch: every lane of the wave is on the same row
-        if (g == 0) acc[0] = add4(acc[0], x);
-        else if (g == 1) acc[1] = add4(acc[1], x);
-        else if (g == 2) acc[2] = add4(acc[2], x);
-        else acc[3] = add4(acc[3], x);
-      } else if (MODE == 1) {
-        const float4 d = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
-        acc[0] = make_float4(fmaf(d.x, d.x, acc[0].x), fmaf(d.y, d.y, acc[0].y), fmaf(d.z, d.z, acc[0].z), fmaf(d.w, d.w, acc[0].w));
-      } else {
-        const float4 h = ld4(X2 + (int64_t)r * ldx2 + col);
-        float4 dy;
-        dy.x = fmaf(h.x, sc.x, sh.x) > 0.f ? x.x : 0.f;
-        dy.y = fmaf(h.y, sc.y, sh.y) > 0.f ? x.y : 0.f;
-        dy.z = fmaf(h.z, sc.z, sh.z) > 0.f ? x.z : 0.f;
-        dy.w = fmaf(h.w, sc.w, sh.w) > 0.f ? x.w : 0.f;
-        acc[0] = add4(acc[0], dy);
-        acc[1].x = fmaf(dy.x, (h.x - mu.x) * is.x, acc[1].x);
-        acc[1].y = fmaf(dy.y, (h.y - mu.y) * is.y, acc[1].y);
-        acc[1].z = fmaf(dy.z, (h.z - mu.z) * is.z, acc[1].z);
-        acc[1].w = fmaf(dy.w, (h.w - mu.w) * is.w, acc[1].w);
+    const int rend = min(R, r0 + CR_WR);
+    // 8 rows per step: the 8 (16 in mode 2) row loads are issued back to back before any of them is consumed
+    for (int rb = r0; rb < rend; rb += 8) {
+      float4 xs[8], hs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = min(rb + u, rend - 1);
+        xs[u] = ld4(X + (int64_t)r * ldx + col);
+        if (MODE == 2) hs[u] = ld4(X2 + (int64_t)r * ldx2 + col);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + u;
+        if (r >= rend) break;
+        const float4 x = xs[u];
+        if (MODE == 0) {
+          const int g = rowidx ? (int)rowidx[r] : 0;
+          // wave-uniform branch: every lane of the wave is on the same row
+          if (g == 0) acc[0] = add4(acc[0], x);
+          else if (g == 1) acc[1] = add4(acc[1], x);
+          else if (g == 2) acc[2] = add4(acc[2], x);
+          else acc[3] = add4(acc[3], x);
+        } else if (MODE == 1) {
+          const float4 d = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
+          acc[0] = make_float4(fmaf(d.x, d.x, acc[0].x), fmaf(d.y, d.y, acc[0].y), fmaf(d.z, d.z, acc[0].z), fmaf(d.w, d.w, acc[0].w));
+        } else {
+          const float4 h = hs[u];
+          float4 dy;
+          dy.x = fmaf(h.x, sc.x, sh.x) > 0.f ? x.x : 0.f;
+          dy.y = fmaf(h.y, sc.y, sh.y) > 0.f ? x.y : 0.f;
+          dy.z = fmaf(h.z, sc.z, sh.z) > 0.f ? x.z : 0.f;
+          dy.w = fmaf(h.w, sc.w, sh.w) > 0.f ? x.w : 0.f;
+          acc[0] = add4(acc[0], dy);
+          acc[1].x = fmaf(dy.x, (h.x - mu.x) * is.x, acc[1].x);
+          acc[1].y = fmaf(dy.y, (h.y - mu.y) * is.y, acc[1].y);
+          acc[1].z = fmaf(dy.z, (h.z - mu.z) * is.z, acc[1].z);
+          acc[1].w = fmaf(dy.w, (h.w - mu.w) * is.w, acc[1].w);
+        }
       }
     }
   }

@@ -29,8 +29,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;                 // float4 per B tile
   constexpr int B_IT = (B_F4 + 255) / 256;
-  __shared__ float As[NN_BM * PA_NN];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * PB];
+  // one LDS array: the k-loop tiles (A 128 x 17, B 16 x PB) and, afterwards, the epilogue staging area (4 waves x 16 x PS)
+  constexpr int PS = BN + 4;                        // staging pitch: PS % 8 == 4 -> the 4 row groups of a store land 16 banks apart
+  constexpr int KLOOP_F = NN_BM * PA_NN + 4 + BK * PB, STAGE_F = 4 * 16 * PS;
+  __shared__ __attribute__((aligned(16))) float smem[KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F];
+  float* const As = smem;
+  float* const Bs = smem + ((NN_BM * PA_NN + 3) & ~3);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // column blocks of one row block are adjacent in blockIdx -> they share the A rows through one XCD's L2 when
@@ -119,25 +123,33 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
     __syncthreads();
   }
 
-  // epilogue: lane holds column (lane & 15) of 4 consecutive rows per accumulator
+  // epilogue.  The MFMA layout gives a lane ONE column of 4 rows per accumulator; storing that directly is 104 dword
+  // stores per lane in 64-byte row fragments (store-issue bound, and in a single-round grid nothing overlaps it).
+  // Instead each wave transposes one 16-row tile at a time through its private LDS slab and writes whole rows with
+  // 16-byte lanes: 4x fewer store instructions, full 128-byte lines.
+  float* const St = smem + w * 16 * PS;
+  constexpr int ROW_F4 = BN / 4, TILE_F4 = 16 * ROW_F4, ST_IT = (TILE_F4 + 63) / 64;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    __syncthreads();  // k-loop reads (i = 0) / previous tile's row reads (i = 1) are done before the slab is overwritten
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + w * 32 + i * 16 + (lane >> 4) * 4 + r;
-      if (row >= a.M) continue;
-      const float* trow = a.rowtab ? a.rowtab + (int64_t)a.rowidx[row] * a.ldt : nullptr;
-      float* crow = a.C + (int64_t)row * a.ldc;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + j * 16 + (lane & 15);
-        if (col >= a.No) continue;
-        float v = acc[i][j][r];
-        if (a.bias) v += a.bias[col];
-        if (trow) v += trow[col];
-        if (a.accumulate) v += crow[col];
-        crow[col] = v;
-      }
+      for (int r = 0; r < 4; ++r) St[((lane >> 4) * 4 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ST_IT; ++it) {
+      const int idx = lane + it * 64;
+      if (idx >= TILE_F4) break;
+      const int lr = idx / ROW_F4, c4 = idx % ROW_F4;
+      const int row = m0 + w * 32 + i * 16 + lr, col = n0 + c4 * 4;
+      if (row >= a.M || col >= a.No) continue;
+      float4 v = ld4(St + lr * PS + c4 * 4);
+      if (a.bias) v = add4(v, ld4(a.bias + col));
+      if (a.rowtab) v = add4(v, ld4(a.rowtab + (int64_t)a.rowidx[row] * a.ldt + col));
+      float* dst = a.C + (int64_t)row * a.ldc + col;
+      if (a.accumulate) v = add4(v, ld4(dst));
+      st4(dst, v);
     }
   }
 }
@@ -249,6 +261,7 @@ __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C,
   if (i >= (int64_t)Ka * No) return;
   const int row = (int)(i / No), col = (int)(i % No);
   float s = 0.f;
+#pragma unroll 8
   for (int c = 0; c < nchunks; ++c) s += P[(int64_t)c * Ka * No + i];
   float* d = C + (int64_t)row * ldc + col;
   *d = accumulate ? *d + s : s;
@@ -303,6 +316,9 @@ extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t str
   QAGNN_REQUIRE(a->K2 == 0 || (a->A2 && a->B2 && a->lda2 % 4 == 0 && a->ldb2 % 4 == 0 && aligned16(a->A2) && aligned16(a->B2)),
                 QAGNN_EINVAL, "gemm_nn: operand 2 must be 16-byte aligned with pitches multiple of 4");
   QAGNN_REQUIRE(!a->rowtab || a->rowidx, QAGNN_EINVAL, "gemm_nn: rowtab without rowidx");
+  QAGNN_REQUIRE(a->ldc % 4 == 0 && aligned16(a->C) && (!a->bias || aligned16(a->bias)) &&
+                    (!a->rowtab || (aligned16(a->rowtab) && a->ldt % 4 == 0)),
+                QAGNN_EINVAL, "gemm_nn: C / bias / rowtab must be 16-byte aligned with pitches multiple of 4");
   QAGNN_REQUIRE(!a->a_scale || (a->a_shift && aligned16(a->a_scale) && aligned16(a->a_shift)), QAGNN_EINVAL,
                 "gemm_nn: a_scale/a_shift must both be given and 16-byte aligned");
   switch (pick_nt(a->No)) {
