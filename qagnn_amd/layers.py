@@ -128,7 +128,9 @@ class CustomizedEmbedding(nn.Module):
             if hasattr(self, 'cpt_transform'):
                 e = self.activation(self.cpt_transform(e))
             return e.gather(1, index.unsqueeze(-1).expand(-1, -1, e.size(-1)))
-        e = self.emb(index) * self.scale
+        e = self.emb(index)
+        if self.scale != 1.0:  # the reference always multiplies; at the default scale 1.0 that is a 260 MB no-op pass
+            e = e * self.scale
         if hasattr(self, 'cpt_transform'):
             e = self.activation(self.cpt_transform(e))
         return e

@@ -218,8 +218,8 @@ class GATConvE(nn.Module):
             with torch.no_grad():
                 R = float(Xp.size(0))
                 m = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.mul_(1 - m).add_(m * L.unpad(mean_p))
-                bn.running_var.mul_(1 - m).add_(m * L.unpad(var_p) * (R / max(R - 1.0, 1.0)))
+                bn.running_mean.lerp_(L.unpad(mean_p), m)
+                bn.running_var.lerp_(L.unpad(var_p) * (R / max(R - 1.0, 1.0)), m)
                 bn.num_batches_tracked += 1
         return y, a
 

@@ -78,11 +78,12 @@ class _PlanGatherFn(torch.autograd.Function):
     def backward(ctx, *grads):
         plan = ctx.plan
         parts = []
+        z = plan.zeros  # cached zeros: operands that received no gradient (the non-transposed weight copies) cost no fill kernel
         for g, (a, n, shape), n4 in zip(grads, plan.slices, plan.padded):
-            parts.append(g.reshape(-1) if g is not None else plan.idx.new_zeros(n, dtype=plan.dtype))
+            parts.append(g.reshape(-1) if g is not None else z[:n])
             if n4 != n:
-                parts.append(plan.idx.new_zeros(n4 - n, dtype=plan.dtype))
-        parts.append(plan.idx.new_zeros(1, dtype=plan.dtype))  # the slot missing multiplicities point to
+                parts.append(z[:n4 - n])
+        parts.append(z[:1])  # the slot missing multiplicities point to
         gflat = torch.cat(parts)
         gsrc = gflat.index_select(0, plan.inv[0])
         for k in range(1, len(plan.inv)):
@@ -132,6 +133,7 @@ class GatherPlan:
             pos += n4
         self.idx = torch.cat(idx)
         self.dtype = sources[0].dtype
+        self.zeros = torch.zeros(max(self.padded) + 1, dtype=self.dtype, device=dev)
         # inverse map: for source element s, the packed positions holding a copy of it (missing -> position `pos`)
         order = torch.sort(self.idx, stable=True).indices
         counts = torch.bincount(self.idx, minlength=total + 1)[:total]

@@ -31,6 +31,17 @@ if [[ "$*" == *prof* ]]; then
   python scripts/trace_by_shape.py /tmp/prof/r1_kernel_trace.csv > gpurun_out/prof/by_shape.txt 2>&1
   ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
 fi
+if [[ "$*" == *pmc* ]]; then
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$ctr; mkdir -p /tmp/pmc_$ctr
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) 2>&1 | tail -n 5 > gpurun_out/pmc_$ctr.log
+    python scripts/pmc_by_kernel.py /tmp/pmc_$ctr/p_counter_collection.csv > gpurun_out/pmc_$ctr.txt 2>&1
+    ls /tmp/pmc_$ctr >> gpurun_out/pmc_$ctr.log
+  done
+fi
+if [[ "$*" == *mfma* ]]; then
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
+fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
 cat gpurun_out/summary.txt
 du -sh gpurun_out
