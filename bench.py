@@ -198,6 +198,11 @@ def main():
         alg_fwd = Ep * 2410 + N * 800
         alg_bwd = Ep * 5610 + N * 800
         achieved = alg_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the committed PMC passes (same workload); cannot be read live
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_edge_fwd.json')
+        if os.path.exists(pmc_path) and B == 320:
+            with open(pmc_path) as f:
+                traffic = json.load(f)['traffic_bytes_per_launch']
         out = {
             'metric': 'QA-subgraphs/sec (batch x num_choice) fwd+bwd', 'value': round(B * world * args.steps / dt, 1),
             'unit': 'QA-subgraphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -210,7 +215,8 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores + k_edge_softmax + k_edge_aggregate), per GAT layer',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
+                         'traffic': traffic, 'traffic_source': 'profiles/pmc_edge_fwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)' if traffic else None,
+                         'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
                          'launches_timed': n_fwd,
                          'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
                                       'achieved': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0}},
