@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;        // k-tile
 constexpr int NN_BM = 128;    // rows per block (4 waves x 2 row tiles of 16)
-constexpr int PA_NN = BK + 1; // LDS pitch of the row-major A tile: odd -> conflict-free column reads
+constexpr int PA_NN = BK + 4; // LDS pitch of the row-major A tile: 16-byte aligned rows (ds_write_b128), 2-way on the 2 A reads per k-step
 
 __host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn : bn + 16; }  // rows k, k+1 land 16 banks apart
 
@@ -31,10 +31,9 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
   constexpr int B_IT = (B_F4 + 255) / 256;
   // one LDS array: the k-loop tiles (A 128 x 17, B 16 x PB) and, afterwards, the epilogue staging area (4 waves x 16 x PS)
   constexpr int PS = BN + 4;                        // staging pitch: PS % 8 == 4 -> the 4 row groups of a store land 16 banks apart
-  constexpr int KLOOP_F = NN_BM * PA_NN + 4 + BK * PB, STAGE_F = 4 * 16 * PS;
+  constexpr int A_F = NN_BM * PA_NN, B_F = BK * PB, BUF_F = A_F + B_F;  // one k-tile: A 128 x 20, B 16 x PB
+  constexpr int KLOOP_F = 2 * BUF_F, STAGE_F = 4 * 16 * PS;              // double-buffered k-tiles | epilogue slabs
   __shared__ __attribute__((aligned(16))) float smem[KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F];
-  float* const As = smem;
-  float* const Bs = smem + ((NN_BM * PA_NN + 3) & ~3);
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // column blocks of one row block are adjacent in blockIdx -> they share the A rows through one XCD's L2 when
@@ -87,12 +86,11 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
       rb[it] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    float* As = smem + buf * BUF_F;
+    float* Bs = As + A_F;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float* d = As + (ar + p * 64) * PA_NN + ac4 * 4;
-      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
-    }
+    for (int p = 0; p < 2; ++p) st4(As + (ar + p * 64) * PA_NN + ac4 * 4, ra[p]);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int idx = tid + it * 256;
@@ -102,24 +100,33 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
       }
     }
   };
-
-  gload(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nkt) gload(kt + 1);  // next tile's HBM/L2 latency hides under this tile's MFMAs
-    const float* Aw = As + (w * 32 + (lane & 15)) * PA_NN + (lane >> 4);
-    const float* Bw = Bs + (lane >> 4) * PB + (lane & 15);
+  auto mma = [&](int buf, int kk) {
+    const float* Aw = smem + buf * BUF_F + (w * 32 + (lane & 15)) * PA_NN + (lane >> 4);
+    const float* Bw = smem + buf * BUF_F + A_F + (lane >> 4) * PB + (lane & 15);
+    const float a0 = Aw[kk * 4], a1 = Aw[16 * PA_NN + kk * 4];
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const float a0 = Aw[kk * 4], a1 = Aw[16 * PA_NN + kk * 4];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float b = Bw[kk * 4 * PB + j * 16];
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
-      }
+    for (int j = 0; j < NT; ++j) {
+      const float b = Bw[kk * 4 * PB + j * 16];
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
     }
+  };
+
+  // double-buffered k-loop, ONE barrier per k-tile: tile t+1 travels global -> registers while tile t's first two k-steps
+  // run, is written to the other LDS buffer between k-steps (so the ds_writes hide under MFMAs), and becomes visible at
+  // the barrier that also retires everybody's reads of tile t.
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) gload(kt + 1);
+    mma(cur, 0);
+    mma(cur, 1);
+    if (more) lstore(cur ^ 1);
+    mma(cur, 2);
+    mma(cur, 3);
     __syncthreads();
   }
 
@@ -170,8 +177,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;
   constexpr int B_IT = (B_F4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float As[BK * PA_TN];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * PB];
+  constexpr int TA_F = BK * PA_TN, TBUF_F = TA_F + BK * PB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * TBUF_F];  // double-buffered k-tiles, one barrier per tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * TN_BM, chunk = blockIdx.z;
   const int r_beg = chunk * TN_RC, r_end = min(R, r_beg + TN_RC);
@@ -214,7 +221,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
       rb[it] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    float* As = smem + buf * TBUF_F;
+    float* Bs = As + TA_F;
     st4(As + akr * PA_TN + ac4 * 4, ra);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -225,21 +234,29 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
       }
     }
   };
+  auto mma = [&](int buf, int kk) {
+    const float* Aw = smem + buf * TBUF_F + (lane >> 4) * PA_TN + w * 16 + (lane & 15);
+    const float* Bw = smem + buf * TBUF_F + TA_F + (lane >> 4) * PB + (lane & 15);
+    const float av = Aw[kk * 4 * PA_TN];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bw[kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
+  };
 
-  if (nkt > 0) gload(0);
+  if (nkt > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nkt) gload(kt + 1);
-    const float* Aw = As + (lane >> 4) * PA_TN + w * 16 + (lane & 15);
-    const float* Bw = Bs + (lane >> 4) * PB + (lane & 15);
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const float av = Aw[kk * 4 * PA_TN];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bw[kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
-    }
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+    if (more) gload(kt + 1);
+    mma(cur, 0);
+    mma(cur, 1);
+    if (more) lstore(cur ^ 1);
+    mma(cur, 2);
+    mma(cur, 3);
     __syncthreads();
   }
   float* Pc = P + (int64_t)chunk * Ka * No;
