@@ -101,6 +101,8 @@ typedef struct qagnn_gemm_nn_args {
   const int64_t* rowidx;             /* [M] row -> table row (node_type ids are int64 in the reference) */
   const float* a_scale; const float* a_shift; /* [K1] or NULL; applies to A1 only */
   int32_t accumulate;                /* 1: C += result */
+  const int64_t* a_rowidx;           /* [M] or NULL: row m of A1 is A1[a_rowidx[m]] (embedding-table gather fused into the
+                                        operand load, utils/layers.py:604-605); a negative index reads a zero row */
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 
@@ -108,6 +110,7 @@ int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);
 int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t Ka,
                       int32_t No, const float* a_scale, const float* a_shift /* BN+ReLU prologue on A, or NULL */,
+                      const int64_t* a_rowidx /* [R] or NULL: row r of A is A[a_rowidx[r]], negative = zero row */,
                       int32_t accumulate, float* workspace, qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('A2', _vp), ('lda2', _i32), ('K2', _i32), ('B2', _vp), ('ldb2', _i32),
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
-                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32)]
+                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp)]
 
 
 def load_library(path=LIB_PATH):
@@ -50,7 +50,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
-    lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]
+    lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -137,9 +137,10 @@ class HipKernels:
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False):
+                out=None, accumulate=False, a_rowidx=None):
         _chk2d(A1, 'A1'), _chk2d(B1, 'B1')
-        M, K1 = A1.shape
+        K1 = A1.size(1)
+        M = A1.size(0) if a_rowidx is None else a_rowidx.numel()
         No = B1.size(1)
         assert B1.size(0) == K1
         a = qagnn_gemm_nn_args()
@@ -166,20 +167,23 @@ class HipKernels:
             assert a_scale.numel() == K1 and a_shift.numel() == K1 and a_scale.is_contiguous() and a_shift.is_contiguous()
             a.a_scale, a.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
         a.accumulate = 1 if accumulate else 0
+        if a_rowidx is not None:
+            assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
+            a.a_rowidx = a_rowidx.data_ptr()
         self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')
         return out
 
-    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False):
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None):
         _chk2d(A, 'A'), _chk2d(B, 'B')
-        R, Ka = A.shape
-        No = B.size(1)
-        assert B.size(0) == R
+        Ka = A.size(1)
+        R, No = B.shape
+        assert (A.size(0) == R) if a_rowidx is None else (a_rowidx.numel() == R and a_rowidx.dtype == torch.long)
         if out is None:
             assert not accumulate
             out = torch.empty((Ka, No), dtype=torch.float32, device=A.device)
         ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka, No), dtype=torch.float32, device=A.device)
         rc = self.lib.qagnn_gemm_tn_f32(A.data_ptr(), Ka, B.data_ptr(), No, out.data_ptr(), No, R, Ka, No, _ptr(a_scale),
-                                        _ptr(a_shift), 1 if accumulate else 0, ws.data_ptr(), self._stream())
+                                        _ptr(a_shift), _ptr(a_rowidx), 1 if accumulate else 0, ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_gemm_tn_f32')
         return out
 

@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
   float4 ra[2];
   float4 rb[B_IT];
   const int ar = tid >> 2, ac4 = tid & 3;  // A tile: 64 rows x 4 float4 per pass, 2 passes
+  int64_t arow[2];                         // source row of A1 for this thread's two tile rows (gathered or identity); -1 = zero row
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = m0 + ar + p * 64;
+    arow[p] = row < a.M ? (a.a_rowidx ? a.a_rowidx[row] : (int64_t)row) : -1;
+  }
 
   auto gload = [&](int kt) {
     const bool first = kt < nk1;
@@ -61,9 +67,10 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = m0 + ar + p * 64;
+      const int64_t srow = first ? arow[p] : (row < a.M ? (int64_t)row : -1);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < a.M) {
-        v = ld4(A + (int64_t)row * lda + k0 + ac4 * 4);
+      if (srow >= 0) {
+        v = ld4(A + srow * lda + k0 + ac4 * 4);
         if (AFFINE && first) {
           const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
           v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
@@ -172,7 +179,7 @@ constexpr int TN_RC = 512;  // rows per chunk (more, smaller chunks: 2+ blocks p
 template <int NT, bool AFFINE>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                  float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
-                                                 const float* __restrict__ a_shift) {
+                                                 const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx) {
   constexpr int BN = NT * 16;
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;
@@ -197,8 +204,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     {
       const int row = r0 + akr, col = m0 + ac4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < r_end && col < Ka) {
-        v = ld4(A + (int64_t)row * lda + col);
+      const int64_t srow = (row < r_end && col < Ka) ? (a_rowidx ? a_rowidx[row] : (int64_t)row) : -1;
+      if (srow >= 0) {
+        v = ld4(A + srow * lda + col);
         if (AFFINE) {
           const float4 sc = a_sc, sh = a_sh;
           v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
@@ -295,10 +303,10 @@ static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
 
 template <int NT>
 static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
-                     const float* sh, int nchunks, hipStream_t stream) {
+                     const float* sh, const int64_t* ridx, int nchunks, hipStream_t stream) {
   dim3 grid(cdiv(No, NT * 16), cdiv(Ka, TN_BM), nchunks);
-  if (sc) k_gemm_tn<NT, true><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh);
-  else k_gemm_tn<NT, false><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh);
+  if (sc) k_gemm_tn<NT, true><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
+  else k_gemm_tn<NT, false><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
   QAGNN_LAUNCH_CHECK("k_gemm_tn");
   return QAGNN_OK;
 }
@@ -352,8 +360,8 @@ extern "C" int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t 
 }
 
 extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
-                                 int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, int32_t accumulate,
-                                 float* workspace, qagnn_stream_t stream_) {
+                                 int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx,
+                                 int32_t accumulate, float* workspace, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(A && B && C && workspace, QAGNN_EINVAL, "gemm_tn: null pointer");
   QAGNN_REQUIRE(R > 0 && Ka > 0 && No > 0 && Ka % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
@@ -365,11 +373,11 @@ extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, in
   const int nchunks = cdiv(R, TN_RC);
   int rc;
   switch (pick_nt(No)) {
-    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
-    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
-    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
-    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
-    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, nchunks, stream); break;
+    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
+    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
+    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
+    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
+    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
   }
   if (rc != QAGNN_OK) return rc;
   const int64_t tot = (int64_t)Ka * No;

@@ -304,11 +304,12 @@ class QAGNN_Message_Passing(nn.Module):
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
         return temb, ops.gelu_dropout(pre, 0.0, False)
 
-    def forward(self, H, A, node_type, node_score, cache_output=False, graph=None):
+    def forward(self, H, A, node_type, node_score, cache_output=False, graph=None, padded_input=False):
         """
         H: (batch_size, n_node, d_node) node features;  A: (edge_index [2, E], edge_type [E]) of the batched graph
         node_type: long (batch_size, n_node): 0 question entity, 1 answer entity, 2 other, 3 context node
         node_score: (batch_size, n_node, 1)
+        padded_input: H is already the head-padded [batch_size * n_node, DP] matrix (QAGNN's fused input stage)
         """
         bs, n = node_type.size()
         d = self.hidden_size
@@ -319,7 +320,7 @@ class QAGNN_Message_Passing(nn.Module):
             graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype)
         per_layer, (Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes) = self.pack_all(L)
         temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
-        Hp = L.pad(H.reshape(bs * n, d))
+        Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
         tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=self.k)
         Xp = Hp
         for layer, pk in zip(self.gnn_layers, per_layer):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
@@ -368,9 +369,21 @@ class QAGNN(nn.Module):
         """
         dev = node_type_ids.device
         n = node_type_ids.size(1)
-        gnn_input0 = self.activation(self.svec2nvec(sent_vecs)).unsqueeze(1)
-        gnn_input1 = self.concept_emb(concept_ids[:, 1:] - 1, emb_data).to(dev)
-        gnn_input = self.dropout_e(torch.cat([gnn_input0, gnn_input1], dim=1))
+        ce = self.concept_emb
+        fused_input = (emb_data is None and not ce.use_contextualized and hasattr(ce, 'cpt_transform') and ce.scale == 1.0
+                       and not ce.emb.weight.requires_grad and ce.emb.weight.size(1) % 16 == 0)
+        if fused_input:
+            # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout
+            L = head_layout(self.concept_dim, dev)
+            ridx = concept_ids - 1
+            ridx[:, 0] = -1  # context-node rows take svec2nvec(sent_vecs) instead of an entity embedding
+            gnn_input = ops.concept_input(ce.emb.weight, ridx.reshape(-1).contiguous(), L.pad(ce.cpt_transform.weight.t()),
+                                          L.pad(ce.cpt_transform.bias), L.pad(self.svec2nvec(sent_vecs)), n,
+                                          self.dropout_e.p, self.training)
+        else:
+            gnn_input0 = self.activation(self.svec2nvec(sent_vecs)).unsqueeze(1)
+            gnn_input1 = self.concept_emb(concept_ids[:, 1:] - 1, emb_data).to(dev)
+            gnn_input = self.dropout_e(torch.cat([gnn_input0, gnn_input1], dim=1))
 
         # node-score normalisation (:160-167): negate, subtract the context node's score, mask PAD, / mean |.|
         ar = torch.arange(n, device=dev)
@@ -380,7 +393,7 @@ class QAGNN(nn.Module):
         mean_norm = node_scores.abs().sum(dim=1) / adj_lengths
         node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
 
-        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores)
+        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, padded_input=fused_input)
         Z_vecs = gnn_output[:, 0]
         mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
         mask[mask.all(1), 0] = 0  # never mask every node (:177)

@@ -302,4 +302,41 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
                           next_seed() if p > 0 else 0, apply_act)
 
 
+class ConceptInputFn(torch.autograd.Function):
+    """Node features entering the GNN, fused (reference modeling_qagnn.py:153-156 + utils/layers.py:604-605):
+
+        Hp = dropout_e( gelu( [ ctx_pre[g] ; emb[concept_ids[g, 1:] - 1] @ Wc^T + bc ] ) )        head-padded [N, DP]
+
+    The frozen entity-table gather is folded into the GEMM's operand load (`a_rowidx`), so the [N, concept_in_dim]
+    gathered matrix (260 MB at the CSQA batch) is never materialised; `rowidx` is -1 on the context-node rows, whose
+    pre-activation `ctx_pre` = svec2nvec(sent_vecs) is written in instead.  The table receives no gradient (frozen,
+    freeze_ent_emb=True is the only mode this path takes)."""
+
+    @staticmethod
+    def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed):
+        K = kernels()
+        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx)
+        B = ctx_pre.size(0)
+        pre.view(B, n, -1)[:, 0] = ctx_pre
+        ctx.save_for_backward(emb_w, rowidx, pre)
+        ctx.cfg = (n, p, seed)
+        return K.gelu_dropout_fwd(pre, p, seed)
+
+    @staticmethod
+    def backward(ctx, dHp):
+        K = kernels()
+        emb_w, rowidx, pre = ctx.saved_tensors
+        n, p, seed = ctx.cfg
+        dpre = K.gelu_dropout_bwd(pre, dHp.contiguous(), p, seed)
+        dctx = dpre.view(-1, n, dpre.size(1))[:, 0].contiguous()
+        dWc_t = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx) if ctx.needs_input_grad[2] else None
+        dbc = (K.colsum(dpre)[0] - dctx.sum(0)) if ctx.needs_input_grad[3] else None
+        return None, None, dWc_t, dbc, dctx, None, None, None
+
+
+def concept_input(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, training):
+    p = float(p) if training else 0.0
+    return ConceptInputFn.apply(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, next_seed() if p > 0 else 0)
+
+
 QSCALE = lambda dh: 1.0 / math.sqrt(dh)  # noqa: E731  (query / sqrt(dim_per_head), modeling_qagnn.py:469)

@@ -79,8 +79,15 @@ class EmuKernels:
     def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype):
         return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype)
 
+    @staticmethod
+    def _gather_rows(A, idx):
+        if idx is None:
+            return A
+        return A[idx.clamp(min=0)] * (idx >= 0).to(A.dtype).unsqueeze(1)
+
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False):
+                out=None, accumulate=False, a_rowidx=None):
+        A1 = self._gather_rows(A1, a_rowidx)
         if a_scale is not None:
             A1 = torch.relu(A1 * a_scale + a_shift)
         C = A1 @ B1
@@ -98,7 +105,8 @@ class EmuKernels:
             return out
         return C
 
-    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False):
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None):
+        A = self._gather_rows(A, a_rowidx)
         if a_scale is not None:
             A = torch.relu(A * a_scale + a_shift)
         C = A.t() @ B

@@ -152,6 +152,30 @@ def test_gemm_tn(R, Ka, No, affine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,V,K,No', [(3000, 500, 1024, 208), (129, 7, 32, 32), (20000, 100000, 1024, 208)])
+def test_gemm_with_fused_row_gather(M, V, K, No):
+    """A-operand rows gathered from an embedding table inside the GEMM (a_rowidx), -1 = zero row; forward (NN) and
+    weight gradient (TN)."""
+    g = torch.Generator().manual_seed(M + V)
+    table = torch.randn(V, K, generator=g)
+    idx = torch.randint(0, V, (M,), generator=g)
+    idx[::17] = -1
+    B = torch.randn(K, No, generator=g)
+    dC = torch.randn(M, No, generator=g)
+    bias = torch.randn(No, generator=g)
+    K_ = hip()
+    got = K_.gemm_nn(table.cuda(), B.cuda(), bias=bias.cuda(), a_rowidx=idx.cuda()).cpu()
+    Ag = EMU._gather_rows(table.double(), idx)
+    ref = Ag @ B.double() + bias.double()
+    err = (got.double() - ref).abs()
+    assert bool((err <= _bound(Ag.abs(), B.abs().double()) + 4 * EPS * ref.abs()).all()), err.max().item()
+    got = K_.gemm_tn(table.cuda(), dC.cuda(), a_rowidx=idx.cuda()).cpu()
+    ref = Ag.t() @ dC.double()
+    err = (got.double() - ref).abs()
+    assert bool((err <= 16 * EPS * (Ag.abs().t() @ dC.abs().double()) + 1e-6).all()), err.max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('R,C', [(1000, 208), (64000, 208), (257, 624), (5, 32)])
 def test_column_reductions_and_bn_backward(R, C):
     g = torch.Generator().manual_seed(R * 7 + C)
