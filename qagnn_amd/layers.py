@@ -87,18 +87,34 @@ class MultiheadAttPoolLayer(nn.Module):
         self.attention = MatrixVectorScaledDotProductAttention(temperature=math.sqrt(self.d_k))
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, q, k, mask=None):
-        """q [b, d_q], k [b, l, d_k], mask [b, l] -> (pooled [b, n_head*d_v], attn [n_head*b, l] head-major)."""
+    def forward(self, q, k, mask=None, layout=None):
+        """q [b, d_q], k [b, l, d_k], mask [b, l] -> (pooled [b, n_head*d_v], attn [n_head*b, l] head-major).
+
+        Same function as the reference (utils/layers.py:344-371), re-associated so that the two [b*l, d] x [d, d]
+        projections of the node matrix disappear: with qs = w_qs(q),
+            score[b,h,l] = <qs[b,h], Wk_h k[b,l] + bk_h> = <Wk_h^T qs[b,h], k[b,l]> + <qs[b,h], bk_h>
+            out[b,h]     = sum_l attn[b,h,l] (Wv_h k[b,l] + bv_h) = Wv_h (sum_l attn[b,h,l] k[b,l]) + bv_h sum_l attn[b,h,l]
+        i.e. project the QUERY back through w_ks (a [b, n_head, d] matrix) and pool the raw node rows first; the node
+        matrix is only read by two skinny batched mat-vec products.  `layout` (ops.HeadLayout): k is the head-padded
+        [b, l, DP] output of the GNN stack and is consumed as is (pads are zero)."""
         nh, dk, dv = self.n_head, self.d_k, self.d_v
         b, l = k.size(0), k.size(1)
-        qs = self.w_qs(q).view(b, nh, dk).transpose(0, 1).reshape(nh * b, dk)
-        ks = self.w_ks(k).view(b, l, nh, dk).permute(2, 0, 1, 3).reshape(nh * b, l, dk)
-        vs = self.w_vs(k).view(b, l, nh, dv).permute(2, 0, 1, 3).reshape(nh * b, l, dv)
+        qs = self.w_qs(q).view(b, nh, dk)
+        Wk = self.w_ks.weight.view(nh, dk, -1)
+        u = torch.einsum('bhk,hkd->bhd', qs, Wk)                                   # query seen from node space
+        c = torch.einsum('bhk,hk->bh', qs, self.w_ks.bias.view(nh, dk))
+        if layout is not None:
+            u = layout.pad(u)
+        scores = (torch.bmm(u, k.transpose(1, 2)) + c.unsqueeze(2)) / self.attention.temperature  # [b, nh, l]
         if mask is not None:
-            mask = mask.repeat(nh, 1)
-        out, attn = self.attention(qs, ks, vs, mask=mask)
-        out = out.view(nh, b, dv).transpose(0, 1).reshape(b, nh * dv)
-        return self.dropout(out), attn
+            scores = scores.masked_fill(mask.unsqueeze(1), -np.inf)
+        attn = self.attention.dropout(torch.softmax(scores, dim=2))
+        z = torch.bmm(attn, k)                                                      # [b, nh, d] pooled raw rows
+        if layout is not None:
+            z = layout.unpad(z)
+        Wv = self.w_vs.weight.view(nh, dv, -1)
+        out = torch.einsum('bhd,hvd->bhv', z, Wv) + self.w_vs.bias.view(nh, dv) * attn.sum(2, keepdim=True)
+        return self.dropout(out.reshape(b, nh * dv)), attn.transpose(0, 1).reshape(nh * b, l)
 
 
 class CustomizedEmbedding(nn.Module):

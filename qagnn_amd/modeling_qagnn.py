@@ -304,12 +304,13 @@ class QAGNN_Message_Passing(nn.Module):
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
         return temb, ops.gelu_dropout(pre, 0.0, False)
 
-    def forward(self, H, A, node_type, node_score, cache_output=False, graph=None, padded_input=False):
+    def forward(self, H, A, node_type, node_score, cache_output=False, graph=None, padded_input=False, padded_output=False):
         """
         H: (batch_size, n_node, d_node) node features;  A: (edge_index [2, E], edge_type [E]) of the batched graph
         node_type: long (batch_size, n_node): 0 question entity, 1 answer entity, 2 other, 3 context node
         node_score: (batch_size, n_node, 1)
         padded_input: H is already the head-padded [batch_size * n_node, DP] matrix (QAGNN's fused input stage)
+        padded_output: return the head-padded [batch_size, n_node, DP] tensor (QAGNN's pooling head consumes it as is)
         """
         bs, n = node_type.size()
         d = self.hidden_size
@@ -327,6 +328,8 @@ class QAGNN_Message_Passing(nn.Module):
             Xp, _ = layer.hop(Xp, None, graph, tab, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S), packed=pk)
         Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
+        if padded_output:
+            return out.view(bs, n, L.DP)
         return L.unpad(out).view(bs, n, d)
 
 
@@ -393,11 +396,12 @@ class QAGNN(nn.Module):
         mean_norm = node_scores.abs().sum(dim=1) / adj_lengths
         node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
 
-        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, padded_input=fused_input)
-        Z_vecs = gnn_output[:, 0]
+        Lh = head_layout(self.concept_dim, dev)
+        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, padded_input=fused_input, padded_output=True)
+        Z_vecs = Lh.unpad(gnn_output[:, 0])
         mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
         mask[mask.all(1), 0] = 0  # never mask every node (:177)
-        graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask)
+        graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask, layout=Lh)
         if cache_output:
             self.concept_ids, self.adj, self.pool_attn = concept_ids, adj, pool_attn
         concat = self.dropout_fc(torch.cat((graph_vecs, sent_vecs, Z_vecs), 1))
