@@ -170,24 +170,27 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
 
 // ------------------------------------------------------------------------------------------------------------
 // TN:  P[chunk][Ka][No] = sum over the chunk's rows of A[r][ka] * B[r][no]; a second kernel sums the chunks in order.
-// block tile 64 (ka) x NT*16 (no); wave w owns ka rows 16w..16w+15; k-tiles of 16 rows.
+// One WAVE per 16-row tile of the output: the block has NW = blockDim.x / 64 waves and owns BM = 16*NW output rows x
+// NT*16 columns, so the host picks NW to tile Ka exactly (Ka = 208 -> 13 waves, 112 -> 7, 1024 -> 16): no MFMA is
+// spent on tile padding (the previous fixed 64-row tile wasted 19 % on 208).  With BM = 16*NW the A k-tile is exactly
+// one float4 per thread.  k-tiles of 16 rows, double-buffered, one barrier per tile.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TN_BM = 64;
-constexpr int PA_TN = 80;   // 64 + 16: rows k, k+1 of the k-major A tile land 16 banks apart
-constexpr int TN_RC = 512;  // rows per chunk (more, smaller chunks: 2+ blocks per CU for the 208x208 gradients)
+constexpr int TN_RC = 256;  // rows per chunk: >= 1 block per CU for the 208 x 208 gradients at N = 64 000
+
+__host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w + 16; }  // rows k, k+1 land 16 banks apart
 
 template <int NT, bool AFFINE>
-__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                 float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
-                                                 const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx) {
+__global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                  float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
+                                                  const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx) {
   constexpr int BN = NT * 16;
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;
-  constexpr int B_IT = (B_F4 + 255) / 256;
-  constexpr int TA_F = BK * PA_TN, TBUF_F = TA_F + BK * PB;
-  __shared__ __attribute__((aligned(16))) float smem[2 * TBUF_F];  // double-buffered k-tiles, one barrier per tile
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * TN_BM, chunk = blockIdx.z;
+  constexpr int B_IT = (NT + 3) / 4;  // float4 of the B tile per thread when the block has >= 4 waves (fewer waves: loop below)
+  extern __shared__ __attribute__((aligned(16))) float smem_tn[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, BM = (nthr >> 6) * 16;
+  const int PA = pitch16(BM), TA_F = BK * PA, TBUF_F = TA_F + BK * PB;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
   const int r_beg = chunk * TN_RC, r_end = min(R, r_beg + TN_RC);
   const int nkt = (r_end - r_beg + BK - 1) / BK;
 
@@ -195,31 +198,32 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 ra, rb[B_IT];
-  const int akr = tid >> 4, ac4 = tid & 15;  // A tile: 16 rows x 16 float4
-  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;  // this thread's A columns never change: load the BN affine once
-  if (AFFINE && m0 + ac4 * 4 < Ka) { a_sc = ld4(a_scale + m0 + ac4 * 4); a_sh = ld4(a_shift + m0 + ac4 * 4); }
+  const int a_f4 = BM / 4;                       // float4 per A tile row; 16 * a_f4 == nthr
+  const int akr = tid / a_f4, ac4 = tid % a_f4;  // this thread's (k row, float4 column) of the A tile
+  const int acol = m0 + ac4 * 4;
+  float4 a_sc = make_float4(0.f, 0.f, 0.f, 0.f), a_sh = a_sc;  // the thread's A columns never change: load the BN affine once
+  if (AFFINE && acol < Ka) { a_sc = ld4(a_scale + acol); a_sh = ld4(a_shift + acol); }
 
   auto gload = [&](int kt) {
     const int r0 = r_beg + kt * BK;
     {
-      const int row = r0 + akr, col = m0 + ac4 * 4;
+      const int row = r0 + akr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int64_t srow = (row < r_end && col < Ka) ? (a_rowidx ? a_rowidx[row] : (int64_t)row) : -1;
+      const int64_t srow = (row < r_end && acol < Ka) ? (a_rowidx ? a_rowidx[row] : (int64_t)row) : -1;
       if (srow >= 0) {
-        v = ld4(A + srow * lda + col);
+        v = ld4(A + srow * lda + acol);
         if (AFFINE) {
-          const float4 sc = a_sc, sh = a_sh;
-          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-          v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-          v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+          v.x = fmaxf(fmaf(v.x, a_sc.x, a_sh.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, a_sc.y, a_sh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, a_sc.z, a_sh.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, a_sc.w, a_sh.w), 0.f);
         }
       }
       ra = v;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * nthr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < B_F4) {
         const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
@@ -230,12 +234,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     }
   };
   auto lstore = [&](int buf) {
-    float* As = smem + buf * TBUF_F;
+    float* As = smem_tn + buf * TBUF_F;
     float* Bs = As + TA_F;
-    st4(As + akr * PA_TN + ac4 * 4, ra);
+    st4(As + akr * PA + ac4 * 4, ra);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * nthr;
       if (idx < B_F4) {
         const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
         st4(Bs + kr * PB + c4 * 4, rb[it]);
@@ -243,9 +247,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     }
   };
   auto mma = [&](int buf, int kk) {
-    const float* Aw = smem + buf * TBUF_F + (lane >> 4) * PA_TN + w * 16 + (lane & 15);
-    const float* Bw = smem + buf * TBUF_F + TA_F + (lane >> 4) * PB + (lane & 15);
-    const float av = Aw[kk * 4 * PA_TN];
+    const float* Aw = smem_tn + buf * TBUF_F + (lane >> 4) * PA + w * 16 + (lane & 15);
+    const float* Bw = smem_tn + buf * TBUF_F + TA_F + (lane >> 4) * PB + (lane & 15);
+    const float av = Aw[kk * 4 * PA];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bw[kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
@@ -301,12 +305,25 @@ static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
   return QAGNN_OK;
 }
 
+// waves per block = 16-row output tiles per block: the count in [4, 16] that wastes the fewest rows of Ka (ties -> more waves)
+static int pick_tn_waves(int Ka) {
+  int best = 4, best_waste = INT32_MAX;
+  for (int nw = 16; nw >= 4; --nw) {
+    const int bm = nw * 16, waste = cdiv(Ka, bm) * bm - Ka;
+    if (waste < best_waste) { best_waste = waste; best = nw; }
+  }
+  return best;
+}
+
 template <int NT>
 static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
                      const float* sh, const int64_t* ridx, int nchunks, hipStream_t stream) {
-  dim3 grid(cdiv(No, NT * 16), cdiv(Ka, TN_BM), nchunks);
-  if (sc) k_gemm_tn<NT, true><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
-  else k_gemm_tn<NT, false><<<grid, 256, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
+  const int nw = pick_tn_waves(Ka), bm = nw * 16;
+  // B tile loop covers B_IT * nthreads float4: needs (NT + 3) / 4 * nw * 64 >= 16 * NT * 4  <=>  nw >= 4  (guaranteed)
+  dim3 grid(cdiv(No, NT * 16), cdiv(Ka, bm), nchunks);
+  const size_t lds = 2 * (size_t)(BK * pitch16(bm) + BK * pitch_b(NT * 16)) * sizeof(float);
+  if (sc) k_gemm_tn<NT, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
+  else k_gemm_tn<NT, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
   QAGNN_LAUNCH_CHECK("k_gemm_tn");
   return QAGNN_OK;
 }
