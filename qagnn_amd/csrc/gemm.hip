@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
     if (more) gload(kt + 1);
     mma(cur, 0);
     mma(cur, 1);
-    if (more) lstore(cur ^ 1);
+    if (more) lstore(cur ^ 1);  // ds_writes hide under the remaining MFMAs (measured: later placement is slower here)
     mma(cur, 2);
     mma(cur, 3);
     __syncthreads();
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
     if (more) gload(kt + 1);
     mma(cur, 0);
     mma(cur, 1);
-    if (more) lstore(cur ^ 1);
     mma(cur, 2);
     mma(cur, 3);
+    if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
   }
   float* Pc = P + (int64_t)chunk * Ka * No;
