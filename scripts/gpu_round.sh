@@ -21,6 +21,7 @@ fi
 if [[ "$*" == *bench* ]]; then
   timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -n 50 > gpurun_out/bench.log
   echo "bench exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+  timeout 300 python bench.py --steps 30 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/bench_b10.log
 fi
 if [[ "$*" == *prof* ]]; then
   rm -rf /tmp/prof; mkdir -p /tmp/prof

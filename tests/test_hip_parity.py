@@ -142,16 +142,18 @@ def test_oracle_parity_odd_shapes(train):
             helpers._close(gh[k], go[k], what='grad::' + k, **BWD)
 
 
-def _full_size_batch(B=320, n=200, seed=77):
-    recs = synthetic.make_records(B, seed=seed, shape='csqa', n_concept_vocab=2000)  # ids must fit the model's table
-    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, 5)
+def _full_size_batch(B=320, n=200, seed=77, shape='csqa', nc=5, n_rel=17):
+    recs = synthetic.make_records(B, seed=seed, shape=shape, n_rel=n_rel, n_concept_vocab=2000)  # ids must fit the model's table
+    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, nc)
     bei, bet = data_utils.batch_graph(ei, et, n)
     g = torch.Generator().manual_seed(seed)
     return torch.randn(B, 64, generator=g), cids, nt, ns, al, bei, bet, ei, et
 
 
-def test_full_size_batch_properties():
-    """BASELINE config-2 size (B = 64 x 5 = 320 subgraphs, n = 200): size-independent properties instead of the oracle.
+@pytest.mark.parametrize('shape,B,nc,n_rel,n_etype', [('csqa', 320, 5, 17, 38), ('csqa', 512, 4, 17, 38), ('medqa', 64, 4, 15, 34)])
+def test_full_size_batch_properties(shape, B, nc, n_rel, n_etype):
+    """BASELINE config sizes -- configs[1] CSQA 64 x 5 = 320 subgraphs, configs[2] OBQA 128 x 4 = 512, configs[4] MedQA
+    64 x 4 per GPU with ~3 k-edge dense subgraphs and no node scores (n = 200): size-independent properties instead of the oracle.
 
     eval mode: (1) subgraphs are independent -> any sub-batch gives the same logits as inside the full batch;
                (2) permuting the edge list leaves the logits unchanged (up to fp32 re-ordering);
@@ -160,14 +162,14 @@ def test_full_size_batch_properties():
     from qagnn_amd import modeling_qagnn as MQ
     cfg = helpers.model_cfg(d=200, k=5, sent_dim=64, n_concept=2000, concept_in_dim=32)
     torch.manual_seed(0)
-    model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
+    model = MQ.QAGNN(None, cfg['k'], 4, n_etype, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
     helpers.det_fill_(model, 5, 0.6)
     model.pooler.dropout.p = model.pooler.attention.dropout.p = 0.0
     model = model.cuda().eval()
-    sv, cids, nt, ns, al, bei, bet, ei_list, et_list = _full_size_batch()
+    sv, cids, nt, ns, al, bei, bet, ei_list, et_list = _full_size_batch(B=B, shape=shape, nc=nc, n_rel=n_rel)
     with torch.no_grad():
         full, _ = model(*cu(sv, cids, nt, ns, al), (bei.cuda(), bet.cuda()))
-        sub = slice(100, 140)
+        sub = slice(B // 4, B // 4 + 2 * nc * 2)
         sei, set_ = data_utils.batch_graph(ei_list[sub], et_list[sub], 200)
         part, _ = model(*cu(sv[sub], cids[sub], nt[sub], ns[sub], al[sub]), (sei.cuda(), set_.cuda()))
         perm = torch.randperm(bei.size(1), generator=torch.Generator().manual_seed(1))
@@ -179,7 +181,7 @@ def test_full_size_batch_properties():
     model.train()
     before = {k: v.clone() for k, v in model.named_buffers()}
     logits, _ = model(*cu(sv, cids, nt, ns, al), (bei.cuda(), bet.cuda()))
-    logits.view(64, 5).log_softmax(1)[:, 0].sum().backward()
+    logits.view(-1, nc).log_softmax(1)[:, 0].sum().backward()
     for k, p in model.named_parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
