@@ -400,7 +400,9 @@ class QAGNN(nn.Module):
         gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, padded_input=fused_input, padded_output=True)
         Z_vecs = Lh.unpad(gnn_output[:, 0])
         mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
-        mask[mask.all(1), 0] = 0  # never mask every node (:177)
+        # never mask every node (:177).  Written without boolean-mask indexing: `mask[mask.all(1), 0] = 0` makes the host
+        # wait for the whole GNN forward (nonzero() synchronises) and lets the GPU idle while the backward is launched.
+        mask[:, 0] = mask[:, 0] & ~mask.all(1)
         graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask, layout=Lh)
         if cache_output:
             self.concept_ids, self.adj, self.pool_attn = concept_ids, adj, pool_attn
