@@ -128,14 +128,29 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
+#ifndef QAGNN_ABLATE_NOGLOAD
     if (more) gload(kt + 1);
+#endif
+#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 0);
     mma(cur, 1);
+#endif
     if (more) lstore(cur ^ 1);  // ds_writes hide under the remaining MFMAs (measured: later placement is slower here)
+#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 2);
     mma(cur, 3);
+#endif
     __syncthreads();
   }
+#ifdef QAGNN_ABLATE_NOEPI
+  {  // keep the accumulators live with one dword store per lane, skip the real epilogue
+    float keep = 0.f;
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NT; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (m0 + (tid >> 1) < a.M) a.C[(int64_t)(m0 + (tid >> 1)) * a.ldc + n0 + (tid & 1)] = keep;
+    return;
+  }
+#endif
 
   // epilogue.  The MFMA layout gives a lane ONE column of 4 rows per accumulator; storing that directly is 104 dword
   // stores per lane in 64-byte row fragments (store-issue bound, and in a single-round grid nothing overlaps it).

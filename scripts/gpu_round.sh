@@ -46,6 +46,12 @@ fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
 fi
+if [[ "$*" == *ablate* ]]; then
+  for v in BASE NOGLOAD NOMMA NOEPI; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DQAGNN_ABLATE_$v -o /tmp/gemm_ablate_$v tools/gemm_ablate.hip 2>/dev/null
+    echo "== $v" >> gpurun_out/gemm_ablate.txt; /tmp/gemm_ablate_$v >> gpurun_out/gemm_ablate.txt 2>&1
+  done
+fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
 cat gpurun_out/summary.txt
 du -sh gpurun_out
