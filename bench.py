@@ -99,7 +99,7 @@ def step(model, b, world, flat_grad_params):
     loss.backward()
     if world > 1:
         parallel.allreduce_gradients(flat_grad_params)  # RCCL all-reduce(sum), one flat bucket of ~2.85 M fp32
-        parallel.allgather_logits(logits)               # per-batch logits of all ranks, for accuracy / reporting
+        parallel.allgather_logits(logits, equal_shards=True)  # per-batch logits of all ranks, for accuracy / reporting
     return logits
 
 
@@ -149,13 +149,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
 
     b = {k: v.to(dev) for k, v in make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept).items()}
     model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)

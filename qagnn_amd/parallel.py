@@ -40,14 +40,19 @@ def allreduce_gradients(params, group=None):
     off = 0
     for p in params:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        p.grad = flat[off:off + n].view_as(p)  # re-point the gradient at its slice of the bucket: no copy-back kernels
         off += n
     return flat.numel()
 
 
-def allgather_logits(logits, group=None):
-    """[bs_local, nc] on every rank -> [bs_global, nc] in rank order.  Ranks may hold different numbers of questions."""
+def allgather_logits(logits, group=None, equal_shards=False):
+    """[bs_local, nc] on every rank -> [bs_global, nc] in rank order.  Ranks may hold different numbers of questions;
+    `equal_shards=True` (every rank has the same bs_local) skips the size exchange and its host synchronisation."""
     world = dist.get_world_size(group)
+    if equal_shards:
+        out = [torch.empty_like(logits) for _ in range(world)]
+        dist.all_gather(out, logits.detach().contiguous(), group=group)
+        return torch.cat(out, dim=0)
     n_local = torch.tensor([logits.size(0)], device=logits.device, dtype=torch.long)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
