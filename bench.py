@@ -150,12 +150,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # QAGNN_BENCH_SHARE_GPU=1 (test rigs with one GPU): all ranks use cuda:0 and talk over gloo instead of RCCL
+    share = os.environ.get('QAGNN_BENCH_SHARE_GPU') == '1'
+    dev = torch.device('cuda', 0 if share else local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     b = {k: v.to(dev) for k, v in make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept).items()}
     model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
