@@ -153,6 +153,48 @@ class GatherPlan:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '1') == '1'
+_SIDE_STREAMS = {}
+
+
+class _WgradStream:
+    """Run weight/bias-gradient kernels on a second HIP stream, forked from and joined back into the current one.
+
+    A single-round GEMM grid has every block in the same phase (operand reads, then MFMAs, then the epilogue writes), so
+    its HBM phases overlap nothing.  The weight-gradient GEMMs of a backward step are independent of
+    the data-gradient chain; issuing them on a side stream lets one kernel's streaming phases overlap the other's MFMAs.
+    Fork/join discipline (side waits for main at every entry, main waits for side in join()) keeps the caching
+    allocator's stream-ordered reuse valid without record_stream().
+    """
+
+    def __init__(self, ref):
+        self.on = SIDE_STREAM_WGRAD and ref.is_cuda
+        if self.on:
+            self.main = torch.cuda.current_stream(ref.device)
+            key = ref.device.index
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=ref.device)
+            self.side = _SIDE_STREAMS[key]
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 class LinearNNFn(torch.autograd.Function):
     """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
 
@@ -170,18 +212,21 @@ class LinearNNFn(torch.autograd.Function):
         A1, B1, A2, B2, rowidx = ctx.saved_tensors
         dC = dC.contiguous()
         need = ctx.needs_input_grad
-        dA1 = K.gemm_nn(dC, B1) if need[0] else None
-        dB1t = K.gemm_tn(A1, dC) if need[1] else None
-        dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
-        dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
         has_bias, has_tab, G = ctx.has
         dbias = drowtab = None
-        if has_tab and need[7]:
-            drowtab = K.colsum(dC, rowidx, G)
-            if has_bias and need[6]:
-                dbias = drowtab.sum(0)
-        elif has_bias and need[6]:
-            dbias = K.colsum(dC)[0]
+        wg = _WgradStream(dC)
+        with wg:  # parameter gradients: side stream
+            dB1t = K.gemm_tn(A1, dC) if need[1] else None
+            dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
+            if has_tab and need[7]:
+                drowtab = K.colsum(dC, rowidx, G)
+                if has_bias and need[6]:
+                    dbias = drowtab.sum(0)
+            elif has_bias and need[6]:
+                dbias = K.colsum(dC)[0]
+        dA1 = K.gemm_nn(dC, B1) if need[0] else None  # data gradients: the critical path stays on the main stream
+        dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
+        wg.join()
         return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
 
 
@@ -278,8 +323,10 @@ class GatMlpFn(torch.autograd.Function):
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
-        dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)  # relu(bn(h1))^T @ dout
-        db2 = K.colsum(dout)[0]
+        wg = _WgradStream(dout)
+        with wg:  # side stream: gradients of the second Linear
+            dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)  # relu(bn(h1))^T @ dout
+            db2 = K.colsum(dout)[0]
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
@@ -288,9 +335,11 @@ class GatMlpFn(torch.autograd.Function):
         else:
             c1 = c2 = torch.zeros_like(red[0])
         dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma * invstd, c1.contiguous(), c2.contiguous())
-        dW1t = K.gemm_tn(aggr, dh1)
-        db1 = K.colsum(dh1)[0]
+        with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
+            dW1t = K.gemm_tn(aggr, dh1)
+            db1 = K.colsum(dh1)[0]
         daggr = K.gemm_nn(dh1, W1)
+        wg.join()
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None
 
 

@@ -43,6 +43,12 @@ fi
 if [[ "$*" == *mfma* ]]; then
   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
 fi
+if [[ "$*" == *sideab* ]]; then
+  for rep in 1 2; do for v in 0 1; do
+    echo "QAGNN_SIDE_STREAM=$v" >> gpurun_out/sideab.txt
+    QAGNN_SIDE_STREAM=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -n 1 | cut -c1-140 >> gpurun_out/sideab.txt
+  done; done
+fi
 if [[ "$*" == *dp2* ]]; then
   QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 2>&1 | tail -n 20 > gpurun_out/bench_dp2_shared_gpu.log
   echo "dp2 exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
