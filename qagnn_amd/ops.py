@@ -155,7 +155,9 @@ class GatherPlan:
 # ------------------------------------------------------------------------------------------------------------------
 import os as _os
 
-SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '1') == '1'
+# Measured on MI355X (interleaved A/B, 30 steps each, run 19): side stream ON 21 618 / 21 673 vs OFF 22 621 / 22 620
+# QA-subgraphs/s -- co-running two GEMMs costs more in L2/HBM contention than the phase overlap wins.  Default OFF.
+SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '0') == '1'
 _SIDE_STREAMS = {}
 
 
