@@ -106,12 +106,19 @@ typedef struct qagnn_gemm_nn_args {
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 
-/* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) */
+/* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) (includes room for the optional column sums of B) */
 int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);
 int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t Ka,
                       int32_t No, const float* a_scale, const float* a_shift /* BN+ReLU prologue on A, or NULL */,
                       const int64_t* a_rowidx /* [R] or NULL: row r of A is A[a_rowidx[r]], negative = zero row */,
                       int32_t accumulate, float* workspace, qagnn_stream_t stream);
+/* Same, and additionally  bsum[g][no] = sum_r [grp(r) == g] B[r][no]  (groups in 1..4; b_rowidx NULL = one group): the
+ * bias gradient (and the node-type-table gradient) of a Linear falls out of the weight-gradient GEMM's B tiles for free
+ * instead of costing separate passes over dC. */
+int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t Ka,
+                             int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx, int32_t accumulate,
+                             float* bsum /* [groups][No] */, const int64_t* b_rowidx /* [R] or NULL */, int32_t groups,
+                             float* workspace, qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Column reductions over rows (bias / BatchNorm gradients, batch statistics).  Replace ATen sum / BatchNorm1d

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
@@ -51,6 +51,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
+    lib.qagnn_gemm_tn_colsum_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                                             _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -173,7 +175,9 @@ class HipKernels:
         self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')
         return out
 
-    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None):
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None, colsum_groups=0,
+                b_rowidx=None):
+        """C = A^T B.  colsum_groups = G > 0 additionally returns bsum [G, No] = per-group column sums of B."""
         _chk2d(A, 'A'), _chk2d(B, 'B')
         Ka = A.size(1)
         R, No = B.shape
@@ -182,10 +186,15 @@ class HipKernels:
             assert not accumulate
             out = torch.empty((Ka, No), dtype=torch.float32, device=A.device)
         ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka, No), dtype=torch.float32, device=A.device)
-        rc = self.lib.qagnn_gemm_tn_f32(A.data_ptr(), Ka, B.data_ptr(), No, out.data_ptr(), No, R, Ka, No, _ptr(a_scale),
-                                        _ptr(a_shift), _ptr(a_rowidx), 1 if accumulate else 0, ws.data_ptr(), self._stream())
-        self._check(rc, 'qagnn_gemm_tn_f32')
-        return out
+        bsum = None
+        if colsum_groups:
+            assert b_rowidx is None or (b_rowidx.dtype == torch.long and b_rowidx.numel() == R and b_rowidx.is_contiguous())
+            bsum = torch.empty((colsum_groups, No), dtype=torch.float32, device=A.device)
+        rc = self.lib.qagnn_gemm_tn_colsum_f32(A.data_ptr(), Ka, B.data_ptr(), No, out.data_ptr(), No, R, Ka, No, _ptr(a_scale),
+                                               _ptr(a_shift), _ptr(a_rowidx), 1 if accumulate else 0, _ptr(bsum), _ptr(b_rowidx),
+                                               colsum_groups, ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_gemm_tn_colsum_f32')
+        return (out, bsum) if colsum_groups else out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------
     def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout):

@@ -197,14 +197,19 @@ __host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w
 template <int NT, bool AFFINE>
 __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                   float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
-                                                  const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx) {
+                                                  const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx,
+                                                  float* __restrict__ Pcs, const int64_t* __restrict__ b_rowidx, int groups) {
   constexpr int BN = NT * 16;
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;
   constexpr int B_IT = (NT + 3) / 4;  // float4 of the B tile per thread when the block has >= 4 waves (fewer waves: loop below)
   extern __shared__ __attribute__((aligned(16))) float smem_tn[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, BM = (nthr >> 6) * 16;
-  const int PA = pitch16(BM), TA_F = BK * PA, TBUF_F = TA_F + BK * PB;
+  const int PA = pitch16(BM), TA_F = BK * PA, TBUF_F = TA_F + BK * PB + BK;  // + 16 group ids of the tile's rows
+  // optional by-product: column sums of B (per row group) taken from the B tiles already sitting in LDS
+  const bool do_cs = Pcs != nullptr && blockIdx.y == 0 && tid < BN;
+  float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+  int rg = 0;  // group id of tile row `tid` (threads 0..15), staged through LDS with the tile
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
   const int r_beg = chunk * TN_RC, r_end = min(R, r_beg + TN_RC);
   const int nkt = (r_end - r_beg + BK - 1) / BK;
@@ -247,10 +252,12 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
       }
       rb[it] = v;
     }
+    if (Pcs && b_rowidx && tid < BK) rg = (r0 + tid < r_end) ? (int)b_rowidx[r0 + tid] : 0;
   };
   auto lstore = [&](int buf) {
     float* As = smem_tn + buf * TBUF_F;
     float* Bs = As + TA_F;
+    if (Pcs && tid < BK) reinterpret_cast<int*>(Bs + BK * PB)[tid] = rg;
     st4(As + akr * PA + ac4 * 4, ra);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -269,6 +276,19 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
     for (int j = 0; j < NT; ++j)
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bw[kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
   };
+  auto colsum_tile = [&](int buf) {  // thread `tid` owns column tid of the B tile; rows in tile order = row order
+    const float* Bs = smem_tn + buf * TBUF_F + TA_F;
+    const int* grp = reinterpret_cast<const int*>(Bs + BK * PB);
+#pragma unroll
+    for (int k = 0; k < BK; ++k) {
+      const float v = Bs[k * PB + tid];
+      const int g = groups > 1 ? grp[k] : 0;
+      if (g == 0) cs0 += v;
+      else if (g == 1) cs1 += v;
+      else if (g == 2) cs2 += v;
+      else cs3 += v;
+    }
+  };
 
   if (nkt > 0) {
     gload(0);
@@ -281,10 +301,18 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
     if (more) gload(kt + 1);
     mma(cur, 0);
     mma(cur, 1);
+    if (do_cs) colsum_tile(cur);
     mma(cur, 2);
     mma(cur, 3);
     if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
+  }
+  if (do_cs && n0 + tid < No) {
+    float* pc = Pcs + (int64_t)chunk * groups * No + n0 + tid;
+    pc[0] = cs0;
+    if (groups > 1) pc[No] = cs1;
+    if (groups > 2) pc[2 * No] = cs2;
+    if (groups > 3) pc[3 * No] = cs3;
   }
   float* Pc = P + (int64_t)chunk * Ka * No;
 #pragma unroll
@@ -332,13 +360,14 @@ static int pick_tn_waves(int Ka) {
 
 template <int NT>
 static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
-                     const float* sh, const int64_t* ridx, int nchunks, hipStream_t stream) {
+                     const float* sh, const int64_t* ridx, int nchunks, float* Pcs, const int64_t* bidx, int groups,
+                     hipStream_t stream) {
   const int nw = pick_tn_waves(Ka), bm = nw * 16;
   // B tile loop covers B_IT * nthreads float4: needs (NT + 3) / 4 * nw * 64 >= 16 * NT * 4  <=>  nw >= 4  (guaranteed)
   dim3 grid(cdiv(No, NT * 16), cdiv(Ka, bm), nchunks);
-  const size_t lds = 2 * (size_t)(BK * pitch16(bm) + BK * pitch_b(NT * 16)) * sizeof(float);
-  if (sc) k_gemm_tn<NT, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
-  else k_gemm_tn<NT, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx);
+  const size_t lds = 2 * (size_t)(BK * pitch16(bm) + BK * pitch_b(NT * 16) + BK) * sizeof(float);
+  if (sc) k_gemm_tn<NT, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups);
+  else k_gemm_tn<NT, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups);
   QAGNN_LAUNCH_CHECK("k_gemm_tn");
   return QAGNN_OK;
 }
@@ -388,12 +417,13 @@ extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t str
 }
 
 extern "C" int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No) {
-  return (int64_t)cdiv(R, TN_RC) * Ka * No;
+  return (int64_t)cdiv(R, TN_RC) * ((int64_t)Ka * No + 4 * (int64_t)No);
 }
 
-extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
-                                 int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx,
-                                 int32_t accumulate, float* workspace, qagnn_stream_t stream_) {
+extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
+                                        int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx,
+                                        int32_t accumulate, float* bsum, const int64_t* b_rowidx, int32_t groups, float* workspace,
+                                        qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(A && B && C && workspace, QAGNN_EINVAL, "gemm_tn: null pointer");
   QAGNN_REQUIRE(R > 0 && Ka > 0 && No > 0 && Ka % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
@@ -402,18 +432,31 @@ extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, in
                 "gemm_tn: operands must be 16-byte aligned with pitches multiple of 4");
   QAGNN_REQUIRE(!a_scale || (a_shift && aligned16(a_scale) && aligned16(a_shift)), QAGNN_EINVAL,
                 "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
+  QAGNN_REQUIRE(!bsum || (groups >= 1 && groups <= 4 && (groups == 1 || b_rowidx)), QAGNN_EINVAL, "gemm_tn: colsum groups=%d (1..4)", groups);
   const int nchunks = cdiv(R, TN_RC);
+  float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;
   switch (pick_nt(No)) {
-    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
-    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
-    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
-    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
-    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, stream); break;
+    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
+    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
+    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
+    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
+    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
   }
   if (rc != QAGNN_OK) return rc;
   const int64_t tot = (int64_t)Ka * No;
   k_sum_chunks<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, accumulate);
   QAGNN_LAUNCH_CHECK("k_sum_chunks");
+  if (bsum) {
+    k_sum_chunks<<<cdiv((int64_t)groups * No, 256), 256, 0, stream>>>(Pcs, bsum, No, groups, No, nchunks, 0);
+    QAGNN_LAUNCH_CHECK("k_sum_chunks(colsum)");
+  }
   return QAGNN_OK;
+}
+
+extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
+                                 int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx,
+                                 int32_t accumulate, float* workspace, qagnn_stream_t stream_) {
+  return qagnn_gemm_tn_colsum_f32(A, lda, B, ldb, C, ldc, R, Ka, No, a_scale, a_shift, a_rowidx, accumulate, nullptr, nullptr, 0,
+                                  workspace, stream_);
 }

@@ -217,15 +217,23 @@ class LinearNNFn(torch.autograd.Function):
         has_bias, has_tab, G = ctx.has
         dbias = drowtab = None
         wg = _WgradStream(dC)
-        with wg:  # parameter gradients: side stream
-            dB1t = K.gemm_tn(A1, dC) if need[1] else None
+        with wg:  # parameter gradients (optionally on a side stream)
+            want_tab, want_bias = has_tab and need[7], has_bias and need[6]
+            cs = None
+            if need[1] and (want_tab or want_bias):
+                # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
+                dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
+            else:
+                dB1t = K.gemm_tn(A1, dC) if need[1] else None
+                if want_tab or want_bias:
+                    cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
             dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
-            if has_tab and need[7]:
-                drowtab = K.colsum(dC, rowidx, G)
-                if has_bias and need[6]:
-                    dbias = drowtab.sum(0)
-            elif has_bias and need[6]:
-                dbias = K.colsum(dC)[0]
+            if want_tab:
+                drowtab = cs
+                if want_bias:
+                    dbias = cs.sum(0)
+            elif want_bias:
+                dbias = cs[0]
         dA1 = K.gemm_nn(dC, B1) if need[0] else None  # data gradients: the critical path stays on the main stream
         dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
         wg.join()
@@ -327,8 +335,8 @@ class GatMlpFn(torch.autograd.Function):
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
         wg = _WgradStream(dout)
         with wg:  # side stream: gradients of the second Linear
-            dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)  # relu(bn(h1))^T @ dout
-            db2 = K.colsum(dout)[0]
+            dW2t, db2 = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, colsum_groups=1)  # relu(bn(h1))^T @ dout, colsum(dout)
+            db2 = db2[0]
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
@@ -338,8 +346,8 @@ class GatMlpFn(torch.autograd.Function):
             c1 = c2 = torch.zeros_like(red[0])
         dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma * invstd, c1.contiguous(), c2.contiguous())
         with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
-            dW1t = K.gemm_tn(aggr, dh1)
-            db1 = K.colsum(dh1)[0]
+            dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
+            db1 = db1[0]
         daggr = K.gemm_nn(dh1, W1)
         wg.join()
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None
@@ -380,8 +388,8 @@ class ConceptInputFn(torch.autograd.Function):
         n, p, seed = ctx.cfg
         dpre = K.gelu_dropout_bwd(pre, dHp.contiguous(), p, seed)
         dctx = dpre.view(-1, n, dpre.size(1))[:, 0].contiguous()
-        dWc_t = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx) if ctx.needs_input_grad[2] else None
-        dbc = (K.colsum(dpre)[0] - dctx.sum(0)) if ctx.needs_input_grad[3] else None
+        dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx, colsum_groups=1)
+        dbc = cs[0] - dctx.sum(0)  # the bias only acts on the entity rows (context-node rows were overwritten)
         return None, None, dWc_t, dbc, dctx, None, None, None
 
 

@@ -105,7 +105,8 @@ class EmuKernels:
             return out
         return C
 
-    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None):
+    def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None, colsum_groups=0,
+                b_rowidx=None):
         A = self._gather_rows(A, a_rowidx)
         if a_scale is not None:
             A = torch.relu(A * a_scale + a_shift)
@@ -115,7 +116,9 @@ class EmuKernels:
                 out += C
             else:
                 out.copy_(C)
-            return out
+            C = out
+        if colsum_groups:
+            return C, self.colsum(B, b_rowidx, colsum_groups)
         return C
 
     def colsum(self, X, rowidx=None, groups=1):

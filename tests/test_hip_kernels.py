@@ -149,6 +149,14 @@ def test_gemm_tn(R, Ka, No, affine):
     bound = 16 * EPS * (Ae.abs().double().t() @ B.abs().double()) + 1e-6
     err = (got.double() - ref).abs()
     assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+    # column sums of B as a by-product (bias / node-type-table gradients), plain and grouped
+    idx = torch.randint(0, 4, (R,), generator=g)
+    for groups, ridx in ((1, None), (4, idx)):
+        got2, cs = hip().gemm_tn(A.cuda(), B.cuda(), colsum_groups=groups, b_rowidx=None if ridx is None else ridx.cuda(),
+                                 **{k: v.cuda() for k, v in kw.items()})
+        assert torch.equal(got2.cpu(), got), 'the by-product must not change the product'
+        ref_cs = EMU.colsum(B.double(), ridx, groups)
+        assert (cs.cpu().double() - ref_cs).abs().max().item() <= 8 * EPS * B.abs().sum(0).max().item() + 1e-6
 
 
 @pytest.mark.gpu
