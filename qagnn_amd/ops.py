@@ -159,6 +159,7 @@ import os as _os
 # QA-subgraphs/s -- co-running two GEMMs costs more in L2/HBM contention than the phase overlap wins.  Default OFF.
 SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '0') == '1'
 _SIDE_STREAMS = {}
+FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '1') == '1'  # bias gradients as a by-product of the wgrad GEMM
 
 
 class _WgradStream:
@@ -220,7 +221,7 @@ class LinearNNFn(torch.autograd.Function):
         with wg:  # parameter gradients (optionally on a side stream)
             want_tab, want_bias = has_tab and need[7], has_bias and need[6]
             cs = None
-            if need[1] and (want_tab or want_bias):
+            if FUSED_COLSUM and need[1] and (want_tab or want_bias):
                 # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
                 dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
             else:
@@ -335,8 +336,12 @@ class GatMlpFn(torch.autograd.Function):
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
         wg = _WgradStream(dout)
         with wg:  # side stream: gradients of the second Linear
-            dW2t, db2 = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, colsum_groups=1)  # relu(bn(h1))^T @ dout, colsum(dout)
-            db2 = db2[0]
+            if FUSED_COLSUM:
+                dW2t, db2 = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, colsum_groups=1)  # relu(bn(h1))^T @ dout, colsum(dout)
+                db2 = db2[0]
+            else:
+                dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
+                db2 = K.colsum(dout)[0]
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
@@ -346,8 +351,12 @@ class GatMlpFn(torch.autograd.Function):
             c1 = c2 = torch.zeros_like(red[0])
         dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma * invstd, c1.contiguous(), c2.contiguous())
         with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
-            dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
-            db1 = db1[0]
+            if FUSED_COLSUM:
+                dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
+                db1 = db1[0]
+            else:
+                dW1t = K.gemm_tn(aggr, dh1)
+                db1 = K.colsum(dh1)[0]
         daggr = K.gemm_nn(dh1, W1)
         wg.join()
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None

@@ -43,6 +43,15 @@ fi
 if [[ "$*" == *mfma* ]]; then
   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
 fi
+for arg in "$@"; do
+  if [[ "$arg" == ab:* ]]; then
+    var="${arg#ab:}"
+    for rep in 1 2; do for v in 0 1; do
+      echo "$var=$v" >> gpurun_out/ab_$var.txt
+      env $var=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -n 1 | cut -c1-140 >> gpurun_out/ab_$var.txt
+    done; done
+  fi
+done
 if [[ "$*" == *sideab* ]]; then
   for rep in 1 2; do for v in 0 1; do
     echo "QAGNN_SIDE_STREAM=$v" >> gpurun_out/sideab.txt
