@@ -159,7 +159,10 @@ import os as _os
 # QA-subgraphs/s -- co-running two GEMMs costs more in L2/HBM contention than the phase overlap wins.  Default OFF.
 SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '0') == '1'
 _SIDE_STREAMS = {}
-FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '1') == '1'  # bias gradients as a by-product of the wgrad GEMM
+# bias gradients as a by-product of the wgrad GEMM (qagnn_gemm_tn_colsum_f32).  Measured (interleaved A/B, run 21): ON 21 138 /
+# 21 156 vs OFF 21 539 / 21 538 QA-subgraphs/s -- the extra LDS sweep of the B tile inside the k-loop costs the GEMM more than
+# the three separate column-sum passes it replaces.  Default OFF; kept (and tested) for a better in-kernel schedule.
+FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '0') == '1'
 
 
 class _WgradStream:
