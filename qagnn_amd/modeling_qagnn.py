@@ -28,6 +28,22 @@ def make_one_hot(labels, C):
     return F.one_hot(labels, C).to(torch.float32)
 
 
+def _fp32_region(fn):
+    """The GNN stack computes in fp32 (north_star fixes fp32 parity): inside torch.autocast (the reference's --fp16 mode,
+    qagnn.py:254-257) run the method with autocast disabled and floating inputs cast back to fp32."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev_type = 'cuda' if torch.cuda.is_available() else 'cpu'
+        if not torch.is_autocast_enabled(dev_type):
+            return fn(self, *args, **kwargs)
+        cast = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t  # noqa: E731
+        with torch.autocast(dev_type, enabled=False):
+            return fn(self, *[cast(a) for a in args], **{k: cast(v) for k, v in kwargs.items()})
+    return wrapped
+
+
 _LAYOUTS = {}
 
 
@@ -223,6 +239,7 @@ class GATConvE(nn.Module):
                 bn.num_batches_tracked += 1
         return y, a
 
+    @_fp32_region
     def forward(self, x, edge_index, edge_type, node_type, node_feature_extra, return_attention_weights=False, graph=None):
         # x: [N, emb_dim]; edge_index: [2, E]; edge_type: [E]; node_type: [N]; node_feature_extra: [N, emb_dim]
         L = head_layout(self.emb_dim, x.device)
@@ -304,6 +321,7 @@ class QAGNN_Message_Passing(nn.Module):
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
         return temb, ops.gelu_dropout(pre, 0.0, False)
 
+    @_fp32_region
     def forward(self, H, A, node_type, node_score, cache_output=False, graph=None, padded_input=False, padded_output=False):
         """
         H: (batch_size, n_node, d_node) node features;  A: (edge_index [2, E], edge_type [E]) of the batched graph

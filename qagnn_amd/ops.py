@@ -11,6 +11,11 @@ floats, DP = H*HP per row, pads are zero.  All matrices handed to the kernels ar
 import math
 
 import torch
+from torch.amp import custom_bwd, custom_fwd
+
+# every operator computes in fp32: inside torch.autocast (the reference's --fp16 mode, qagnn.py:254-257) inputs are cast back
+_fwd = custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+_bwd = custom_bwd(device_type='cuda')
 
 _K = None
 
@@ -67,6 +72,7 @@ class _PlanGatherFn(torch.autograd.Function):
     """outputs = split(cat(sources, 0)[idx]);  backward = K inverse gathers (no atomics, fixed order)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, plan, *sources):
         flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
         packed = flat.index_select(0, plan.idx)
@@ -75,6 +81,7 @@ class _PlanGatherFn(torch.autograd.Function):
         return tuple(packed[a:a + n].view(shape) for a, n, shape in plan.slices)
 
     @staticmethod
+    @_bwd
     def backward(ctx, *grads):
         plan = ctx.plan
         parts = []
@@ -205,6 +212,7 @@ class LinearNNFn(torch.autograd.Function):
     """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx):
         K = kernels()
         C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx)
@@ -213,6 +221,7 @@ class LinearNNFn(torch.autograd.Function):
         return C
 
     @staticmethod
+    @_bwd
     def backward(ctx, dC):
         K = kernels()
         A1, B1, A2, B2, rowidx = ctx.saved_tensors
@@ -253,12 +262,14 @@ class GeluDropoutFn(torch.autograd.Function):
     """Y = dropout(gelu_tanh(X), p)   (utils/layers.py:10-14 + F.dropout); the keep mask is regenerated in backward."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, X, p, seed):
         ctx.save_for_backward(X)
         ctx.p, ctx.seed = p, seed
         return kernels().gelu_dropout_fwd(X, p, seed)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dY):
         (X,) = ctx.saved_tensors
         return kernels().gelu_dropout_bwd(X, dY.contiguous(), ctx.p, ctx.seed), None, None
@@ -283,6 +294,7 @@ class EdgeAttnFn(torch.autograd.Function):
     """aggr = edge attention + aggregation (see qagnn_edge_attn_fwd_f32); also returns the un-scaled attention a."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, KMQ, EkEm, graph, HP, qscale):
         aggr, a, alpha = kernels().edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
         ctx.save_for_backward(KMQ, EkEm, a, alpha)
@@ -291,6 +303,7 @@ class EdgeAttnFn(torch.autograd.Function):
         return aggr, a
 
     @staticmethod
+    @_bwd
     def backward(ctx, G, _da):
         KMQ, EkEm, a, alpha = ctx.saved_tensors
         dKMQ, dEkEm = kernels().edge_attn_bwd(ctx.graph, KMQ, EkEm, ctx.HP, ctx.qscale, a, alpha, G.contiguous())
@@ -312,6 +325,7 @@ class GatMlpFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @_fwd
     def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act):
         K = kernels()
         R = aggr.size(0)
@@ -332,6 +346,7 @@ class GatMlpFn(torch.autograd.Function):
         return y, mean, var
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy, _dm, _dv):
         K = kernels()
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma = ctx.saved_tensors
@@ -384,6 +399,7 @@ class ConceptInputFn(torch.autograd.Function):
     freeze_ent_emb=True is the only mode this path takes)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed):
         K = kernels()
         pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx)
@@ -394,6 +410,7 @@ class ConceptInputFn(torch.autograd.Function):
         return K.gelu_dropout_fwd(pre, p, seed)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dHp):
         K = kernels()
         emb_w, rowidx, pre = ctx.saved_tensors

@@ -188,6 +188,24 @@ def test_full_size_batch_properties(shape, B, nc, n_rel, n_etype):
     assert any(not torch.equal(before[k], v) for k, v in model.named_buffers())
 
 
+def test_autocast_leaves_the_gnn_stack_in_fp32():
+    """The reference trains under torch.cuda.amp.autocast (--fp16); the GNN stack must stay fp32 there, bit for bit."""
+    case = 'config1_train'
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    model = build(case).cuda().eval()
+    _, _, nt, _, al, ei, et = golden_inputs(case, fix)
+    H, ns, x, extra = helpers.mp_inputs(case)
+    args = (H.cuda(), (ei.cuda(), et.cuda()), nt.cuda(), ns.cuda())
+    with torch.no_grad():
+        ref = model.gnn(*args)
+        with torch.autocast('cuda', dtype=torch.float16):
+            amp = model.gnn(*args)
+            logits, _ = model(*cu(*golden_inputs(case, fix)[:5]), (ei.cuda(), et.cuda()))
+    assert amp.dtype == torch.float32 and torch.equal(amp, ref)
+    assert torch.isfinite(logits).all()
+
+
 def test_dropout_train_mode_runs_and_is_seeded():
     from qagnn_amd import modeling_qagnn as MQ
     c = helpers.GOLDEN_CASES['config1_train']
