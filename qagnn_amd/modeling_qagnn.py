@@ -432,3 +432,48 @@ def batch_graph(edge_index_init, edge_type_init, n_nodes):
     """LM_QAGNN.batch_graph (reference modeling_qagnn.py:244-251); see qagnn_amd.data_utils.batch_graph."""
     from .data_utils import batch_graph as _bg
     return _bg(edge_index_init, edge_type_init, n_nodes)
+
+
+class LM_QAGNN(nn.Module):
+    """LM encoder + QA-GNN decoder (reference modeling_qagnn.py:192-251): flattens (batch, num_choice), batches the
+    per-choice subgraphs, runs the encoder, hands `sent_vecs` to the decoder.
+
+    The LM encoder is outside the hot path (north_star: it stays on stock PyTorch-ROCm), so it is injected: `encoder` is any
+    module with `.sent_dim` and `forward(*lm_inputs, layer_id=-1) -> (sent_vecs [B, sent_dim], all_hidden_states)` -- the
+    reference's `modeling_encoder.TextEncoder` satisfies this.  With `encoder=None` the reference behaviour is kept:
+    `TextEncoder(model_name, **encoder_config)` is imported from the reference's `modeling.modeling_encoder`.
+    """
+
+    def __init__(self, args, model_name, k, n_ntype, n_etype, n_concept, concept_dim, concept_in_dim, n_attention_head,
+                 fc_dim, n_fc_layer, p_emb, p_gnn, p_fc, pretrained_concept_emb=None, freeze_ent_emb=True, init_range=0.0,
+                 encoder_config={}, encoder=None):
+        super().__init__()
+        if encoder is None:
+            from modeling.modeling_encoder import TextEncoder  # the reference's own module, when it is on sys.path
+            encoder = TextEncoder(model_name, **encoder_config)
+        self.encoder = encoder
+        self.decoder = QAGNN(args, k, n_ntype, n_etype, self.encoder.sent_dim, n_concept, concept_dim, concept_in_dim,
+                             n_attention_head, fc_dim, n_fc_layer, p_emb, p_gnn, p_fc,
+                             pretrained_concept_emb=pretrained_concept_emb, freeze_ent_emb=freeze_ent_emb, init_range=init_range)
+
+    def forward(self, *inputs, layer_id=-1, cache_output=False, detail=False):
+        """inputs = [*lm_tensors (bs, nc, ...), concept_ids, node_type_ids, node_scores, adj_lengths (bs, nc, ...),
+        edge_index, edge_type (nested lists [bs][nc] of [2, E_g] / [E_g])]  ->  logits (bs, nc), pool_attn."""
+        bs, nc = inputs[0].size(0), inputs[0].size(1)
+        edge_index_orig, edge_type_orig = inputs[-2:]
+        flat = [x.reshape(bs * nc, *x.shape[2:]) for x in inputs[:-2]]
+        *lm_inputs, concept_ids, node_type_ids, node_scores, adj_lengths = flat
+        edge_index = [g for row in edge_index_orig for g in row]  # (:224) nested [bs][nc] -> flat [bs*nc]
+        edge_type = [g for row in edge_type_orig for g in row]
+        edge_index, edge_type = batch_graph(edge_index, edge_type, concept_ids.size(1))
+        dev = node_type_ids.device
+        adj = (edge_index.to(dev), edge_type.to(dev))
+        sent_vecs, all_hidden_states = self.encoder(*lm_inputs, layer_id=layer_id)
+        logits, attn = self.decoder(sent_vecs.to(dev), concept_ids, node_type_ids, node_scores, adj_lengths, adj,
+                                    emb_data=None, cache_output=cache_output)
+        logits = logits.view(bs, nc)
+        if not detail:
+            return logits, attn
+        return logits, attn, concept_ids.view(bs, nc, -1), node_type_ids.view(bs, nc, -1), edge_index_orig, edge_type_orig
+
+    batch_graph = staticmethod(batch_graph)

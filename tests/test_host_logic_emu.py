@@ -151,6 +151,43 @@ def test_float64_exactness(case):
         assert (g1[n] - g2[n]).abs().max().item() / scale < 1e-9, n
 
 
+def test_lm_qagnn_flatten_and_batching_matches_decoder_call():
+    """a1/a2: LM_QAGNN.forward (reference modeling_qagnn.py:207-239) = flatten (bs, nc) + batch_graph + encoder + decoder."""
+    case = 'small_train'
+    fix = helpers.load_golden(case)
+    c = helpers.GOLDEN_CASES[case]
+    nq, nc, n = c['nq'], c['nc'], c['n']
+    sv, cids, nt, ns, al, ei, et = golden_inputs(case, fix)
+
+    class DummyEncoder(torch.nn.Module):
+        sent_dim = c['cfg']['sent_dim']
+
+        def forward(self, x, layer_id=-1):
+            return x, None  # the "LM input" is the sentence vector itself
+
+    cfg = c['cfg']
+    torch.manual_seed(0)
+    lm = MQ.LM_QAGNN(None, 'dummy', cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['n_concept'], cfg['concept_dim'],
+                     cfg['concept_in_dim'], cfg['n_attention_head'], cfg['fc_dim'], cfg['n_fc_layer'], 0.0, 0.0, 0.0,
+                     init_range=cfg['init_range'], encoder=DummyEncoder())
+    helpers.det_fill_(lm.decoder, c['seed'], c['std'])
+    lm.decoder.pooler.dropout.p = lm.decoder.pooler.attention.dropout.p = 0.0
+    lm.train(c['train'])
+    counts = fix['edge_counts']
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    ei_local = torch.from_numpy(fix['edge_index_cat'].astype(np.int64))
+    et_cat = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
+    nested_ei = [[ei_local[:, offs[q * nc + j]:offs[q * nc + j + 1]] for j in range(nc)] for q in range(nq)]
+    nested_et = [[et_cat[offs[q * nc + j]:offs[q * nc + j + 1]] for j in range(nc)] for q in range(nq)]
+    logits, attn = lm(sv.view(nq, nc, -1), cids.view(nq, nc, n), nt.view(nq, nc, n), ns.view(nq, nc, n, 1), al.view(nq, nc),
+                      nested_ei, nested_et)
+    assert logits.shape == (nq, nc)
+    helpers.check_plain(fix, 'logits', logits.reshape(-1, 1), **FWD)
+    out = lm(sv.view(nq, nc, -1), cids.view(nq, nc, n), nt.view(nq, nc, n), ns.view(nq, nc, n, 1), al.view(nq, nc),
+             nested_ei, nested_et, detail=True)
+    assert len(out) == 6 and out[2].shape == (nq, nc, n) and out[4] is nested_ei
+
+
 def test_no_kernel_provider_without_gpu():
     """The package has no CPU fallback: without the emulation installed, asking for kernels must raise."""
     ops.set_kernels(None)
