@@ -103,6 +103,7 @@ typedef struct qagnn_gemm_nn_args {
   int32_t accumulate;                /* 1: C += result */
   const int64_t* a_rowidx;           /* [M] or NULL: row m of A1 is A1[a_rowidx[m]] (embedding-table gather fused into the
                                         operand load, utils/layers.py:604-605); a negative index reads a zero row */
+  int32_t xcd_remap;                 /* set by the library (XCD-contiguous tile order); callers leave it 0 */
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 

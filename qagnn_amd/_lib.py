@@ -34,7 +34,7 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('A2', _vp), ('lda2', _i32), ('K2', _i32), ('B2', _vp), ('ldb2', _i32),
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
-                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp)]
+                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32)]
 
 
 def load_library(path=LIB_PATH):

@@ -7,6 +7,8 @@
 // MFMA 16x16x4 f32 operand layout (wave64), from the CDNA4 ISA:
 //   A: lane l holds A[i = l & 15][k = l >> 4]       B: lane l holds B[k = l >> 4][j = l & 15]
 //   D: lane l, reg r holds D[row = (l >> 4) * 4 + r][col = l & 15]
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace qagnn {
@@ -36,9 +38,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
   __shared__ __attribute__((aligned(16))) float smem[KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // column blocks of one row block are adjacent in blockIdx -> they share the A rows through one XCD's L2 when
-  // gridDim.x (column blocks) is small; rows vary with blockIdx.y.
-  const int m0 = blockIdx.y * NN_BM, n0 = blockIdx.x * BN;
+  // 1-D grid of row-block x column-block tiles.  Workgroup b runs on XCD b % 8 (observed; speed only), so tiles are
+  // re-indexed with xcd_remap(): each XCD gets a CONTIGUOUS range of tiles, and the column blocks of one row block
+  // (consecutive tile ids) read their shared A rows through ONE L2 instead of up to three.
+  const int ncb = (a.No + BN - 1) / BN;
+  const int tile = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int m0 = (tile / ncb) * NN_BM, n0 = (tile % ncb) * BN;
   const int nk1 = a.K1 / BK, nkt = nk1 + a.K2 / BK;
 
   f32x4 acc[2][NT];
@@ -341,9 +346,12 @@ __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C,
 
 template <int NT>
 static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
-  dim3 grid(cdiv(a.No, NT * 16), cdiv(a.M, NN_BM));
-  if (a.a_scale) k_gemm_nn<NT, true><<<grid, 256, 0, stream>>>(a);
-  else k_gemm_nn<NT, false><<<grid, 256, 0, stream>>>(a);
+  static const int xcd_env = getenv("QAGNN_NN_XCD") ? atoi(getenv("QAGNN_NN_XCD")) : 1;
+  qagnn_gemm_nn_args b = a;
+  b.xcd_remap = xcd_env;
+  dim3 grid(cdiv(a.No, NT * 16) * cdiv(a.M, NN_BM));
+  if (a.a_scale) k_gemm_nn<NT, true><<<grid, 256, 0, stream>>>(b);
+  else k_gemm_nn<NT, false><<<grid, 256, 0, stream>>>(b);
   QAGNN_LAUNCH_CHECK("k_gemm_nn");
   return QAGNN_OK;
 }
