@@ -62,6 +62,9 @@ if [[ "$*" == *dp2* ]]; then
   QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 2>&1 | tail -n 20 > gpurun_out/bench_dp2_shared_gpu.log
   echo "dp2 exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
+if [[ "$*" == *census* ]]; then
+  timeout 300 python tools/op_census.py 2>&1 | cut -c1-220 | head -n 90 > gpurun_out/op_census.txt
+fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
 fi
