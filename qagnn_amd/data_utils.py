@@ -129,6 +129,41 @@ def load_sparse_adj_data_with_contextnode(adj_pk_path, max_node_num, num_choice,
     return concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Flat binary cache.  The reference's `.loaded_cache` is a pickle of Python lists holding tens of
+# thousands of tiny tensors (slow to load, 2 objects per subgraph).  The flat form is ONE .npz with CSR offsets + int32
+# edges + uint8 edge types + the four dense arrays; it can be np.load()-ed with mmap_mode='r' and sliced per batch without
+# touching Python objects per graph.
+# ---------------------------------------------------------------------------------------------------------------------
+def save_flat_cache(path, concept_ids, node_type_ids, node_scores, adj_lengths, edge_index, edge_type, half_n_rel):
+    """`edge_index` / `edge_type`: flat lists (one entry per subgraph) as produced by records_to_tensors()."""
+    counts = np.array([e.size(1) for e in edge_index], dtype=np.int64)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    ei = torch.cat(edge_index, dim=1).numpy().astype(np.int32) if len(edge_index) else np.zeros((2, 0), np.int32)
+    et = torch.cat(edge_type, dim=0).numpy()
+    assert et.max(initial=0) < 256
+    np.savez(path, concept_ids=concept_ids.numpy().astype(np.int32), node_type_ids=node_type_ids.numpy().astype(np.uint8),
+             node_scores=node_scores.numpy(), adj_lengths=adj_lengths.numpy().astype(np.int32), edge_ptr=ptr, edge_index=ei,
+             edge_type=et.astype(np.uint8), half_n_rel=np.array(half_n_rel))
+
+
+def load_flat_cache(path, num_choice):
+    """Inverse of save_flat_cache(): returns exactly what load_sparse_adj_data_with_contextnode() returns."""
+    z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+    ptr = z['edge_ptr']
+    ei_all = torch.from_numpy(z['edge_index'].astype(np.int64))
+    et_all = torch.from_numpy(z['edge_type'].astype(np.int64))
+    n_samples = len(ptr) - 1
+    ei = [ei_all[:, ptr[i]:ptr[i + 1]] for i in range(n_samples)]
+    et = [et_all[ptr[i]:ptr[i + 1]] for i in range(n_samples)]
+    edge_index = [ei[q:q + num_choice] for q in range(0, n_samples, num_choice)]
+    edge_type = [et[q:q + num_choice] for q in range(0, n_samples, num_choice)]
+    dense = [torch.from_numpy(z['concept_ids'].astype(np.int64)), torch.from_numpy(z['node_type_ids'].astype(np.int64)),
+             torch.from_numpy(z['node_scores']), torch.from_numpy(z['adj_lengths'].astype(np.int64))]
+    concept_ids, node_type_ids, node_scores, adj_lengths = [x.view(-1, num_choice, *x.size()[1:]) for x in dense]
+    return concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type)
+
+
 def batch_graph(edge_index_init, edge_type_init, n_nodes):
     """LM_QAGNN.batch_graph (reference modeling_qagnn.py:244-251): offset subgraph i by i*n and concatenate.
 

@@ -74,6 +74,20 @@ def test_loader_matches_reference_loader(case, tmp_path):
     assert os.path.exists(p + '.loaded_cache')
 
 
+def test_flat_cache_round_trip(tmp_path):
+    recs = synthetic.make_records(12, seed=21, shape='csqa')
+    out = data_utils.records_to_tensors(recs, 200, 4)
+    p = os.path.join(tmp_path, 'train.graph.flat')
+    data_utils.save_flat_cache(p, *out[1:])
+    cids, nt, ns, al, (ei, et) = data_utils.load_flat_cache(p, 4)
+    assert torch.equal(cids.view(12, 200), out[1]) and torch.equal(nt.view(12, 200), out[2])
+    assert torch.equal(ns.view(12, 200, 1), out[3]) and torch.equal(al.view(12), out[4])
+    flat_ei = [t for r in ei for t in r]
+    flat_et = [t for r in et for t in r]
+    assert all(torch.equal(a, b) for a, b in zip(flat_ei, out[5])) and all(torch.equal(a, b) for a, b in zip(flat_et, out[6]))
+    assert flat_ei[0].dtype == torch.long and len(ei) == 3 and len(ei[0]) == 4
+
+
 def test_loader_invariants():
     """symmetric edge multiset, no edge touches a PAD node, node 0 is the context node."""
     recs = synthetic.make_records(8, seed=3, shape='csqa')
