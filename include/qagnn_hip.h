@@ -72,7 +72,9 @@ typedef struct qagnn_graph {
   int32_t* n_chunks;           /* [1] device scalar */
   int32_t* chunkptr;           /* [C+1] first chunk of each class */
   int32_t max_chunks;          /* Ep / QAGNN_CLS_CHUNK + C + 1 */
-  int32_t* err;                /* [1] device flag: 1 = an index was out of range (it was clamped) */
+  int32_t* err;                /* [4] device flags: [0] = 1: an index was out of range (it was clamped);
+                                  [1] = 1: some edge leaves its block of block_n consecutive node rows */
+  int32_t block_n;             /* 0, or the node-block size the graph was checked against (subgraph = n consecutive rows) */
 } qagnn_graph;
 
 #define QAGNN_CLS_CHUNK 64
@@ -82,6 +84,12 @@ int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T);
 /* Carve `storage` (int32, qagnn_graph_storage_elems elements, 16-byte aligned) into *g and build everything. */
 int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t* edge_index /* [2][E] */, const int64_t* edge_type /* [E] */,
                      const int64_t* node_type /* [N] */, int32_t N, int32_t E, int32_t R, int32_t T, qagnn_stream_t stream);
+/* Same; additionally records (device flag err[1]) whether every edge stays inside its block of `block_n` consecutive node
+ * rows -- true for batches built by LM_QAGNN.batch_graph (modeling_qagnn.py:244-251: subgraph i owns rows [i*n, (i+1)*n)).
+ * The LDS-resident edge kernel below is taken only for such graphs; the decision is made ON THE DEVICE (no host sync). */
+int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const int64_t* edge_index, const int64_t* edge_type,
+                             const int64_t* node_type, int32_t N, int32_t E, int32_t R, int32_t T, int32_t block_n,
+                             qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Dense fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32).  Replace the cuBLAS SGEMMs of
@@ -167,6 +175,15 @@ int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t
 int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                             qagnn_stream_t stream);
+/* Forward for block-structured batches (g->block_n = n > 0): one workgroup per (subgraph, head) stages that head's K, M and Q
+ * rows of the subgraph in LDS (3 * n * HP floats: 125 KB at n = 200, d = 200) plus the subgraph's alpha values, computes
+ * scores / segment softmax / aggregation entirely out of LDS and touches HBM only for the compulsory bytes (each K|M|Q row
+ * once, indices, outputs).  If the device flag says the graph is NOT block-structured the workgroups exit at once and the
+ * generic three kernels run instead (and vice versa), so the result is always right and the host never synchronises.
+ * Returns QAGNN_EUNSUPPORTED when 3 * n * HP floats do not fit the 160 KB LDS (callers then use qagnn_edge_attn_fwd_f32). */
+int qagnn_edge_attn_fwd_blocked_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
+                                    float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
+                                    qagnn_stream_t stream);
 int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ,
                             float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream);

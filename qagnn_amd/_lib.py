@@ -12,7 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libqagnn_hip.so')
 
-EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep',
+EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
+           'qagnn_edge_attn_fwd_blocked_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
@@ -26,7 +27,7 @@ class qagnn_graph(C.Structure):
                 [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'cls_t', 'pos_t',
                                     'clsptr', 'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
-                [('max_chunks', _i32), ('err', _vp)])
+                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32)])
 
 
 class qagnn_gemm_nn_args(C.Structure):
@@ -47,6 +48,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_storage_elems.restype = _i64
     lib.qagnn_graph_storage_elems.argtypes = [_i32, _i32, _i32, _i32]
     lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
+    lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
@@ -61,6 +63,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
+    lib.qagnn_edge_attn_fwd_blocked_f32.argtypes = lib.qagnn_edge_attn_fwd_f32.argtypes
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
     for name in EXPORTS:
@@ -83,9 +86,10 @@ def _chk2d(t, name, dtype=torch.float32):
 class HipGraph:
     """Device-side prepared graph (see qagnn_graph in include/qagnn_hip.h)."""
 
-    def __init__(self, storage, cstruct, N, E, R, T):
+    def __init__(self, storage, cstruct, N, E, R, T, block_n=0):
         self.storage, self.c = storage, cstruct
         self.N, self.E, self.Ep, self.R, self.T = N, E, E + N, R, T
+        self.block_n = block_n
         self.C = R * T * T + T
         self.max_chunks = cstruct.max_chunks
 
@@ -113,6 +117,7 @@ class HipKernels:
         self.lib = load_library()
         if self.lib.qagnn_abi_version() != 1:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
+        self.edge_blocked = os.environ.get('QAGNN_EDGE_BLOCKED', '1') == '1'  # A/B switch for the LDS-resident edge forward
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -123,7 +128,9 @@ class HipKernels:
             raise RuntimeError(f'{what} failed (code {rc}): {self.lib.qagnn_last_error().decode()}')
 
     # -- graph -------------------------------------------------------------------------------------------------
-    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype):
+    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype, block_n=0):
+        """block_n = n > 0: the caller expects subgraph i to own node rows [i*n, (i+1)*n) (LM_QAGNN.batch_graph); whether the
+        edges really respect that is recorded in a device flag and decides, on the device, which edge kernel runs."""
         assert edge_index.dtype == torch.long and edge_type.dtype == torch.long and node_type.dtype == torch.long
         assert edge_index.dim() == 2 and edge_index.size(0) == 2
         edge_index, edge_type, node_type = edge_index.contiguous(), edge_type.contiguous(), node_type.contiguous()
@@ -131,11 +138,13 @@ class HipKernels:
         elems = self.lib.qagnn_graph_storage_elems(N, E, n_etype, n_ntype)
         storage = torch.empty(elems, dtype=torch.int32, device=node_type.device)
         g = qagnn_graph()
-        rc = self.lib.qagnn_graph_prep(C.byref(g), storage.data_ptr(), _ptr(edge_index) if E else None,
-                                       _ptr(edge_type) if E else None, node_type.data_ptr(), N, E, n_etype, n_ntype,
-                                       self._stream())
-        self._check(rc, 'qagnn_graph_prep')
-        return HipGraph(storage, g, N, E, n_etype, n_ntype)
+        if block_n and N % block_n:
+            block_n = 0
+        rc = self.lib.qagnn_graph_prep_blocked(C.byref(g), storage.data_ptr(), _ptr(edge_index) if E else None,
+                                               _ptr(edge_type) if E else None, node_type.data_ptr(), N, E, n_etype, n_ntype,
+                                               int(block_n), self._stream())
+        self._check(rc, 'qagnn_graph_prep_blocked')
+        return HipGraph(storage, g, N, E, n_etype, n_ntype, int(block_n))
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
@@ -259,10 +268,12 @@ class HipKernels:
         a = torch.empty_like(score)
         alpha = torch.empty_like(score)
         aggr = torch.empty((graph.N, DP), dtype=torch.float32, device=dev)
-        rc = self.lib.qagnn_edge_attn_fwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP,
-                                              float(qscale), score.data_ptr(), a.data_ptr(), alpha.data_ptr(),
-                                              aggr.data_ptr(), DP, self._stream())
-        self._check(rc, 'qagnn_edge_attn_fwd_f32')
+        # block-structured batch whose per-head K|M|Q slabs fit the LDS: LDS-resident kernel (decided again on the device)
+        blocked = (self.edge_blocked and graph.block_n > 0 and 3 * graph.block_n * HP * 4 + 4096 <= 160 * 1024)
+        fn = self.lib.qagnn_edge_attn_fwd_blocked_f32 if blocked else self.lib.qagnn_edge_attn_fwd_f32
+        rc = fn(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale), score.data_ptr(),
+                a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, self._stream())
+        self._check(rc, 'qagnn_edge_attn_fwd_blocked_f32' if blocked else 'qagnn_edge_attn_fwd_f32')
         return aggr, a, alpha
 
     def edge_attn_bwd(self, graph, KMQ, EkEm, HP, qscale, a, alpha, G):

@@ -45,7 +45,8 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
                                                      const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale,
-                                                     float* __restrict__ score, int N) {
+                                                     float* __restrict__ score, int N, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;  // the LDS-resident kernel took this graph (device-side decision)
   const int s = wave_node();
   if (s >= N) return;
   const Lane L = lane_info(HP);
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
 
 // forward 2/3: softmax over each source segment (PyG softmax: max, exp, sum, / (sum + 1e-16)), then * out-degree
 __global__ __launch_bounds__(256) void k_edge_softmax(const int* __restrict__ rowptr_s, const float* __restrict__ score,
-                                                      float* __restrict__ a, float* __restrict__ alpha, int N) {
+                                                      float* __restrict__ a, float* __restrict__ alpha, int N,
+                                                      const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int s = wave_node();
   if (s >= N) return;
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
                                                         const int* __restrict__ cls_t, const int* __restrict__ pos_t,
                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
                                                         int lde, int HP, const float* __restrict__ alpha,
-                                                        float* __restrict__ aggr, int lda, int N) {
+                                                        float* __restrict__ aggr, int lda, int N, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int t = wave_node();
   if (t >= N) return;
   const Lane L = lane_info(HP);
@@ -314,6 +318,107 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// forward, LDS-resident: one workgroup per (subgraph, head).  A QA subgraph is n consecutive node rows and its edges never
+// leave it (LM_QAGNN.batch_graph), so the head's K, M and Q rows of the subgraph -- 3 x n x HP floats, 125 KB at n = 200,
+// d = 200 -- fit the 160 KB LDS of a CU.  All per-edge gathers then hit LDS; HBM sees each K|M|Q row once.
+// 16 lanes own one edge (13 of them carry the head's 52 floats as float4), so a wave works on 4 edges at a time.
+// The softmax is three sweeps over the segment (max, sum, normalise), each recomputing the score from LDS: no per-edge state.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float grp4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float grp4_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+__global__ __launch_bounds__(512) void k_edge_fwd_blocked(const int* __restrict__ cross_block, const int* __restrict__ rowptr_s,
+                                                          const int* __restrict__ tgt_s, const int* __restrict__ cls_s,
+                                                          const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
+                                                          const int* __restrict__ cls_t, const int* __restrict__ pos_t,
+                                                          const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
+                                                          int lde, int HP, float qscale, int n, int alpha_cap,
+                                                          float* __restrict__ a, float* __restrict__ alpha,
+                                                          float* __restrict__ aggr, int lda) {
+  if (*cross_block != 0) return;  // not block-structured: the generic kernels handle this graph
+  extern __shared__ __attribute__((aligned(16))) float sm_blk[];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // the 4 heads of a subgraph stay on one XCD (shared indices, tables)
+  const int gph = tile >> 2, h = tile & 3, node0 = gph * n;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, j = lane & 15;
+  const int DP = 4 * HP, f4 = HP >> 2;
+  const bool act = j < f4;
+  float* const Ks = sm_blk;
+  float* const Ms = Ks + n * HP;
+  float* const Qs = Ms + n * HP;
+  float* const alphaL = Qs + n * HP;
+  for (int idx = tid; idx < n * f4; idx += 512) {  // stage the head's K, M, Q slices: 208-byte runs, each read once
+    const int row = idx / f4, c4 = idx - row * f4;
+    const float* src = KMQ + (int64_t)(node0 + row) * ldk + h * HP + c4 * 4;
+    st4(Ks + row * HP + c4 * 4, ld4(src));
+    st4(Ms + row * HP + c4 * 4, ld4(src + DP));
+    st4(Qs + row * HP + c4 * 4, ld4(src + 2 * DP));
+  }
+  const int ebase = rowptr_s[node0], Eg = rowptr_s[node0 + n] - ebase;
+  const bool in_lds = Eg <= alpha_cap;
+  __syncthreads();
+
+  // phase 1: scores + softmax over the out-edges of every source node of the subgraph
+  for (int sl = w; sl < n; sl += 8) {
+    const int s = node0 + sl;
+    const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+    const float4 q4 = act ? ld4(Qs + sl * HP + j * 4) : zero4();
+    const float deg = (float)(end - beg);
+    auto score_at = [&](int e) {  // all 64 lanes call this (shuffles inside); e is clamped by the caller
+      const int t = tgt_s[e] - node0, c = cls_s[e];
+      const float4 k4 = act ? ld4(Ks + t * HP + j * 4) : zero4();
+      const float4 ek = act ? ld4(EkEm + (int64_t)c * lde + h * HP + j * 4) : zero4();
+      return row16_sum(dot4(q4, add4(k4, ek))) * qscale;
+    };
+    float m = -INFINITY;
+    for (int e0 = beg; e0 < end; e0 += 4) {
+      const int e = e0 + grp;
+      const float p = score_at(min(e, end - 1));
+      if (e < end) m = fmaxf(m, p);
+    }
+    m = grp4_max(m);
+    float sum = 0.f;
+    for (int e0 = beg; e0 < end; e0 += 4) {
+      const int e = e0 + grp;
+      const float p = score_at(min(e, end - 1));
+      if (e < end) sum += expf(p - m);
+    }
+    sum = grp4_sum(sum);
+    for (int e0 = beg; e0 < end; e0 += 4) {
+      const int e = e0 + grp;
+      const float p = score_at(min(e, end - 1));
+      if (e < end && j == 0) {
+        const float av = expf(p - m) / (sum + 1e-16f), al = av * deg;
+        a[(int64_t)e * 4 + h] = av;
+        alpha[(int64_t)e * 4 + h] = al;
+        if (in_lds) alphaL[e - ebase] = al;
+      }
+    }
+  }
+  if (!in_lds) __threadfence();  // oversized subgraph: phase 2 reads alpha back from global memory
+  __syncthreads();
+
+  // phase 2: weighted sum of messages into every target node of the subgraph
+  for (int tl = w; tl < n; tl += 8) {
+    const int t = node0 + tl;
+    const int beg = __builtin_amdgcn_readfirstlane(rowptr_t[t]), end = __builtin_amdgcn_readfirstlane(rowptr_t[t + 1]);
+    float4 acc = zero4();
+    for (int e0 = beg; e0 < end; e0 += 4) {
+      const int e = e0 + grp, ec = min(e, end - 1);
+      const int sl = src_t[ec] - node0, c = cls_t[ec], p = pos_t[ec];
+      const float al = e < end ? (in_lds ? alphaL[p - ebase] : alpha[(int64_t)p * 4 + h]) : 0.f;
+      const float4 m4 = act ? ld4(Ms + sl * HP + j * 4) : zero4();
+      const float4 em = act ? ld4(EkEm + (int64_t)c * lde + DP + h * HP + j * 4) : zero4();
+      acc = fma4(al, add4(m4, em), acc);
+    }
+    acc.x = grp4_sum(acc.x);
+    acc.y = grp4_sum(acc.y);
+    acc.z = grp4_sum(acc.z);
+    acc.w = grp4_sum(acc.w);
+    if (grp == 0 && act) st4(aggr + (int64_t)t * lda + h * HP + j * 4, acc);
+  }
+}
+
 static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const float* EkEm, int lde, int HP, const char* who) {
   QAGNN_REQUIRE(g && KMQ && EkEm, QAGNN_EINVAL, "%s: null pointer", who);
   QAGNN_REQUIRE(HP > 0 && HP % 4 == 0 && HP <= 64, QAGNN_EUNSUPPORTED, "%s: head pitch HP=%d must be a multiple of 4, <= 64", who, HP);
@@ -327,22 +432,53 @@ static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const f
 
 using namespace qagnn;
 
-extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
-                                       int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
-                                       qagnn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
+                                 float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda, const int* gate,
+                                 hipStream_t stream) {
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
                 "edge_attn_fwd: bad output arguments");
   const int nb = cdiv(g->N, 4);
-  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, g->N);
+  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, g->N, gate);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
-  k_edge_softmax<<<nb, 256, 0, stream>>>(g->rowptr_s, score, a, alpha, g->N);
+  k_edge_softmax<<<nb, 256, 0, stream>>>(g->rowptr_s, score, a, alpha, g->N, gate);
   QAGNN_LAUNCH_CHECK("k_edge_softmax");
-  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N);
+  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, gate);
   QAGNN_LAUNCH_CHECK("k_edge_aggregate");
   return QAGNN_OK;
+}
+
+extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
+                                       int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
+                                       qagnn_stream_t stream_) {
+  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int qagnn_edge_attn_fwd_blocked_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
+                                               int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr,
+                                               int32_t lda, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd_blocked");
+  if (rc != QAGNN_OK) return rc;
+  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0, QAGNN_EINVAL, "edge_attn_fwd_blocked: graph was not prepared with a block size");
+  const int n = g->block_n;
+  const size_t lds_max = 160 * 1024, slabs = (size_t)3 * n * HP * sizeof(float);
+  QAGNN_REQUIRE(slabs + 4096 <= lds_max, QAGNN_EUNSUPPORTED, "edge_attn_fwd_blocked: 3 x %d x %d floats do not fit the LDS", n, HP);
+  const int alpha_cap = (int)((lds_max - slabs) / sizeof(float)) & ~3;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    if (e != hipSuccess) { set_error("edge_attn_fwd_blocked: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
+    attr_set = true;
+  }
+  const int* cross = g->err + 1;
+  k_edge_fwd_blocked<<<(g->N / n) * 4, 512, slabs + (size_t)alpha_cap * sizeof(float), stream>>>(
+      cross, g->rowptr_s, g->tgt_s, g->cls_s, g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, qscale, n,
+      alpha_cap, a, alpha, aggr, lda);
+  QAGNN_LAUNCH_CHECK("k_edge_fwd_blocked");
+  // graphs that are not block-structured fall through to the generic kernels (gated on the same device flag)
+  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, cross, stream);
 }
 
 extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,

@@ -27,7 +27,7 @@ void set_error(const char* fmt, ...) {
 __global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
                                const int64_t* __restrict__ node_type, int N, int E, int R, int T, int* __restrict__ es,
                                int* __restrict__ et, int* __restrict__ ec, int* __restrict__ cnt_s, int* __restrict__ cnt_t,
-                               int* __restrict__ err) {
+                               int* __restrict__ err, int block_n) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int Ep = E + N;
   if (e >= Ep) return;
@@ -50,6 +50,7 @@ __global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int
     c = R * T * T + (int)min(max(hs, (int64_t)0), (int64_t)T - 1);
   }
   if (bad) *err = 1;
+  if (block_n > 0 && s / block_n != t / block_n) err[1] = 1;  // an edge leaves its block of block_n node rows
   es[e] = s;
   et[e] = t;
   ec[e] = c;
@@ -258,7 +259,14 @@ extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, in
 
 extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t* edge_index, const int64_t* edge_type,
                                 const int64_t* node_type, int32_t N, int32_t E, int32_t R, int32_t T, qagnn_stream_t stream_) {
+  return qagnn_graph_prep_blocked(g, storage, edge_index, edge_type, node_type, N, E, R, T, 0, stream_);
+}
+
+extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const int64_t* edge_index, const int64_t* edge_type,
+                                        const int64_t* node_type, int32_t N, int32_t E, int32_t R, int32_t T, int32_t block_n,
+                                        qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(block_n >= 0 && (block_n == 0 || N % block_n == 0), QAGNN_EINVAL, "graph_prep: N=%d is not a multiple of block_n=%d", N, block_n);
   QAGNN_REQUIRE(g && storage && node_type, QAGNN_EINVAL, "graph_prep: null pointer");
   QAGNN_REQUIRE(N > 0 && E >= 0 && R > 0 && T > 0, QAGNN_EINVAL, "graph_prep: bad sizes N=%d E=%d R=%d T=%d", N, E, R, T);
   QAGNN_REQUIRE(E == 0 || (edge_index && edge_type), QAGNN_EINVAL, "graph_prep: null edge arrays with E=%d", E);
@@ -271,7 +279,7 @@ extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t*
   const int nblk = cdiv(Ep, CLS_BLK);
   int32_t* p = storage;
   auto take = [&](int64_t n) { int32_t* r = p; p += up4(n); return r; };
-  g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch;
+  g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch; g->block_n = block_n;
   g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
   g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
   g->src_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
@@ -292,7 +300,7 @@ extern "C" int qagnn_graph_prep(qagnn_graph* g, int32_t* storage, const int64_t*
   if (he != hipSuccess) { set_error("graph_prep: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   const int TB = 256;
   k_decode_count<<<cdiv(Ep, TB), TB, 0, stream>>>(edge_index, edge_type, node_type, N, E, R, T, es, et, ec, cnt_s, cnt_t,
-                                                   g->err);
+                                                   g->err, block_n);
   QAGNN_LAUNCH_CHECK("k_decode_count");
   k_scan3<<<2, 1024, 0, stream>>>(cnt_s, g->rowptr_s, N, cnt_t, g->rowptr_t, N, nullptr, nullptr, 0);
   QAGNN_LAUNCH_CHECK("k_scan3");

@@ -336,7 +336,8 @@ class QAGNN_Message_Passing(nn.Module):
         edge_index, edge_type = A
         ntype = node_type.reshape(-1).contiguous()
         if graph is None:
-            graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype)
+            # subgraph i owns node rows [i*n, (i+1)*n) (LM_QAGNN.batch_graph): lets the edge forward run out of LDS
+            graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype, block_n=n)
         per_layer, (Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes) = self.pack_all(L)
         temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))

@@ -14,7 +14,8 @@ CLS_CHUNK = 64
 class EmuGraph:
     """Same arrays, same canonical order (group key, then edge id) as qagnn_graph_prep."""
 
-    def __init__(self, edge_index, edge_type, node_type, R, T):
+    def __init__(self, edge_index, edge_type, node_type, R, T, block_n=0):
+        self.block_n = block_n
         dev = node_type.device
         N, E = node_type.numel(), edge_index.size(1)
         self.N, self.E, self.Ep, self.R, self.T = N, E, E + N, R, T
@@ -76,8 +77,8 @@ def _gelu_grad(x):
 class EmuKernels:
     name = 'emu'
 
-    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype):
-        return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype)
+    def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype, block_n=0):
+        return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype, block_n)
 
     @staticmethod
     def _gather_rows(A, idx):

@@ -299,6 +299,37 @@ def test_edge_attention_forward_backward(name, HP):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,HP,block_n,expect_blocked', [('csqa_b10', 52, 200, True), ('medqa_b8', 52, 200, True),
+                                                            ('small_train', 8, 20, True), ('config1_train', 52, 100, True),
+                                                            ('rand_hub', 52, 100, False), ('rand_small', 28, 10, False),
+                                                            ('no_edges', 16, 8, True)])
+def test_edge_attention_forward_lds_resident(name, HP, block_n, expect_blocked):
+    """qagnn_edge_attn_fwd_blocked_f32: block-structured batches run out of LDS; graphs with an edge that leaves its block
+    are detected ON THE DEVICE and fall through to the generic kernels.  Same answer either way."""
+    (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs(name, HP, 33)
+    K = hip()
+    assert K.edge_blocked
+    g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T, block_n=block_n)
+    assert g.block_n == block_n
+    aggr, a, alpha = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
+    torch.cuda.synchronize()
+    assert bool(g.array('err', 2)[1].item() == 0) == expect_blocked
+    e = EmuGraph(ei, et, nt, R, T)
+    aggr_r, a_r, alpha_r = EMU.edge_attn_fwd(e, KMQ.double(), EkEm.double(), HP, qs)
+    for nm, got, ref, tol in (('a', a, a_r, 2e-6), ('alpha', alpha, alpha_r, 2e-6), ('aggr', aggr, aggr_r, 5e-6)):
+        got = got.cpu().double()
+        scale = ref.abs().max().item() + 1e-30
+        assert (got - ref).abs().max().item() <= tol * scale, nm
+    # the backward consumes a / alpha produced by either forward
+    dKMQ, dEkEm = K.edge_attn_bwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs, a, alpha, G.cuda())
+    dKMQ_r, dEkEm_r = EMU.edge_attn_bwd(e, KMQ.double(), EkEm.double(), HP, qs, a_r, alpha_r, G.double())
+    assert (dKMQ.cpu().double() - dKMQ_r).abs().max().item() <= 2e-5 * (dKMQ_r.abs().max().item() + 1e-30)
+    # deterministic
+    aggr2, a2, _ = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
+    assert torch.equal(aggr2, aggr) and torch.equal(a2, a)
+
+
+@pytest.mark.gpu
 def test_edge_attention_is_deterministic():
     (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs('rand_hub', 52, 3)
     K = hip()
