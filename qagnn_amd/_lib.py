@@ -117,7 +117,10 @@ class HipKernels:
         self.lib = load_library()
         if self.lib.qagnn_abi_version() != 1:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
-        self.edge_blocked = os.environ.get('QAGNN_EDGE_BLOCKED', '1') == '1'  # A/B switch for the LDS-resident edge forward
+        # LDS-resident edge forward (qagnn_edge_attn_fwd_blocked_f32).  Correct, but in its first form 5x slower than the generic
+        # gather kernels (interleaved A/B, run 26: 17 786 / 17 751 vs 21 449 / 21 452 QA-subgraphs/s): one 157 KB workgroup per CU
+        # leaves 8 waves to hide the latency of the per-edge index and class-table loads, the generic path has 32.  Default OFF.
+        self.edge_blocked = os.environ.get('QAGNN_EDGE_BLOCKED', '0') == '1'
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):

@@ -308,7 +308,7 @@ def test_edge_attention_forward_lds_resident(name, HP, block_n, expect_blocked):
     are detected ON THE DEVICE and fall through to the generic kernels.  Same answer either way."""
     (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs(name, HP, 33)
     K = hip()
-    assert K.edge_blocked
+    K.edge_blocked = True  # off by default (slower than the generic kernels in its first form); exercised here
     g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T, block_n=block_n)
     assert g.block_n == block_n
     aggr, a, alpha = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
@@ -326,6 +326,7 @@ def test_edge_attention_forward_lds_resident(name, HP, block_n, expect_blocked):
     assert (dKMQ.cpu().double() - dKMQ_r).abs().max().item() <= 2e-5 * (dKMQ_r.abs().max().item() + 1e-30)
     # deterministic
     aggr2, a2, _ = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
+    K.edge_blocked = False
     assert torch.equal(aggr2, aggr) and torch.equal(a2, a)
 
 
