@@ -78,6 +78,7 @@ class _PlanGatherFn(torch.autograd.Function):
         packed = flat.index_select(0, plan.idx)
         ctx.plan = plan
         ctx.src_shapes = [t.shape for t in sources]
+        ctx.set_materialize_grads(False)  # operands without a gradient arrive as None, not as ~50 freshly zero-filled tensors
         return tuple(packed[a:a + n].view(shape) for a, n, shape in plan.slices)
 
     @staticmethod
