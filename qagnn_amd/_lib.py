@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libqagnn_hip.so')
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_edge_attn_fwd_blocked_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
-           'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_relu_bwd_f32',
+           'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
 
@@ -57,8 +57,9 @@ def load_library(path=LIB_PATH):
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
-    lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
-    lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]
+    lib.qagnn_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
+    lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp]
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
@@ -209,33 +210,52 @@ class HipKernels:
         return (out, bsum) if colsum_groups else out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------
-    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout):
+    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0):
         _chk2d(X, 'X')
         R, Cc = X.shape
         out = torch.empty((nout, Cc), dtype=torch.float32, device=X.device)
         ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, groups), dtype=torch.float32, device=X.device)
         rc = self.lib.qagnn_colreduce_f32(mode, X.data_ptr(), Cc, _ptr(X2), Cc, R, Cc, _ptr(rowidx), groups, _ptr(mean),
-                                          _ptr(invstd), _ptr(scale), _ptr(shift), out.data_ptr(), ws.data_ptr(), self._stream())
+                                          _ptr(invstd), _ptr(scale), _ptr(shift), float(out_scale), out.data_ptr(), ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_colreduce_f32')
         return out
 
-    def colsum(self, X, rowidx=None, groups=1):
-        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups)
+    def colsum(self, X, rowidx=None, groups=1, scale=1.0):
+        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups, scale)
 
-    def colvar_sum(self, X, mean):
-        return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1)[0]
+    def colvar_sum(self, X, mean, scale=1.0):
+        return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1, scale)[0]
+
+    def bn_finalize(self, mean, var, gamma, beta, eps, running=None):
+        """-> invstd, scale, shift [Cc]; running = (run_mean [d], run_var [d], num_batches_tracked, dense_pos [d], momentum, unbias)
+        additionally applies the train-mode running-statistics update in the same launch."""
+        Cc = mean.numel()
+        out = torch.empty((3, Cc), dtype=torch.float32, device=mean.device)
+        rm = rv = nbt = pos = None
+        d, mom, unb = 0, 0.0, 1.0
+        if running is not None:
+            rm, rv, nbt, pos, mom, unb = running
+            d = rm.numel()
+            assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and nbt.dtype == torch.long
+        rc = self.lib.qagnn_bn_finalize_f32(mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), Cc, _ptr(rm), _ptr(rv), _ptr(nbt),
+                                            _ptr(pos), d, float(mom), float(unb), self._stream())
+        self._check(rc, 'qagnn_bn_finalize_f32')
+        return out[0], out[1], out[2]
 
     def bn_bwd_reduce(self, dR, H, mean, invstd, scale, shift):
         _chk2d(H, 'H')
         return self._colreduce(2, dR, H, None, 1, mean, invstd, scale, shift, 2)
 
-    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gscale, c1, c2):
+    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows):
+        """red = bn_bwd_reduce(...) [2, Cc]; inv_rows = 1/R (batch statistics) or 0 (running statistics)."""
+        assert red.is_contiguous() and red.shape == (2, H.size(1))
         _chk2d(dR, 'dR'), _chk2d(H, 'H')
         R, Cc = H.shape
         dH = torch.empty_like(H)
         rc = self.lib.qagnn_bn_relu_bwd_f32(dR.data_ptr(), H.data_ptr(), dH.data_ptr(), Cc, R, Cc, mean.data_ptr(),
-                                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gscale.data_ptr(),
-                                            c1.data_ptr(), c2.data_ptr(), self._stream())
+                                            invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(),
+                                            red[0].data_ptr(), red[1].data_ptr(), float(inv_rows), self._stream())
         self._check(rc, 'qagnn_bn_relu_bwd_f32')
         return dH
 

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
 }
 
 // ordered sum of the chunk partials: 64 outputs x 4 chunk partitions per block, partitions combined in fixed order
-__global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot) {
+__global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot,
+                                                         float out_scale) {
   __shared__ float red[4][64];
   const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s = 0.f;
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict
   }
   red[q][threadIdx.x & 63] = s;
   __syncthreads();
-  if (q == 0 && o < tot) out[o] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (q == 0 && o < tot) out[o] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * out_scale;
 }
 
 __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH, int ld, int R,
                               int Cc, const float* __restrict__ mean, const float* __restrict__ invstd,
-                              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ gscale,
-                              const float* __restrict__ c1, const float* __restrict__ c2) {
+                              const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ gamma,
+                              const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_hhat, float inv_rows) {
   const int c4n = Cc >> 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)R * c4n) return;
@@ -109,17 +110,40 @@ __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restr
   const int64_t off = (int64_t)r * ld + col;
   const float4 g = ld4(dR + off), h = ld4(Hh + off);
   const float4 mu = ld4(mean + col), is = ld4(invstd + col), sc = ld4(scale + col), sh = ld4(shift + col);
-  const float4 gs = ld4(gscale + col), k1 = ld4(c1 + col), k2 = ld4(c2 + col);
+  const float4 ga = ld4(gamma + col), k1 = ld4(sum_dy + col), k2 = ld4(sum_dy_hhat + col);
   float4 o;
 #define ONE(f)                                              \
   {                                                         \
     const float dy = fmaf(h.f, sc.f, sh.f) > 0.f ? g.f : 0.f; \
     const float hh = (h.f - mu.f) * is.f;                   \
-    o.f = gs.f * (dy - k1.f - hh * k2.f);                   \
+    o.f = ga.f * is.f * (dy - k1.f * inv_rows - hh * (k2.f * inv_rows)); \
   }
   ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
   st4(dH + off, o);
+}
+
+// BatchNorm1d bookkeeping of GATConvE.mlp in ONE launch (torch.nn.BatchNorm1d semantics, modeling_qagnn.py:408):
+//   invstd = 1/sqrt(var + eps), scale = gamma * invstd, shift = beta - mean * scale   (the GEMM operand prologue's affine)
+//   training: running_mean/var <- lerp(., batch mean / UNBIASED batch var, momentum), num_batches_tracked += 1
+// mean/var/gamma/beta are head-padded [Cc]; the module's running buffers are dense [d], dense_pos[k] = padded index of k.
+__global__ void k_bn_finalize(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps, float* __restrict__ invstd, float* __restrict__ scale,
+                              float* __restrict__ shift, int Cc, float* __restrict__ run_mean, float* __restrict__ run_var,
+                              int64_t* __restrict__ nbt, const int64_t* __restrict__ dense_pos, int d, float momentum, float unbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Cc) {
+    const float is = rsqrtf(var[i] + eps), sc = gamma[i] * is;
+    invstd[i] = is;
+    scale[i] = sc;
+    shift[i] = beta[i] - mean[i] * sc;
+  }
+  if (run_mean && i < d) {
+    const int64_t p = dense_pos[i];
+    run_mean[i] += momentum * (mean[p] - run_mean[i]);
+    run_var[i] += momentum * (var[p] * unbias - run_var[i]);
+  }
+  if (nbt && i == 0) *nbt += 1;
 }
 
 // ---- GELU (tanh form) + dropout -----------------------------------------------------------------------------
@@ -180,7 +204,7 @@ extern "C" int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_
 
 extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
                                    const int64_t* rowidx, int32_t groups, const float* mean, const float* invstd,
-                                   const float* scale, const float* shift, float* out, float* workspace, qagnn_stream_t stream_) {
+                                   const float* scale, const float* shift, float out_scale, float* out, float* workspace, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(X && out && workspace, QAGNN_EINVAL, "colreduce: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ldx % 4 == 0 && aligned16(X), QAGNN_EINVAL, "colreduce: bad sizes/alignment");
@@ -203,20 +227,35 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
   }
   QAGNN_LAUNCH_CHECK("k_colreduce");
   const int tot = nout * Cc;
-  k_colreduce_final<<<cdiv(tot, 64), 256, 0, stream>>>(workspace, out, grid.y, tot);
+  k_colreduce_final<<<cdiv(tot, 64), 256, 0, stream>>>(workspace, out, grid.y, tot, out_scale);
   QAGNN_LAUNCH_CHECK("k_colreduce_final");
   return QAGNN_OK;
 }
 
 extern "C" int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc,
                                      const float* mean, const float* invstd, const float* scale, const float* shift,
-                                     const float* gscale, const float* c1, const float* c2, qagnn_stream_t stream_) {
+                                     const float* gamma, const float* sum_dy, const float* sum_dy_hhat, float inv_rows,
+                                     qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gscale && c1 && c2, QAGNN_EINVAL, "bn_relu_bwd: null pointer");
+  QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gamma && sum_dy && sum_dy_hhat, QAGNN_EINVAL,
+                "bn_relu_bwd: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd: bad sizes");
   const int64_t tot = (int64_t)R * (Cc / 4);
-  k_bn_relu_bwd<<<cdiv(tot, 256), 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gscale, c1, c2);
+  k_bn_relu_bwd<<<cdiv(tot, 256), 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
+                                                    inv_rows);
   QAGNN_LAUNCH_CHECK("k_bn_relu_bwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_bn_finalize_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* invstd,
+                                     float* scale, float* shift, int32_t Cc, float* run_mean, float* run_var, int64_t* num_batches_tracked,
+                                     const int64_t* dense_pos, int32_t d, float momentum, float unbias, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(mean && var && gamma && beta && invstd && scale && shift && Cc > 0, QAGNN_EINVAL, "bn_finalize: null pointer");
+  QAGNN_REQUIRE(!run_mean || (run_var && dense_pos && d > 0 && d <= Cc), QAGNN_EINVAL, "bn_finalize: running-stat arguments");
+  k_bn_finalize<<<cdiv(Cc, 256), 256, 0, stream>>>(mean, var, gamma, beta, eps, invstd, scale, shift, Cc, run_mean, run_var,
+                                                   num_batches_tracked, dense_pos, d, momentum, unbias);
+  QAGNN_LAUNCH_CHECK("k_bn_finalize");
   return QAGNN_OK;
 }
 

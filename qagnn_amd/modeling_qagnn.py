@@ -228,15 +228,13 @@ class GATConvE(nn.Module):
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
         use_batch_stats = self.training or not bn.track_running_stats
+        running = None
+        if self.training and bn.track_running_stats:  # train-mode buffer update, done inside the BN bookkeeping kernel
+            R = float(Xp.size(0))
+            running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos,
+                       bn.momentum if bn.momentum is not None else 0.1, R / max(R - 1.0, 1.0))
         y, mean_p, var_p = ops.gat_mlp(aggr, *mlp_ops, use_batch_stats, bn.eps, p_drop if self.training else 0.0,
-                                       apply_act)
-        if self.training and bn.track_running_stats:
-            with torch.no_grad():
-                R = float(Xp.size(0))
-                m = bn.momentum if bn.momentum is not None else 0.1
-                bn.running_mean.lerp_(L.unpad(mean_p), m)
-                bn.running_var.lerp_(L.unpad(var_p) * (R / max(R - 1.0, 1.0)), m)
-                bn.num_batches_tracked += 1
+                                       apply_act, running)
         return y, a
 
     @_fp32_region

@@ -327,18 +327,17 @@ class GatMlpFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act):
+    def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act, running):
         K = kernels()
         R = aggr.size(0)
         h1 = K.gemm_nn(aggr, W1t, bias=b1)
         if training:
-            mean = K.colsum(h1)[0] / R
-            var = K.colvar_sum(h1, mean) / R  # biased
+            mean = K.colsum(h1, scale=1.0 / R)[0]
+            var = K.colvar_sum(h1, mean, scale=1.0 / R)  # biased
         else:
             mean, var = run_mean, run_var
-        invstd = torch.rsqrt(var + eps)
-        scale = gamma * invstd
-        shift = beta - mean * scale
+        # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
+        invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
         out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
         ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma)
@@ -364,11 +363,7 @@ class GatMlpFn(torch.autograd.Function):
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
-        if training:
-            c1, c2 = red[0] / R, red[1] / R
-        else:
-            c1 = c2 = torch.zeros_like(red[0])
-        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma * invstd, c1.contiguous(), c2.contiguous())
+        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0)
         with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
             if FUSED_COLSUM:
                 dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
@@ -378,15 +373,15 @@ class GatMlpFn(torch.autograd.Function):
                 db1 = K.colsum(dh1)[0]
         daggr = K.gemm_nn(dh1, W1)
         wg.join()
-        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None
+        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None
 
 
-def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True):
+def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True, running=None):
     """`batch_stats`: BatchNorm uses batch statistics (train mode); `p`: dropout rate (0 disables); `apply_act`: GELU+dropout
     fused after the second Linear (False returns the raw GATConvE output)."""
     p = float(p) if apply_act else 0.0
     return GatMlpFn.apply(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p,
-                          next_seed() if p > 0 else 0, apply_act)
+                          next_seed() if p > 0 else 0, apply_act, running)
 
 
 class ConceptInputFn(torch.autograd.Function):

@@ -208,13 +208,45 @@ def test_column_reductions_and_bn_backward(R, C):
     # mask flips at |y| ~ 1e-7 are legal; give the bound the size of a few elements
     tol = 8 * EPS * (X.abs() * (1 + ((H - mean) * invstd).abs())).sum(0).max().item() + 3 * X.abs().max().item() * 4
     assert (got.double() - ref).abs().max().item() <= tol
-    c1, c2 = ref[0].float() / R, ref[1].float() / R
-    args2 = args + (gamma * invstd, c1, c2)
-    got = K.bn_relu_bwd(*[t.cuda() for t in args2]).cpu()
-    ref = EMU.bn_relu_bwd(*[t.double() for t in args2])
-    err = (got.double() - ref).abs()
-    flips = (err > 1e-4 * (1 + ref.abs())).sum().item()
-    assert flips <= 2, f'{flips} elements differ beyond fp32 rounding'
+    red = ref.float().contiguous()
+    for inv_rows in (1.0 / R, 0.0):  # batch statistics / running statistics
+        args2 = args + (gamma, red)
+        got = K.bn_relu_bwd(*[t.cuda() for t in args2], inv_rows).cpu()
+        ref2 = EMU.bn_relu_bwd(*[t.double() for t in args2], inv_rows)
+        err = (got.double() - ref2).abs()
+        flips = (err > 1e-4 * (1 + ref2.abs())).sum().item()
+        assert flips <= 2, f'{flips} elements differ beyond fp32 rounding'
+    # scaled reductions (mean / biased variance come straight out of the reduction)
+    got = K.colsum(H.cuda(), scale=1.0 / R).cpu()[0]
+    assert torch.allclose(got, mean, rtol=1e-5, atol=1e-6)
+    got = K.colvar_sum(H.cuda(), mean.cuda(), scale=1.0 / R).cpu()
+    assert torch.allclose(got, var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('train', [True, False])
+def test_bn_finalize_matches_torch_batchnorm_bookkeeping(train):
+    from qagnn_amd.ops import HeadLayout
+    L = HeadLayout(200, torch.device('cuda'))
+    g = torch.Generator().manual_seed(5)
+    Cc, d = L.DP, 200
+    mean, var = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.1
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    rm, rv, nbt = torch.randn(d, generator=g), torch.rand(d, generator=g) + 0.5, torch.tensor(7)
+    K = hip()
+    running, erunning = None, None
+    rm_g, rv_g, nbt_g = rm.cuda(), rv.cuda(), nbt.cuda()
+    rm_e, rv_e, nbt_e = rm.double(), rv.double(), nbt.clone()
+    if train:
+        running = (rm_g, rv_g, nbt_g, L.dense_pos, 0.1, 64000.0 / 63999.0)
+        erunning = (rm_e, rv_e, nbt_e, L.dense_pos.cpu(), 0.1, 64000.0 / 63999.0)
+    got = K.bn_finalize(mean.cuda(), var.cuda(), gamma.cuda(), beta.cuda(), 1e-5, running)
+    ref = EMU.bn_finalize(mean.double(), var.double(), gamma.double(), beta.double(), 1e-5, erunning)
+    for a, b in zip(got, ref):
+        assert torch.allclose(a.cpu().double(), b, rtol=2e-6, atol=1e-6)
+    assert torch.allclose(rm_g.cpu().double(), rm_e, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rv_g.cpu().double(), rv_e, rtol=1e-6, atol=1e-7)
+    assert int(nbt_g) == int(nbt_e) == (8 if train else 7)
 
 
 @pytest.mark.gpu
