@@ -23,167 +23,197 @@ __host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn 
 
 // ------------------------------------------------------------------------------------------------------------
 // NN:  C[M][No] (+)= [A1|A2] * [B1;B2] + bias + rowtab[rowidx]
-// block = 256 threads; tile 128 x (NT*16); wave w owns row tiles 2w, 2w+1 and all NT column tiles.
+// block = WAVES x 64 threads; output tile BM x (NT*16) with BM = WAVES*RT*16: wave w owns row tiles w*RT .. w*RT+RT-1 and
+// all NT column tiles.  The block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (persistent when the grid is smaller
+// than the tile count): the row stores of tile t are fire-and-forget, so they drain to HBM under the MFMAs of tile t+1.
+// Two shapes are instantiated: <4 waves, RT=2> (one tile per block, the original mapping) and <8 waves, RT=1> (same
+// 128-row tile shared by 8 waves, launched persistent).
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, bool AFFINE>
-__global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
+// Register budget: QAGNN_NN_OCC co-resident blocks per CU (LDS allows 2).  The budget is a trade: 2 blocks per CU let one
+// block's epilogue stores overlap the other's MFMAs, but cap a wave at 512 / (OCC * WAVES / 4) registers.
+#ifndef QAGNN_NN_OCC
+#define QAGNN_NN_OCC 0  // 0 = leave it to the compiler (it takes ~300 registers for NT = 13: one block per CU)
+#endif
+#if QAGNN_NN_OCC > 0
+#define QAGNN_NN_ATTR __attribute__((amdgpu_waves_per_eu(QAGNN_NN_OCC * WAVES / 4, QAGNN_NN_OCC * WAVES / 4)))
+#else
+#define QAGNN_NN_ATTR
+#endif
+
+template <int NT, bool AFFINE, int WAVES, int RT>
+__global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm_nn_args a, int ntiles) {
+  constexpr int NTHR = WAVES * 64, BM = WAVES * RT * 16;
   constexpr int BN = NT * 16;
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;                 // float4 per B tile
-  constexpr int B_IT = (B_F4 + 255) / 256;
-  // one LDS array: the k-loop tiles (A 128 x 17, B 16 x PB) and, afterwards, the epilogue staging area (4 waves x 16 x PS)
+  constexpr int B_IT = (B_F4 + NTHR - 1) / NTHR;
+  // one LDS array: the k-loop tiles (A BM x 20, B 16 x PB) and, afterwards, the epilogue staging slabs (one per wave)
   constexpr int PS = BN + 4;                        // staging pitch: PS % 8 == 4 -> the 4 row groups of a store land 16 banks apart
-  constexpr int A_F = NN_BM * PA_NN, B_F = BK * PB, BUF_F = A_F + B_F;  // one k-tile: A 128 x 20, B 16 x PB
-  constexpr int KLOOP_F = 2 * BUF_F, STAGE_F = 4 * 16 * PS;              // double-buffered k-tiles | epilogue slabs
+  constexpr int SLAB_ROWS = WAVES <= 4 ? 16 : 8;    // rows a wave transposes at a time (keeps 8 waves inside 64 KB)
+  constexpr int SUB = 16 / SLAB_ROWS;
+  constexpr int A_F = BM * PA_NN, B_F = BK * PB, BUF_F = A_F + B_F;
+  constexpr int KLOOP_F = 2 * BUF_F, STAGE_F = WAVES * SLAB_ROWS * PS;   // double-buffered k-tiles | epilogue slabs
   __shared__ __attribute__((aligned(16))) float smem[KLOOP_F > STAGE_F ? KLOOP_F : STAGE_F];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // 1-D grid of row-block x column-block tiles.  Workgroup b runs on XCD b % 8 (observed; speed only), so tiles are
-  // re-indexed with xcd_remap(): each XCD gets a CONTIGUOUS range of tiles, and the column blocks of one row block
-  // (consecutive tile ids) read their shared A rows through ONE L2 instead of up to three.
   const int ncb = (a.No + BN - 1) / BN;
-  const int tile = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int m0 = (tile / ncb) * NN_BM, n0 = (tile % ncb) * BN;
   const int nk1 = a.K1 / BK, nkt = nk1 + a.K2 / BK;
+  const int ar = tid >> 2, ac4 = tid & 3;  // A tile: NTHR/4 rows x 4 float4 per pass, RT passes
 
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    // Workgroup b runs on XCD b % 8 (observed; speed only), so tiles are re-indexed with xcd_remap(): each XCD gets a
+    // CONTIGUOUS range of tiles, and the column blocks of one row block (consecutive tile ids) read their shared A rows
+    // through ONE L2 instead of up to three.  (gridDim.x is a multiple of 8 or equals ntiles, so vb % 8 is the XCD too.)
+    const int tile = a.xcd_remap ? xcd_remap(vb, ntiles) : vb;
+    const int m0 = (tile / ncb) * BM, n0 = (tile % ncb) * BN;
 
-  float4 ra[2];
-  float4 rb[B_IT];
-  const int ar = tid >> 2, ac4 = tid & 3;  // A tile: 64 rows x 4 float4 per pass, 2 passes
-  int64_t arow[2];                         // source row of A1 for this thread's two tile rows (gathered or identity); -1 = zero row
+    f32x4 acc[RT][NT];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int row = m0 + ar + p * 64;
-    arow[p] = row < a.M ? (a.a_rowidx ? a.a_rowidx[row] : (int64_t)row) : -1;
-  }
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto gload = [&](int kt) {
-    const bool first = kt < nk1;
-    const float* A = first ? a.A1 : a.A2;
-    const int lda = first ? a.lda1 : a.lda2;
-    const float* B = first ? a.B1 : a.B2;
-    const int ldb = first ? a.ldb1 : a.ldb2;
-    const int k0 = (first ? kt : kt - nk1) * BK;
+    float4 ra[RT];
+    float4 rb[B_IT];
+    int64_t arow[RT];  // source row of A1 for this thread's tile rows (gathered or identity); -1 = zero row
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = m0 + ar + p * 64;
-      const int64_t srow = first ? arow[p] : (row < a.M ? (int64_t)row : -1);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (srow >= 0) {
-        v = ld4(A + srow * lda + k0 + ac4 * 4);
-        if (AFFINE && first) {
-          const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
-          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-          v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-          v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    for (int p = 0; p < RT; ++p) {
+      const int row = m0 + ar + p * (NTHR / 4);
+      arow[p] = row < a.M ? (a.a_rowidx ? a.a_rowidx[row] : (int64_t)row) : -1;
+    }
+
+    auto gload = [&](int kt) {
+      const bool first = kt < nk1;
+      const float* A = first ? a.A1 : a.A2;
+      const int lda = first ? a.lda1 : a.lda2;
+      const float* B = first ? a.B1 : a.B2;
+      const int ldb = first ? a.ldb1 : a.ldb2;
+      const int k0 = (first ? kt : kt - nk1) * BK;
+#pragma unroll
+      for (int p = 0; p < RT; ++p) {
+        const int row = m0 + ar + p * (NTHR / 4);
+        const int64_t srow = first ? arow[p] : (row < a.M ? (int64_t)row : -1);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (srow >= 0) {
+          v = ld4(A + srow * lda + k0 + ac4 * 4);
+          if (AFFINE && first) {
+            const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
+            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+            v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+            v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+          }
+        }
+        ra[p] = v;
+      }
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) {
+        const int idx = tid + it * NTHR;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < B_F4) {
+          const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+          const int col = n0 + c4 * 4;
+          if (col < a.No) v = ld4(B + (int64_t)(k0 + kr) * ldb + col);
+        }
+        rb[it] = v;
+      }
+    };
+    auto lstore = [&](int buf) {
+      float* As = smem + buf * BUF_F;
+      float* Bs = As + A_F;
+#pragma unroll
+      for (int p = 0; p < RT; ++p) st4(As + (ar + p * (NTHR / 4)) * PA_NN + ac4 * 4, ra[p]);
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) {
+        const int idx = tid + it * NTHR;
+        if (idx < B_F4) {
+          const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+          st4(Bs + kr * PB + c4 * 4, rb[it]);
         }
       }
-      ra[p] = v;
-    }
+    };
+    auto mma = [&](int buf, int kk) {
+      const float* Aw = smem + buf * BUF_F + (w * RT * 16 + (lane & 15)) * PA_NN + (lane >> 4);
+      const float* Bw = smem + buf * BUF_F + A_F + (lane >> 4) * PB + (lane & 15);
+      float av[RT];
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < B_F4) {
-        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-        const int col = n0 + c4 * 4;
-        if (col < a.No) v = ld4(B + (int64_t)(k0 + kr) * ldb + col);
+      for (int i = 0; i < RT; ++i) av[i] = Aw[i * 16 * PA_NN + kk * 4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float b = Bw[kk * 4 * PB + j * 16];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[i][j], 0, 0, 0);
       }
-      rb[it] = v;
-    }
-  };
-  auto lstore = [&](int buf) {
-    float* As = smem + buf * BUF_F;
-    float* Bs = As + A_F;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) st4(As + (ar + p * 64) * PA_NN + ac4 * 4, ra[p]);
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < B_F4) {
-        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-        st4(Bs + kr * PB + c4 * 4, rb[it]);
-      }
-    }
-  };
-  auto mma = [&](int buf, int kk) {
-    const float* Aw = smem + buf * BUF_F + (w * 32 + (lane & 15)) * PA_NN + (lane >> 4);
-    const float* Bw = smem + buf * BUF_F + A_F + (lane >> 4) * PB + (lane & 15);
-    const float a0 = Aw[kk * 4], a1 = Aw[16 * PA_NN + kk * 4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float b = Bw[kk * 4 * PB + j * 16];
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
-    }
-  };
+    };
 
-  // double-buffered k-loop, ONE barrier per k-tile: tile t+1 travels global -> registers while tile t's first two k-steps
-  // run, is written to the other LDS buffer between k-steps (so the ds_writes hide under MFMAs), and becomes visible at
-  // the barrier that also retires everybody's reads of tile t.
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nkt;
+    // double-buffered k-loop, ONE barrier per k-tile: tile t+1 travels global -> registers while tile t's first two
+    // k-steps run, is written to the other LDS buffer between k-steps (so the ds_writes hide under MFMAs), and becomes
+    // visible at the barrier that also retires everybody's reads of tile t.
+    gload(0);
+    __syncthreads();  // the previous output tile's slab reads are done before the k-loop buffers are overwritten
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < nkt;
 #ifndef QAGNN_ABLATE_NOGLOAD
-    if (more) gload(kt + 1);
+      if (more) gload(kt + 1);
 #endif
 #ifndef QAGNN_ABLATE_NOMMA
-    mma(cur, 0);
-    mma(cur, 1);
+      mma(cur, 0);
+      mma(cur, 1);
 #endif
-    if (more) lstore(cur ^ 1);  // ds_writes hide under the remaining MFMAs (measured: later placement is slower here)
+      if (more) lstore(cur ^ 1);  // ds_writes hide under the remaining MFMAs (measured: later placement is slower here)
 #ifndef QAGNN_ABLATE_NOMMA
-    mma(cur, 2);
-    mma(cur, 3);
+      mma(cur, 2);
+      mma(cur, 3);
 #endif
-    __syncthreads();
-  }
+      __syncthreads();
+    }
 #ifdef QAGNN_ABLATE_NOEPI
-  {  // keep the accumulators live with one dword store per lane, skip the real epilogue
-    float keep = 0.f;
-    for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < NT; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (m0 + (tid >> 1) < a.M) a.C[(int64_t)(m0 + (tid >> 1)) * a.ldc + n0 + (tid & 1)] = keep;
-    return;
-  }
+    {  // keep the accumulators live with one dword store per lane, skip the real epilogue
+      float keep = 0.f;
+      for (int i = 0; i < RT; ++i)
+        for (int j = 0; j < NT; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (m0 + (tid >> 1) < a.M) a.C[(int64_t)(m0 + (tid >> 1)) * a.ldc + n0 + (tid & 1)] = keep;
+      continue;
+    }
 #endif
 
-  // epilogue.  The MFMA layout gives a lane ONE column of 4 rows per accumulator; storing that directly is 104 dword
-  // stores per lane in 64-byte row fragments (store-issue bound, and in a single-round grid nothing overlaps it).
-  // Instead each wave transposes one 16-row tile at a time through its private LDS slab and writes whole rows with
-  // 16-byte lanes: 4x fewer store instructions, full 128-byte lines.
-  float* const St = smem + w * 16 * PS;
-  constexpr int ROW_F4 = BN / 4, TILE_F4 = 16 * ROW_F4, ST_IT = (TILE_F4 + 63) / 64;
+    // epilogue.  The MFMA layout gives a lane ONE column of 4 rows per accumulator; storing that directly is 104 dword
+    // stores per lane in 64-byte row fragments (store-issue bound).  Instead each wave transposes SLAB_ROWS rows at a
+    // time through its private LDS slab and writes whole rows with 16-byte lanes: 4x fewer store instructions, full
+    // 128-byte lines.
+    float* const St = smem + w * SLAB_ROWS * PS;
+    constexpr int ROW_F4 = BN / 4, TILE_F4 = SLAB_ROWS * ROW_F4, ST_IT = (TILE_F4 + 63) / 64;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    __syncthreads();  // k-loop reads (i = 0) / previous tile's row reads (i = 1) are done before the slab is overwritten
+    for (int i = 0; i < RT; ++i) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int h = 0; h < SUB; ++h) {
+        __syncthreads();  // k-loop reads (first pass) / the previous pass's slab reads are done before the slab is overwritten
+        const int lr0 = (lane >> 4) * 4 - h * SLAB_ROWS;  // this lane's first row inside the slab (in range for its half only)
+        if (lr0 >= 0 && lr0 < SLAB_ROWS) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) St[((lane >> 4) * 4 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
-    __syncthreads();
+          for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int it = 0; it < ST_IT; ++it) {
-      const int idx = lane + it * 64;
-      if (idx >= TILE_F4) break;
-      const int lr = idx / ROW_F4, c4 = idx % ROW_F4;
-      const int row = m0 + w * 32 + i * 16 + lr, col = n0 + c4 * 4;
-      if (row >= a.M || col >= a.No) continue;
-      float4 v = ld4(St + lr * PS + c4 * 4);
-      if (a.bias) v = add4(v, ld4(a.bias + col));
-      if (a.rowtab) v = add4(v, ld4(a.rowtab + (int64_t)a.rowidx[row] * a.ldt + col));
-      float* dst = a.C + (int64_t)row * a.ldc + col;
-      if (a.accumulate) v = add4(v, ld4(dst));
-      st4(dst, v);
+            for (int r = 0; r < 4; ++r) St[(lr0 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+          const int idx = lane + it * 64;
+          if (idx >= TILE_F4) break;
+          const int lr = idx / ROW_F4, c4 = idx % ROW_F4;
+          const int row = m0 + (w * RT + i) * 16 + h * SLAB_ROWS + lr, col = n0 + c4 * 4;
+          if (row >= a.M || col >= a.No) continue;
+          float4 v = ld4(St + lr * PS + c4 * 4);
+          if (a.bias) v = add4(v, ld4(a.bias + col));
+          if (a.rowtab) v = add4(v, ld4(a.rowtab + (int64_t)a.rowidx[row] * a.ldt + col));
+          float* dst = a.C + (int64_t)row * a.ldc + col;
+          if (a.accumulate) v = add4(v, ld4(dst));
+          st4(dst, v);
+        }
+      }
     }
   }
 }
@@ -195,7 +225,8 @@ __global__ __launch_bounds__(256) void k_gemm_nn(qagnn_gemm_nn_args a) {
 // spent on tile padding (the previous fixed 64-row tile wasted 19 % on 208).  With BM = 16*NW the A k-tile is exactly
 // one float4 per thread.  k-tiles of 16 rows, double-buffered, one barrier per tile.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int TN_RC = 256;  // rows per chunk: >= 1 block per CU for the 208 x 208 gradients at N = 64 000
+constexpr int TN_RC = 256;  // minimum rows per chunk (and the chunking the workspace query assumes): >= 1 block per CU for the
+                            // 208 x 208 gradients at N = 64 000; launches with several tiles per chunk use longer chunks
 
 __host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w + 16; }  // rows k, k+1 land 16 banks apart
 
@@ -203,7 +234,8 @@ template <int NT, bool AFFINE>
 __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                   float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
                                                   const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx,
-                                                  float* __restrict__ Pcs, const int64_t* __restrict__ b_rowidx, int groups) {
+                                                  float* __restrict__ Pcs, const int64_t* __restrict__ b_rowidx, int groups,
+                                                  int chunk_rows) {
   constexpr int BN = NT * 16;
   constexpr int PB = pitch_b(BN);
   constexpr int B_F4 = BK * BN / 4;
@@ -216,7 +248,7 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
   float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
   int rg = 0;  // group id of tile row `tid` (threads 0..15), staged through LDS with the tile
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
-  const int r_beg = chunk * TN_RC, r_end = min(R, r_beg + TN_RC);
+  const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int nkt = (r_end - r_beg + BK - 1) / BK;
 
   f32x4 acc[NT];
@@ -303,15 +335,29 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
+#ifndef QAGNN_ABLATE_NOGLOAD
     if (more) gload(kt + 1);
+#endif
+#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 0);
     mma(cur, 1);
+#endif
     if (do_cs) colsum_tile(cur);
+#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 2);
     mma(cur, 3);
+#endif
     if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
   }
+#ifdef QAGNN_ABLATE_NOEPI
+  {
+    float keep = 0.f;
+    for (int j = 0; j < NT; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (keep == 123.456f) P[tid] = keep;
+    return;
+  }
+#endif
   if (do_cs && n0 + tid < No) {
     float* pc = Pcs + (int64_t)chunk * groups * No + n0 + tid;
     pc[0] = cs0;
@@ -332,6 +378,165 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// TN, flat tile partition (NT = 13 shapes: every weight gradient of the stack).  Same split-K chunking and LDS tiles as
+// k_gemm_tn, different ownership: the block's rb x NT output tiles are numbered row-major and dealt to the waves in
+// CONTIGUOUS runs of q or q+1 tiles (169 tiles of a 208 x 208 gradient over 16 waves: 11,11,...,10), so the four SIMDs carry
+// 43/42/42/42 tiles instead of the 52/39/39/39 of "one wave per 16-row strip" with 13 waves.  A run spans at most two row
+// tiles (TPW <= NT), so a k-step needs two A fragments and one B fragment per tile; all fragments of k-step kk+1 are
+// fetched from LDS before the MFMAs of k-step kk are issued (the register budget at 4 waves/SIMD is 128: accumulators
+// 52 + two fragment sets 30 + the two global-load float4 in flight).
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int TPW, bool AFFINE>
+__global__ __launch_bounds__(1024) void k_gemm_tn_flat(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
+                                                       const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx,
+                                                       int chunk_rows, int rb) {
+  static_assert(TPW <= NT, "a wave's run of tiles may span two row tiles at most");
+  constexpr int BN = NT * 16;
+  constexpr int PB = pitch_b(BN);
+  constexpr int B_F4 = BK * BN / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem_tn[];
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nw = nthr >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int BM = rb * 16, PA = pitch16(BM), TA_F = BK * PA, TBUF_F = TA_F + BK * PB;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
+  const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
+  const int nkt = (r_end - r_beg + BK - 1) / BK;
+
+  // this wave's run of tiles [base, base + count) in the row-major numbering of the block's rb x NT tiles
+  const int tiles = rb * NT, q = tiles / nw, rem = tiles % nw;
+  const int base = w * q + min(w, rem), count = q + (w < rem ? 1 : 0);
+  const int row0 = base / NT, c0 = base - row0 * NT;  // first tile's (row tile, column tile)
+
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // global -> register staging: one float4 of the A tile (threads < 4 * BM) and up to two of the B tile per thread
+  constexpr int B_IT = 2;  // covers B_F4 = 832 float4 with >= 512 threads
+  float4 ra, rbv[B_IT];
+  const int a_f4 = BM / 4;
+  const bool a_thr = tid < BK * a_f4;
+  const int akr = tid / a_f4, ac4 = tid % a_f4;
+  const int acol = m0 + ac4 * 4;
+
+  auto gload = [&](int kt) {
+    const int r0 = r_beg + kt * BK;
+    if (a_thr) {
+      const int row = r0 + akr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t srow = (row < r_end && acol < Ka) ? (a_rowidx ? a_rowidx[row] : (int64_t)row) : -1;
+      if (srow >= 0) {
+        v = ld4(A + srow * lda + acol);
+        if (AFFINE) {  // the BN affine of this thread's 4 columns: re-read per tile (L1 hit) rather than held in 8 registers
+          const float4 a_sc = ld4(a_scale + acol), a_sh = ld4(a_shift + acol);
+          v.x = fmaxf(fmaf(v.x, a_sc.x, a_sh.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, a_sc.y, a_sh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, a_sc.z, a_sh.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, a_sc.w, a_sh.w), 0.f);
+        }
+      }
+      ra = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * nthr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int row = r0 + kr, col = n0 + c4 * 4;
+        if (row < r_end && col < No) v = ld4(B + (int64_t)row * ldb + col);
+      }
+      rbv[it] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* As = smem_tn + buf * TBUF_F;
+    float* Bs = As + TA_F;
+    if (a_thr) st4(As + akr * PA + ac4 * 4, ra);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * nthr;
+      if (idx < B_F4) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        st4(Bs + kr * PB + c4 * 4, rbv[it]);
+      }
+    }
+  };
+  // fragments of one k-step: A for row tiles row0 and row0 + 1 (the second is only consumed by tiles past the row wrap; when
+  // row0 is the block's last row tile it reads 16 floats past the row inside the same LDS buffer and is never used), B per tile
+  float fa[2][2], fb[2][TPW];
+  auto frags = [&](int buf, int kk, int s) {
+    const float* Ab = smem_tn + buf * TBUF_F + (kk * 4 + (lane >> 4)) * PA + row0 * 16 + (lane & 15);
+    const float* Bb = smem_tn + buf * TBUF_F + TA_F + (kk * 4 + (lane >> 4)) * PB + (lane & 15);
+    fa[s][0] = Ab[0];
+    fa[s][1] = Ab[16];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      int c = c0 + j;
+      if (c >= NT) c -= NT;
+      fb[s][j] = Bb[c * 16];
+    }
+  };
+  auto mma = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (j < count) {  // wave-uniform
+        const float av = (c0 + j >= NT) ? fa[s][1] : fa[s][0];
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fb[s][j], acc[j], 0, 0, 0);
+      }
+    }
+  };
+
+  if (nkt > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nkt;
+#ifndef QAGNN_ABLATE_NOGLOAD
+    if (more) gload(kt + 1);
+#endif
+#ifndef QAGNN_ABLATE_NOMMA
+    frags(cur, 0, 0);
+    frags(cur, 1, 1);
+    mma(0);
+    frags(cur, 2, 0);
+    mma(1);
+    frags(cur, 3, 1);
+    mma(0);
+    mma(1);
+#endif
+    if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
+    __syncthreads();
+  }
+#ifdef QAGNN_ABLATE_NOEPI
+  {
+    float keep = 0.f;
+    for (int j = 0; j < TPW; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (keep == 123.456f) P[tid] = keep;
+    return;
+  }
+#endif
+  float* Pc = P + (int64_t)chunk * Ka * No;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (j >= count) continue;
+    int c = c0 + j, rt = row0;
+    if (c >= NT) { c -= NT; rt += 1; }
+    const int col = n0 + c * 16 + (lane & 15);
+    if (col >= No) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + rt * 16 + (lane >> 4) * 4 + r;
+      if (row < Ka) Pc[(int64_t)row * No + col] = acc[j][r];
+    }
+  }
+}
+
 __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C, int ldc, int Ka, int No, int nchunks,
                              int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,14 +549,36 @@ __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C,
   *d = accumulate ? *d + s : s;
 }
 
+// NN launch shapes (QAGNN_NN_PERSIST): 0 = one 128-row tile per 4-wave block, grid = tiles; 1 = 8-wave blocks walking the
+// tiles persistently, QAGNN_NN_BLOCKS_PER_CU (default 1) blocks per CU; 2 = the 4-wave block, persistent, 2 per CU.
+static int num_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
 template <int NT>
 static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
   static const int xcd_env = getenv("QAGNN_NN_XCD") ? atoi(getenv("QAGNN_NN_XCD")) : 1;
+  static const int persist = getenv("QAGNN_NN_PERSIST") ? atoi(getenv("QAGNN_NN_PERSIST")) : 0;
+  static const int per_cu = getenv("QAGNN_NN_BLOCKS_PER_CU") ? atoi(getenv("QAGNN_NN_BLOCKS_PER_CU")) : (persist == 2 ? 2 : 1);
   qagnn_gemm_nn_args b = a;
   b.xcd_remap = xcd_env;
-  dim3 grid(cdiv(a.No, NT * 16) * cdiv(a.M, NN_BM));
-  if (a.a_scale) k_gemm_nn<NT, true><<<grid, 256, 0, stream>>>(b);
-  else k_gemm_nn<NT, false><<<grid, 256, 0, stream>>>(b);
+  const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, NN_BM);
+  const int cap = (num_cus() * (per_cu > 0 ? per_cu : 1)) & ~7;  // multiple of 8: block -> XCD mapping survives the tile walk
+  if (persist == 1) {
+    const int grid = ntiles < cap ? ntiles : cap;
+    if (a.a_scale) k_gemm_nn<NT, true, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
+    else k_gemm_nn<NT, false, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
+  } else {
+    const int grid = (persist == 2 && ntiles > cap) ? cap : ntiles;
+    if (a.a_scale) k_gemm_nn<NT, true, 4, 2><<<grid, 256, 0, stream>>>(b, ntiles);
+    else k_gemm_nn<NT, false, 4, 2><<<grid, 256, 0, stream>>>(b, ntiles);
+  }
   QAGNN_LAUNCH_CHECK("k_gemm_nn");
   return QAGNN_OK;
 }
@@ -368,16 +595,48 @@ static int pick_tn_waves(int Ka) {
 
 template <int NT>
 static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
-                     const float* sh, const int64_t* ridx, int nchunks, float* Pcs, const int64_t* bidx, int groups,
+                     const float* sh, const int64_t* ridx, int chunk_rows, float* Pcs, const int64_t* bidx, int groups,
                      hipStream_t stream) {
-  const int nw = pick_tn_waves(Ka), bm = nw * 16;
+  const int nw = pick_tn_waves(Ka), bm = nw * 16, nchunks = cdiv(R, chunk_rows);
   // B tile loop covers B_IT * nthreads float4: needs (NT + 3) / 4 * nw * 64 >= 16 * NT * 4  <=>  nw >= 4  (guaranteed)
   dim3 grid(cdiv(No, NT * 16), cdiv(Ka, bm), nchunks);
   const size_t lds = 2 * (size_t)(BK * pitch16(bm) + BK * pitch_b(NT * 16) + BK) * sizeof(float);
-  if (sc) k_gemm_tn<NT, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups);
-  else k_gemm_tn<NT, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups);
+  if (sc) k_gemm_tn<NT, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups, chunk_rows);
+  else k_gemm_tn<NT, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, Pcs, bidx, groups, chunk_rows);
   QAGNN_LAUNCH_CHECK("k_gemm_tn");
   return QAGNN_OK;
+}
+
+// flat-partition launch (NT = 13): row tiles per block as in pick_tn_waves, 8 waves when the block has <= 8 * 13 tiles
+static bool tn_flat_enabled() {
+  static const int v = getenv("QAGNN_TN_FLAT") ? atoi(getenv("QAGNN_TN_FLAT")) : 1;
+  return v != 0;
+}
+static int tn_flat_waves(int rb) { return rb * 13 <= 8 * 13 && rb <= 8 ? 8 : 16; }
+
+static int launch_tn_flat(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
+                          const float* sh, const int64_t* ridx, int chunk_rows, hipStream_t stream) {
+  const int rb = pick_tn_waves(Ka), nw = tn_flat_waves(rb), nchunks = cdiv(R, chunk_rows);
+  dim3 grid(cdiv(No, 13 * 16), cdiv(Ka, rb * 16), nchunks);
+  const size_t lds = 2 * (size_t)(BK * pitch16(rb * 16) + BK * pitch_b(13 * 16)) * sizeof(float);
+  if (sc) k_gemm_tn_flat<13, 13, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, rb);
+  else k_gemm_tn_flat<13, 13, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, rb);
+  QAGNN_LAUNCH_CHECK("k_gemm_tn_flat");
+  return QAGNN_OK;
+}
+
+// Rows per split-K chunk.  Every chunk costs one Ka x No partial (written, then re-read by k_sum_chunks), so a launch whose
+// chunk already spans several blocks (column blocks x row blocks) takes longer chunks: just enough blocks to fill the CUs
+// once (twice for blocks of <= 8 waves).  Never below TN_RC, which is what qagnn_gemm_tn_workspace_elems() sizes for.
+// QAGNN_TN_CHUNK=<rows> pins it (256 = the fixed chunking of earlier revisions).
+static int pick_tn_chunk_rows(int R, int Ka, int No, int nt, bool flat) {
+  static const int env = getenv("QAGNN_TN_CHUNK") ? atoi(getenv("QAGNN_TN_CHUNK")) : 0;
+  if (env >= TN_RC) return (env + 15) & ~15;
+  const int rb = pick_tn_waves(Ka), nw = flat ? tn_flat_waves(rb) : rb;
+  const int blocks_per_chunk = cdiv(No, nt * 16) * cdiv(Ka, rb * 16);
+  const int target = (num_cus() * (nw <= 8 ? 2 : 1)) / blocks_per_chunk;
+  const int rows = (cdiv(R, target > 0 ? target : 1) + 15) & ~15;
+  return rows > TN_RC ? rows : TN_RC;
 }
 
 // column-tile count per block: the widest instantiation that divides No, else the one wasting the least
@@ -441,15 +700,19 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
   QAGNN_REQUIRE(!a_scale || (a_shift && aligned16(a_scale) && aligned16(a_shift)), QAGNN_EINVAL,
                 "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
   QAGNN_REQUIRE(!bsum || (groups >= 1 && groups <= 4 && (groups == 1 || b_rowidx)), QAGNN_EINVAL, "gemm_tn: colsum groups=%d (1..4)", groups);
-  const int nchunks = cdiv(R, TN_RC);
+  const int nt = pick_nt(No);
+  const bool flat = nt == 13 && !bsum && tn_flat_enabled();
+  const int crows = pick_tn_chunk_rows(R, Ka, No, nt, flat);
+  const int nchunks = cdiv(R, crows);
   float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;
-  switch (pick_nt(No)) {
-    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
-    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
-    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
-    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
-    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, nchunks, Pcs, b_rowidx, groups, stream); break;
+  if (flat) rc = launch_tn_flat(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, stream);
+  else switch (nt) {
+    case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
+    case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
+    case 7: rc = launch_tn<7>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
+    case 4: rc = launch_tn<4>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
+    default: rc = launch_tn<2>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
   }
   if (rc != QAGNN_OK) return rc;
   const int64_t tot = (int64_t)Ka * No;

@@ -9,6 +9,11 @@ export TMPDIR=/tmp
 if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
   echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+  # the non-default GEMM launch shapes go through the same tests
+  for cfg in "QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=0" "QAGNN_NN_PERSIST=2 QAGNN_TN_CHUNK=256" "QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2"; do
+    env $cfg timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "gemm" 2>&1 | tail -n 40 >> gpurun_out/test_kernels_variants.log
+    echo "kernels[$cfg] exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+  done
 fi
 if [[ "$*" == *parity* ]]; then
   timeout 1200 python -X faulthandler -m pytest tests/test_hip_parity.py -m gpu -q --tb=short -rf --timeout 300 -p no:cacheprovider > /tmp/parity_full.log 2>&1; ( head -c 40000 /tmp/parity_full.log; echo; echo "......"; tail -c 20000 /tmp/parity_full.log ) > gpurun_out/test_parity.log
@@ -68,11 +73,16 @@ fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
 fi
-if [[ "$*" == *ablate* ]]; then
-  for v in BASE NOGLOAD NOMMA NOEPI; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DQAGNN_ABLATE_$v -o /tmp/gemm_ablate_$v tools/gemm_ablate.hip 2>/dev/null
-    echo "== $v" >> gpurun_out/gemm_ablate.txt; /tmp/gemm_ablate_$v >> gpurun_out/gemm_ablate.txt 2>&1
-  done
+if [[ "$*" == *ablate* ]]; then   # prebuilt here by tools/build_micro.sh (compiling on the box would burn GPU minutes)
+  run() { echo "== $*" >> gpurun_out/gemm_micro.txt; env "${@:2}" timeout 120 tools/bin/gemm_ablate_$1 >> gpurun_out/gemm_micro.txt 2>&1; }
+  run BASE QAGNN_NN_PERSIST=0 QAGNN_TN_FLAT=0 QAGNN_TN_CHUNK=256
+  run BASE QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=0
+  run BASE QAGNN_NN_PERSIST=2 QAGNN_TN_FLAT=1 QAGNN_TN_CHUNK=256
+  run BASE QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2 QAGNN_TN_FLAT=1
+  run OCC2 QAGNN_NN_PERSIST=0
+  run OCC2 QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2
+  run OCC2 QAGNN_NN_PERSIST=2
+  for v in NOGLOAD NOMMA NOEPI; do run $v QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=1; done
 fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
 cat gpurun_out/summary.txt
