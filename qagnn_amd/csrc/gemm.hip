@@ -32,7 +32,7 @@ __host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn 
 // Register budget: QAGNN_NN_OCC co-resident blocks per CU (LDS allows 2).  The budget is a trade: 2 blocks per CU let one
 // block's epilogue stores overlap the other's MFMAs, but cap a wave at 512 / (OCC * WAVES / 4) registers.
 #ifndef QAGNN_NN_OCC
-#define QAGNN_NN_OCC 0  // 0 = leave it to the compiler (it takes ~300 registers for NT = 13: one block per CU)
+#define QAGNN_NN_OCC 2  // 0 = leave it to the compiler (it takes ~300 registers for NT = 13: one block per CU)
 #endif
 #if QAGNN_NN_OCC > 0
 #define QAGNN_NN_ATTR __attribute__((amdgpu_waves_per_eu(QAGNN_NN_OCC * WAVES / 4, QAGNN_NN_OCC * WAVES / 4)))
@@ -379,57 +379,46 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// TN, flat tile partition (NT = 13 shapes: every weight gradient of the stack).  Same split-K chunking and LDS tiles as
-// k_gemm_tn, different ownership: the block's rb x NT output tiles are numbered row-major and dealt to the waves in
-// CONTIGUOUS runs of q or q+1 tiles (169 tiles of a 208 x 208 gradient over 16 waves: 11,11,...,10), so the four SIMDs carry
-// 43/42/42/42 tiles instead of the 52/39/39/39 of "one wave per 16-row strip" with 13 waves.  A run spans at most two row
-// tiles (TPW <= NT), so a k-step needs two A fragments and one B fragment per tile; all fragments of k-step kk+1 are
-// fetched from LDS before the MFMAs of k-step kk are issued (the register budget at 4 waves/SIMD is 128: accumulators
-// 52 + two fragment sets 30 + the two global-load float4 in flight).
+// TN, compile-time strip shape: the k_gemm_tn mapping (wave w owns output rows 16w .. 16w+15 and all NT column tiles)
+// with the wave count NWT fixed at compile time and the two LDS buffers addressed by constants (k-loop unrolled by two),
+// so every LDS fragment read is `base VGPR + immediate` and the k-loop carries no address arithmetic: the run-time
+// version spends 2-4 VALU instructions per MFMA on addresses and sits at ~48 % MFMA-busy.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int TPW, bool AFFINE>
-__global__ __launch_bounds__(1024) void k_gemm_tn_flat(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                       float* __restrict__ P, int R, int Ka, int No, const float* __restrict__ a_scale,
-                                                       const float* __restrict__ a_shift, const int64_t* __restrict__ a_rowidx,
-                                                       int chunk_rows, int rb) {
-  static_assert(TPW <= NT, "a wave's run of tiles may span two row tiles at most");
+template <int V> struct ic { static constexpr int value = V; };
+
+template <int NT, int NWT, bool AFFINE>
+__global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                            float* __restrict__ P, int R, int Ka, int No,
+                                                            const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                            const int64_t* __restrict__ a_rowidx, int chunk_rows) {
+  constexpr int NTHR = NWT * 64, BM = NWT * 16;
   constexpr int BN = NT * 16;
-  constexpr int PB = pitch_b(BN);
-  constexpr int B_F4 = BK * BN / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem_tn[];
-  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x, nw = nthr >> 6;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int BM = rb * 16, PA = pitch16(BM), TA_F = BK * PA, TBUF_F = TA_F + BK * PB;
+  constexpr int PA = pitch16(BM), PB = pitch_b(BN);
+  constexpr int TA_F = BK * PA, TBUF_F = TA_F + BK * PB;
+  constexpr int B_F4 = BK * BN / 4, B_IT = (B_F4 + NTHR - 1) / NTHR;
+  constexpr int A_F4 = BM / 4;  // float4 per A tile row; 16 * A_F4 == NTHR: one float4 per thread
+  __shared__ __attribute__((aligned(16))) float smem[2 * TBUF_F];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int nkt = (r_end - r_beg + BK - 1) / BK;
 
-  // this wave's run of tiles [base, base + count) in the row-major numbering of the block's rb x NT tiles
-  const int tiles = rb * NT, q = tiles / nw, rem = tiles % nw;
-  const int base = w * q + min(w, rem), count = q + (w < rem ? 1 : 0);
-  const int row0 = base / NT, c0 = base - row0 * NT;  // first tile's (row tile, column tile)
-
-  f32x4 acc[TPW];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int j = 0; j < TPW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // global -> register staging: one float4 of the A tile (threads < 4 * BM) and up to two of the B tile per thread
-  constexpr int B_IT = 2;  // covers B_F4 = 832 float4 with >= 512 threads
-  float4 ra, rbv[B_IT];
-  const int a_f4 = BM / 4;
-  const bool a_thr = tid < BK * a_f4;
-  const int akr = tid / a_f4, ac4 = tid % a_f4;
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ra, rb[B_IT];
+  const int akr = tid / A_F4, ac4 = tid % A_F4;
   const int acol = m0 + ac4 * 4;
 
   auto gload = [&](int kt) {
     const int r0 = r_beg + kt * BK;
-    if (a_thr) {
+    {
       const int row = r0 + akr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int64_t srow = (row < r_end && acol < Ka) ? (a_rowidx ? a_rowidx[row] : (int64_t)row) : -1;
       if (srow >= 0) {
         v = ld4(A + srow * lda + acol);
-        if (AFFINE) {  // the BN affine of this thread's 4 columns: re-read per tile (L1 hit) rather than held in 8 registers
+        if (AFFINE) {  // BN affine of these 4 columns: re-read per tile (L1 hit) rather than held in 8 registers
           const float4 a_sc = ld4(a_scale + acol), a_sh = ld4(a_shift + acol);
           v.x = fmaxf(fmaf(v.x, a_sc.x, a_sh.x), 0.f);
           v.y = fmaxf(fmaf(v.y, a_sc.y, a_sh.y), 0.f);
@@ -441,98 +430,76 @@ __global__ __launch_bounds__(1024) void k_gemm_tn_flat(const float* __restrict__
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * nthr;
+      const int idx = tid + it * NTHR;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < B_F4) {
         const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
         const int row = r0 + kr, col = n0 + c4 * 4;
         if (row < r_end && col < No) v = ld4(B + (int64_t)row * ldb + col);
       }
-      rbv[it] = v;
+      rb[it] = v;
     }
   };
-  auto lstore = [&](int buf) {
-    float* As = smem_tn + buf * TBUF_F;
-    float* Bs = As + TA_F;
-    if (a_thr) st4(As + akr * PA + ac4 * 4, ra);
+  float* const a_dst = smem + akr * PA + ac4 * 4;
+  auto lstore = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    st4(a_dst + buf * TBUF_F, ra);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * nthr;
+      const int idx = tid + it * NTHR;
       if (idx < B_F4) {
         const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-        st4(Bs + kr * PB + c4 * 4, rbv[it]);
+        st4(smem + buf * TBUF_F + TA_F + kr * PB + c4 * 4, rb[it]);
       }
     }
   };
-  // fragments of one k-step: A for row tiles row0 and row0 + 1 (the second is only consumed by tiles past the row wrap; when
-  // row0 is the block's last row tile it reads 16 floats past the row inside the same LDS buffer and is never used), B per tile
-  float fa[2][2], fb[2][TPW];
-  auto frags = [&](int buf, int kk, int s) {
-    const float* Ab = smem_tn + buf * TBUF_F + (kk * 4 + (lane >> 4)) * PA + row0 * 16 + (lane & 15);
-    const float* Bb = smem_tn + buf * TBUF_F + TA_F + (kk * 4 + (lane >> 4)) * PB + (lane & 15);
-    fa[s][0] = Ab[0];
-    fa[s][1] = Ab[16];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      int c = c0 + j;
-      if (c >= NT) c -= NT;
-      fb[s][j] = Bb[c * 16];
-    }
-  };
-  auto mma = [&](int s) {
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      if (j < count) {  // wave-uniform
-        const float av = (c0 + j >= NT) ? fa[s][1] : fa[s][0];
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, fb[s][j], acc[j], 0, 0, 0);
-      }
-    }
-  };
-
-  if (nkt > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+  const float* const a_frag = smem + (lane >> 4) * PA + w * 16 + (lane & 15);
+  const float* const b_frag = smem + TA_F + (lane >> 4) * PB + (lane & 15);
+  auto ktile = [&](auto curc, int kt) {
+    constexpr int cur = decltype(curc)::value;
     const bool more = kt + 1 < nkt;
 #ifndef QAGNN_ABLATE_NOGLOAD
     if (more) gload(kt + 1);
 #endif
 #ifndef QAGNN_ABLATE_NOMMA
-    frags(cur, 0, 0);
-    frags(cur, 1, 1);
-    mma(0);
-    frags(cur, 2, 0);
-    mma(1);
-    frags(cur, 3, 1);
-    mma(0);
-    mma(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float av = a_frag[cur * TBUF_F + kk * 4 * PA];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_frag[cur * TBUF_F + kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
+    }
 #endif
-    if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
+    if (more) lstore(ic<cur ^ 1>{});  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
+  };
+
+  if (nkt > 0) {
+    gload(0);
+    lstore(ic<0>{});
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(ic<0>{}, kt);
+    if (kt + 1 < nkt) ktile(ic<1>{}, kt + 1);
   }
 #ifdef QAGNN_ABLATE_NOEPI
   {
     float keep = 0.f;
-    for (int j = 0; j < TPW; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    for (int j = 0; j < NT; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
     if (keep == 123.456f) P[tid] = keep;
     return;
   }
 #endif
   float* Pc = P + (int64_t)chunk * Ka * No;
 #pragma unroll
-  for (int j = 0; j < TPW; ++j) {
-    if (j >= count) continue;
-    int c = c0 + j, rt = row0;
-    if (c >= NT) { c -= NT; rt += 1; }
-    const int col = n0 + c * 16 + (lane & 15);
-    if (col >= No) continue;
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + w * 16 + (lane >> 4) * 4 + r;
+    if (row >= Ka) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + rt * 16 + (lane >> 4) * 4 + r;
-      if (row < Ka) Pc[(int64_t)row * No + col] = acc[j][r];
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 16 + (lane & 15);
+      if (col < No) Pc[(int64_t)row * No + col] = acc[j][r];
     }
   }
 }
@@ -549,8 +516,41 @@ __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C,
   *d = accumulate ? *d + s : s;
 }
 
-// NN launch shapes (QAGNN_NN_PERSIST): 0 = one 128-row tile per 4-wave block, grid = tiles; 1 = 8-wave blocks walking the
-// tiles persistently, QAGNN_NN_BLOCKS_PER_CU (default 1) blocks per CU; 2 = the 4-wave block, persistent, 2 per CU.
+// Same reduction, bandwidth-shaped: a thread owns one float4 column, the block's 8 waves split the chunks (wave g takes
+// chunks g, g+8, ...: 8x the loads in flight of the scalar kernel, which was latency-bound at ~3 TB/s), and the 8 partial
+// sums meet in LDS and are added in wave order.  The summation order is fixed by (nchunks), never by timing.
+constexpr int SC_G = 8;
+__global__ __launch_bounds__(SC_G * 64) void k_sum_chunks4(const float* __restrict__ P, float* __restrict__ C, int ldc, int Ka, int No,
+                                                           int nchunks, int accumulate) {
+  __shared__ float4 part[SC_G][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t n4 = (int64_t)Ka * No / 4, i4 = (int64_t)blockIdx.x * 64 + lane;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (i4 < n4) {
+    const float4* src = reinterpret_cast<const float4*>(P) + i4;
+    int c = g;
+    for (; c + SC_G < nchunks; c += 2 * SC_G) {  // two independent chains keep 2 x 16 B per lane in flight
+      s0 = add4(s0, src[(int64_t)c * n4]);
+      s1 = add4(s1, src[(int64_t)(c + SC_G) * n4]);
+    }
+    if (c < nchunks) s0 = add4(s0, src[(int64_t)c * n4]);
+  }
+  part[g][lane] = add4(s0, s1);
+  __syncthreads();
+  if (g == 0 && i4 < n4) {
+    float4 s = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < SC_G; ++k) s = add4(s, part[k][lane]);
+    const int64_t e = i4 * 4;
+    float* d = C + (e / No) * ldc + (e % No);
+    if (accumulate) s = add4(s, ld4(d));
+    st4(d, s);
+  }
+}
+
+// NN launch shapes (QAGNN_NN_PERSIST): 1 (default) = 8-wave blocks walking the tiles persistently, QAGNN_NN_BLOCKS_PER_CU
+// (default: the build's QAGNN_NN_OCC = 2) blocks per CU; 0 = one 128-row tile per 4-wave block, grid = tiles; 2 = the
+// 4-wave block, persistent.  Measured at M = 64000 (profiles/r1_gemm_micro.txt): 1 is 10-18 % faster than 0.
 static int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -564,8 +564,8 @@ static int num_cus() {
 template <int NT>
 static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
   static const int xcd_env = getenv("QAGNN_NN_XCD") ? atoi(getenv("QAGNN_NN_XCD")) : 1;
-  static const int persist = getenv("QAGNN_NN_PERSIST") ? atoi(getenv("QAGNN_NN_PERSIST")) : 0;
-  static const int per_cu = getenv("QAGNN_NN_BLOCKS_PER_CU") ? atoi(getenv("QAGNN_NN_BLOCKS_PER_CU")) : (persist == 2 ? 2 : 1);
+  static const int persist = getenv("QAGNN_NN_PERSIST") ? atoi(getenv("QAGNN_NN_PERSIST")) : 1;
+  static const int per_cu = getenv("QAGNN_NN_BLOCKS_PER_CU") ? atoi(getenv("QAGNN_NN_BLOCKS_PER_CU")) : (QAGNN_NN_OCC > 0 ? QAGNN_NN_OCC : 1);
   qagnn_gemm_nn_args b = a;
   b.xcd_remap = xcd_env;
   const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, NN_BM);
@@ -607,21 +607,28 @@ static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P,
   return QAGNN_OK;
 }
 
-// flat-partition launch (NT = 13): row tiles per block as in pick_tn_waves, 8 waves when the block has <= 8 * 13 tiles
-static bool tn_flat_enabled() {
-  static const int v = getenv("QAGNN_TN_FLAT") ? atoi(getenv("QAGNN_TN_FLAT")) : 1;
+// QAGNN_TN_STRIP=0 falls back to the run-time-shaped k_gemm_tn everywhere (A/B switch)
+static bool tn_strip_enabled() {
+  static const int v = getenv("QAGNN_TN_STRIP") ? atoi(getenv("QAGNN_TN_STRIP")) : 1;
   return v != 0;
 }
-static int tn_flat_waves(int rb) { return rb * 13 <= 8 * 13 && rb <= 8 ? 8 : 16; }
 
-static int launch_tn_flat(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
-                          const float* sh, const int64_t* ridx, int chunk_rows, hipStream_t stream) {
-  const int rb = pick_tn_waves(Ka), nw = tn_flat_waves(rb), nchunks = cdiv(R, chunk_rows);
-  dim3 grid(cdiv(No, 13 * 16), cdiv(Ka, rb * 16), nchunks);
-  const size_t lds = 2 * (size_t)(BK * pitch16(rb * 16) + BK * pitch_b(13 * 16)) * sizeof(float);
-  if (sc) k_gemm_tn_flat<13, 13, true><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, rb);
-  else k_gemm_tn_flat<13, 13, false><<<grid, nw * 64, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, rb);
-  QAGNN_LAUNCH_CHECK("k_gemm_tn_flat");
+// compile-time strip launch (NT = 13 and 7 / 13 / 16 waves: every weight gradient of the stack at d = 200)
+template <int NWT>
+static void launch_tn_strip_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
+                              const float* sc, const float* sh, const int64_t* ridx, int chunk_rows) {
+  if (sc) k_gemm_tn_strip<13, NWT, true><<<grid, NWT * 64, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+  else k_gemm_tn_strip<13, NWT, false><<<grid, NWT * 64, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+}
+static bool tn_strip_ok(int Ka) { const int nw = pick_tn_waves(Ka); return nw == 7 || nw == 13 || nw == 16; }
+static int launch_tn_strip(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
+                           const float* sh, const int64_t* ridx, int chunk_rows, hipStream_t stream) {
+  const int nw = pick_tn_waves(Ka);
+  dim3 grid(cdiv(No, 13 * 16), cdiv(Ka, nw * 16), cdiv(R, chunk_rows));
+  if (nw == 7) launch_tn_strip_i<7>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+  else if (nw == 13) launch_tn_strip_i<13>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+  else launch_tn_strip_i<16>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+  QAGNN_LAUNCH_CHECK("k_gemm_tn_strip");
   return QAGNN_OK;
 }
 
@@ -629,10 +636,10 @@ static int launch_tn_flat(const float* A, int lda, const float* B, int ldb, floa
 // chunk already spans several blocks (column blocks x row blocks) takes longer chunks: just enough blocks to fill the CUs
 // once (twice for blocks of <= 8 waves).  Never below TN_RC, which is what qagnn_gemm_tn_workspace_elems() sizes for.
 // QAGNN_TN_CHUNK=<rows> pins it (256 = the fixed chunking of earlier revisions).
-static int pick_tn_chunk_rows(int R, int Ka, int No, int nt, bool flat) {
+static int pick_tn_chunk_rows(int R, int Ka, int No, int nt) {
   static const int env = getenv("QAGNN_TN_CHUNK") ? atoi(getenv("QAGNN_TN_CHUNK")) : 0;
   if (env >= TN_RC) return (env + 15) & ~15;
-  const int rb = pick_tn_waves(Ka), nw = flat ? tn_flat_waves(rb) : rb;
+  const int rb = pick_tn_waves(Ka), nw = rb;
   const int blocks_per_chunk = cdiv(No, nt * 16) * cdiv(Ka, rb * 16);
   const int target = (num_cus() * (nw <= 8 ? 2 : 1)) / blocks_per_chunk;
   const int rows = (cdiv(R, target > 0 ? target : 1) + 15) & ~15;
@@ -701,12 +708,12 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
                 "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
   QAGNN_REQUIRE(!bsum || (groups >= 1 && groups <= 4 && (groups == 1 || b_rowidx)), QAGNN_EINVAL, "gemm_tn: colsum groups=%d (1..4)", groups);
   const int nt = pick_nt(No);
-  const bool flat = nt == 13 && !bsum && tn_flat_enabled();
-  const int crows = pick_tn_chunk_rows(R, Ka, No, nt, flat);
+  const bool strip = nt == 13 && !bsum && tn_strip_enabled() && tn_strip_ok(Ka);
+  const int crows = pick_tn_chunk_rows(R, Ka, No, nt);
   const int nchunks = cdiv(R, crows);
   float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;
-  if (flat) rc = launch_tn_flat(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, stream);
+  if (strip) rc = launch_tn_strip(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, stream);
   else switch (nt) {
     case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
     case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
@@ -716,7 +723,8 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
   }
   if (rc != QAGNN_OK) return rc;
   const int64_t tot = (int64_t)Ka * No;
-  k_sum_chunks<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, accumulate);
+  if (ldc % 4 == 0 && aligned16(C)) k_sum_chunks4<<<cdiv(tot / 4, 64), SC_G * 64, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, accumulate);
+  else k_sum_chunks<<<cdiv(tot, 256), 256, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, accumulate);
   QAGNN_LAUNCH_CHECK("k_sum_chunks");
   if (bsum) {
     k_sum_chunks<<<cdiv((int64_t)groups * No, 256), 256, 0, stream>>>(Pcs, bsum, No, groups, No, nchunks, 0);

@@ -10,7 +10,7 @@ if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
   echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   # the non-default GEMM launch shapes go through the same tests
-  for cfg in "QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=0" "QAGNN_NN_PERSIST=2 QAGNN_TN_CHUNK=256" "QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2"; do
+  for cfg in "QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0" "QAGNN_NN_PERSIST=2 QAGNN_TN_CHUNK=256" "QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=1"; do
     env $cfg timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "gemm" 2>&1 | tail -n 40 >> gpurun_out/test_kernels_variants.log
     echo "kernels[$cfg] exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   done
@@ -45,6 +45,14 @@ if [[ "$*" == *pmc* ]]; then
     ls /tmp/pmc_$ctr >> gpurun_out/pmc_$ctr.log
   done
 fi
+if [[ "$*" == *sqpmc* ]]; then   # SQ counters of the GEMM micro-benchmark (own pass, kernel-trace only)
+  rm -rf /tmp/sqpmc; mkdir -p /tmp/sqpmc
+  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d /tmp/sqpmc -o p -- "$REPO/tools/bin/gemm_ablate_BASE" ) 2>&1 | tail -n 12 > gpurun_out/sqpmc.log
+  python scripts/pmc_table.py /tmp/sqpmc/p_counter_collection.csv > gpurun_out/sqpmc_gemm.txt 2>&1
+  rm -rf /tmp/sqpmc2; mkdir -p /tmp/sqpmc2
+  ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d /tmp/sqpmc2 -o p -- "$REPO/tools/bin/gemm_ablate_BASE" ) 2>&1 | tail -n 12 >> gpurun_out/sqpmc.log
+  python scripts/pmc_table.py /tmp/sqpmc2/p_counter_collection.csv > gpurun_out/sqpmc_gemm2.txt 2>&1
+fi
 if [[ "$*" == *mfma* ]]; then
   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
 fi
@@ -75,14 +83,10 @@ if [[ "$*" == *hostprof* ]]; then
 fi
 if [[ "$*" == *ablate* ]]; then   # prebuilt here by tools/build_micro.sh (compiling on the box would burn GPU minutes)
   run() { echo "== $*" >> gpurun_out/gemm_micro.txt; env "${@:2}" timeout 120 tools/bin/gemm_ablate_$1 >> gpurun_out/gemm_micro.txt 2>&1; }
-  run BASE QAGNN_NN_PERSIST=0 QAGNN_TN_FLAT=0 QAGNN_TN_CHUNK=256
-  run BASE QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=0
-  run BASE QAGNN_NN_PERSIST=2 QAGNN_TN_FLAT=1 QAGNN_TN_CHUNK=256
-  run BASE QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2 QAGNN_TN_FLAT=1
-  run OCC2 QAGNN_NN_PERSIST=0
-  run OCC2 QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=2
-  run OCC2 QAGNN_NN_PERSIST=2
-  for v in NOGLOAD NOMMA NOEPI; do run $v QAGNN_NN_PERSIST=1 QAGNN_TN_FLAT=1; done
+  run BASE
+  run BASE QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0 QAGNN_TN_CHUNK=256
+  run OCC0 QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0 QAGNN_TN_CHUNK=256
+  for v in NOGLOAD NOMMA NOEPI; do run $v; done
 fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
 cat gpurun_out/summary.txt
