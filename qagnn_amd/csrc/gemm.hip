@@ -29,6 +29,8 @@ __host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn 
 // Two shapes are instantiated: <4 waves, RT=2> (one tile per block, the original mapping) and <8 waves, RT=1> (same
 // 128-row tile shared by 8 waves, launched persistent).
 // ------------------------------------------------------------------------------------------------------------
+template <int V> struct ic { static constexpr int value = V; };  // compile-time buffer index for generic lambdas
+
 // Register budget: QAGNN_NN_OCC co-resident blocks per CU (LDS allows 2).  The budget is a trade: 2 blocks per CU let one
 // block's epilogue stores overlap the other's MFMAs, but cap a wave at 512 / (OCC * WAVES / 4) registers.
 #ifndef QAGNN_NN_OCC
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[RT];
+    float4 raS[2][RT];
     float4 rb[B_IT];
     int64_t arow[RT];  // source row of A1 for this thread's tile rows (gathered or identity); -1 = zero row
 #pragma unroll
@@ -82,47 +84,52 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
       arow[p] = row < a.M ? (a.a_rowidx ? a.a_rowidx[row] : (int64_t)row) : -1;
     }
 
-    auto gload = [&](int kt) {
+    // global -> register staging.  A (the HBM stream: 64-byte row segments, ~2 us under load) is fetched TWO k-tiles ahead
+    // into alternating register sets; B (weights, L2-resident) one k-tile ahead.  B is issued before the younger A loads so
+    // that the in-order vmcnt wait in front of the LDS store leaves exactly the A loads of tile kt+2 in flight.
+    // Every load is unconditional (addresses clamped into the operand; rows >= M and columns >= No only ever feed
+    // accumulator rows / columns that are never stored): with branches around the loads hipcc falls back to vmcnt(0).
+    auto gloadA = [&](int kt, float4 (&dst)[RT]) {
       const bool first = kt < nk1;
       const float* A = first ? a.A1 : a.A2;
       const int lda = first ? a.lda1 : a.lda2;
+      const int k0 = (first ? kt : kt - nk1) * BK;
+#pragma unroll
+      for (int p = 0; p < RT; ++p) {
+        const int64_t srow = first ? (arow[p] >= 0 ? arow[p] : 0) : (int64_t)min(m0 + ar + p * (NTHR / 4), a.M - 1);
+        dst[p] = ld4(A + srow * lda + k0 + ac4 * 4);
+      }
+    };
+    auto gloadB = [&](int kt) {
+      const bool first = kt < nk1;
       const float* B = first ? a.B1 : a.B2;
       const int ldb = first ? a.ldb1 : a.ldb2;
       const int k0 = (first ? kt : kt - nk1) * BK;
 #pragma unroll
-      for (int p = 0; p < RT; ++p) {
-        const int row = m0 + ar + p * (NTHR / 4);
-        const int64_t srow = first ? arow[p] : (row < a.M ? (int64_t)row : -1);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (srow >= 0) {
-          v = ld4(A + srow * lda + k0 + ac4 * 4);
-          if (AFFINE && first) {
-            const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
-            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-            v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-            v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-          }
-        }
-        ra[p] = v;
-      }
-#pragma unroll
       for (int it = 0; it < B_IT; ++it) {
-        const int idx = tid + it * NTHR;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < B_F4) {
-          const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-          const int col = n0 + c4 * 4;
-          if (col < a.No) v = ld4(B + (int64_t)(k0 + kr) * ldb + col);
-        }
-        rb[it] = v;
+        const int idx = min(tid + it * NTHR, B_F4 - 1);
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        rb[it] = ld4(B + (int64_t)(k0 + kr) * ldb + min(n0 + c4 * 4, a.No - 4));
       }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto bufc, int kt, const float4 (&src)[RT]) {  // tile kt -> LDS buffer buf (BN affine + ReLU applied here)
+      constexpr int buf = decltype(bufc)::value;
       float* As = smem + buf * BUF_F;
       float* Bs = As + A_F;
 #pragma unroll
-      for (int p = 0; p < RT; ++p) st4(As + (ar + p * (NTHR / 4)) * PA_NN + ac4 * 4, ra[p]);
+      for (int p = 0; p < RT; ++p) {
+        float4 v = src[p];
+        if (AFFINE && kt < nk1) {
+          const int k0 = kt * BK;
+          const float4 sc = ld4(a.a_scale + k0 + ac4 * 4), sh = ld4(a.a_shift + k0 + ac4 * 4);
+          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        }
+        if (a.a_rowidx && kt < nk1 && arow[p] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);  // gathered "-1" rows are zero rows
+        st4(As + (ar + p * (NTHR / 4)) * PA_NN + ac4 * 4, v);
+      }
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) {
         const int idx = tid + it * NTHR;
@@ -132,43 +139,43 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
         }
       }
     };
-    auto mma = [&](int buf, int kk) {
-      const float* Aw = smem + buf * BUF_F + (w * RT * 16 + (lane & 15)) * PA_NN + (lane >> 4);
-      const float* Bw = smem + buf * BUF_F + A_F + (lane >> 4) * PB + (lane & 15);
-      float av[RT];
+    const float* const Aw = smem + (w * RT * 16 + (lane & 15)) * PA_NN + (lane >> 4);
+    const float* const Bw = smem + A_F + (lane >> 4) * PB + (lane & 15);
+    auto ktile = [&](auto curc, int kt) {  // cur = kt & 1 names both the LDS buffer of tile kt and the A register set of tile kt+2
+      constexpr int cur = decltype(curc)::value;
+#ifndef QAGNN_ABLATE_NOGLOAD
+      gloadB(min(kt + 1, nkt - 1));               // past the last tile: a redundant reload, never consumed
+      gloadA(min(kt + 2, nkt - 1), raS[cur]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to the LDS store
+#endif
+#ifndef QAGNN_ABLATE_NOMMA
 #pragma unroll
-      for (int i = 0; i < RT; ++i) av[i] = Aw[i * 16 * PA_NN + kk * 4];
+      for (int kk = 0; kk < 4; ++kk) {
+        float av[RT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float b = Bw[kk * 4 * PB + j * 16];
+        for (int i = 0; i < RT; ++i) av[i] = Aw[cur * BUF_F + i * 16 * PA_NN + kk * 4];
 #pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+          const float bv = Bw[cur * BUF_F + kk * 4 * PB + j * 16];
+#pragma unroll
+          for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][j], 0, 0, 0);
+        }
       }
+#endif
+      lstore(ic<cur ^ 1>{}, min(kt + 1, nkt - 1), raS[cur ^ 1]);  // after the MFMAs: the loads had one k-tile (B) / two (A) to land
+      __syncthreads();
     };
 
-    // double-buffered k-loop, ONE barrier per k-tile: tile t+1 travels global -> registers while tile t's first two
-    // k-steps run, is written to the other LDS buffer between k-steps (so the ds_writes hide under MFMAs), and becomes
-    // visible at the barrier that also retires everybody's reads of tile t.
-    gload(0);
+    // double-buffered k-loop, ONE barrier per k-tile (it publishes tile kt+1 and retires everybody's reads of tile kt)
+    gloadA(0, raS[0]);
+    gloadB(0);
+    gloadA(min(1, nkt - 1), raS[1]);
     __syncthreads();  // the previous output tile's slab reads are done before the k-loop buffers are overwritten
-    lstore(0);
+    lstore(ic<0>{}, 0, raS[0]);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int cur = kt & 1;
-      const bool more = kt + 1 < nkt;
-#ifndef QAGNN_ABLATE_NOGLOAD
-      if (more) gload(kt + 1);
-#endif
-#ifndef QAGNN_ABLATE_NOMMA
-      mma(cur, 0);
-      mma(cur, 1);
-#endif
-      if (more) lstore(cur ^ 1);  // ds_writes hide under the remaining MFMAs (measured: later placement is slower here)
-#ifndef QAGNN_ABLATE_NOMMA
-      mma(cur, 2);
-      mma(cur, 3);
-#endif
-      __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+      ktile(ic<0>{}, kt);
+      if (kt + 1 < nkt) ktile(ic<1>{}, kt + 1);
     }
 #ifdef QAGNN_ABLATE_NOEPI
     {  // keep the accumulators live with one dword store per lane, skip the real epilogue
@@ -384,8 +391,6 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
 // so every LDS fragment read is `base VGPR + immediate` and the k-loop carries no address arithmetic: the run-time
 // version spends 2-4 VALU instructions per MFMA on addresses and sits at ~48 % MFMA-busy.
 // ------------------------------------------------------------------------------------------------------------
-template <int V> struct ic { static constexpr int value = V; };
-
 template <int NT, int NWT, bool AFFINE>
 __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                             float* __restrict__ P, int R, int Ka, int No,
