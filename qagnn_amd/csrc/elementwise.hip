@@ -84,20 +84,35 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   }
 }
 
-// ordered sum of the chunk partials: 64 outputs x 4 chunk partitions per block, partitions combined in fixed order
-__global__ __launch_bounds__(256) void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks, int tot,
-                                                         float out_scale) {
-  __shared__ float red[4][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float s = 0.f;
+// ordered sum of the chunk partials: 64 outputs x 16 chunk partitions per block (partition q takes chunks q, q+16, ...),
+// partitions combined in fixed order.  16 partitions because the kernel is pure latency: 500 partials per output behind
+// 4 partitions took 8 us, 31 times per step.
+constexpr int CF_Q = 16;
+__global__ __launch_bounds__(64 * CF_Q) void k_colreduce_final(const float* __restrict__ part, float* __restrict__ out, int nchunks,
+                                                               int tot, float out_scale) {
+  __shared__ float red[CF_Q][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
   if (o < tot) {
-#pragma unroll 8
-    for (int c = q; c < nchunks; c += 4) s += part[(int64_t)c * tot + o];
+    int c = q;
+#pragma unroll 4
+    for (; c + CF_Q < nchunks; c += 2 * CF_Q) {
+      s0 += part[(int64_t)c * tot + o];
+      s1 += part[(int64_t)(c + CF_Q) * tot + o];
+    }
+    if (c < nchunks) s0 += part[(int64_t)c * tot + o];
   }
-  red[q][threadIdx.x & 63] = s;
+  red[q][lane] = s0 + s1;
   __syncthreads();
-  if (q == 0 && o < tot) out[o] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * out_scale;
+  if (q == 0 && o < tot) {
+    float s = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < CF_Q; ++k) s += red[k][lane];
+    out[o] = s * out_scale;
+  }
 }
+
 
 __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH, int ld, int R,
                               int Cc, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -227,7 +242,7 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
   }
   QAGNN_LAUNCH_CHECK("k_colreduce");
   const int tot = nout * Cc;
-  k_colreduce_final<<<cdiv(tot, 64), 256, 0, stream>>>(workspace, out, grid.y, tot, out_scale);
+  k_colreduce_final<<<cdiv(tot, 64), 64 * CF_Q, 0, stream>>>(workspace, out, grid.y, tot, out_scale);
   QAGNN_LAUNCH_CHECK("k_colreduce_final");
   return QAGNN_OK;
 }

@@ -31,6 +31,26 @@ __host__ __device__ constexpr int pitch_b(int bn) { return (bn % 32 == 16) ? bn 
 // ------------------------------------------------------------------------------------------------------------
 template <int V> struct ic { static constexpr int value = V; };  // compile-time buffer index for generic lambdas
 
+// Scheduling shape of one unrolled k-tile (4 k-steps of NM MFMAs each, fragments read from LDS): the fragment reads of
+// k-step kk+1 are interleaved 1 : 2 with the MFMAs of k-step kk, so an MFMA never waits on a read issued just before it
+// (hipcc's own order is read -> lgkmcnt(0) -> 2 MFMAs, which exposes one LDS latency per MFMA pair).  Speed only: +2-3 % on
+// the TN strip kernel (90 registers, room for the fragments in flight); the NN kernel sits at its 128-register cap and loses.
+template <int NM>
+__device__ __forceinline__ void sched_ktile_pipeline() {
+  constexpr int DS = 0x100, MFMA = 0x008, NR = (NM + 1) / 2 + 1;  // ds_read(2) instructions per k-step incl. the A fragment
+#pragma unroll
+  for (int r = 0; r < NR; ++r) __builtin_amdgcn_sched_group_barrier(DS, 1, 0);
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      __builtin_amdgcn_sched_group_barrier(MFMA, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(DS, 1, 0);
+    }
+  }
+  __builtin_amdgcn_sched_group_barrier(MFMA, 2 * NR, 0);
+}
+
 // Register budget: QAGNN_NN_OCC co-resident blocks per CU (LDS allows 2).  The budget is a trade: 2 blocks per CU let one
 // block's epilogue stores overlap the other's MFMAs, but cap a wave at 512 / (OCC * WAVES / 4) registers.
 #ifndef QAGNN_NN_OCC
@@ -470,10 +490,13 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const float av = a_frag[cur * TBUF_F + kk * 4 * PA];
+      float bv[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_frag[cur * TBUF_F + kk * 4 * PB + j * 16], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) bv[j] = b_frag[cur * TBUF_F + kk * 4 * PB + j * 16];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
     }
+    sched_ktile_pipeline<NT>();
 #endif
     if (more) lstore(ic<cur ^ 1>{});  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();

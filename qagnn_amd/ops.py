@@ -413,7 +413,10 @@ class ConceptInputFn(torch.autograd.Function):
         n, p, seed = ctx.cfg
         dpre = K.gelu_dropout_bwd(pre, dHp.contiguous(), p, seed)
         dctx = dpre.view(-1, n, dpre.size(1))[:, 0].contiguous()
-        dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx, colsum_groups=1)
+        if FUSED_COLSUM:
+            dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx, colsum_groups=1)
+        else:
+            dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx), K.colsum(dpre)
         dbc = cs[0] - dctx.sum(0)  # the bias only acts on the entity rows (context-node rows were overwritten)
         return None, None, dWc_t, dbc, dctx, None, None, None
 

@@ -84,7 +84,8 @@ fi
 if [[ "$*" == *ablate* ]]; then   # prebuilt here by tools/build_micro.sh (compiling on the box would burn GPU minutes)
   run() { echo "== $*" >> gpurun_out/gemm_micro.txt; env "${@:2}" timeout 120 tools/bin/gemm_ablate_$1 >> gpurun_out/gemm_micro.txt 2>&1; }
   run BASE
-  run BASE QAGNN_NN_PERSIST=0
+  run BASE
+  run BASE QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0 QAGNN_TN_CHUNK=256
   for v in NOGLOAD NOMMA NOEPI; do run $v; done
 fi
 for f in gpurun_out/*.log; do echo "== $f"; tail -n 6 "$f"; done
