@@ -109,10 +109,10 @@ def edge_class_table(edge_encoder, graph, training, n_updates=1):
         if training and bn.track_running_stats:
             with torch.no_grad():
                 m = bn.momentum if bn.momentum is not None else 0.1
-                unbiased = var * (Ep / max(Ep - 1.0, 1.0))
-                for _ in range(n_updates):
-                    bn.running_mean.mul_(1 - m).add_(m * mu)
-                    bn.running_var.mul_(1 - m).add_(m * unbiased)
+                # n identical updates r <- (1-m) r + m x in closed form: r <- r + (1 - (1-m)^n) (x - r)
+                wgt = 1.0 - (1.0 - m) ** n_updates
+                bn.running_mean.lerp_(mu, wgt)
+                bn.running_var.lerp_(var * (Ep / max(Ep - 1.0, 1.0)), wgt)
                 bn.num_batches_tracked += n_updates
     else:
         mu, var = bn.running_mean, bn.running_var
