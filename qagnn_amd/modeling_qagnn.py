@@ -90,6 +90,38 @@ def _edge_class_features(n_etype, n_ntype, device):
     return feat
 
 
+def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
+    """edge_class_table() in the kernels' head-padded layout, for the stack: tab_p [C, DP] (pads exactly 0).
+
+    `enc` = (W1t [FP, DP], W1 [DP, FP], b1, gamma, beta [DP], W2t, W2 [DP, DP], b2 [DP]) from QAGNN_Message_Passing.pack_all
+    (FP = the 47 one-hot columns rounded up to 16).  Both Linears run on the MFMA GEMM kernels with their hand-written
+    backward: for these shapes ([612, 200] x [612, 200] weight gradients) rocBLAS picks a single-workgroup kernel that takes
+    142 us.  The count-weighted BatchNorm vector math stays on torch (C x DP elements)."""
+    W1t, W1, b1, gamma, beta, W2t, W2, b2 = enc
+    bn = edge_encoder[1]
+    FP = W1t.size(0)
+    key = ('padded', graph.R, graph.T, str(W1t.device), W1t.dtype, FP)
+    if key not in _CLASS_FEATS:
+        _CLASS_FEATS[key] = F.pad(edge_class_features(graph.R, graph.T, W1t.device, W1t.dtype), (0, FP - (graph.R + 1 + 2 * graph.T)))
+    h = ops.linear_nn(_CLASS_FEATS[key], W1t, W1, bias=b1)
+    if training or not bn.track_running_stats:
+        Ep = float(graph.Ep)
+        w = (graph.cls_count.to(h.dtype) / Ep).unsqueeze(1)
+        mu = (w * h).sum(0)
+        var = (w * (h - mu) ** 2).sum(0)
+        if training and bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 0.1
+                wgt = 1.0 - (1.0 - m) ** n_updates  # n identical momentum updates in closed form
+                bn.running_mean.lerp_(L.unpad(mu), wgt)
+                bn.running_var.lerp_(L.unpad(var) * (Ep / max(Ep - 1.0, 1.0)), wgt)
+                bn.num_batches_tracked += n_updates
+    else:
+        mu, var = L.pad(bn.running_mean), L.pad(bn.running_var)
+    hn = (h - mu) * torch.rsqrt(var + bn.eps) * gamma + beta
+    return ops.linear_nn(F.relu(hn), W2t, W2, bias=b2)
+
+
 def edge_class_table(edge_encoder, graph, training, n_updates=1):
     """tab[c] = edge_encoder(one-hot features of class c)  -> [C, d].
 
@@ -205,12 +237,13 @@ class GATConvE(nn.Module):
 
     N_PACKED = 18
 
-    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None):
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None):
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
         decomposed form is used instead (see packed_projection_typed).  `packed` = this layer's pack_build() outputs
-        when the caller packed all layers with one gather."""
+        when the caller packed all layers with one gather; `tables` = (TT [T, 3DP], EkEm [C, 2DP]) when the caller also
+        computed this layer's node-type and edge-class tables (for all layers at once)."""
         if typed is None:
             W_t, W_nt, bias = self.packed_projection(L)
             KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)
@@ -221,9 +254,12 @@ class GATConvE(nn.Module):
             if packed is None:
                 packed = self.pack_build(self.pack_sources(), L, S.size(1))
             Wx_t, Wx, Ws_t, Ws, Wtype, bias, We_p, be_p = packed[:8]
-            TT = torch.addmm(bias, temb, Wtype)                      # [T, 3DP] type-embedding half of the projection + bq
+            if tables is not None:
+                TT, ekem = tables
+            else:
+                TT = torch.addmm(bias, temb, Wtype)                  # [T, 3DP] type-embedding half of the projection + bq
+                ekem = torch.addmm(be_p, tab, We_p.t())              # [C, 2DP]: Ek | Em, pads exactly 0
             KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype)
-            ekem = torch.addmm(be_p, tab, We_p.t())                  # [C, 2DP]: Ek | Em, pads exactly 0
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
@@ -293,18 +329,31 @@ class QAGNN_Message_Passing(nn.Module):
         h = self.hidden_size // 2
         JP = ops.roundup(h, 16)
         nsrc = GATConvE.N_SOURCES
+        ee = self.edge_encoder
         sources = [t for layer in self.gnn_layers for t in layer.pack_sources()] + \
-                  [self.Vh.weight, self.Vh.bias, self.Vx.weight, self.Vx.bias, self.emb_score.weight, self.emb_score.bias]
+                  [self.Vh.weight, self.Vh.bias, self.Vx.weight, self.Vx.bias, self.emb_score.weight, self.emb_score.bias,
+                   ee[0].weight, ee[0].bias, ee[1].weight, ee[1].bias, ee[3].weight, ee[3].bias]
+        FP = ops.roundup(ee[0].weight.size(1), 16)
 
         def build(src):
             outs = []
             for l in range(self.k):
                 outs += GATConvE.pack_build(src[l * nsrc:(l + 1) * nsrc], L, JP)
-            Vhw, Vhb, Vxw, Vxb, Wes, bes = src[self.k * nsrc:]
+            Vhw, Vhb, Vxw, Vxb, Wes, bes, eW1, eb1, egam, ebet, eW2, eb2 = src[self.k * nsrc:]
             Vh_t, Vh = _pad2(Vhw, L)
             Vx_t, Vx = _pad2(Vxw, L)
             Wes_t = F.pad(Wes.t(), (0, JP - h, 0, JP - h)).contiguous()
-            return outs + [Vh_t, Vh, Vx_t, Vx, L.pad(Vhb), L.pad(Vxb), Wes_t, Wes_t.t().contiguous(), F.pad(bes, (0, JP - h))]
+            npk = GATConvE.N_PACKED
+            # the per-layer class-table / type-table operands side by side: one GEMM serves all k layers
+            We_all = torch.cat([L.pad(outs[l * npk + 6]) for l in range(self.k)], 0)        # [k*2DP, DP]
+            be_all = torch.cat([outs[l * npk + 7] for l in range(self.k)])                   # [k*2DP]
+            Wtype_all = torch.cat([outs[l * npk + 4] for l in range(self.k)], 1)            # [d/2, k*3DP]
+            bias_all = torch.cat([outs[l * npk + 5] for l in range(self.k)])                 # [k*3DP]
+            eW1t = L.pad(F.pad(eW1, (0, FP - eW1.size(1))).t())                             # [FP, DP]
+            eW2t, eW2p = _pad2(eW2, L)
+            return outs + [Vh_t, Vh, Vx_t, Vx, L.pad(Vhb), L.pad(Vxb), Wes_t, Wes_t.t().contiguous(), F.pad(bes, (0, JP - h)),
+                           We_all.t().contiguous(), We_all, be_all, Wtype_all.contiguous(), bias_all,
+                           eW1t.contiguous(), eW1t.t().contiguous(), L.pad(eb1), L.pad(egam), L.pad(ebet), eW2t, eW2p, L.pad(eb2)]
         packed = self._plan(sources, build)
         npk = GATConvE.N_PACKED
         return [packed[l * npk:(l + 1) * npk] for l in range(self.k)], packed[self.k * npk:]
@@ -336,13 +385,18 @@ class QAGNN_Message_Passing(nn.Module):
         if graph is None:
             # subgraph i owns node rows [i*n, (i+1)*n) (LM_QAGNN.batch_graph): lets the edge forward run out of LDS
             graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype, block_n=n)
-        per_layer, (Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes) = self.pack_all(L)
+        per_layer, extras = self.pack_all(L)
+        Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes, We_t_all, We_all, be_all, Wtype_all, bias_all = extras[:14]
         temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
-        tab = edge_class_table(self.edge_encoder, graph, self.training, n_updates=self.k)
+        # shared edge encoder on the C distinct classes, then every layer's Ek|Em and node-type tables with one GEMM each
+        tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
+        ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
+        TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
         Xp = Hp
-        for layer, pk in zip(self.gnn_layers, per_layer):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused into the hop
-            Xp, _ = layer.hop(Xp, None, graph, tab, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S), packed=pk)
+        for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
+            Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
+                              packed=pk, tables=(TT[l], ekem[l]))
         Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
         if padded_output:

@@ -258,6 +258,28 @@ def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, r
     return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx)
 
 
+class SplitColsFn(torch.autograd.Function):
+    """[R, k*W] -> k contiguous [R, W] blocks (one copy); backward = one stack + one copy instead of k slice-backward
+    (zeros + copy) pairs.  Used for the per-layer tables that the stack computes for all k layers with one GEMM."""
+
+    @staticmethod
+    def forward(ctx, X, k):
+        R, W = X.size(0), X.size(1) // k
+        ctx.shape = (R, k, W)
+        return tuple(X.view(R, k, W).transpose(0, 1).contiguous().unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        R, k, W = ctx.shape
+        ref = next(g for g in grads if g is not None)
+        gs = [g if g is not None else torch.zeros_like(ref) for g in grads]
+        return torch.stack(gs, 1).reshape(R, k * W), None
+
+
+def split_cols(X, k):
+    return SplitColsFn.apply(X, k)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 class GeluDropoutFn(torch.autograd.Function):
     """Y = dropout(gelu_tanh(X), p)   (utils/layers.py:10-14 + F.dropout); the keep mask is regenerated in backward."""

@@ -76,7 +76,7 @@ if [[ "$*" == *dp2* ]]; then
   echo "dp2 exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
 if [[ "$*" == *census* ]]; then
-  timeout 300 python tools/op_census.py 2>&1 | cut -c1-220 | head -n 90 > gpurun_out/op_census.txt
+  timeout 300 python tools/op_census.py 2>&1 | cut -c1-260 | grep -v "Warning\|warn" | head -n 220 > gpurun_out/op_census.txt
 fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
