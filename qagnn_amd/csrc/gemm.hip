@@ -254,6 +254,8 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TN_RC = 256;  // minimum rows per chunk (and the chunking the workspace query assumes): >= 1 block per CU for the
                             // 208 x 208 gradients at N = 64 000; launches with several tiles per chunk use longer chunks
+constexpr int TN_RC_SMALL = 64;  // ... and for reductions over <= 4096 rows (class tables, C = 612): the k-loop of a chunk is serial
+__host__ __device__ constexpr int tn_min_chunk(int R) { return R <= 4096 ? TN_RC_SMALL : TN_RC; }
 
 __host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w + 16; }  // rows k, k+1 land 16 banks apart
 
@@ -666,12 +668,13 @@ static int launch_tn_strip(const float* A, int lda, const float* B, int ldb, flo
 // QAGNN_TN_CHUNK=<rows> pins it (256 = the fixed chunking of earlier revisions).
 static int pick_tn_chunk_rows(int R, int Ka, int No, int nt) {
   static const int env = getenv("QAGNN_TN_CHUNK") ? atoi(getenv("QAGNN_TN_CHUNK")) : 0;
-  if (env >= TN_RC) return (env + 15) & ~15;
+  const int lo = tn_min_chunk(R);
+  if (env >= lo) return (env + 15) & ~15;
   const int rb = pick_tn_waves(Ka), nw = rb;
   const int blocks_per_chunk = cdiv(No, nt * 16) * cdiv(Ka, rb * 16);
   const int target = (num_cus() * (nw <= 8 ? 2 : 1)) / blocks_per_chunk;
   const int rows = (cdiv(R, target > 0 ? target : 1) + 15) & ~15;
-  return rows > TN_RC ? rows : TN_RC;
+  return rows > lo ? rows : lo;
 }
 
 // column-tile count per block: the widest instantiation that divides No, else the one wasting the least
@@ -719,7 +722,7 @@ extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t str
 }
 
 extern "C" int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No) {
-  return (int64_t)cdiv(R, TN_RC) * ((int64_t)Ka * No + 4 * (int64_t)No);
+  return (int64_t)cdiv(R, tn_min_chunk(R)) * ((int64_t)Ka * No + 4 * (int64_t)No);
 }
 
 extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,

@@ -248,7 +248,12 @@ class LinearNNFn(torch.autograd.Function):
                     dbias = cs.sum(0)
             elif want_bias:
                 dbias = cs[0]
-        dA1 = K.gemm_nn(dC, B1) if need[0] else None  # data gradients: the critical path stays on the main stream
+        if need[0] and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
+            # few rows, long reduction (the class tables: 612 x 2080): an NN launch would be 5 blocks walking 130 k-tiles one
+            # after the other; the split-K weight-gradient kernel computes the same product as (dC^T)^T B1 in parallel chunks
+            dA1 = K.gemm_tn(dC.t().contiguous(), B1)
+        else:
+            dA1 = K.gemm_nn(dC, B1) if need[0] else None  # data gradients: the critical path stays on the main stream
         dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
         wg.join()
         return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
