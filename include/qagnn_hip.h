@@ -141,7 +141,8 @@ int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float* B, int32_
 int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_t groups);
 int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
                         const int64_t* rowidx, int32_t groups, const float* mean, const float* invstd, const float* scale,
-                        const float* shift, float out_scale /* multiplies the result, e.g. 1/R for a mean */, float* out, float* workspace,
+                        const float* shift, const float* roww /* optional per-row weight (modes 0, 1): weighted sums */,
+                        float out_scale /* multiplies the result, e.g. 1/R for a mean */, float* out, float* workspace,
                         qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -161,7 +162,7 @@ int qagnn_bn_finalize_f32(const float* mean, const float* var, const float* gamm
 int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
                           const float* invstd, const float* scale, const float* shift, const float* gamma, const float* sum_dy,
                           const float* sum_dy_hhat, float inv_rows /* 1/R with batch statistics, 0 with running statistics */,
-                          qagnn_stream_t stream);
+                          const float* roww /* optional: per-row statistics weight instead of inv_rows */, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);

@@ -57,9 +57,9 @@ def load_library(path=LIB_PATH):
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
-    lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]
+    lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]
     lib.qagnn_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
-    lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp]
+    lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
@@ -210,21 +210,21 @@ class HipKernels:
         return (out, bsum) if colsum_groups else out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------
-    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0):
+    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0, roww=None):
         _chk2d(X, 'X')
         R, Cc = X.shape
         out = torch.empty((nout, Cc), dtype=torch.float32, device=X.device)
         ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, groups), dtype=torch.float32, device=X.device)
         rc = self.lib.qagnn_colreduce_f32(mode, X.data_ptr(), Cc, _ptr(X2), Cc, R, Cc, _ptr(rowidx), groups, _ptr(mean),
-                                          _ptr(invstd), _ptr(scale), _ptr(shift), float(out_scale), out.data_ptr(), ws.data_ptr(), self._stream())
+                                          _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(roww), float(out_scale), out.data_ptr(), ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_colreduce_f32')
         return out
 
-    def colsum(self, X, rowidx=None, groups=1, scale=1.0):
-        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups, scale)
+    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None):
+        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups, scale, roww)
 
-    def colvar_sum(self, X, mean, scale=1.0):
-        return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1, scale)[0]
+    def colvar_sum(self, X, mean, scale=1.0, roww=None):
+        return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1, scale, roww)[0]
 
     def bn_finalize(self, mean, var, gamma, beta, eps, running=None):
         """-> invstd, scale, shift [Cc]; running = (run_mean [d], run_var [d], num_batches_tracked, dense_pos [d], momentum, unbias)
@@ -236,7 +236,7 @@ class HipKernels:
         if running is not None:
             rm, rv, nbt, pos, mom, unb = running
             d = rm.numel()
-            assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and nbt.dtype == torch.long
+            assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
         rc = self.lib.qagnn_bn_finalize_f32(mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), Cc, _ptr(rm), _ptr(rv), _ptr(nbt),
                                             _ptr(pos), d, float(mom), float(unb), self._stream())
@@ -247,15 +247,16 @@ class HipKernels:
         _chk2d(H, 'H')
         return self._colreduce(2, dR, H, None, 1, mean, invstd, scale, shift, 2)
 
-    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows):
-        """red = bn_bwd_reduce(...) [2, Cc]; inv_rows = 1/R (batch statistics) or 0 (running statistics)."""
+    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
+        """red = bn_bwd_reduce(...) [2, Cc]; inv_rows = 1/R (batch statistics) or 0 (running statistics); roww [R]: the
+        per-row statistics weights when they were not uniform."""
         assert red.is_contiguous() and red.shape == (2, H.size(1))
         _chk2d(dR, 'dR'), _chk2d(H, 'H')
         R, Cc = H.shape
         dH = torch.empty_like(H)
         rc = self.lib.qagnn_bn_relu_bwd_f32(dR.data_ptr(), H.data_ptr(), dH.data_ptr(), Cc, R, Cc, mean.data_ptr(),
                                             invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(),
-                                            red[0].data_ptr(), red[1].data_ptr(), float(inv_rows), self._stream())
+                                            red[0].data_ptr(), red[1].data_ptr(), float(inv_rows), _ptr(roww), self._stream())
         self._check(rc, 'qagnn_bn_relu_bwd_f32')
         return dH
 

@@ -11,12 +11,13 @@ constexpr int CR_ROWS = 128;  // rows per block (4 waves x 32 rows): >= 2 blocks
 constexpr int CR_WR = CR_ROWS / 4;
 
 // MODE 0: grouped column sums   MODE 1: sum (x-mean)^2   MODE 2: BN+ReLU backward reductions (2 outputs)
+// roww (modes 0, 1): optional per-row weight -> weighted sums (count-weighted BatchNorm statistics of the edge-class table)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, int ldx, const float* __restrict__ X2, int ldx2,
                                                    int R, int Cc, const int64_t* __restrict__ rowidx, int groups,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                   float* __restrict__ part) {
+                                                   const float* __restrict__ roww, float* __restrict__ part) {
   constexpr int NOUT = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);
   __shared__ __attribute__((aligned(16))) float red[4][NOUT][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -44,8 +45,10 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
       for (int u = 0; u < 8; ++u) {
         const int r = rb + u;
         if (r >= rend) break;
-        const float4 x = xs[u];
+        float4 x = xs[u];
+        const float wr = (MODE != 2 && roww) ? roww[r] : 1.f;  // wave-uniform
         if (MODE == 0) {
+          x = make_float4(x.x * wr, x.y * wr, x.z * wr, x.w * wr);
           const int g = rowidx ? (int)rowidx[r] : 0;
           // wave-uniform branch: every lane of the wave is on the same row
           if (g == 0) acc[0] = add4(acc[0], x);
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
           else acc[3] = add4(acc[3], x);
         } else if (MODE == 1) {
           const float4 d = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
-          acc[0] = make_float4(fmaf(d.x, d.x, acc[0].x), fmaf(d.y, d.y, acc[0].y), fmaf(d.z, d.z, acc[0].z), fmaf(d.w, d.w, acc[0].w));
+          acc[0] = make_float4(fmaf(d.x * wr, d.x, acc[0].x), fmaf(d.y * wr, d.y, acc[0].y), fmaf(d.z * wr, d.z, acc[0].z),
+                               fmaf(d.w * wr, d.w, acc[0].w));
         } else {
           const float4 h = hs[u];
           float4 dy;
@@ -117,11 +121,13 @@ __global__ __launch_bounds__(64 * CF_Q) void k_colreduce_final(const float* __re
 __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH, int ld, int R,
                               int Cc, const float* __restrict__ mean, const float* __restrict__ invstd,
                               const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ gamma,
-                              const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_hhat, float inv_rows) {
+                              const float* __restrict__ sum_dy, const float* __restrict__ sum_dy_hhat, float inv_rows,
+                              const float* __restrict__ roww) {
   const int c4n = Cc >> 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)R * c4n) return;
   const int r = (int)(i / c4n), col = (int)(i % c4n) * 4;
+  if (roww) inv_rows = roww[r];  // weighted statistics: row r entered mean / variance with weight roww[r] instead of 1/R
   const int64_t off = (int64_t)r * ld + col;
   const float4 g = ld4(dR + off), h = ld4(Hh + off);
   const float4 mu = ld4(mean + col), is = ld4(invstd + col), sc = ld4(scale + col), sh = ld4(shift + col);
@@ -219,7 +225,7 @@ extern "C" int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_
 
 extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
                                    const int64_t* rowidx, int32_t groups, const float* mean, const float* invstd,
-                                   const float* scale, const float* shift, float out_scale, float* out, float* workspace, qagnn_stream_t stream_) {
+                                   const float* scale, const float* shift, const float* roww, float out_scale, float* out, float* workspace, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(X && out && workspace, QAGNN_EINVAL, "colreduce: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ldx % 4 == 0 && aligned16(X), QAGNN_EINVAL, "colreduce: bad sizes/alignment");
@@ -229,16 +235,16 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
   if (mode == 0) {
     QAGNN_REQUIRE(groups >= 1 && groups <= 4 && (groups == 1 || rowidx), QAGNN_EINVAL, "colreduce: groups=%d (1..4)", groups);
     nout = groups;
-    k_colreduce<0><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+    k_colreduce<0><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   } else if (mode == 1) {
     QAGNN_REQUIRE(mean && aligned16(mean), QAGNN_EINVAL, "colreduce: mode 1 needs mean");
     nout = 1;
-    k_colreduce<1><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+    k_colreduce<1><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   } else {
     QAGNN_REQUIRE(X2 && mean && invstd && scale && shift && ldx2 % 4 == 0 && aligned16(X2), QAGNN_EINVAL,
                   "colreduce: mode 2 needs X2, mean, invstd, scale, shift");
     nout = 2;
-    k_colreduce<2><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, workspace);
+    k_colreduce<2><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   }
   QAGNN_LAUNCH_CHECK("k_colreduce");
   const int tot = nout * Cc;
@@ -250,14 +256,14 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
 extern "C" int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc,
                                      const float* mean, const float* invstd, const float* scale, const float* shift,
                                      const float* gamma, const float* sum_dy, const float* sum_dy_hhat, float inv_rows,
-                                     qagnn_stream_t stream_) {
+                                     const float* roww, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gamma && sum_dy && sum_dy_hhat, QAGNN_EINVAL,
                 "bn_relu_bwd: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd: bad sizes");
   const int64_t tot = (int64_t)R * (Cc / 4);
   k_bn_relu_bwd<<<cdiv(tot, 256), 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
-                                                    inv_rows);
+                                                    inv_rows, roww);
   QAGNN_LAUNCH_CHECK("k_bn_relu_bwd");
   return QAGNN_OK;
 }

@@ -94,32 +94,28 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
     """edge_class_table() in the kernels' head-padded layout, for the stack: tab_p [C, DP] (pads exactly 0).
 
     `enc` = (W1t [FP, DP], W1 [DP, FP], b1, gamma, beta [DP], W2t, W2 [DP, DP], b2 [DP]) from QAGNN_Message_Passing.pack_all
-    (FP = the 47 one-hot columns rounded up to 16).  Both Linears run on the MFMA GEMM kernels with their hand-written
-    backward: for these shapes ([612, 200] x [612, 200] weight gradients) rocBLAS picks a single-workgroup kernel that takes
-    142 us.  The count-weighted BatchNorm vector math stays on torch (C x DP elements)."""
+    (FP = the 47 one-hot columns rounded up to 16).  It is the same Linear -> BatchNorm -> ReLU -> Linear pipeline as GATConvE.mlp,
+    so it runs on the same fused operator (ops.gat_mlp: MFMA GEMMs, BN + ReLU folded into the second GEMM's operand load,
+    hand-written backward) with count-weighted statistics; for these shapes ([612, 200] x [612, 200] weight gradients) rocBLAS
+    picks a single-workgroup kernel that takes 142 us."""
     W1t, W1, b1, gamma, beta, W2t, W2, b2 = enc
     bn = edge_encoder[1]
     FP = W1t.size(0)
     key = ('padded', graph.R, graph.T, str(W1t.device), W1t.dtype, FP)
     if key not in _CLASS_FEATS:
         _CLASS_FEATS[key] = F.pad(edge_class_features(graph.R, graph.T, W1t.device, W1t.dtype), (0, FP - (graph.R + 1 + 2 * graph.T)))
-    h = ops.linear_nn(_CLASS_FEATS[key], W1t, W1, bias=b1)
-    if training or not bn.track_running_stats:
-        Ep = float(graph.Ep)
-        w = (graph.cls_count.to(h.dtype) / Ep).unsqueeze(1)
-        mu = (w * h).sum(0)
-        var = (w * (h - mu) ** 2).sum(0)
-        if training and bn.track_running_stats:
-            with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 0.1
-                wgt = 1.0 - (1.0 - m) ** n_updates  # n identical momentum updates in closed form
-                bn.running_mean.lerp_(L.unpad(mu), wgt)
-                bn.running_var.lerp_(L.unpad(var) * (Ep / max(Ep - 1.0, 1.0)), wgt)
-                bn.num_batches_tracked += n_updates
-    else:
-        mu, var = L.pad(bn.running_mean), L.pad(bn.running_var)
-    hn = (h - mu) * torch.rsqrt(var + bn.eps) * gamma + beta
-    return ops.linear_nn(F.relu(hn), W2t, W2, bias=b2)
+    use_batch_stats = training or not bn.track_running_stats
+    Ep = float(graph.Ep)
+    running = None
+    if training and bn.track_running_stats:
+        m = bn.momentum if bn.momentum is not None else 0.1
+        # n identical momentum updates in closed form; the batch counter is bumped by n below (the kernel would add 1)
+        running = (bn.running_mean, bn.running_var, None, L.dense_pos, 1.0 - (1.0 - m) ** n_updates, Ep / max(Ep - 1.0, 1.0))
+        bn.num_batches_tracked += n_updates
+    tab_p, _, _ = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, L.pad(bn.running_mean), L.pad(bn.running_var),
+                              use_batch_stats, bn.eps, 0.0, apply_act=False, running=running,
+                              row_weight=graph.cls_count.to(W1t.dtype) / Ep if use_batch_stats else None)
+    return tab_p
 
 
 def edge_class_table(edge_encoder, graph, training, n_updates=1):

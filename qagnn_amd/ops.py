@@ -354,20 +354,22 @@ class GatMlpFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act, running):
+    def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act, running,
+                row_weight):
         K = kernels()
         R = aggr.size(0)
         h1 = K.gemm_nn(aggr, W1t, bias=b1)
         if training:
-            mean = K.colsum(h1, scale=1.0 / R)[0]
-            var = K.colvar_sum(h1, mean, scale=1.0 / R)  # biased
+            sc = 1.0 / R if row_weight is None else 1.0  # row_weight [R] (sums to 1): weighted statistics
+            mean = K.colsum(h1, scale=sc, roww=row_weight)[0]
+            var = K.colvar_sum(h1, mean, scale=sc, roww=row_weight)  # biased
         else:
             mean, var = run_mean, run_var
         # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
         invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
         out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
-        ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma)
+        ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight)
         ctx.cfg = (training, p, seed, R, apply_act)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
@@ -376,7 +378,7 @@ class GatMlpFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, dy, _dm, _dv):
         K = kernels()
-        aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma = ctx.saved_tensors
+        aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
         wg = _WgradStream(dout)
@@ -390,7 +392,8 @@ class GatMlpFn(torch.autograd.Function):
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
-        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0)
+        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
+                            roww=row_weight if training else None)
         with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
             if FUSED_COLSUM:
                 dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
@@ -398,17 +401,19 @@ class GatMlpFn(torch.autograd.Function):
             else:
                 dW1t = K.gemm_tn(aggr, dh1)
                 db1 = K.colsum(dh1)[0]
-        daggr = K.gemm_nn(dh1, W1)
+        daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
         wg.join()
-        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None
+        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
 
 
-def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True, running=None):
+def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True, running=None,
+            row_weight=None):
     """`batch_stats`: BatchNorm uses batch statistics (train mode); `p`: dropout rate (0 disables); `apply_act`: GELU+dropout
-    fused after the second Linear (False returns the raw GATConvE output)."""
+    fused after the second Linear (False returns the raw GATConvE output); `row_weight` [R] (sums to 1): rows enter the batch
+    statistics with these weights instead of 1/R (the edge encoder on distinct edge classes, weighted by class counts)."""
     p = float(p) if apply_act else 0.0
     return GatMlpFn.apply(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p,
-                          next_seed() if p > 0 else 0, apply_act, running)
+                          next_seed() if p > 0 else 0, apply_act, running, row_weight)
 
 
 class ConceptInputFn(torch.autograd.Function):

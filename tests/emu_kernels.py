@@ -122,13 +122,18 @@ class EmuKernels:
             return C, self.colsum(B, b_rowidx, colsum_groups)
         return C
 
-    def colsum(self, X, rowidx=None, groups=1, scale=1.0):
+    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None):
+        if roww is not None:
+            X = X * roww.unsqueeze(1)
         if rowidx is None:
             return X.sum(0, keepdim=True) * scale
         return torch.zeros(groups, X.size(1), dtype=X.dtype, device=X.device).index_add_(0, rowidx, X) * scale
 
-    def colvar_sum(self, X, mean, scale=1.0):
-        return ((X - mean) ** 2).sum(0) * scale
+    def colvar_sum(self, X, mean, scale=1.0, roww=None):
+        d2 = (X - mean) ** 2
+        if roww is not None:
+            d2 = d2 * roww.unsqueeze(1)
+        return d2.sum(0) * scale
 
     def bn_finalize(self, mean, var, gamma, beta, eps, running=None):
         invstd = torch.rsqrt(var + eps)
@@ -138,16 +143,18 @@ class EmuKernels:
             rm, rv, nbt, pos, mom, unb = running
             rm += mom * (mean[pos] - rm)
             rv += mom * (var[pos] * unb - rv)
-            nbt += 1
+            if nbt is not None:
+                nbt += 1
         return invstd, scale, shift
 
     def bn_bwd_reduce(self, dR, H, mean, invstd, scale, shift):
         dy = dR * ((H * scale + shift) > 0)
         return torch.stack([dy.sum(0), (dy * (H - mean) * invstd).sum(0)])
 
-    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows):
+    def bn_relu_bwd(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
         dy = dR * ((H * scale + shift) > 0)
-        return gamma * invstd * (dy - red[0] * inv_rows - (H - mean) * invstd * (red[1] * inv_rows))
+        w = inv_rows if roww is None else roww.unsqueeze(1)
+        return gamma * invstd * (dy - red[0] * w - (H - mean) * invstd * (red[1] * w))
 
     def _keep(self, X, p, seed):
         if p <= 0:

@@ -216,6 +216,18 @@ def test_column_reductions_and_bn_backward(R, C):
         err = (got.double() - ref2).abs()
         flips = (err > 1e-4 * (1 + ref2.abs())).sum().item()
         assert flips <= 2, f'{flips} elements differ beyond fp32 rounding'
+    # row-weighted statistics (count-weighted BatchNorm of the edge-class table) and the matching backward
+    w = torch.rand(R, generator=g) + 0.1
+    w = w / w.sum()
+    wmean = K.colsum(H.cuda(), roww=w.cuda()).cpu()[0]
+    ref_m = EMU.colsum(H.double(), roww=w.double())[0]
+    assert torch.allclose(wmean.double(), ref_m, rtol=1e-5, atol=1e-6)
+    wvar = K.colvar_sum(H.cuda(), wmean.cuda(), roww=w.cuda()).cpu()
+    assert torch.allclose(wvar.double(), EMU.colvar_sum(H.double(), wmean.double(), roww=w.double()), rtol=1e-5, atol=1e-6)
+    args2 = args + (gamma, red)
+    got = K.bn_relu_bwd(*[t.cuda() for t in args2], 0.0, roww=w.cuda()).cpu()
+    ref2 = EMU.bn_relu_bwd(*[t.double() for t in args2], 0.0, roww=w.double())
+    assert ((got.double() - ref2).abs() > 1e-4 * (1 + ref2.abs())).sum().item() <= 2
     # scaled reductions (mean / biased variance come straight out of the reduction)
     got = K.colsum(H.cuda(), scale=1.0 / R).cpu()[0]
     assert torch.allclose(got, mean, rtol=1e-5, atol=1e-6)
