@@ -163,6 +163,17 @@ int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t l
                           const float* invstd, const float* scale, const float* shift, const float* gamma, const float* sum_dy,
                           const float* sum_dy_hhat, float inv_rows /* 1/R with batch statistics, 0 with running statistics */,
                           const float* roww /* optional: per-row statistics weight instead of inv_rows */, qagnn_stream_t stream);
+/* Pooling head (reference utils/layers.py:284-299 inside :344-371, called at modeling_qagnn.py:178), node-sized part, one
+ * workgroup per subgraph.  u [B, NH, Cc]: query seen from node space (Wk_h^T w_qs(q)); cvec [B, NH]: <w_qs(q)_h, bk_h>;
+ * K [B*n, ldk]: node rows (head-padded GNN output); mask [B, n]: 1 = node excluded (score -inf).
+ *   score = (<u, k> + c) * inv_temp;  attn = softmax over the n nodes;  attn_d = dropout(attn, p, seed);  z = sum_l attn_d k
+ * NH <= 4, Cc <= 256 (multiple of 4), n <= 1024.  bwd writes dK (not accumulates); dattn_d may be NULL. */
+int qagnn_pool_attn_fwd_f32(const float* u, const float* cvec, const float* K, int32_t ldk, const uint8_t* mask, int32_t B, int32_t n,
+                            int32_t NH, int32_t Cc, float inv_temp, float p, uint64_t seed, float* attn, float* attn_d, float* z,
+                            qagnn_stream_t stream);
+int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t B, int32_t n, int32_t NH, int32_t Cc, float inv_temp,
+                            float p, uint64_t seed, const float* attn, const float* dz, const float* dattn_d, float* dK, int32_t lddk,
+                            float* du, float* dc, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);

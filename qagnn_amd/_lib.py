@@ -17,6 +17,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
+           'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
@@ -63,6 +64,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
+    lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_fwd_blocked_f32.argtypes = lib.qagnn_edge_attn_fwd_f32.argtypes
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
@@ -259,6 +262,34 @@ class HipKernels:
                                             red[0].data_ptr(), red[1].data_ptr(), float(inv_rows), _ptr(roww), self._stream())
         self._check(rc, 'qagnn_bn_relu_bwd_f32')
         return dH
+
+    POOL_LIMITS = (4, 256, 1024)  # heads, row width, nodes per subgraph
+
+    def pool_attn_fwd(self, u, cvec, K, mask, inv_temp, p, seed):
+        """u [B, NH, Cc], cvec [B, NH], K [B, n, Cc] (contiguous rows), mask [B, n] bool -> attn, attn_d [B, NH, n], z [B, NH, Cc]."""
+        B, NH, Cc = u.shape
+        n = K.size(1)
+        assert u.is_contiguous() and cvec.is_contiguous() and K.is_contiguous() and mask.is_contiguous() and mask.dtype == torch.bool
+        attn = torch.empty((2, B, NH, n), dtype=torch.float32, device=u.device)
+        z = torch.empty((B, NH, Cc), dtype=torch.float32, device=u.device)
+        rc = self.lib.qagnn_pool_attn_fwd_f32(u.data_ptr(), cvec.data_ptr(), K.data_ptr(), K.size(2), mask.data_ptr(), B, n, NH, Cc,
+                                              float(inv_temp), float(p), int(seed), attn[0].data_ptr(), attn[1].data_ptr(),
+                                              z.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_pool_attn_fwd_f32')
+        return attn[0], attn[1], z
+
+    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, dz, dattn_d):
+        B, NH, Cc = u.shape
+        n = K.size(1)
+        assert dz.is_contiguous() and attn.is_contiguous() and (dattn_d is None or dattn_d.is_contiguous())
+        dK = torch.empty_like(K)
+        du = torch.empty_like(u)
+        dc = torch.empty((B, NH), dtype=torch.float32, device=u.device)
+        rc = self.lib.qagnn_pool_attn_bwd_f32(u.data_ptr(), K.data_ptr(), K.size(2), B, n, NH, Cc, float(inv_temp), float(p), int(seed),
+                                              attn.data_ptr(), dz.data_ptr(), _ptr(dattn_d), dK.data_ptr(), K.size(2), du.data_ptr(),
+                                              dc.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_pool_attn_bwd_f32')
+        return dK, du, dc
 
     def gelu_dropout_fwd(self, X, p, seed):
         assert X.is_contiguous() and X.dtype == torch.float32

@@ -40,6 +40,36 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return base + slot;
 }
 
+// counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index); same value in fwd and bwd
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+
+// sum over all 64 lanes of the wave; every lane ends up with the total
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64));
+  v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 1, 64));
+  return v;
+}
+
 // sum over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane ends up with the total.
 __device__ __forceinline__ float row16_sum(float v) {
   v += __shfl_xor(v, 1, 64);

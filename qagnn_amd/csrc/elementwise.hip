@@ -178,15 +178,6 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float t = tanhf(u);
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
 }
-// counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index); same value in fwd and bwd
-__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 template <bool BWD>
 __global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
                                float p, uint64_t seed) {

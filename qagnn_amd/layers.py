@@ -105,11 +105,17 @@ class MultiheadAttPoolLayer(nn.Module):
         c = torch.einsum('bhk,hk->bh', qs, self.w_ks.bias.view(nh, dk))
         if layout is not None:
             u = layout.pad(u)
-        scores = (torch.bmm(u, k.transpose(1, 2)) + c.unsqueeze(2)) / self.attention.temperature  # [b, nh, l]
-        if mask is not None:
-            scores = scores.masked_fill(mask.unsqueeze(1), -np.inf)
-        attn = self.attention.dropout(torch.softmax(scores, dim=2))
-        z = torch.bmm(attn, k)                                                      # [b, nh, d] pooled raw rows
+        from . import ops
+        if layout is not None and ops.pool_attention_supported(nh, k.size(2), l):
+            # the node-sized part as one HIP kernel per direction (scores, mask, softmax, attention dropout, weighted row sum)
+            m = mask if mask is not None else torch.zeros(b, l, dtype=torch.bool, device=k.device)
+            z, attn = ops.pool_attention(u, c, k, m, 1.0 / self.attention.temperature, self.attention.dropout.p, self.training)
+        else:
+            scores = (torch.bmm(u, k.transpose(1, 2)) + c.unsqueeze(2)) / self.attention.temperature  # [b, nh, l]
+            if mask is not None:
+                scores = scores.masked_fill(mask.unsqueeze(1), -np.inf)
+            attn = self.attention.dropout(torch.softmax(scores, dim=2))
+            z = torch.bmm(attn, k)                                                  # [b, nh, d] pooled raw rows
         if layout is not None:
             z = layout.unpad(z)
         Wv = self.w_vs.weight.view(nh, dv, -1)

@@ -416,6 +416,44 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
                           next_seed() if p > 0 else 0, apply_act, running, row_weight)
 
 
+class PoolAttnFn(torch.autograd.Function):
+    """Node-sized part of the pooling head (utils/layers.py:284-299 inside :344-371): masked softmax attention of NH query
+    vectors over the n node rows of every subgraph, attention dropout, weighted sum of the rows.  Returns (z [B, NH, Cc],
+    attn_d [B, NH, n] = the attention after dropout, which is what the reference returns as pool_attn)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, u, cvec, K3, mask, inv_temp, p, seed):
+        Kn = kernels()
+        u, cvec, K3 = u.contiguous(), cvec.contiguous(), K3.contiguous()
+        attn, attn_d, z = Kn.pool_attn_fwd(u, cvec, K3, mask.contiguous(), inv_temp, p, seed)
+        ctx.save_for_backward(u, K3, attn)
+        ctx.cfg = (inv_temp, p, seed)
+        ctx.set_materialize_grads(False)
+        return z, attn_d
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dz, dattn_d):
+        u, K3, attn = ctx.saved_tensors
+        inv_temp, p, seed = ctx.cfg
+        if dz is None:
+            dz = torch.zeros_like(u)
+        dK, du, dc = kernels().pool_attn_bwd(u, K3, inv_temp, p, seed, attn, dz.contiguous(),
+                                             dattn_d.contiguous() if dattn_d is not None else None)
+        return du, dc, dK, None, None, None, None
+
+
+def pool_attention(u, cvec, K3, mask, inv_temp, p, training):
+    p = float(p) if training else 0.0
+    return PoolAttnFn.apply(u, cvec, K3, mask, inv_temp, p, next_seed() if p > 0 else 0)
+
+
+def pool_attention_supported(nh, width, n):
+    lim = getattr(kernels(), 'POOL_LIMITS', None)
+    return lim is not None and nh <= lim[0] and width <= lim[1] and width % 4 == 0 and n <= lim[2]
+
+
 class ConceptInputFn(torch.autograd.Function):
     """Node features entering the GNN, fused (reference modeling_qagnn.py:153-156 + utils/layers.py:604-605):
 

@@ -163,6 +163,32 @@ class EmuKernels:
         keep = torch.from_numpy((u >= np.float32(p)).astype(np.float32)).view_as(X).to(X.device, X.dtype)
         return keep / (1.0 - p)
 
+    POOL_LIMITS = (4, 256, 1024)
+
+    def _pool_keep(self, shape, p, seed, like):
+        if p <= 0:
+            return torch.ones(shape, dtype=like.dtype, device=like.device)
+        n = int(np.prod(shape))
+        u = _uniform01(seed, np.arange(n, dtype=np.uint64))
+        return torch.from_numpy((u >= np.float32(p)).astype(np.float32)).view(shape).to(like.device, like.dtype) / (1.0 - p)
+
+    def pool_attn_fwd(self, u, cvec, K, mask, inv_temp, p, seed):
+        scores = (torch.bmm(u, K.transpose(1, 2)) + cvec.unsqueeze(2)) * inv_temp
+        scores = scores.masked_fill(mask.unsqueeze(1), float('-inf'))
+        attn = torch.softmax(scores, dim=2)
+        attn_d = attn * self._pool_keep(attn.shape, p, seed, attn)
+        return attn, attn_d, torch.bmm(attn_d, K)
+
+    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, dz, dattn_d):
+        keep = self._pool_keep(attn.shape, p, seed, attn)
+        dat = torch.bmm(dz, K.transpose(1, 2))
+        if dattn_d is not None:
+            dat = dat + dattn_d
+        dat = dat * keep
+        ds = attn * (dat - (attn * dat).sum(2, keepdim=True)) * inv_temp
+        dK = torch.bmm((attn * keep).transpose(1, 2), dz) + torch.bmm(ds.transpose(1, 2), u)
+        return dK, torch.bmm(ds, K), ds.sum(2)
+
     def gelu_dropout_fwd(self, X, p, seed):
         return _gelu(X) * self._keep(X, p, seed)
 

@@ -387,3 +387,27 @@ def test_edge_attention_is_deterministic():
     for o in outs[1:]:
         for x, y in zip(outs[0], o):
             assert torch.equal(x, y), 'run-to-run bit difference: a reduction order is not fixed'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,n,NH,Cc,p', [(7, 200, 2, 208, 0.0), (3, 37, 4, 32, 0.0), (5, 200, 2, 208, 0.3), (2, 1024, 1, 256, 0.1)])
+def test_pool_attention_forward_backward(B, n, NH, Cc, p):
+    g = torch.Generator().manual_seed(B * 100 + n)
+    u, c = torch.randn(B, NH, Cc, generator=g) * 0.3, torch.randn(B, NH, generator=g)
+    Kx = torch.randn(B, n, Cc, generator=g)
+    lens = torch.randint(1, n + 1, (B,), generator=g)
+    mask = torch.arange(n).unsqueeze(0) >= lens.unsqueeze(1)
+    dz, da = torch.randn(B, NH, Cc, generator=g), torch.randn(B, NH, n, generator=g)
+    K, seed, it = hip(), 12345, 0.2
+    attn, attn_d, z = [t.cpu() for t in K.pool_attn_fwd(u.cuda(), c.cuda(), Kx.cuda(), mask.cuda(), it, p, seed)]
+    r_attn, r_attn_d, r_z = EMU.pool_attn_fwd(u.double(), c.double(), Kx.double(), mask, it, p, seed)
+    assert torch.allclose(attn.double(), r_attn, rtol=1e-4, atol=1e-6)
+    assert ((attn_d == 0) == (r_attn_d == 0)).all(), 'dropout masks differ'
+    assert torch.allclose(attn_d.double(), r_attn_d, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(z.double(), r_z, rtol=1e-4, atol=1e-5)
+    assert (attn[mask.unsqueeze(1).expand_as(attn)] == 0).all()
+    for dattn in (da, None):
+        got = K.pool_attn_bwd(u.cuda(), Kx.cuda(), it, p, seed, attn.cuda(), dz.cuda(), None if dattn is None else dattn.cuda())
+        ref = EMU.pool_attn_bwd(u.double(), Kx.double(), it, p, seed, r_attn, dz.double(), None if dattn is None else dattn.double())
+        for a, b_ in zip(got, ref):
+            assert torch.allclose(a.cpu().double(), b_, rtol=2e-4, atol=2e-5 * max(1.0, b_.abs().max().item()))
