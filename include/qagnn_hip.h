@@ -172,8 +172,8 @@ int qagnn_pool_attn_fwd_f32(const float* u, const float* cvec, const float* K, i
                             int32_t NH, int32_t Cc, float inv_temp, float p, uint64_t seed, float* attn, float* attn_d, float* z,
                             qagnn_stream_t stream);
 int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t B, int32_t n, int32_t NH, int32_t Cc, float inv_temp,
-                            float p, uint64_t seed, const float* attn, const float* dz, const float* dattn_d, float* dK, int32_t lddk,
-                            float* du, float* dc, qagnn_stream_t stream);
+                            float p, uint64_t seed, const float* attn, const float* attn_d, const float* dz, const float* dattn_d,
+                            float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);

@@ -65,7 +65,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
-    lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
+    lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_fwd_blocked_f32.argtypes = lib.qagnn_edge_attn_fwd_f32.argtypes
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
@@ -278,15 +278,15 @@ class HipKernels:
         self._check(rc, 'qagnn_pool_attn_fwd_f32')
         return attn[0], attn[1], z
 
-    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, dz, dattn_d):
+    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, attn_d, dz, dattn_d):
         B, NH, Cc = u.shape
         n = K.size(1)
-        assert dz.is_contiguous() and attn.is_contiguous() and (dattn_d is None or dattn_d.is_contiguous())
+        assert dz.is_contiguous() and attn.is_contiguous() and attn_d.is_contiguous() and (dattn_d is None or dattn_d.is_contiguous())
         dK = torch.empty_like(K)
         du = torch.empty_like(u)
         dc = torch.empty((B, NH), dtype=torch.float32, device=u.device)
         rc = self.lib.qagnn_pool_attn_bwd_f32(u.data_ptr(), K.data_ptr(), K.size(2), B, n, NH, Cc, float(inv_temp), float(p), int(seed),
-                                              attn.data_ptr(), dz.data_ptr(), _ptr(dattn_d), dK.data_ptr(), K.size(2), du.data_ptr(),
+                                              attn.data_ptr(), attn_d.data_ptr(), dz.data_ptr(), _ptr(dattn_d), dK.data_ptr(), K.size(2), du.data_ptr(),
                                               dc.data_ptr(), self._stream())
         self._check(rc, 'qagnn_pool_attn_bwd_f32')
         return dK, du, dc

@@ -14,13 +14,15 @@ namespace qagnn {
 constexpr int POOL_MAXH = 4;     // attention heads (reference: 2)
 constexpr int POOL_MAXN = 1024;  // node slots per subgraph (reference: 200)
 
-// grid = B, block = 256 (4 waves)
-__global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ u, const float* __restrict__ cvec, const float* __restrict__ K,
+constexpr int POOL_W = 8;  // waves per workgroup; a wave takes 4 consecutive rows per step (4 row loads in flight)
+
+// grid = B, block = 512 (8 waves)
+__global__ __launch_bounds__(64 * POOL_W) void k_pool_fwd(const float* __restrict__ u, const float* __restrict__ cvec, const float* __restrict__ K,
                                                   int ldk, const uint8_t* __restrict__ mask, int n, int NH, int Cc, float inv_temp,
                                                   float p, uint64_t seed, float* __restrict__ attn, float* __restrict__ attn_d,
                                                   float* __restrict__ z) {
   __shared__ float sc[POOL_MAXH * POOL_MAXN];
-  __shared__ __attribute__((aligned(16))) float red[4][POOL_MAXH][256];
+  __shared__ __attribute__((aligned(16))) float red[POOL_W][POOL_MAXH][256];
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = lane * 4;
   const bool act = col < Cc;
@@ -31,14 +33,21 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ u, c
   const float* Kb = K + (int64_t)b * n * ldk;
 
   // sweep 1: scores
-  for (int l = w; l < n; l += 4) {
-    const float4 kv = act ? ld4(Kb + (int64_t)l * ldk + col) : zero;
-    const bool out = mask[(int64_t)b * n + l] != 0;
+  for (int l0 = w * 4; l0 < n; l0 += 4 * POOL_W) {
+    float4 kv[4];
 #pragma unroll
-    for (int h = 0; h < POOL_MAXH; ++h) {
-      if (h >= NH) break;
-      const float d = wave_sum(dot4(kv, u4[h]));
-      if (lane == 0) sc[h * n + l] = out ? -INFINITY : (d + cvec[(int64_t)b * NH + h]) * inv_temp;
+    for (int j = 0; j < 4; ++j) kv[j] = (act && l0 + j < n) ? ld4(Kb + (int64_t)(l0 + j) * ldk + col) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int l = l0 + j;
+      if (l >= n) break;
+      const bool out = mask[(int64_t)b * n + l] != 0;
+#pragma unroll
+      for (int h = 0; h < POOL_MAXH; ++h) {
+        if (h >= NH) break;
+        const float d = wave_sum(dot4(kv[j], u4[h]));
+        if (lane == 0) sc[h * n + l] = out ? -INFINITY : (d + cvec[(int64_t)b * NH + h]) * inv_temp;
+      }
     }
   }
   __syncthreads();
@@ -70,12 +79,18 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ u, c
   float4 acc[POOL_MAXH];
 #pragma unroll
   for (int h = 0; h < POOL_MAXH; ++h) acc[h] = zero;
-  for (int l = w; l < n; l += 4) {
-    const float4 kv = act ? ld4(Kb + (int64_t)l * ldk + col) : zero;
+  for (int l0 = w * 4; l0 < n; l0 += 4 * POOL_W) {
+    float4 kv[4];
 #pragma unroll
-    for (int h = 0; h < POOL_MAXH; ++h) {
-      if (h >= NH) break;
-      acc[h] = fma4(sc[h * n + l], kv, acc[h]);
+    for (int j = 0; j < 4; ++j) kv[j] = (act && l0 + j < n) ? ld4(Kb + (int64_t)(l0 + j) * ldk + col) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (l0 + j >= n) break;
+#pragma unroll
+      for (int h = 0; h < POOL_MAXH; ++h) {
+        if (h >= NH) break;
+        acc[h] = fma4(sc[h * n + l0 + j], kv[j], acc[h]);
+      }
     }
   }
 #pragma unroll
@@ -85,20 +100,22 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ u, c
 #pragma unroll
     for (int h = 0; h < POOL_MAXH; ++h) {
       if (h >= NH) break;
-      float4 s = add4(add4(ld4(&red[0][h][col]), ld4(&red[1][h][col])), add4(ld4(&red[2][h][col]), ld4(&red[3][h][col])));
+      float4 s = ld4(&red[0][h][col]);
+#pragma unroll
+      for (int k = 1; k < POOL_W; ++k) s = add4(s, ld4(&red[k][h][col]));
       st4(z + ((int64_t)b * NH + h) * Cc + col, s);
     }
   }
 }
 
 // backward: given dz [B, NH, Cc] and (optionally) d attn_d [B, NH, n] -> dK rows (written, not accumulated), du, dc
-__global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ u, const float* __restrict__ K, int ldk, int n, int NH, int Cc,
+__global__ __launch_bounds__(64 * POOL_W) void k_pool_bwd(const float* __restrict__ u, const float* __restrict__ K, int ldk, int n, int NH, int Cc,
                                                   float inv_temp, float p, uint64_t seed, const float* __restrict__ attn,
-                                                  const float* __restrict__ dz, const float* __restrict__ dattn_d,
+                                                  const float* __restrict__ attn_d, const float* __restrict__ dz,
+                                                  const float* __restrict__ dattn_d,
                                                   float* __restrict__ dK, int lddk, float* __restrict__ du, float* __restrict__ dc) {
-  __shared__ float ga[POOL_MAXH * POOL_MAXN];   // sweep 1: d attn_d from the z path; then ds (already x 1/temperature)
-  __shared__ float ad[POOL_MAXH * POOL_MAXN];   // attn after dropout
-  __shared__ __attribute__((aligned(16))) float red[4][POOL_MAXH][256];
+  __shared__ float ga[POOL_MAXH * POOL_MAXN];  // sweep 1: d attn_d from the z path; then ds (already x 1/temperature)
+  __shared__ __attribute__((aligned(16))) float red[POOL_W][POOL_MAXH][256];
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = lane * 4;
   const bool act = col < Cc;
@@ -111,13 +128,19 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ u, c
     g4[h] = on ? ld4(dz + ((int64_t)b * NH + h) * Cc + col) : zero;
   }
   const float* Kb = K + (int64_t)b * n * ldk;
-  for (int l = w; l < n; l += 4) {
-    const float4 kv = act ? ld4(Kb + (int64_t)l * ldk + col) : zero;
+  for (int l0 = w * 4; l0 < n; l0 += 4 * POOL_W) {
+    float4 kv[4];
 #pragma unroll
-    for (int h = 0; h < POOL_MAXH; ++h) {
-      if (h >= NH) break;
-      const float d = wave_sum(dot4(kv, g4[h]));
-      if (lane == 0) ga[h * n + l] = d;
+    for (int j = 0; j < 4; ++j) kv[j] = (act && l0 + j < n) ? ld4(Kb + (int64_t)(l0 + j) * ldk + col) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (l0 + j >= n) break;
+#pragma unroll
+      for (int h = 0; h < POOL_MAXH; ++h) {
+        if (h >= NH) break;
+        const float d = wave_sum(dot4(kv[j], g4[h]));
+        if (lane == 0) ga[h * n + l0 + j] = d;
+      }
     }
   }
   __syncthreads();
@@ -131,7 +154,6 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ u, c
       const float keep = (p > 0.f && uniform01(seed, (uint64_t)(base + l)) < p) ? 0.f : keep_scale;
       const float dat = (ga[h * n + l] + (dattn_d ? dattn_d[base + l] : 0.f)) * keep;  // gradient w.r.t. the softmax output
       ga[h * n + l] = dat;
-      ad[h * n + l] = a * keep;
       sdot += a * dat;
     }
     sdot = wave_sum(sdot);
@@ -148,18 +170,25 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ u, c
   float4 acc[POOL_MAXH];
 #pragma unroll
   for (int h = 0; h < POOL_MAXH; ++h) acc[h] = zero;
-  for (int l = w; l < n; l += 4) {
-    const float4 kv = act ? ld4(Kb + (int64_t)l * ldk + col) : zero;
-    float4 o = zero;
+  for (int l0 = w * 4; l0 < n; l0 += 4 * POOL_W) {
+    float4 kv[4];
 #pragma unroll
-    for (int h = 0; h < POOL_MAXH; ++h) {
-      if (h >= NH) break;
-      const float ds = ga[h * n + l];
-      o = fma4(ad[h * n + l], g4[h], o);
-      o = fma4(ds, u4[h], o);
-      acc[h] = fma4(ds, kv, acc[h]);
+    for (int j = 0; j < 4; ++j) kv[j] = (act && l0 + j < n) ? ld4(Kb + (int64_t)(l0 + j) * ldk + col) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int l = l0 + j;
+      if (l >= n) break;
+      float4 o = zero;
+#pragma unroll
+      for (int h = 0; h < POOL_MAXH; ++h) {
+        if (h >= NH) break;
+        const float ds = ga[h * n + l];
+        o = fma4(attn_d[((int64_t)b * NH + h) * n + l], g4[h], o);  // attention after dropout, as the forward stored it
+        o = fma4(ds, u4[h], o);
+        acc[h] = fma4(ds, kv[j], acc[h]);
+      }
+      if (act) st4(dK + ((int64_t)b * n + l) * lddk + col, o);
     }
-    if (act) st4(dK + ((int64_t)b * n + l) * lddk + col, o);
   }
 #pragma unroll
   for (int h = 0; h < POOL_MAXH; ++h) st4(&red[w][h][col], acc[h]);
@@ -168,7 +197,9 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ u, c
 #pragma unroll
     for (int h = 0; h < POOL_MAXH; ++h) {
       if (h >= NH) break;
-      float4 s = add4(add4(ld4(&red[0][h][col]), ld4(&red[1][h][col])), add4(ld4(&red[2][h][col]), ld4(&red[3][h][col])));
+      float4 s = ld4(&red[0][h][col]);
+#pragma unroll
+      for (int k = 1; k < POOL_W; ++k) s = add4(s, ld4(&red[k][h][col]));
       st4(du + ((int64_t)b * NH + h) * Cc + col, s);
     }
   }
@@ -194,20 +225,20 @@ extern "C" int qagnn_pool_attn_fwd_f32(const float* u, const float* cvec, const 
   QAGNN_REQUIRE(u && cvec && K && mask && attn && attn_d && z, QAGNN_EINVAL, "pool_attn_fwd: null pointer");
   QAGNN_REQUIRE(aligned16(u) && aligned16(K) && aligned16(z), QAGNN_EINVAL, "pool_attn_fwd: u / K / z must be 16-byte aligned");
   if (int rc = pool_check("pool_attn_fwd", B, n, NH, Cc, ldk, p)) return rc;
-  k_pool_fwd<<<B, 256, 0, stream>>>(u, cvec, K, ldk, mask, n, NH, Cc, inv_temp, p, seed, attn, attn_d, z);
+  k_pool_fwd<<<B, 64 * POOL_W, 0, stream>>>(u, cvec, K, ldk, mask, n, NH, Cc, inv_temp, p, seed, attn, attn_d, z);
   QAGNN_LAUNCH_CHECK("k_pool_fwd");
   return QAGNN_OK;
 }
 
 extern "C" int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t B, int32_t n, int32_t NH, int32_t Cc,
-                                       float inv_temp, float p, uint64_t seed, const float* attn, const float* dz, const float* dattn_d,
-                                       float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream_) {
+                                       float inv_temp, float p, uint64_t seed, const float* attn, const float* attn_d, const float* dz,
+                                       const float* dattn_d, float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  QAGNN_REQUIRE(u && K && attn && dz && dK && du && dc, QAGNN_EINVAL, "pool_attn_bwd: null pointer");
+  QAGNN_REQUIRE(u && K && attn && attn_d && dz && dK && du && dc, QAGNN_EINVAL, "pool_attn_bwd: null pointer");
   QAGNN_REQUIRE(aligned16(u) && aligned16(K) && aligned16(dz) && aligned16(dK) && aligned16(du) && lddk % 4 == 0 && lddk >= Cc, QAGNN_EINVAL,
                 "pool_attn_bwd: operands must be 16-byte aligned, lddk=%d", lddk);
   if (int rc = pool_check("pool_attn_bwd", B, n, NH, Cc, ldk, p)) return rc;
-  k_pool_bwd<<<B, 256, 0, stream>>>(u, K, ldk, n, NH, Cc, inv_temp, p, seed, attn, dz, dattn_d, dK, lddk, du, dc);
+  k_pool_bwd<<<B, 64 * POOL_W, 0, stream>>>(u, K, ldk, n, NH, Cc, inv_temp, p, seed, attn, attn_d, dz, dattn_d, dK, lddk, du, dc);
   QAGNN_LAUNCH_CHECK("k_pool_bwd");
   return QAGNN_OK;
 }

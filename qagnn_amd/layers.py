@@ -53,6 +53,12 @@ class MLP(nn.Module):
             self.layers[-1].bias.data.fill_(0)
 
     def forward(self, input):
+        if self.num_layers == 0 and self.output_size == 1 and input.is_cuda and input.dim() == 2:
+            # QAGNN's head at the reference default (fc_layer_num = 0) is one Linear(d + sent_dim + d -> 1): a matrix-vector
+            # product.  As addmm it lands on a 41-us single-workgroup rocBLAS GEMM (and two more in backward); as multiply +
+            # row sum it is two streaming kernels of a few us.
+            lin = self.layers[0]
+            return (input * lin.weight).sum(1, keepdim=True) + lin.bias
         return self.layers(input)
 
 

@@ -427,7 +427,7 @@ class PoolAttnFn(torch.autograd.Function):
         Kn = kernels()
         u, cvec, K3 = u.contiguous(), cvec.contiguous(), K3.contiguous()
         attn, attn_d, z = Kn.pool_attn_fwd(u, cvec, K3, mask.contiguous(), inv_temp, p, seed)
-        ctx.save_for_backward(u, K3, attn)
+        ctx.save_for_backward(u, K3, attn, attn_d)
         ctx.cfg = (inv_temp, p, seed)
         ctx.set_materialize_grads(False)
         return z, attn_d
@@ -435,11 +435,11 @@ class PoolAttnFn(torch.autograd.Function):
     @staticmethod
     @_bwd
     def backward(ctx, dz, dattn_d):
-        u, K3, attn = ctx.saved_tensors
+        u, K3, attn, attn_d = ctx.saved_tensors
         inv_temp, p, seed = ctx.cfg
         if dz is None:
             dz = torch.zeros_like(u)
-        dK, du, dc = kernels().pool_attn_bwd(u, K3, inv_temp, p, seed, attn, dz.contiguous(),
+        dK, du, dc = kernels().pool_attn_bwd(u, K3, inv_temp, p, seed, attn, attn_d, dz.contiguous(),
                                              dattn_d.contiguous() if dattn_d is not None else None)
         return du, dc, dK, None, None, None, None
 

@@ -179,7 +179,7 @@ class EmuKernels:
         attn_d = attn * self._pool_keep(attn.shape, p, seed, attn)
         return attn, attn_d, torch.bmm(attn_d, K)
 
-    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, dz, dattn_d):
+    def pool_attn_bwd(self, u, K, inv_temp, p, seed, attn, attn_d, dz, dattn_d):
         keep = self._pool_keep(attn.shape, p, seed, attn)
         dat = torch.bmm(dz, K.transpose(1, 2))
         if dattn_d is not None:

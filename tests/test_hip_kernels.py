@@ -407,7 +407,7 @@ def test_pool_attention_forward_backward(B, n, NH, Cc, p):
     assert torch.allclose(z.double(), r_z, rtol=1e-4, atol=1e-5)
     assert (attn[mask.unsqueeze(1).expand_as(attn)] == 0).all()
     for dattn in (da, None):
-        got = K.pool_attn_bwd(u.cuda(), Kx.cuda(), it, p, seed, attn.cuda(), dz.cuda(), None if dattn is None else dattn.cuda())
-        ref = EMU.pool_attn_bwd(u.double(), Kx.double(), it, p, seed, r_attn, dz.double(), None if dattn is None else dattn.double())
+        got = K.pool_attn_bwd(u.cuda(), Kx.cuda(), it, p, seed, attn.cuda(), attn_d.cuda(), dz.cuda(), None if dattn is None else dattn.cuda())
+        ref = EMU.pool_attn_bwd(u.double(), Kx.double(), it, p, seed, r_attn, r_attn_d, dz.double(), None if dattn is None else dattn.double())
         for a, b_ in zip(got, ref):
             assert torch.allclose(a.cpu().double(), b_, rtol=2e-4, atol=2e-5 * max(1.0, b_.abs().max().item()))
