@@ -36,6 +36,7 @@ from qagnn_amd import modeling_qagnn as MQ  # noqa: E402
 
 D, K_LAYERS, N_ETYPE, N_NTYPE, SENT_DIM, CONCEPT_IN, N_NODE, NC = 200, 5, 38, 4, 1024, 1024, 200, 5
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_16x16x4_f32: 32 cyc/SIMD)
 
 
 def make_batch(n_questions, seed, n_concept):
@@ -62,10 +63,12 @@ def build_model(cls_module, n_concept, p=0.2, seed=0):
 class TimedKernels:
     """Proxy around the kernel provider that brackets selected calls with HIP events on the launch stream."""
 
-    def __init__(self, inner, names):
+    def __init__(self, inner, names, work=None):
         self._inner, self._names = inner, set(names)
         self.name = inner.name
         self.events = {n: [] for n in names}
+        self.work = {n: 0.0 for n in names}   # e.g. FLOPs, accumulated per timed call by work[name](*args, **kwargs)
+        self._work_fn = work or {}
         self.enabled = False
 
     def __getattr__(self, attr):
@@ -81,12 +84,26 @@ class TimedKernels:
             out = fn(*a, **kw)
             e1.record()
             self.events[attr].append((e0, e1))
+            if attr in self._work_fn:
+                self.work[attr] += self._work_fn[attr](*a, **kw)
             return out
         return wrapped
 
     def mean_ms(self, name):
         ev = self.events[name]
         return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
+
+    def total_ms(self, name):
+        return sum(a.elapsed_time(b) for a, b in self.events[name])
+
+
+def _nn_flops(A1, B1, A2=None, B2=None, **kw):
+    rows = kw['a_rowidx'].numel() if kw.get('a_rowidx') is not None else A1.size(0)
+    return 2.0 * rows * (B1.size(0) + (B2.size(0) if B2 is not None else 0)) * B1.size(1)
+
+
+def _tn_flops(A, B, **kw):
+    return 2.0 * B.size(0) * A.size(1) * B.size(1)
 
 
 def step(model, b, world, flat_grad_params):
@@ -166,7 +183,8 @@ def main():
     model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep'])
+    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'gemm_nn', 'gemm_tn'],
+                         work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
     ops.set_kernels(timed)
 
     def sync():
@@ -200,6 +218,8 @@ def main():
         fwd_ms, n_fwd = timed.mean_ms('edge_attn_fwd')
         bwd_ms, n_bwd = timed.mean_ms('edge_attn_bwd')
         prep_ms, _ = timed.mean_ms('graph_prep')
+        gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn')
+        gemm_flops = timed.work['gemm_nn'] + timed.work['gemm_tn']
         alg_fwd = Ep * 2410 + N * 800
         alg_bwd = Ep * 5610 + N * 800
         achieved = alg_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
@@ -225,8 +245,16 @@ def main():
                          'launches_timed': n_fwd,
                          'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
                                       'achieved': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0}},
+            # the dense side of the step: every fp32-MFMA GEMM launch (k_gemm_nn, k_gemm_tn_strip / k_gemm_tn + chunk sum),
+            # algorithmic FLOPs of the products over their HIP-event time, against the dense fp32 matrix peak
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'qagnn_gemm_nn_f32 + qagnn_gemm_tn_f32 (all launches of the step)',
+                              'achieved': round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
+                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if gemm_ms > 0 else 0.0,
+                              'gflop_per_step': round(gemm_flops / args.steps / 1e9, 1), 'ms_per_step': round(gemm_ms / args.steps, 3),
+                              'launches_per_step': (len(timed.events['gemm_nn']) + len(timed.events['gemm_tn'])) // max(args.steps, 1)},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
-                                      'graph_prep': round(prep_ms, 3)},
+                                      'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms / args.steps, 3)},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
