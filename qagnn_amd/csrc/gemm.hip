@@ -413,11 +413,12 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
 // so every LDS fragment read is `base VGPR + immediate` and the k-loop carries no address arithmetic: the run-time
 // version spends 2-4 VALU instructions per MFMA on addresses and sits at ~48 % MFMA-busy.
 // ------------------------------------------------------------------------------------------------------------
-template <int NT, int NWT, bool AFFINE>
+template <int NT, int NWT, bool AFFINE, bool COLSUM>
 __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                             float* __restrict__ P, int R, int Ka, int No,
                                                             const float* __restrict__ a_scale, const float* __restrict__ a_shift,
-                                                            const int64_t* __restrict__ a_rowidx, int chunk_rows) {
+                                                            const int64_t* __restrict__ a_rowidx, int chunk_rows,
+                                                            float* __restrict__ Pcs, const int64_t* __restrict__ b_rowidx, int groups) {
   constexpr int NTHR = NWT * 64, BM = NWT * 16;
   constexpr int BN = NT * 16;
   constexpr int PA = pitch16(BM), PB = pitch_b(BN);
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
   constexpr int B_F4 = BK * BN / 4, B_IT = (B_F4 + NTHR - 1) / NTHR;
   constexpr int A_F4 = BM / 4;  // float4 per A tile row; 16 * A_F4 == NTHR: one float4 per thread
   __shared__ __attribute__((aligned(16))) float smem[2 * TBUF_F];
+  __shared__ int grp_s[2][BK];  // COLSUM with row groups: group id of the tile's 16 rows
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, chunk = blockIdx.z;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
@@ -436,6 +438,11 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
   float4 ra, rb[B_IT];
   const int akr = tid / A_F4, ac4 = tid % A_F4;
   const int acol = m0 + ac4 * 4;
+  // optional by-product (first row block only): column sums of B per row group, taken from the B tiles sitting in LDS --
+  // thread `tid` < BN owns column tid; saves the separate pass over B that a bias / type-table gradient would need
+  const bool do_cs = COLSUM && blockIdx.y == 0 && tid < BN;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  int rg = 0;
 
   auto gload = [&](int kt) {
     const int r0 = r_beg + kt * BK;
@@ -466,10 +473,12 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
       }
       rb[it] = v;
     }
+    if (COLSUM && b_rowidx && tid < BK) rg = (r0 + tid < r_end) ? (int)b_rowidx[r0 + tid] : 0;
   };
   float* const a_dst = smem + akr * PA + ac4 * 4;
   auto lstore = [&](auto bufc) {
     constexpr int buf = decltype(bufc)::value;
+    if (COLSUM && tid < BK) grp_s[buf][tid] = rg;
     st4(a_dst + buf * TBUF_F, ra);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -500,6 +509,18 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
     }
     sched_ktile_pipeline<NT>();
 #endif
+    if (do_cs) {  // rows in tile order = row order: the summation order is fixed
+      const float* Bs = smem + cur * TBUF_F + TA_F + tid;
+#pragma unroll
+      for (int kq = 0; kq < BK; ++kq) {
+        const float v = Bs[kq * PB];
+        const int g = groups > 1 ? grp_s[cur][kq] : 0;
+        if (g == 0) cs[0] += v;
+        else if (g == 1) cs[1] += v;
+        else if (g == 2) cs[2] += v;
+        else cs[3] += v;
+      }
+    }
     if (more) lstore(ic<cur ^ 1>{});  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
   };
@@ -521,6 +542,13 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
     return;
   }
 #endif
+  if (do_cs && n0 + tid < No) {
+    float* pc = Pcs + (int64_t)chunk * groups * No + n0 + tid;
+    pc[0] = cs[0];
+    if (groups > 1) pc[No] = cs[1];
+    if (groups > 2) pc[2 * No] = cs[2];
+    if (groups > 3) pc[3 * No] = cs[3];
+  }
   float* Pc = P + (int64_t)chunk * Ka * No;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -646,18 +674,28 @@ static bool tn_strip_enabled() {
 // compile-time strip launch (NT = 13 and 7 / 13 / 16 waves: every weight gradient of the stack at d = 200)
 template <int NWT>
 static void launch_tn_strip_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
-                              const float* sc, const float* sh, const int64_t* ridx, int chunk_rows) {
-  if (sc) k_gemm_tn_strip<13, NWT, true><<<grid, NWT * 64, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
-  else k_gemm_tn_strip<13, NWT, false><<<grid, NWT * 64, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+                              const float* sc, const float* sh, const int64_t* ridx, int chunk_rows, float* Pcs, const int64_t* bidx,
+                              int groups) {
+#define QAGNN_STRIP_GO(AFF, CS) \
+  k_gemm_tn_strip<13, NWT, AFF, CS><<<grid, NWT * 64, 0, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, Pcs, bidx, groups)
+  if (Pcs) {
+    if (sc) QAGNN_STRIP_GO(true, true);
+    else QAGNN_STRIP_GO(false, true);
+  } else {
+    if (sc) QAGNN_STRIP_GO(true, false);
+    else QAGNN_STRIP_GO(false, false);
+  }
+#undef QAGNN_STRIP_GO
 }
 static bool tn_strip_ok(int Ka) { const int nw = pick_tn_waves(Ka); return nw == 7 || nw == 13 || nw == 16; }
 static int launch_tn_strip(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc,
-                           const float* sh, const int64_t* ridx, int chunk_rows, hipStream_t stream) {
+                           const float* sh, const int64_t* ridx, int chunk_rows, float* Pcs, const int64_t* bidx, int groups,
+                           hipStream_t stream) {
   const int nw = pick_tn_waves(Ka);
   dim3 grid(cdiv(No, 13 * 16), cdiv(Ka, nw * 16), cdiv(R, chunk_rows));
-  if (nw == 7) launch_tn_strip_i<7>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
-  else if (nw == 13) launch_tn_strip_i<13>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
-  else launch_tn_strip_i<16>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows);
+  if (nw == 7) launch_tn_strip_i<7>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, Pcs, bidx, groups);
+  else if (nw == 13) launch_tn_strip_i<13>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, Pcs, bidx, groups);
+  else launch_tn_strip_i<16>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, ridx, chunk_rows, Pcs, bidx, groups);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_strip");
   return QAGNN_OK;
 }
@@ -739,12 +777,12 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
                 "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
   QAGNN_REQUIRE(!bsum || (groups >= 1 && groups <= 4 && (groups == 1 || b_rowidx)), QAGNN_EINVAL, "gemm_tn: colsum groups=%d (1..4)", groups);
   const int nt = pick_nt(No);
-  const bool strip = nt == 13 && !bsum && tn_strip_enabled() && tn_strip_ok(Ka);
+  const bool strip = nt == 13 && tn_strip_enabled() && tn_strip_ok(Ka);
   const int crows = pick_tn_chunk_rows(R, Ka, No, nt);
   const int nchunks = cdiv(R, crows);
   float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;
-  if (strip) rc = launch_tn_strip(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, stream);
+  if (strip) rc = launch_tn_strip(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream);
   else switch (nt) {
     case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;
     case 8: rc = launch_tn<8>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;

@@ -386,10 +386,11 @@ class QAGNN_Message_Passing(nn.Module):
         temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
         # shared edge encoder on the C distinct classes, then every layer's Ek|Em and node-type tables with one GEMM each
-        tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
-        ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
-        TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
         Xp = Hp
+        if self.k > 0:
+            tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
+            ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
+            TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
         for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
             Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
                               packed=pk, tables=(TT[l], ekem[l]))
