@@ -58,6 +58,7 @@ typedef struct qagnn_graph {
   /* grouped by TARGET (aggregation segments) */
   int32_t* rowptr_t;           /* [N+1] */
   int32_t* src_t;              /* [Ep] */
+  int32_t* tgt_t;              /* [Ep] target node of position p (segment owner, for the bucket-walk kernels) */
   int32_t* cls_t;              /* [Ep] */
   int32_t* pos_t;              /* [Ep] position of the same edge in the source order */
   /* grouped by CLASS, cut into chunks of <= QAGNN_CLS_CHUNK edges that never straddle a class */

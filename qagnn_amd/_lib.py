@@ -20,12 +20,14 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
 
+ABI_VERSION = 2  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t)
+
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
 
 class qagnn_graph(C.Structure):
     _fields_ = ([(n, _i32) for n in ('N', 'E', 'Ep', 'R', 'T', 'C')] +
-                [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'cls_t', 'pos_t',
+                [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'tgt_t', 'cls_t', 'pos_t',
                                     'clsptr', 'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
                 [('max_chunks', _i32), ('err', _vp), ('block_n', _i32)])
@@ -119,7 +121,7 @@ class HipKernels:
         if not torch.cuda.is_available():
             raise RuntimeError('qagnn_amd needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback')
         self.lib = load_library()
-        if self.lib.qagnn_abi_version() != 1:
+        if self.lib.qagnn_abi_version() != ABI_VERSION:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
         # LDS-resident edge forward (qagnn_edge_attn_fwd_blocked_f32).  Correct, but in its first form 5x slower than the generic
         # gather kernels (interleaved A/B, run 26: 17 786 / 17 751 vs 21 449 / 21 452 QA-subgraphs/s): one 157 KB workgroup per CU

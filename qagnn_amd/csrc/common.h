@@ -50,39 +50,43 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
 }
 
 
-// sum over all 64 lanes of the wave; every lane ends up with the total
-__device__ __forceinline__ float wave_sum(float v) {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
-  return v;
+// Cross-lane reductions.  `__shfl_xor` compiles to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles, with an
+// s_waitcnt lgkmcnt(0) behind every step); inside a 16-lane DPP row the same butterfly is four v_add_f32_dpp with
+// row_ror:8/4/2/1 (a cyclic rotation inside the row), issued back to back.  After a rotation by r the partial sums are
+// periodic with period r and the add is commutative, so all 16 lanes end up with the bit-identical total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 8, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64));
-  v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 1, 64));
-  return v;
-}
+constexpr int DPP_ROW_ROR = 0x120;  // + n: rotate right by n lanes inside each row of 16
 
-// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane ends up with the total.
+// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane ends up with the total.  All 64 lanes must be active.
 __device__ __forceinline__ float row16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  v += dpp_f32<DPP_ROW_ROR + 8>(v);
+  v += dpp_f32<DPP_ROW_ROR + 4>(v);
+  v += dpp_f32<DPP_ROW_ROR + 2>(v);
+  v += dpp_f32<DPP_ROW_ROR + 1>(v);
   return v;
 }
 __device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64));
-  v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64));
-  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, dpp_f32<DPP_ROW_ROR + 8>(v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_ROR + 4>(v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_ROR + 2>(v));
+  v = fmaxf(v, dpp_f32<DPP_ROW_ROR + 1>(v));
+  return v;
+}
+
+// sum over all 64 lanes of the wave; every lane ends up with the total (rows by DPP, the 4 row totals by two bpermutes)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

@@ -13,11 +13,16 @@
 // of 4 edges are issued back to back so their L2/HBM latencies overlap.
 //
 // Everything here is HBM/L2-bound gather work: no MFMA, no atomics; every reduction has a fixed order.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace qagnn {
 
 #define EDGE_UNROLL 4
+#ifndef SRC1W_UNROLL
+#define SRC1W_UNROLL 3  // k_edge_bwd_src1_w gathers three rows per edge: 3 edges in flight keep it at 8 waves per SIMD
+#endif
 
 struct Lane {
   int g, j, off;
@@ -319,6 +324,280 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// "Bucket walk" variants of the segment kernels (QAGNN_EDGE_WALK, default on).
+//
+// The node-per-wave kernels above pay a dependent chain rowptr -> segment indices -> rows for every node, and a QA
+// subgraph's segments are short: 7 edges on average, ONE (the self loop) for the ~40 % PAD rows.  At 64 000 waves of
+// ~2 four-edge batches each the kernels are bound by that start-up chain and by the imbalance between PAD rows and hubs,
+// not by the gather itself.  Here a wave owns a BUCKET of 64 consecutive positions of a CSR order instead: it processes
+// the segments that START inside its bucket (running over the bucket end to finish the last one), so every wave has
+// 64..127 edges of work, the index arrays are read with one coalesced load per 64 edges and there is no rowptr lookup
+// at all -- segment boundaries come from the per-position owner array (src_s / tgt_t) with one ballot.  A segment is
+// still accumulated by ONE wave in edge order and flushed when its last edge is reached, so the results are
+// bit-identical to the node-per-wave kernels (no atomics, fixed order).  Requires every node to own >= 1 position in
+// both orders, which qagnn_graph_prep guarantees (a self loop is appended for all N rows, modeling_qagnn.py:436-438).
+// The raw scores need no segment at all: k_edge_scores_e is purely edge-parallel.
+// ---------------------------------------------------------------------------------------------------------------
+struct WalkChunk {
+  int ov;                     // lane: owner (node) of position c0 + lane; -1 past the end
+  unsigned long long lastm;   // uniform: bit i set = position c0 + i is the last edge of its segment
+  int i_lo, i_hi;             // uniform: this wave owns positions [c0 + i_lo, c0 + i_hi) of the chunk
+};
+// first = true: the wave owns the segments that START inside this chunk (from the first head on); false if none does.
+// first = false: the wave is finishing a segment that ran over the previous chunk's end: it owns the positions up to the next head.
+__device__ __forceinline__ bool walk_open(const int* __restrict__ own, int Ep, int c0, bool first, WalkChunk& w) {
+  const int lane = threadIdx.x & 63, p = c0 + lane;
+  const int o = p < Ep ? own[p] : -1;
+  const int op = (p > 0 && p < Ep) ? own[p - 1] : -1;
+  const int on = p + 1 < Ep ? own[p + 1] : -1;
+  const unsigned long long hm = __ballot(p < Ep && o != op);
+  w.ov = o;
+  w.lastm = __ballot(p < Ep && o != on);
+  w.i_lo = 0;
+  w.i_hi = min(64, Ep - c0);
+  if (first) {
+    if (hm == 0) return false;
+    w.i_lo = __builtin_ctzll(hm);
+  } else if (hm != 0) {
+    w.i_hi = __builtin_ctzll(hm);
+  }
+  return w.i_lo < w.i_hi;
+}
+__device__ __forceinline__ int wave_bucket() {
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  return __builtin_amdgcn_readfirstlane(lb * 4 + (threadIdx.x >> 6));
+}
+__device__ __forceinline__ bool bit_at(unsigned long long m, int i) { return (m >> i) & 1ull; }
+
+// forward 1/3, edge-parallel: wave b scores positions [64 b, 64 b + 64) of the source order
+__global__ __launch_bounds__(256) void k_edge_scores_e(const int* __restrict__ src_s, const int* __restrict__ tgt_s,
+                                                       const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
+                                                       const float* __restrict__ EkEm, int lde, int HP, float qscale,
+                                                       float* __restrict__ score, int Ep, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const int c0 = wave_bucket() * 64;
+  if (c0 >= Ep) return;
+  const Lane L = lane_info(HP);
+  const int lane = threadIdx.x & 63, DP = 4 * HP;
+  const int cnt = min(64, Ep - c0), pc = c0 + min(lane, cnt - 1);
+  const int sv = src_s[pc], tv = tgt_s[pc], cv = cls_s[pc];
+  for (int i = 0; i < cnt; i += EDGE_UNROLL) {
+    float4 q[EDGE_UNROLL], k[EDGE_UNROLL], ek[EDGE_UNROLL];
+#pragma unroll
+    for (int u = 0; u < EDGE_UNROLL; ++u) {
+      const int idx = min(i + u, cnt - 1);
+      const int s = __builtin_amdgcn_readlane(sv, idx), t = __builtin_amdgcn_readlane(tv, idx);
+      const int c = __builtin_amdgcn_readlane(cv, idx);
+      q[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + 2 * DP + L.off) : zero4();
+      k[u] = L.act ? ld4(KMQ + (int64_t)t * ldk + L.off) : zero4();
+      ek[u] = L.act ? ld4(EkEm + (int64_t)c * lde + L.off) : zero4();
+    }
+#pragma unroll
+    for (int u = 0; u < EDGE_UNROLL; ++u) {
+      const float p = row16_sum(dot4(q[u], add4(k[u], ek[u]))) * qscale;
+      if (i + u < cnt && L.j == 0) score[(int64_t)(c0 + i + u) * 4 + L.g] = p;
+    }
+  }
+}
+
+// forward 3/3: weighted sum of messages by TARGET, bucket walk over the target order
+__global__ __launch_bounds__(256) void k_edge_aggregate_w(const int* __restrict__ tgt_t, const int* __restrict__ src_t,
+                                                          const int* __restrict__ cls_t, const int* __restrict__ pos_t,
+                                                          const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
+                                                          int lde, int HP, const float* __restrict__ alpha,
+                                                          float* __restrict__ aggr, int lda, int Ep, const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
+  const int b = wave_bucket();
+  if (b * 64 >= Ep) return;
+  const Lane L = lane_info(HP);
+  const int lane = threadIdx.x & 63, DP = 4 * HP;
+  float4 acc = zero4();
+  bool first = true;
+  for (int c0 = b * 64; c0 < Ep; c0 += 64) {
+    const int pc = min(c0 + lane, Ep - 1);
+    const int sv = src_t[pc], cv = cls_t[pc], pv = pos_t[pc];
+    WalkChunk w;
+    if (!walk_open(tgt_t, Ep, c0, first, w)) return;
+    first = false;
+    for (int i = w.i_lo; i < w.i_hi; i += EDGE_UNROLL) {
+      float4 m[EDGE_UNROLL], em[EDGE_UNROLL];
+      float wgt[EDGE_UNROLL];
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const int idx = min(i + u, w.i_hi - 1);
+        const int s = __builtin_amdgcn_readlane(sv, idx), c = __builtin_amdgcn_readlane(cv, idx);
+        const int p = __builtin_amdgcn_readlane(pv, idx);
+        m[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + DP + L.off) : zero4();
+        em[u] = L.act ? ld4(EkEm + (int64_t)c * lde + DP + L.off) : zero4();
+        wgt[u] = i + u < w.i_hi ? alpha[(int64_t)p * 4 + L.g] : 0.f;
+      }
+      // every gathered row is consumed on every path (clamped duplicates enter with weight 0): a path that skipped them
+      // would leave their loads pending at the loop back edge and cost a conservative vmcnt wait in front of the next batch
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        acc = fma4(wgt[u], add4(m[u], em[u]), acc);
+        if (i + u < w.i_hi && bit_at(w.lastm, i + u)) {
+          const int t = __builtin_amdgcn_readlane(w.ov, i + u);
+          if (L.act) st4(aggr + (int64_t)t * lda + L.off, acc);
+          acc = zero4();
+        }
+      }
+    }
+    if (bit_at(w.lastm, w.i_hi - 1)) return;
+  }
+}
+
+// backward, source pass 1 (see k_edge_bwd_src1), bucket walk over the source order.  deg(s) comes from rowptr_s, read per
+// lane for the chunk's owners (the loads land under the first row gathers).
+__global__ __launch_bounds__(256) void k_edge_bwd_src1_w(const int* __restrict__ rowptr_s, const int* __restrict__ src_s,
+                                                         const int* __restrict__ tgt_s, const int* __restrict__ cls_s,
+                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
+                                                         int lde, int HP, const float* __restrict__ a,
+                                                         const float* __restrict__ alpha, const float* __restrict__ G, int ldg,
+                                                         float* __restrict__ dKMQ, float* __restrict__ ga, float* __restrict__ rs,
+                                                         int Ep) {
+  const int b = wave_bucket();
+  if (b * 64 >= Ep) return;
+  const Lane L = lane_info(HP);
+  const int lane = threadIdx.x & 63, DP = 4 * HP;
+  float4 dM = zero4();
+  float r = 0.f;
+  bool first = true;
+  for (int c0 = b * 64; c0 < Ep; c0 += 64) {
+    const int pc = min(c0 + lane, Ep - 1);
+    const int tv = tgt_s[pc], cv = cls_s[pc];
+    WalkChunk w;
+    if (!walk_open(src_s, Ep, c0, first, w)) return;
+    first = false;
+    const int oc = max(w.ov, 0);
+    const int dv = rowptr_s[oc + 1] - rowptr_s[oc];
+    for (int i = w.i_lo; i < w.i_hi; i += SRC1W_UNROLL) {
+      float4 g4[SRC1W_UNROLL], em[SRC1W_UNROLL], mr[SRC1W_UNROLL];
+      float al[SRC1W_UNROLL], av[SRC1W_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SRC1W_UNROLL; ++u) {
+        const int idx = min(i + u, w.i_hi - 1);
+        const int t = __builtin_amdgcn_readlane(tv, idx), c = __builtin_amdgcn_readlane(cv, idx);
+        const int s = __builtin_amdgcn_readlane(w.ov, idx);
+        g4[u] = L.act ? ld4(G + (int64_t)t * ldg + L.off) : zero4();
+        em[u] = L.act ? ld4(EkEm + (int64_t)c * lde + DP + L.off) : zero4();
+        mr[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + DP + L.off) : zero4();
+        const bool ok = i + u < w.i_hi;
+        al[u] = ok ? alpha[(int64_t)(c0 + idx) * 4 + L.g] : 0.f;
+        av[u] = ok ? a[(int64_t)(c0 + idx) * 4 + L.g] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SRC1W_UNROLL; ++u) {  // clamped duplicates enter with weight 0 (see k_edge_aggregate_w)
+        const int idx = min(i + u, w.i_hi - 1);
+        const float deg = (float)__builtin_amdgcn_readlane(dv, idx);
+        const float gae = deg * row16_sum(dot4(add4(mr[u], em[u]), g4[u]));  // all 64 lanes take part (DPP)
+        dM = fma4(al[u], g4[u], dM);
+        r = fmaf(av[u], gae, r);
+        if (i + u < w.i_hi) {
+          if (L.j == 0) ga[(int64_t)(c0 + i + u) * 4 + L.g] = gae;
+          if (bit_at(w.lastm, i + u)) {
+            const int s = __builtin_amdgcn_readlane(w.ov, i + u);
+            if (L.act) st4(dKMQ + (int64_t)s * ldk + DP + L.off, dM);
+            if (L.j == 0) rs[(int64_t)s * 4 + L.g] = r;
+            dM = zero4();
+            r = 0.f;
+          }
+        }
+      }
+    }
+    if (bit_at(w.lastm, w.i_hi - 1)) return;
+  }
+}
+
+// backward, source pass 2 (see k_edge_bwd_src2), bucket walk over the source order
+__global__ __launch_bounds__(256) void k_edge_bwd_src2_w(const int* __restrict__ src_s, const int* __restrict__ tgt_s,
+                                                         const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
+                                                         const float* __restrict__ EkEm, int lde, int HP, float qscale,
+                                                         const float* __restrict__ a, float* __restrict__ dKMQ,
+                                                         float* __restrict__ ga, const float* __restrict__ rs, int Ep) {
+  const int b = wave_bucket();
+  if (b * 64 >= Ep) return;
+  const Lane L = lane_info(HP);
+  const int lane = threadIdx.x & 63, DP = 4 * HP;
+  float4 dQ = zero4();
+  bool first = true;
+  for (int c0 = b * 64; c0 < Ep; c0 += 64) {
+    const int pc = min(c0 + lane, Ep - 1);
+    const int tv = tgt_s[pc], cv = cls_s[pc];
+    WalkChunk w;
+    if (!walk_open(src_s, Ep, c0, first, w)) return;
+    first = false;
+    for (int i = w.i_lo; i < w.i_hi; i += EDGE_UNROLL) {
+      float4 k[EDGE_UNROLL], ek[EDGE_UNROLL];
+      float gs[EDGE_UNROLL];
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const int idx = min(i + u, w.i_hi - 1);
+        const int t = __builtin_amdgcn_readlane(tv, idx), c = __builtin_amdgcn_readlane(cv, idx);
+        const int s = __builtin_amdgcn_readlane(w.ov, idx);
+        k[u] = L.act ? ld4(KMQ + (int64_t)t * ldk + L.off) : zero4();
+        ek[u] = L.act ? ld4(EkEm + (int64_t)c * lde + L.off) : zero4();
+        const int64_t o = (int64_t)(c0 + idx) * 4 + L.g;
+        gs[u] = i + u < w.i_hi ? qscale * a[o] * (ga[o] - rs[(int64_t)s * 4 + L.g]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {  // clamped duplicates enter with weight 0 (see k_edge_aggregate_w)
+        dQ = fma4(gs[u], add4(k[u], ek[u]), dQ);
+        if (i + u < w.i_hi) {
+          if (L.j == 0) ga[(int64_t)(c0 + i + u) * 4 + L.g] = gs[u];  // every lane of the group already read it
+          if (bit_at(w.lastm, i + u)) {
+            const int s = __builtin_amdgcn_readlane(w.ov, i + u);
+            if (L.act) st4(dKMQ + (int64_t)s * ldk + 2 * DP + L.off, dQ);
+            dQ = zero4();
+          }
+        }
+      }
+    }
+    if (bit_at(w.lastm, w.i_hi - 1)) return;
+  }
+}
+
+// backward, target pass (see k_edge_bwd_tgt), bucket walk over the target order
+__global__ __launch_bounds__(256) void k_edge_bwd_tgt_w(const int* __restrict__ tgt_t, const int* __restrict__ src_t,
+                                                        const int* __restrict__ pos_t, const float* __restrict__ KMQ, int ldk,
+                                                        int HP, const float* __restrict__ gsb, float* __restrict__ dKMQ, int Ep) {
+  const int b = wave_bucket();
+  if (b * 64 >= Ep) return;
+  const Lane L = lane_info(HP);
+  const int lane = threadIdx.x & 63, DP = 4 * HP;
+  float4 dK = zero4();
+  bool first = true;
+  for (int c0 = b * 64; c0 < Ep; c0 += 64) {
+    const int pc = min(c0 + lane, Ep - 1);
+    const int sv = src_t[pc], pv = pos_t[pc];
+    WalkChunk w;
+    if (!walk_open(tgt_t, Ep, c0, first, w)) return;
+    first = false;
+    for (int i = w.i_lo; i < w.i_hi; i += EDGE_UNROLL) {
+      float4 qv[EDGE_UNROLL];
+      float gs[EDGE_UNROLL];
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const int idx = min(i + u, w.i_hi - 1);
+        const int s = __builtin_amdgcn_readlane(sv, idx), p = __builtin_amdgcn_readlane(pv, idx);
+        qv[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + 2 * DP + L.off) : zero4();
+        gs[u] = i + u < w.i_hi ? gsb[(int64_t)p * 4 + L.g] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < EDGE_UNROLL; ++u) {  // clamped duplicates enter with weight 0 (see k_edge_aggregate_w)
+        dK = fma4(gs[u], qv[u], dK);
+        if (i + u < w.i_hi && bit_at(w.lastm, i + u)) {
+          const int t = __builtin_amdgcn_readlane(w.ov, i + u);
+          if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
+          dK = zero4();
+        }
+      }
+    }
+    if (bit_at(w.lastm, w.i_hi - 1)) return;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // forward, LDS-resident: one workgroup per (subgraph, head).  A QA subgraph is n consecutive node rows and its edges never
 // leave it (LM_QAGNN.batch_graph), so the head's K, M and Q rows of the subgraph -- 3 x n x HP floats, 125 KB at n = 200,
 // d = 200 -- fit the 160 KB LDS of a CU.  All per-edge gathers then hit LDS; HBM sees each K|M|Q row once.
@@ -419,6 +698,12 @@ __global__ __launch_bounds__(512) void k_edge_fwd_blocked(const int* __restrict_
   }
 }
 
+// QAGNN_EDGE_WALK=0 falls back to the node-per-wave kernels (A/B switch)
+static bool edge_walk_enabled() {
+  static const int v = getenv("QAGNN_EDGE_WALK") ? atoi(getenv("QAGNN_EDGE_WALK")) : 1;
+  return v != 0;
+}
+
 static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const float* EkEm, int lde, int HP, const char* who) {
   QAGNN_REQUIRE(g && KMQ && EkEm, QAGNN_EINVAL, "%s: null pointer", who);
   QAGNN_REQUIRE(HP > 0 && HP % 4 == 0 && HP <= 64, QAGNN_EUNSUPPORTED, "%s: head pitch HP=%d must be a multiple of 4, <= 64", who, HP);
@@ -440,6 +725,16 @@ static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
                 "edge_attn_fwd: bad output arguments");
   const int nb = cdiv(g->N, 4);
+  if (edge_walk_enabled()) {
+    const int nbw = cdiv(cdiv(g->Ep, 64), 4);  // one wave per 64 positions of the source / target order
+    k_edge_scores_e<<<nbw, 256, 0, stream>>>(g->src_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, g->Ep, gate);
+    QAGNN_LAUNCH_CHECK("k_edge_scores_e");
+    k_edge_softmax<<<nb, 256, 0, stream>>>(g->rowptr_s, score, a, alpha, g->N, gate);
+    QAGNN_LAUNCH_CHECK("k_edge_softmax");
+    k_edge_aggregate_w<<<nbw, 256, 0, stream>>>(g->tgt_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->Ep, gate);
+    QAGNN_LAUNCH_CHECK("k_edge_aggregate_w");
+    return QAGNN_OK;
+  }
   k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, g->N, gate);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
   k_edge_softmax<<<nb, 256, 0, stream>>>(g->rowptr_s, score, a, alpha, g->N, gate);
@@ -493,12 +788,22 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
   const int DP2 = 8 * HP;
   QAGNN_REQUIRE(DP2 / 4 <= 1024, QAGNN_EUNSUPPORTED, "edge_attn_bwd: HP too large");
   const int nb = cdiv(g->N, 4);
-  k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N);
-  QAGNN_LAUNCH_CHECK("k_edge_bwd_src1");
-  k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N);
-  QAGNN_LAUNCH_CHECK("k_edge_bwd_src2");
-  k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N);
-  QAGNN_LAUNCH_CHECK("k_edge_bwd_tgt");
+  if (edge_walk_enabled()) {
+    const int nbw = cdiv(cdiv(g->Ep, 64), 4);
+    k_edge_bwd_src1_w<<<nbw, 256, 0, stream>>>(g->rowptr_s, g->src_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->Ep);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_src1_w");
+    k_edge_bwd_src2_w<<<nbw, 256, 0, stream>>>(g->src_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->Ep);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_src2_w");
+    k_edge_bwd_tgt_w<<<nbw, 256, 0, stream>>>(g->tgt_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->Ep);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_tgt_w");
+  } else {
+    k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_src1");
+    k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_src2");
+    k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N);
+    QAGNN_LAUNCH_CHECK("k_edge_bwd_tgt");
+  }
   k_edge_bwd_cls<<<cdiv(g->max_chunks, 4), 256, 0, stream>>>(g->n_chunks, g->chunk_beg, g->chunk_len, g->src_c, g->tgt_c, g->pos_c,
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_cls");

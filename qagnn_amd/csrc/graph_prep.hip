@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_sort_segments(const int* __restrict__ r
 __global__ void k_payload(const int* __restrict__ es, const int* __restrict__ et, const int* __restrict__ ec,
                           const int* __restrict__ eid_s, const int* __restrict__ eid_t, const int* __restrict__ srcpos,
                           int* __restrict__ tgt_s, int* __restrict__ src_s, int* __restrict__ cls_s, int* __restrict__ src_t,
-                          int* __restrict__ cls_t, int* __restrict__ pos_t, int Ep) {
+                          int* __restrict__ tgt_t, int* __restrict__ cls_t, int* __restrict__ pos_t, int Ep) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= Ep) return;
   const int e = eid_s[p];
@@ -149,6 +149,7 @@ __global__ void k_payload(const int* __restrict__ es, const int* __restrict__ et
   cls_s[p] = ec[e];
   const int e2 = eid_t[p];
   src_t[p] = es[e2];
+  tgt_t[p] = et[e2];
   cls_t[p] = ec[e2];
   pos_t[p] = srcpos[e2];
 }
@@ -238,7 +239,7 @@ static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 using namespace qagnn;
 
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 1; }
+extern "C" int qagnn_abi_version(void) { return 2; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;
@@ -246,7 +247,7 @@ extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, in
   const int64_t nblk = (Ep + CLS_BLK - 1) / CLS_BLK;
   int64_t tot = 0;
   tot += 2 * up4(N + 1);      // rowptr_s, rowptr_t
-  tot += 11 * up4(Ep);        // tgt_s src_s cls_s eid_s src_t cls_t pos_t src_c tgt_c pos_c + eid_t
+  tot += 12 * up4(Ep);        // tgt_s src_s cls_s eid_s src_t tgt_t cls_t pos_t src_c tgt_c pos_c + eid_t
   tot += 3 * up4(C + 1);      // clsptr, chunkptr, nch scratch
   tot += up4(C);              // cls_count
   tot += 3 * up4(maxch);      // chunk tables
@@ -282,7 +283,7 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch; g->block_n = block_n;
   g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
   g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
-  g->src_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
+  g->src_t = take(Ep); g->tgt_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
   g->src_c = take(Ep); g->tgt_c = take(Ep); g->pos_c = take(Ep);
   int32_t* eid_t = take(Ep);
   g->clsptr = take(C + 1); g->chunkptr = take(C + 1);
@@ -309,7 +310,7 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   k_sort_segments<<<cdiv(2 * (int64_t)N, 4), 256, 0, stream>>>(g->rowptr_s, g->rowptr_t, tmp_s, tmp_t, g->eid_s, eid_t, srcpos, N);
   QAGNN_LAUNCH_CHECK("k_sort_segments");
   k_payload<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, ec, g->eid_s, eid_t, srcpos, g->tgt_s, g->src_s, g->cls_s, g->src_t,
-                                              g->cls_t, g->pos_t, Ep);
+                                              g->tgt_t, g->cls_t, g->pos_t, Ep);
   QAGNN_LAUNCH_CHECK("k_payload");
   k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_hist");

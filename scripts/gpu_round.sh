@@ -6,6 +6,14 @@ rm -rf gpurun_out; mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( rocm-smi --showproductname 2>/dev/null | head -8; nproc; free -g | head -2 ) > gpurun_out/gpu.txt
 ( time python __graft_entry__.py ) > gpurun_out/build.log 2>&1
+if [[ "$*" == *alltests* ]]; then   # what the driver runs at round end
+  timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -rf --timeout 300 -p no:cacheprovider --durations=8 2>&1 | tail -n 60 > gpurun_out/test_all.log
+  echo "alltests exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+fi
+if [[ "$*" == *edgeold* ]]; then    # the node-per-wave edge kernels stay tested behind their A/B switch
+  QAGNN_EDGE_WALK=0 timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "edge" 2>&1 | tail -n 30 > gpurun_out/test_edge_old.log
+  echo "edgeold exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+fi
 if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
   echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
@@ -57,6 +65,15 @@ if [[ "$*" == *mfma* ]]; then
   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
 fi
 for arg in "$@"; do
+  if [[ "$arg" == ab1:* ]]; then   # one interleaved pair (GPU minutes are short)
+    var="${arg#ab1:}"
+    for v in 0 1 0 1; do
+      echo "$var=$v" >> gpurun_out/ab_$var.txt
+      env $var=$v timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline 2>&1 | tail -n 1 > /tmp/ab_line.txt
+      cut -c1-140 /tmp/ab_line.txt >> gpurun_out/ab_$var.txt
+      grep -o '"breakdown_ms_per_step.*' /tmp/ab_line.txt | cut -c1-160 >> gpurun_out/ab_$var.txt
+    done
+  fi
   if [[ "$arg" == ab:* ]]; then
     var="${arg#ab:}"
     for rep in 1 2; do for v in 0 1; do

@@ -35,6 +35,7 @@ class EmuGraph:
         srcpos = torch.empty_like(eid_s)
         srcpos[eid_s] = torch.arange(self.Ep, device=dev)
         self.src_t, self.cls_t, self.pos_t = es[eid_t].int(), ec[eid_t].int(), srcpos[eid_t].int()
+        self.tgt_t = et[eid_t].int()
         pos_c = torch.sort(self.cls_s.long(), stable=True).indices
         self.pos_c = pos_c.int()
         self.src_c, self.tgt_c = self.src_s[pos_c], self.tgt_s[pos_c]
@@ -52,6 +53,36 @@ class EmuGraph:
         self.chunk_cls = torch.tensor(cc, dtype=torch.int32)
         self.chunk_beg = torch.tensor(cb, dtype=torch.int32)
         self.chunk_len = torch.tensor(cl, dtype=torch.int32)
+
+
+def bucket_walk(own, b):
+    """Python twin of the control flow of walk_open() + the chunk loop of the bucket-walk kernels in csrc/edge_attn.hip:
+    the positions wave `b` processes, as a list of (position, flush) pairs (flush = the segment's accumulator is stored
+    and reset after this position).  own[p] = segment owner of position p of a CSR order."""
+    Ep = len(own)
+    out = []
+    first = True
+    c0 = b * 64
+    while c0 < Ep:
+        lanes = range(c0, min(c0 + 64, Ep))
+        head = [p for p in lanes if p == 0 or own[p] != own[p - 1]]
+        last = {p for p in lanes if p + 1 >= Ep or own[p] != own[p + 1]}
+        i_lo, i_hi = c0, min(c0 + 64, Ep)
+        if first:
+            if not head:
+                return out
+            i_lo = head[0]
+        elif head:
+            i_hi = head[0]
+        if i_lo >= i_hi:
+            return out
+        first = False
+        for p in range(i_lo, i_hi):
+            out.append((p, p in last))
+        if (i_hi - 1) in last:
+            return out
+        c0 += 64
+    return out
 
 
 def _uniform01(seed, idx):

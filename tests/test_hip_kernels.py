@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in qagnn_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == declared
     _lib.load_library()  # prototypes resolve
-    assert lib.qagnn_abi_version() == 1
+    assert lib.qagnn_abi_version() == _lib.ABI_VERSION
 
 
 def hip():
@@ -66,7 +66,7 @@ def golden_graph(case):
 
 
 GRAPH_ARRAYS = [('rowptr_s', 'N+1'), ('tgt_s', 'Ep'), ('src_s', 'Ep'), ('cls_s', 'Ep'), ('eid_s', 'Ep'), ('rowptr_t', 'N+1'),
-                ('src_t', 'Ep'), ('cls_t', 'Ep'), ('pos_t', 'Ep'), ('clsptr', 'C+1'), ('cls_count', 'C'), ('src_c', 'Ep'),
+                ('src_t', 'Ep'), ('tgt_t', 'Ep'), ('cls_t', 'Ep'), ('pos_t', 'Ep'), ('clsptr', 'C+1'), ('cls_count', 'C'), ('src_c', 'Ep'),
                 ('tgt_c', 'Ep'), ('pos_c', 'Ep'), ('chunkptr', 'C+1')]
 
 
