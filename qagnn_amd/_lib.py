@@ -215,18 +215,21 @@ class HipKernels:
         return (out, bsum) if colsum_groups else out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------
-    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0, roww=None):
+    def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0, roww=None, out=None):
         _chk2d(X, 'X')
         R, Cc = X.shape
-        out = torch.empty((nout, Cc), dtype=torch.float32, device=X.device)
+        if out is None:
+            out = torch.empty((nout, Cc), dtype=torch.float32, device=X.device)
+        else:
+            assert out.shape == (nout, Cc) and out.is_contiguous() and out.dtype == torch.float32
         ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, groups), dtype=torch.float32, device=X.device)
         rc = self.lib.qagnn_colreduce_f32(mode, X.data_ptr(), Cc, _ptr(X2), Cc, R, Cc, _ptr(rowidx), groups, _ptr(mean),
                                           _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(roww), float(out_scale), out.data_ptr(), ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_colreduce_f32')
         return out
 
-    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None):
-        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups, scale, roww)
+    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None, out=None):
+        return self._colreduce(0, X, None, rowidx, groups, None, None, None, None, groups, scale, roww, out=out)
 
     def colvar_sum(self, X, mean, scale=1.0, roww=None):
         return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1, scale, roww)[0]

@@ -324,12 +324,18 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// "Bucket walk" variants of the segment kernels (QAGNN_EDGE_WALK, default on).
+// "Bucket walk" variants of the segment kernels (QAGNN_EDGE_WALK=1; default OFF, measured slower -- see below).
 //
 // The node-per-wave kernels above pay a dependent chain rowptr -> segment indices -> rows for every node, and a QA
-// subgraph's segments are short: 7 edges on average, ONE (the self loop) for the ~40 % PAD rows.  At 64 000 waves of
-// ~2 four-edge batches each the kernels are bound by that start-up chain and by the imbalance between PAD rows and hubs,
-// not by the gather itself.  Here a wave owns a BUCKET of 64 consecutive positions of a CSR order instead: it processes
+// subgraph's segments are short: 7 edges on average, ONE (the self loop) for the ~40 % PAD rows.  The hypothesis was that
+// at 64 000 waves of ~2 four-edge batches each the kernels are bound by that start-up chain and by the imbalance between
+// PAD rows and hubs.  MEASURED (profiles/r1_run56_edge_walk_ab.txt, r1_run56_by_shape_edge_walk.txt): they are not -- the
+// time of every edge kernel is proportional to the number of 832-byte row gathers it issues (~33 us per gather per edge
+// at E' = 460 800, i.e. ~11 TB/s out of L1/L2), whatever the wave shape: aggregate 66.6 us vs 65, target pass 55 vs 48,
+// source pass 2 92.7 vs 102 (the one win), and the two kernels that trade a register-held row for a per-edge gather pay
+// for it exactly (source pass 1: 3 gathers instead of 2, 160 us vs 107).  Step: 24 290 vs 25 075 QA-subgraphs/s.
+// Kept behind the switch (parity-tested both ways) as the balanced baseline for a gather-count-reducing design.
+// Here a wave owns a BUCKET of 64 consecutive positions of a CSR order instead: it processes
 // the segments that START inside its bucket (running over the bucket end to finish the last one), so every wave has
 // 64..127 edges of work, the index arrays are read with one coalesced load per 64 edges and there is no rowptr lookup
 // at all -- segment boundaries come from the per-position owner array (src_s / tgt_t) with one ballot.  A segment is
@@ -698,9 +704,9 @@ __global__ __launch_bounds__(512) void k_edge_fwd_blocked(const int* __restrict_
   }
 }
 
-// QAGNN_EDGE_WALK=0 falls back to the node-per-wave kernels (A/B switch)
+// QAGNN_EDGE_WALK=1 selects the bucket-walk kernels (A/B switch; measured 3 % slower on the step, default off)
 static bool edge_walk_enabled() {
-  static const int v = getenv("QAGNN_EDGE_WALK") ? atoi(getenv("QAGNN_EDGE_WALK")) : 1;
+  static const int v = getenv("QAGNN_EDGE_WALK") ? atoi(getenv("QAGNN_EDGE_WALK")) : 0;
   return v != 0;
 }
 

@@ -383,18 +383,21 @@ class QAGNN_Message_Passing(nn.Module):
             graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype, block_n=n)
         per_layer, extras = self.pack_all(L)
         Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes, We_t_all, We_all, be_all, Wtype_all, bias_all = extras[:14]
-        temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
-        # shared edge encoder on the C distinct classes, then every layer's Ek|Em and node-type tables with one GEMM each
-        Xp = Hp
-        if self.k > 0:
-            tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
-            ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
-            TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
-        for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
-            Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
-                              packed=pk, tables=(TT[l], ekem[l]))
-        Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
+        # Every weight operand below comes straight out of pack_all (GatherPlan), whose backward is the only reader of its
+        # gradient: the operators may queue their weight-gradient GEMMs and run them under the edge backward kernels.
+        with ops.wgrad_scope():
+            temb, S = self.node_feature_extra(ntype, node_score.reshape(-1), Wes_t, Wes, bes)
+            # shared edge encoder on the C distinct classes, then every layer's Ek|Em and node-type tables with one GEMM each
+            Xp = Hp
+            if self.k > 0:
+                tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
+                ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
+                TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
+            for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
+                Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
+                                  packed=pk, tables=(TT[l], ekem[l]))
+            Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
         if padded_output:
             return out.view(bs, n, L.DP)

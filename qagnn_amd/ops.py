@@ -85,6 +85,7 @@ class _PlanGatherFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, *grads):
         plan = ctx.plan
+        join_wgrads(next((g for g in grads if g is not None), None))  # the packed operands' gradients may still be in flight
         parts = []
         z = plan.zeros  # cached zeros: operands that received no gradient (the non-transposed weight copies) cost no fill kernel
         for g, (a, n, shape), n4 in zip(grads, plan.slices, plan.padded):
@@ -209,6 +210,106 @@ class _WgradStream:
             self.main.wait_stream(self.side)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Weight-gradient GEMMs under the edge backward (QAGNN_WGRAD_OVERLAP).
+#
+# The edge backward kernels are bound by the row-gather rate of the texture path (time = gathers x ~33 us at E' = 460 800,
+# profiles/r1_run56_*): they leave the matrix cores idle.  The weight-gradient GEMMs are MFMA-bound, independent of the
+# data-gradient chain, and per layer they take about as long as the edge backward (~430 us vs ~417 us).  So inside the
+# stack they are not launched where autograd reaches them: they are QUEUED, and the whole queue is issued on a second HIP
+# stream right before the next edge backward starts on the main stream.  Unlike QAGNN_SIDE_STREAM (fork/join inside one
+# operator: a GEMM could only ever overlap another GEMM, measured -4 %), the join is deferred to the one consumer of these
+# gradients, GatherPlan's backward (plus an end-of-backward engine callback as a safety net).  Rules that make this safe:
+#   * only operators created inside `wgrad_scope()` defer, and the stack guarantees that every weight operand there comes
+#     straight out of GatherPlan, so nothing on the main stream reads a deferred gradient before the join;
+#   * gradients consumed inside the graph (the node-type-table gradient) are never deferred;
+#   * outputs are allocated on the main stream up front; every input of a queued launch is kept alive until the join, so
+#     the caching allocator cannot hand its memory to a main-stream kernel while the side stream still reads it.
+WGRAD_OVERLAP = _os.environ.get('QAGNN_WGRAD_OVERLAP', '1') == '1'
+_DEFER = [False]
+
+
+class wgrad_scope:
+    """Operators built inside this scope may defer their weight-gradient launches (see above)."""
+
+    def __enter__(self):
+        self.prev = _DEFER[0]
+        _DEFER[0] = WGRAD_OVERLAP and not SIDE_STREAM_WGRAD and not FUSED_COLSUM
+        return self
+
+    def __exit__(self, *exc):
+        _DEFER[0] = self.prev
+        return False
+
+
+# QAGNN_WGRAD_POISON=1 (tests): deferred outputs start as NaN, so a reader that runs before the queued launch shows up
+WGRAD_POISON = _os.environ.get('QAGNN_WGRAD_POISON', '0') == '1'
+
+
+def _wg_empty(ref, shape):
+    t = ref.new_empty(shape)
+    return t.fill_(float('nan')) if WGRAD_POISON else t
+
+
+class _WgradQueue:
+    n_deferred = 0      # launches queued so far (tests)
+    pending = []        # closures that launch weight-gradient kernels into pre-allocated outputs
+    keep = []           # tensors those launches read: alive until the join
+    unjoined = None     # (main stream, side stream) with queued work that the main stream has not waited for
+    callback_queued = False
+
+
+def _end_of_backward():
+    _WgradQueue.callback_queued = False
+    join_wgrads()
+
+
+def defer_wgrads(jobs, keep):
+    """Queue weight-gradient launches (called from inside a backward)."""
+    q = _WgradQueue
+    q.n_deferred += len(jobs)
+    q.pending.extend(jobs)
+    q.keep.extend(t for t in keep if t is not None)
+    if not q.callback_queued:  # whatever happens, the queue is issued and joined before backward() returns
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        q.callback_queued = True
+
+
+def flush_wgrads(ref=None):
+    """Issue everything queued on the side stream, forked from the current (main) stream; returns at once."""
+    q = _WgradQueue
+    if not q.pending:
+        return
+    jobs, q.pending = q.pending, []
+    ref = ref if ref is not None else (q.keep[0] if q.keep else None)
+    if ref is not None and not ref.is_cuda:  # host-logic tests (torch emulation of the kernels): no streams, same order
+        for job in jobs:
+            job()
+        return
+    main = torch.cuda.current_stream()
+    if q.unjoined is not None and q.unjoined[0] != main:
+        q.unjoined[0].wait_stream(q.unjoined[1])
+    key = main.device_index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
+    side = _SIDE_STREAMS[key]
+    side.wait_stream(main)  # the queued launches read tensors the main stream produced
+    with torch.cuda.stream(side):
+        for job in jobs:
+            job()
+    q.unjoined = (main, side)
+
+
+def join_wgrads(ref=None):
+    """Issue what is still queued, then make the main stream wait for the side stream; releases the kept inputs."""
+    q = _WgradQueue
+    flush_wgrads(ref)
+    if q.unjoined is not None:
+        q.unjoined[0].wait_stream(q.unjoined[1])
+        q.unjoined = None
+    q.keep.clear()
+
+
 class LinearNNFn(torch.autograd.Function):
     """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
 
@@ -219,6 +320,7 @@ class LinearNNFn(torch.autograd.Function):
         C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx)
         ctx.save_for_backward(A1, B1, A2, B2, rowidx)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
+        ctx.defer = _DEFER[0]
         return C
 
     @staticmethod
@@ -230,9 +332,35 @@ class LinearNNFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         has_bias, has_tab, G = ctx.has
         dbias = drowtab = None
+        want_tab, want_bias = has_tab and need[7], has_bias and need[6]
+        if ctx.defer:  # weight gradients queued for the next edge backward (see defer_wgrads)
+            jobs, dB1t, dB2t = [], None, None
+            if need[1]:
+                dB1t = _wg_empty(dC, (A1.size(1), dC.size(1)))
+                jobs.append(lambda: K.gemm_tn(A1, dC, out=dB1t))
+            if A2 is not None and need[4]:
+                dB2t = _wg_empty(dC, (A2.size(1), dC.size(1)))
+                jobs.append(lambda: K.gemm_tn(A2, dC, out=dB2t))
+            if want_tab:  # consumed inside the graph (table GEMM backward): stays on the main stream
+                drowtab = K.colsum(dC, rowidx, G)
+                if want_bias:
+                    dbias = drowtab.sum(0)
+            elif want_bias:
+                cs = _wg_empty(dC, (1, dC.size(1)))
+                jobs.append(lambda: K.colsum(dC, out=cs))
+                dbias = cs[0]
+            defer_wgrads(jobs, (A1, A2, dC))
+            dA1 = dA2 = None
+            if need[0]:
+                if A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
+                    dA1 = K.gemm_tn(dC.t().contiguous(), B1)  # few rows, long reduction: see below
+                else:
+                    dA1 = K.gemm_nn(dC, B1)
+            if A2 is not None and need[3]:
+                dA2 = K.gemm_nn(dC, B2)
+            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
         wg = _WgradStream(dC)
         with wg:  # parameter gradients (optionally on a side stream)
-            want_tab, want_bias = has_tab and need[7], has_bias and need[6]
             cs = None
             if FUSED_COLSUM and need[1] and (want_tab or want_bias):
                 # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
@@ -334,6 +462,7 @@ class EdgeAttnFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, G, _da):
         KMQ, EkEm, a, alpha = ctx.saved_tensors
+        flush_wgrads(G)  # queued weight-gradient GEMMs go out on the side stream now: they run under the gather-bound kernels
         dKMQ, dEkEm = kernels().edge_attn_bwd(ctx.graph, KMQ, EkEm, ctx.HP, ctx.qscale, a, alpha, G.contiguous())
         return dKMQ, dEkEm, None, None, None
 
@@ -371,6 +500,7 @@ class GatMlpFn(torch.autograd.Function):
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
         ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight)
         ctx.cfg = (training, p, seed, R, apply_act)
+        ctx.defer = _DEFER[0]
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
@@ -381,6 +511,20 @@ class GatMlpFn(torch.autograd.Function):
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
+        if ctx.defer:  # weight / bias gradients of both Linears queued for the next edge backward (see defer_wgrads)
+            Cc = dout.size(1)
+            dW2t, db2 = _wg_empty(dout, (h1.size(1), Cc)), _wg_empty(dout, (1, Cc))
+            dr = K.gemm_nn(dout, W2)
+            red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
+            dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
+                                roww=row_weight if training else None)
+            dW1t, db1 = _wg_empty(dout, (aggr.size(1), h1.size(1))), _wg_empty(dout, (1, h1.size(1)))
+            defer_wgrads([lambda: K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, out=dW2t), lambda: K.colsum(dout, out=db2),
+                          lambda: K.gemm_tn(aggr, dh1, out=dW1t), lambda: K.colsum(dh1, out=db1)],
+                         (h1, dout, scale, shift, aggr, dh1))
+            daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
+            return (daggr, dW1t, None, db1[0], red[1], red[0], dW2t, None, db2[0], None, None, None, None, None, None, None, None,
+                    None)
         wg = _WgradStream(dout)
         with wg:  # side stream: gradients of the second Linear
             if FUSED_COLSUM:

@@ -10,9 +10,13 @@ if [[ "$*" == *alltests* ]]; then   # what the driver runs at round end
   timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -rf --timeout 300 -p no:cacheprovider --durations=8 2>&1 | tail -n 60 > gpurun_out/test_all.log
   echo "alltests exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
-if [[ "$*" == *edgeold* ]]; then    # the node-per-wave edge kernels stay tested behind their A/B switch
-  QAGNN_EDGE_WALK=0 timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "edge" 2>&1 | tail -n 30 > gpurun_out/test_edge_old.log
-  echo "edgeold exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+if [[ "$*" == *poison* ]]; then   # deferred weight gradients start as NaN: any reader that runs before the join fails parity
+  QAGNN_WGRAD_POISON=1 timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q --tb=short -rf --timeout 300 -p no:cacheprovider 2>&1 | tail -n 30 > gpurun_out/test_poison.log
+  echo "poison exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
+fi
+if [[ "$*" == *edgewalk* ]]; then    # the bucket-walk edge kernels stay tested behind their A/B switch
+  QAGNN_EDGE_WALK=1 timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "edge" 2>&1 | tail -n 30 > gpurun_out/test_edge_walk.log
+  echo "edgewalk exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
 if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
@@ -36,7 +40,7 @@ if [[ "$*" == *bench* ]]; then
   echo "bench exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   timeout 300 python bench.py --steps 30 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/bench_b10.log
 fi
-if [[ "$*" == *prof* ]]; then
+if [[ " $* " == *" prof "* ]]; then
   rm -rf /tmp/prof; mkdir -p /tmp/prof
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
   echo "prof exit $?" >> gpurun_out/summary.txt

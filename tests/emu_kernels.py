@@ -153,12 +153,14 @@ class EmuKernels:
             return C, self.colsum(B, b_rowidx, colsum_groups)
         return C
 
-    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None):
+    def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None, out=None):
         if roww is not None:
             X = X * roww.unsqueeze(1)
         if rowidx is None:
-            return X.sum(0, keepdim=True) * scale
-        return torch.zeros(groups, X.size(1), dtype=X.dtype, device=X.device).index_add_(0, rowidx, X) * scale
+            res = X.sum(0, keepdim=True) * scale
+        else:
+            res = torch.zeros(groups, X.size(1), dtype=X.dtype, device=X.device).index_add_(0, rowidx, X) * scale
+        return res if out is None else out.copy_(res)
 
     def colvar_sum(self, X, mean, scale=1.0, roww=None):
         d2 = (X - mean) ** 2

@@ -229,3 +229,39 @@ def test_bucket_walk_covers_every_segment_once(seed, N, E, hub):
         assert sorted(seen) == list(range(Ep)) and len(seen) == Ep
         ends = [p for p in range(Ep) if p + 1 == Ep or own[p + 1] != own[p]]
         assert sorted(flushed_at) == ends and len(ends) == N  # every node owns a segment (its self loop)
+
+
+def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch):
+    """QAGNN_WGRAD_OVERLAP: inside the stack the weight-gradient launches are queued and issued later (on the GPU: on a side
+    stream under the edge backward).  With the queued outputs poisoned (NaN until the launch runs) the gradients must still
+    equal those of the immediate path -- i.e. nobody reads a deferred gradient before GatherPlan's backward joins."""
+    case = dict(shape='csqa', nq=2, nc=3, n=20, n_rel=17, std=0.3, train=True, seed=5,
+                cfg=helpers.model_cfg(d=32, k=3, sent_dim=24, n_concept=200, concept_in_dim=16))
+    inp = helpers.make_case_inputs(case)
+    cfg = case['cfg']
+    B, n = 6, 20
+    grads = {}
+    old = ops.set_kernels(EmuKernels())
+    try:
+        for overlap in (False, True):
+            monkeypatch.setattr(ops, 'WGRAD_OVERLAP', overlap)
+            monkeypatch.setattr(ops, 'WGRAD_POISON', overlap)
+            torch.manual_seed(0)
+            model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], cfg['concept_dim'], cfg['concept_in_dim'], 2, cfg['concept_dim'], 0,
+                             0.0, 0.0, 0.0)
+            helpers.det_fill_(model, 3, 0.3)
+            model.pooler.dropout.p = model.pooler.attention.dropout.p = 0.0
+            model.train()
+            n0 = ops._WgradQueue.n_deferred
+            logits, _ = model(inp['sent_vecs'], inp['concept_ids'].view(B, n), inp['node_type_ids'].view(B, n),
+                              inp['node_scores'].view(B, n, 1), inp['adj_lengths'].view(B), (inp['edge_index'], inp['edge_type']))
+            logits.sum().backward()
+            assert (ops._WgradQueue.n_deferred > n0) == overlap
+            assert not ops._WgradQueue.pending and not ops._WgradQueue.keep and not ops._WgradQueue.callback_queued
+            grads[overlap] = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    finally:
+        ops.set_kernels(old)
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 40
+    for k in grads[True]:
+        assert torch.isfinite(grads[True][k]).all(), k
+        assert torch.equal(grads[True][k], grads[False][k]), k
