@@ -209,6 +209,58 @@ int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk,
                             float qscale, const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ,
                             float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * One GATConvE hop of the stack, sequenced natively (csrc/hop.hip).  Replaces, per layer, the reference's
+ *   QAGNN_Message_Passing.mp_helper loop body (modeling_qagnn.py:45-50): GATConvE.forward (:411-452) -> message (:455-484)
+ *   -> mlp (:443, :408) -> GELU -> dropout, and its autograd backward,
+ * by exactly the launches above in a fixed order (results bit-identical to composing the entry points by hand):
+ *   fwd:  KMQ = [X | S][Wx ; Ws] + TT[ntype];  (a, alpha, aggr) = edge attention;  h1 = aggr W1^T + b1;  BatchNorm statistics
+ *         (batch or running) + bookkeeping;  out = relu(bn(h1)) W2^T + b2;  y = dropout(gelu(out))  (apply_act)
+ *   bwd:  the hand-derived backward of the same chain (SURVEY.md 9.2 for the attention part)
+ * All operands are in the kernels' packed layout (head-padded, weights pre-transposed; qagnn_amd/modeling_qagnn.py packs
+ * them from the reference's state-dict layout).  One struct serves both directions; the forward ignores the gradient fields.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct qagnn_hop_args {
+  const qagnn_graph* g;
+  int32_t N, DP, SP, HP, T;        /* node rows, padded row width (4*HP), width of S (multiple of 16, may be 0), head pitch, node types */
+  float qscale;                    /* 1/sqrt(dim_per_head) */
+  const float* X;                  /* [N, DP]   node features entering the hop */
+  const float* S;                  /* [N, SP]   layer-invariant score half of node_feature_extra (:86) */
+  const int64_t* ntype;            /* [N] */
+  const float* Wx_t; const float* Wx;   /* [DP, 3DP], [3DP, DP]  K|M|Q projection of X */
+  const float* Ws_t; const float* Ws;   /* [SP, 3DP], [3DP, SP]  ... of S */
+  const float* TT;                 /* [T, 3DP]  node-type half of the projection + query bias */
+  const float* EkEm;               /* [C, 2DP]  per-class tables Ek | Em */
+  const float* W1t; const float* W1; const float* b1;      /* mlp[0]: [DP, DP] x2, [DP] */
+  const float* gamma; const float* beta;                   /* mlp[1] affine, head-padded */
+  const float* W2t; const float* W2; const float* b2;      /* mlp[3] */
+  int32_t batch_stats;             /* 1: BatchNorm uses batch statistics (train mode) */
+  float eps;
+  const float* run_mean_p; const float* run_var_p;  /* [DP] head-padded running statistics (read when batch_stats == 0) */
+  float* run_mean; float* run_var; int64_t* num_batches_tracked;  /* the module's dense buffers, updated in train mode; or NULL */
+  const int64_t* dense_pos; int32_t d; float momentum;            /* see qagnn_bn_finalize_f32 */
+  int32_t apply_act; float p_drop; uint64_t seed;                 /* y = dropout(gelu(out), p_drop, seed); 0: the hop returns `out` */
+  /* forward results, kept by the caller for the backward */
+  float* KMQ;                      /* [N, 3DP] */
+  float* a; float* alpha;          /* [Ep, 4] each, source order */
+  float* aggr; float* h1; float* out; float* y;   /* [N, DP]; y unused when apply_act == 0 */
+  float* stats;                    /* [5, DP]: mean, var, invstd, scale, shift */
+  /* backward only */
+  const float* dy;                 /* [N, DP] */
+  float* dX;                       /* [N, DP] or NULL */
+  float* dS; int32_t accumulate_dS;/* [N, SP] or NULL; 1: dS += */
+  float* dWx_t; float* dWs_t;      /* [DP, 3DP], [SP, 3DP] */
+  float* dTT; float* dEkEm;        /* [T, 3DP], [C, 2DP] */
+  float* dW1t; float* db1;         /* [DP, DP], [DP] */
+  float* dbn;                      /* [2, DP]: d beta, d gamma */
+  float* dW2t; float* db2;         /* [DP, DP], [DP] */
+  float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
+} qagnn_hop_args;
+int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);
+int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t max_chunks);
+int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
+int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,8 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
-           'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32']
+           'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
+           'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 ABI_VERSION = 2  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t)
 
@@ -39,6 +40,20 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
                 ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32)]
+
+
+class qagnn_hop_args(C.Structure):
+    """Mirror of qagnn_hop_args in include/qagnn_hip.h (field order is the ABI)."""
+    _fields_ = ([('g', C.POINTER(qagnn_graph))] + [(n, _i32) for n in ('N', 'DP', 'SP', 'HP', 'T')] + [('qscale', _f32)] +
+                [(n, _vp) for n in ('X', 'S', 'ntype', 'Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta',
+                                    'W2t', 'W2', 'b2')] +
+                [('batch_stats', _i32), ('eps', _f32), ('run_mean_p', _vp), ('run_var_p', _vp), ('run_mean', _vp), ('run_var', _vp),
+                 ('num_batches_tracked', _vp), ('dense_pos', _vp), ('d', _i32), ('momentum', _f32),
+                 ('apply_act', _i32), ('p_drop', _f32), ('seed', _u64)] +
+                [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
+                [('accumulate_dS', _i32)] +
+                [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
+                [('ws_elems', _i64)])
 
 
 def load_library(path=LIB_PATH):
@@ -72,6 +87,12 @@ def load_library(path=LIB_PATH):
     lib.qagnn_edge_attn_fwd_blocked_f32.argtypes = lib.qagnn_edge_attn_fwd_f32.argtypes
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_hop_fwd_workspace_elems.restype = _i64
+    lib.qagnn_hop_fwd_workspace_elems.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_hop_bwd_workspace_elems.restype = _i64
+    lib.qagnn_hop_bwd_workspace_elems.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.qagnn_hop_fwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _vp]
+    lib.qagnn_hop_bwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('qagnn_abi_version',):
@@ -351,3 +372,86 @@ class HipKernels:
                                               cls_part.data_ptr(), self._stream())
         self._check(rc, 'qagnn_edge_attn_bwd_f32')
         return dKMQ, dEkEm
+
+    # -- one GATConvE hop per call (csrc/hop.hip) ---------------------------------------------------------------------------
+    def _hop_struct(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act):
+        Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
+        DP = 4 * HP
+        _chk2d(X, 'X'), _chk2d(Wx_t, 'Wx_t'), _chk2d(Wx, 'Wx'), _chk2d(TT, 'TT'), _chk2d(EkEm, 'EkEm')
+        for t in (W1t, W1, W2t, W2):
+            _chk2d(t, 'mlp weight')
+        for t in (b1, gamma, beta, b2, run_mean_p, run_var_p):
+            assert t.is_contiguous() and t.numel() == DP and t.dtype == torch.float32
+        assert X.shape == (graph.N, DP) and Wx_t.shape == (DP, 3 * DP) and Wx.shape == (3 * DP, DP) and EkEm.shape == (graph.C, 2 * DP)
+        assert ntype.dtype == torch.long and ntype.numel() == graph.N and ntype.is_contiguous() and TT.size(1) == 3 * DP
+        h = qagnn_hop_args()
+        h.g = C.pointer(graph.c)
+        h.N, h.DP, h.HP, h.T, h.qscale = graph.N, DP, HP, TT.size(0), float(qscale)
+        h.X, h.ntype = X.data_ptr(), ntype.data_ptr()
+        if S is not None:
+            _chk2d(S, 'S'), _chk2d(Ws_t, 'Ws_t'), _chk2d(Ws, 'Ws')
+            SP = S.size(1)
+            assert S.size(0) == graph.N and Ws_t.shape == (SP, 3 * DP) and Ws.shape == (3 * DP, SP)
+            h.SP, h.S, h.Ws_t, h.Ws = SP, S.data_ptr(), Ws_t.data_ptr(), Ws.data_ptr()
+        h.Wx_t, h.Wx, h.TT, h.EkEm = Wx_t.data_ptr(), Wx.data_ptr(), TT.data_ptr(), EkEm.data_ptr()
+        h.W1t, h.W1, h.b1, h.gamma, h.beta = W1t.data_ptr(), W1.data_ptr(), b1.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        h.W2t, h.W2, h.b2 = W2t.data_ptr(), W2.data_ptr(), b2.data_ptr()
+        h.batch_stats, h.eps = (1 if batch_stats else 0), float(eps)
+        h.run_mean_p, h.run_var_p = run_mean_p.data_ptr(), run_var_p.data_ptr()
+        h.apply_act, h.p_drop, h.seed = (1 if apply_act else 0), float(p), int(seed)
+        return h
+
+    def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
+        """-> (y, saved) with saved = (KMQ, aa [2, Ep, 4] = a | alpha, aggr, h1, out, stats [5, DP]); y is `out` when not apply_act."""
+        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
+        N, DP, dev = graph.N, 4 * HP, X.device
+        KMQ = torch.empty((N, 3 * DP), dtype=torch.float32, device=dev)
+        aa = torch.empty((2, graph.Ep, 4), dtype=torch.float32, device=dev)
+        rows = torch.empty((4 if apply_act else 3, N, DP), dtype=torch.float32, device=dev)  # aggr, h1, out (, y)
+        stats = torch.empty((5, DP), dtype=torch.float32, device=dev)
+        ws = torch.empty(self.lib.qagnn_hop_fwd_workspace_elems(N, graph.Ep, DP), dtype=torch.float32, device=dev)
+        h.KMQ, h.a, h.alpha, h.stats = KMQ.data_ptr(), aa[0].data_ptr(), aa[1].data_ptr(), stats.data_ptr()
+        h.aggr, h.h1, h.out = rows[0].data_ptr(), rows[1].data_ptr(), rows[2].data_ptr()
+        if apply_act:
+            h.y = rows[3].data_ptr()
+        if running is not None:
+            rm, rv, nbt, pos, mom, _unb = running
+            assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
+            h.run_mean, h.run_var, h.num_batches_tracked, h.dense_pos = rm.data_ptr(), rv.data_ptr(), _ptr(nbt), pos.data_ptr()
+            h.d, h.momentum = rm.numel(), float(mom)
+        h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
+        self._check(self.lib.qagnn_hop_fwd_f32(C.byref(h), self._stream()), 'qagnn_hop_fwd_f32')
+        return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats)
+
+    def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS):
+        """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)"""
+        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
+        KMQ, aa, aggr, h1, out, stats = saved
+        N, DP, dev, SP, T = graph.N, 4 * HP, X.device, h.SP, h.T
+        _chk2d(dy, 'dy')
+        h.KMQ, h.a, h.alpha, h.stats = KMQ.data_ptr(), aa[0].data_ptr(), aa[1].data_ptr(), stats.data_ptr()
+        h.aggr, h.h1, h.out, h.y = aggr.data_ptr(), h1.data_ptr(), out.data_ptr(), out.data_ptr()
+        h.dy = dy.data_ptr()
+        sizes = [DP * 3 * DP, SP * 3 * DP, T * 3 * DP, graph.C * 2 * DP, DP * DP, DP, 2 * DP, DP * DP, DP]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)  # every size is a multiple of 4: 16-byte aligned views
+        parts, off = [], 0
+        for n in sizes:
+            parts.append(flat[off:off + n])
+            off += n
+        dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = parts
+        h.dWx_t, h.dTT, h.dEkEm, h.dW1t, h.db1 = dWx_t.data_ptr(), dTT.data_ptr(), dEkEm.data_ptr(), dW1t.data_ptr(), db1.data_ptr()
+        h.dbn, h.dW2t, h.db2 = dbn.data_ptr(), dW2t.data_ptr(), db2.data_ptr()
+        dX = dS = None
+        if need_dX:
+            dX = torch.empty((N, DP), dtype=torch.float32, device=dev)
+            h.dX = dX.data_ptr()
+        if SP:
+            h.dWs_t = dWs_t.data_ptr()
+            if need_dS:
+                dS = torch.empty((N, SP), dtype=torch.float32, device=dev)
+                h.dS = dS.data_ptr()
+        ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks), dtype=torch.float32, device=dev)
+        h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
+        self._check(self.lib.qagnn_hop_bwd_f32(C.byref(h), self._stream()), 'qagnn_hop_bwd_f32')
+        return (dX, dS, dWx_t.view(DP, 3 * DP), dWs_t.view(SP, 3 * DP) if SP else None, dTT.view(T, 3 * DP), dEkEm.view(graph.C, 2 * DP),
+                dW1t.view(DP, DP), db1, dbn[DP:], dbn[:DP], dW2t.view(DP, DP), db2)

@@ -1,0 +1,180 @@
+// One GATConvE hop of the stack as ONE C call each way: the host-side sequencing of the kernels of this library.
+//
+// Reference: QAGNN_Message_Passing.mp_helper (modeling/modeling_qagnn.py:45-50) calling GATConvE.forward (:411-452) -> message
+// (:455-484) -> mlp (:443, def :408) -> GELU -> dropout, and the autograd backward of all of it.  qagnn_amd/ops.py composes the
+// same launches from Python (three autograd operators per hop, ~45 C-ABI calls and ~60 tensor allocations per layer and step);
+// at the reference's own mini-batch (2 questions x 5 choices) that host work, not the GPU, bounds the step.  Here the sequence
+// is native: 2 calls and a handful of allocations per layer.  The launches, their order and their arguments are exactly those
+// of the composed path, so the results are bit-identical (tests/test_hip_kernels.py::test_fused_hop_equals_composed_path).
+//
+// No allocation, no synchronisation: the caller hands in every buffer, including one scratch region whose size comes from
+// qagnn_hop_{fwd,bwd}_workspace_elems().
+#include "common.h"
+
+namespace qagnn {
+
+static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+struct Carver {
+  float* p;
+  float* end;
+  float* take(int64_t n) {
+    float* r = p;
+    p += up4(n);
+    return r;
+  }
+  bool ok() const { return p <= end; }
+};
+
+static int check_hop(const qagnn_hop_args* h, const char* who) {
+  QAGNN_REQUIRE(h && h->g, QAGNN_EINVAL, "%s: null argument block / graph", who);
+  QAGNN_REQUIRE(h->N == h->g->N && h->N > 0, QAGNN_EINVAL, "%s: N=%d does not match the graph (N=%d)", who, h->N, h->g->N);
+  QAGNN_REQUIRE(h->HP > 0 && h->HP % 4 == 0 && h->DP == 4 * h->HP, QAGNN_EINVAL, "%s: DP=%d must be 4*HP (HP=%d)", who, h->DP, h->HP);
+  QAGNN_REQUIRE(h->DP % 16 == 0 && h->SP >= 0 && h->SP % 16 == 0, QAGNN_EUNSUPPORTED,
+                "%s: DP=%d and SP=%d must be multiples of 16 (GEMM k-tile)", who, h->DP, h->SP);
+  QAGNN_REQUIRE(h->T >= 1 && h->T <= 4, QAGNN_EUNSUPPORTED, "%s: %d node types (the type-table gradient handles 1..4)", who, h->T);
+  QAGNN_REQUIRE(h->X && h->ntype && h->Wx_t && h->Wx && h->TT && h->EkEm && h->W1t && h->W1 && h->b1 && h->gamma && h->beta &&
+                    h->W2t && h->W2 && h->b2,
+                QAGNN_EINVAL, "%s: null parameter pointer", who);
+  QAGNN_REQUIRE(h->SP == 0 || (h->S && h->Ws_t && h->Ws), QAGNN_EINVAL, "%s: SP=%d but S / Ws_t / Ws missing", who, h->SP);
+  QAGNN_REQUIRE(h->KMQ && h->a && h->alpha && h->aggr && h->h1 && h->out && h->stats, QAGNN_EINVAL, "%s: null saved-buffer pointer", who);
+  QAGNN_REQUIRE(h->batch_stats || (h->run_mean_p && h->run_var_p), QAGNN_EINVAL, "%s: running statistics missing", who);
+  QAGNN_REQUIRE(!h->apply_act || h->y, QAGNN_EINVAL, "%s: apply_act without an output buffer y", who);
+  QAGNN_REQUIRE(h->ws, QAGNN_EINVAL, "%s: null workspace", who);
+  return QAGNN_OK;
+}
+
+}  // namespace qagnn
+
+using namespace qagnn;
+
+#define HOP_TRY(call)              \
+  do {                             \
+    int rc__ = (call);             \
+    if (rc__ != QAGNN_OK) return rc__; \
+  } while (0)
+
+extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP) {
+  return up4((int64_t)Ep * 4) + up4(qagnn_colreduce_workspace_elems(N, DP, 1));
+}
+
+extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+  HOP_TRY(check_hop(h, "hop_fwd"));
+  const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
+  Carver w{h->ws, h->ws + h->ws_elems};
+  float* score = w.take((int64_t)Ep * 4);
+  float* crws = w.take(qagnn_colreduce_workspace_elems(N, DP, 1));
+  QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_fwd: workspace of %lld floats is too small", (long long)h->ws_elems);
+  float* mean = h->stats, *var = h->stats + DP, *invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
+
+  // K | M | Q = [X | S] [Wx ; Ws] + TT[node type]      (project-then-gather: linear_key/msg/query on N node rows, :464-466)
+  qagnn_gemm_nn_args ga = {};
+  ga.A1 = h->X; ga.lda1 = DP; ga.K1 = DP; ga.B1 = h->Wx_t; ga.ldb1 = 3 * DP;
+  if (SP > 0) { ga.A2 = h->S; ga.lda2 = SP; ga.K2 = SP; ga.B2 = h->Ws_t; ga.ldb2 = 3 * DP; }
+  ga.C = h->KMQ; ga.ldc = 3 * DP; ga.M = N; ga.No = 3 * DP;
+  ga.rowtab = h->TT; ga.ldt = 3 * DP; ga.rowidx = h->ntype;
+  HOP_TRY(qagnn_gemm_nn_f32(&ga, stream));
+  // attention + aggregation (:442, 455-484)
+  HOP_TRY(qagnn_edge_attn_fwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP, stream));
+  // mlp: Linear -> BatchNorm1d -> ReLU -> Linear (:443, 408); BN + ReLU are folded into the second GEMM's operand load
+  qagnn_gemm_nn_args g1 = {};
+  g1.A1 = h->aggr; g1.lda1 = DP; g1.K1 = DP; g1.B1 = h->W1t; g1.ldb1 = DP; g1.C = h->h1; g1.ldc = DP; g1.M = N; g1.No = DP; g1.bias = h->b1;
+  HOP_TRY(qagnn_gemm_nn_f32(&g1, stream));
+  const float* mean_u = mean;
+  const float* var_u = var;
+  if (h->batch_stats) {
+    const float inv_rows = (float)(1.0 / (double)N);  // rounded like the composed path's Python double -> float
+    HOP_TRY(qagnn_colreduce_f32(0, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, inv_rows, mean, crws,
+                                stream));
+    HOP_TRY(qagnn_colreduce_f32(1, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, mean, nullptr, nullptr, nullptr, nullptr, inv_rows, var, crws,
+                                stream));
+  } else {
+    mean_u = h->run_mean_p;
+    var_u = h->run_var_p;
+  }
+  const double Rd = (double)N;
+  HOP_TRY(qagnn_bn_finalize_f32(mean_u, var_u, h->gamma, h->beta, h->eps, invstd, scale, shift, DP, h->run_mean, h->run_var,
+                                h->num_batches_tracked, h->dense_pos, h->d, h->momentum, (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0)), stream));
+  qagnn_gemm_nn_args g2 = {};
+  g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
+  g2.a_scale = scale; g2.a_shift = shift;
+  HOP_TRY(qagnn_gemm_nn_f32(&g2, stream));
+  if (h->apply_act)  // X' = dropout(GELU(out))  (:48-49)
+    HOP_TRY(qagnn_gelu_dropout_fwd_f32(h->out, h->y, (int64_t)N * DP, h->p_drop, h->seed, stream));
+  return QAGNN_OK;
+}
+
+extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t max_chunks) {
+  int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
+  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
+  return 2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
+         up4((int64_t)max_chunks * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
+}
+
+extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+  HOP_TRY(check_hop(h, "hop_bwd"));
+  QAGNN_REQUIRE(h->dy && h->dWx_t && h->dTT && h->dEkEm && h->dW1t && h->db1 && h->dbn && h->dW2t && h->db2, QAGNN_EINVAL,
+                "hop_bwd: null gradient pointer");
+  QAGNN_REQUIRE(h->SP == 0 || h->dWs_t, QAGNN_EINVAL, "hop_bwd: dWs_t missing");
+  const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
+  Carver w{h->ws, h->ws + h->ws_elems};
+  float* bufA = w.take((int64_t)N * DP);  // d out, then d h1
+  float* bufB = w.take((int64_t)N * DP);  // d relu(bn(h1)), then d aggr
+  float* dKMQ = w.take((int64_t)N * 3 * DP);
+  float* gab = w.take((int64_t)Ep * 4);
+  float* rs = w.take((int64_t)N * 4);
+  float* cls_part = w.take((int64_t)h->g->max_chunks * 2 * DP);
+  int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
+  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
+  float* tnws = w.take(tn);
+  float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
+  QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
+  const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
+  const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
+  const int64_t nel = (int64_t)N * DP;
+
+  // GELU + dropout backward
+  const float* dout = h->dy;
+  if (h->apply_act) {
+    HOP_TRY(qagnn_gelu_dropout_bwd_f32(h->out, h->dy, bufA, nel, h->p_drop, h->seed, stream));
+    dout = bufA;
+  }
+  // second Linear: dW2^T = relu(bn(h1))^T dout, db2 = colsum(dout), d r = dout W2
+  HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
+  HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
+  qagnn_gemm_nn_args gr = {};
+  gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
+  HOP_TRY(qagnn_gemm_nn_f32(&gr, stream));
+  // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1 (overwrites d out: it is dead by now)
+  HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
+  HOP_TRY(qagnn_bn_relu_bwd_f32(bufB, h->h1, bufA, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
+                                h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, stream));
+  // first Linear
+  HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufA, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+  HOP_TRY(qagnn_colreduce_f32(0, bufA, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db1, crws, stream));
+  qagnn_gemm_nn_args gg = {};
+  gg.A1 = bufA; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
+  HOP_TRY(qagnn_gemm_nn_f32(&gg, stream));
+  // attention backward
+  HOP_TRY(qagnn_edge_attn_bwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs,
+                                  cls_part, stream));
+  // projection: weight gradients, node-type-table gradient, data gradients
+  HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+  if (SP > 0)
+    HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+  HOP_TRY(qagnn_colreduce_f32(0, dKMQ, 3 * DP, nullptr, 3 * DP, N, 3 * DP, h->ntype, h->T, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->dTT,
+                              crws, stream));
+  if (h->dX) {
+    qagnn_gemm_nn_args gx = {};
+    gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
+    HOP_TRY(qagnn_gemm_nn_f32(&gx, stream));
+  }
+  if (SP > 0 && h->dS) {
+    qagnn_gemm_nn_args gs = {};
+    gs.A1 = dKMQ; gs.lda1 = 3 * DP; gs.K1 = 3 * DP; gs.B1 = h->Ws; gs.ldb1 = SP; gs.C = h->dS; gs.ldc = SP; gs.M = N; gs.No = SP;
+    gs.accumulate = h->accumulate_dS;
+    HOP_TRY(qagnn_gemm_nn_f32(&gs, stream));
+  }
+  return QAGNN_OK;
+}

@@ -255,6 +255,19 @@ class GATConvE(nn.Module):
             else:
                 TT = torch.addmm(bias, temb, Wtype)                  # [T, 3DP] type-embedding half of the projection + bq
                 ekem = torch.addmm(be_p, tab, We_p.t())              # [C, 2DP]: Ek | Em, pads exactly 0
+            if ops.FUSED_HOP and not getattr(ops.kernels(), 'edge_blocked', False):
+                # the whole hop (projection, attention, mlp, GELU + dropout, and its backward) as one native call each way
+                bn = self.mlp[1]
+                running = None
+                if self.training and bn.track_running_stats:
+                    R = float(Xp.size(0))
+                    running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos,
+                               bn.momentum if bn.momentum is not None else 0.1, R / max(R - 1.0, 1.0))
+                W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p = packed[8:]
+                return ops.gat_hop(Xp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head),
+                                   (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
+                                   self.training or not bn.track_running_stats, bn.eps, p_drop if self.training else 0.0, apply_act,
+                                   running)
             KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype)
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))

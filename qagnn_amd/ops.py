@@ -560,6 +560,94 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
                           next_seed() if p > 0 else 0, apply_act, running, row_weight)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# One GATConvE hop as ONE autograd operator over qagnn_hop_{fwd,bwd}_f32 (csrc/hop.hip): the same launches as
+# LinearNNFn -> EdgeAttnFn -> GatMlpFn above, sequenced in C.  hop_fwd_composed / hop_bwd_composed are that same sequence
+# written against the per-kernel provider interface: the definition the native sequencing is tested against
+# (bit-identical), and what a provider without a native hop (the torch emulation in tests/) runs.
+FUSED_HOP = _os.environ.get('QAGNN_FUSED_HOP', '1') == '1'
+HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta', 'W2t', 'W2', 'b2', 'run_mean_p', 'run_var_p')
+
+
+def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
+    Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
+    KMQ = K.gemm_nn(X, Wx_t, S, Ws_t, rowtab=TT, rowidx=ntype)
+    aggr, a, alpha = K.edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
+    h1 = K.gemm_nn(aggr, W1t, bias=b1)
+    if batch_stats:
+        sc = 1.0 / aggr.size(0)
+        mean = K.colsum(h1, scale=sc)[0]
+        var = K.colvar_sum(h1, mean, scale=sc)
+    else:
+        mean, var = run_mean_p, run_var_p
+    invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
+    out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
+    y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
+    return y, (KMQ, torch.stack([a, alpha]), aggr, h1, out, torch.stack([mean, var, invstd, scale, shift]))
+
+
+def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS):
+    Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
+    KMQ, aa, aggr, h1, out, stats = saved
+    mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
+    R = aggr.size(0)
+    dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
+    dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
+    db2 = K.colsum(dout)[0]
+    dr = K.gemm_nn(dout, W2)
+    red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
+    dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
+    dW1t = K.gemm_tn(aggr, dh1)
+    db1 = K.colsum(dh1)[0]
+    daggr = K.gemm_nn(dh1, W1)
+    dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
+    dWx_t = K.gemm_tn(X, dKMQ)
+    dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
+    dTT = K.colsum(dKMQ, ntype, TT.size(0))
+    dX = K.gemm_nn(dKMQ, Wx) if need_dX else None
+    dS = K.gemm_nn(dKMQ, Ws) if (S is not None and need_dS) else None
+    return dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, red[1], red[0], dW2t, db2
+
+
+class HopFn(torch.autograd.Function):
+    """(X', a) = one GATConvE hop in packed layout; see qagnn_hop_args in include/qagnn_hip.h for every operand."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seed, apply_act, running, *prm):
+        K = kernels()
+        fwd = getattr(K, 'hop_fwd', None)
+        args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
+        y, saved = fwd(*args, running) if fwd is not None else hop_fwd_composed(K, *args, running)
+        ctx.save_for_backward(X, S, ntype, *prm, *saved)
+        ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seed, apply_act, len(prm))
+        a = saved[1][0]
+        ctx.mark_non_differentiable(a)
+        return y, a
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy, _da):
+        K = kernels()
+        graph, HP, qscale, batch_stats, eps, p, seed, apply_act, nprm = ctx.cfg
+        t = ctx.saved_tensors
+        X, S, ntype, prm, saved = t[0], t[1], t[2], t[3:3 + nprm], t[3 + nprm:]
+        flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under this hop
+        bwd = getattr(K, 'hop_bwd', None)
+        args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy.contiguous(),
+                ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2 = bwd(*args) if bwd is not None else hop_bwd_composed(K, *args)
+        #        X   S   ntype graph HP    qscale bstats eps  p     seed  act   running | Wx_t  Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1
+        return (dX, dS, None, None, None, None, None, None, None, None, None, None, dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None, db1,
+                dgamma, dbeta, dW2t, None, db2, None, None)
+
+
+def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act, running):
+    """prm: the 16 packed operands named in HOP_PARAMS.  `p`: dropout rate after the GELU (0 disables)."""
+    p = float(p) if apply_act else 0.0
+    return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, *prm)
+
+
 class PoolAttnFn(torch.autograd.Function):
     """Node-sized part of the pooling head (utils/layers.py:284-299 inside :344-371): masked softmax attention of NH query
     vectors over the n node rows of every subgraph, attention dropout, weighted sum of the rows.  Returns (z [B, NH, Cc],

@@ -78,6 +78,13 @@ for arg in "$@"; do
       grep -o '"breakdown_ms_per_step.*' /tmp/ab_line.txt | cut -c1-160 >> gpurun_out/ab_$var.txt
     done
   fi
+  if [[ "$arg" == ab10:* ]]; then   # the same at the reference's own mini-batch (2 questions x 5 choices): host-bound
+    var="${arg#ab10:}"
+    for v in 0 1 0 1; do
+      echo "$var=$v (B=10)" >> gpurun_out/ab10_$var.txt
+      env $var=$v timeout 300 python bench.py --steps 60 --warmup 8 --questions 2 --no-cpu-baseline 2>&1 | tail -n 1 | cut -c1-140 >> gpurun_out/ab10_$var.txt
+    done
+  fi
   if [[ "$arg" == ab:* ]]; then
     var="${arg#ab:}"
     for rep in 1 2; do for v in 0 1; do

@@ -411,3 +411,55 @@ def test_pool_attention_forward_backward(B, n, NH, Cc, p):
         ref = EMU.pool_attn_bwd(u.double(), Kx.double(), it, p, seed, r_attn, r_attn_d, dz.double(), None if dattn is None else dattn.double())
         for a, b_ in zip(got, ref):
             assert torch.allclose(a.cpu().double(), b_, rtol=2e-4, atol=2e-5 * max(1.0, b_.abs().max().item()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,HP,mode', [('csqa_b10', 52, 'train'), ('csqa_b10', 52, 'eval'), ('small_train', 8, 'train'),
+                                          ('rand_hub', 52, 'train_noact'), ('medqa_b8', 52, 'train_noS'), ('big', 52, 'train')])
+def test_fused_hop_equals_composed_path(name, HP, mode):
+    """qagnn_hop_{fwd,bwd}_f32 (csrc/hop.hip) sequences the library's own launchers: every forward buffer, every gradient and
+    the BatchNorm running buffers must be BIT-identical to composing the per-kernel entry points from Python
+    (ops.hop_*_composed, the definition of the hop that the host-logic tests hold against the oracle)."""
+    from qagnn_amd import ops
+    (ei, et, nt, R, T), _, _, _, qs = edge_inputs(name, HP, 5)
+    K = hip()
+    dev = 'cuda'
+    g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    gen = torch.Generator().manual_seed(77)
+    N, DP, C = nt.numel(), 4 * HP, R * T * T + T
+    dh = {52: 50, 8: 8}[HP]
+    SP = 0 if mode == 'train_noS' else (112 if HP == 52 else 16)
+    rnd = lambda *shape, s=0.3: (torch.randn(*shape, generator=gen) * s).to(dev)  # noqa: E731
+    Wx_t, Ws_t = rnd(DP, 3 * DP, s=0.1), (rnd(SP, 3 * DP, s=0.1) if SP else None)
+    W1t, W2t = rnd(DP, DP, s=0.1), rnd(DP, DP, s=0.1)
+    prm = (Wx_t, Wx_t.t().contiguous(), Ws_t, Ws_t.t().contiguous() if SP else None, rnd(T, 3 * DP), rnd(C, 2 * DP),
+           W1t, W1t.t().contiguous(), rnd(DP), 1 + rnd(DP), rnd(DP), W2t, W2t.t().contiguous(), rnd(DP), rnd(DP), 0.5 + rnd(DP).abs())
+    X, S, dy = rnd(N, DP, s=1.0), (rnd(N, SP, s=1.0) if SP else None), rnd(N, DP, s=1.0)
+    ntype = nt.cuda()
+    batch_stats, apply_act = mode != 'eval', mode != 'train_noact'
+    p, seed = (0.2, 12345) if apply_act else (0.0, 0)
+    pos = torch.nonzero(torch.arange(DP) % HP < dh).flatten().to(dev)
+    res = []
+    for fused in (True, False):
+        run = (torch.zeros(4 * dh, device=dev), torch.ones(4 * dh, device=dev), torch.zeros((), dtype=torch.long, device=dev), pos, 0.1,
+               N / max(N - 1.0, 1.0)) if batch_stats else None
+        args = (g, HP, qs, X, S, ntype, prm, batch_stats, 1e-5, p, seed, apply_act)
+        y, saved = K.hop_fwd(*args, run) if fused else ops.hop_fwd_composed(K, *args, run)
+        grads = (K.hop_bwd if fused else lambda *a: ops.hop_bwd_composed(K, *a))(*args, saved, dy, True, True)
+        torch.cuda.synchronize()
+        res.append(([y] + list(saved), grads, run[:3] if run else ()))
+    (f_fwd, f_bwd, f_run), (c_fwd, c_bwd, c_run) = res
+    names_f = ['y', 'KMQ', 'a|alpha', 'aggr', 'h1', 'out', 'stats']
+    names_b = ['dX', 'dS', 'dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dgamma', 'dbeta', 'dW2t', 'db2']
+    for nm, a, b in zip(names_f, f_fwd, c_fwd):
+        if nm == 'stats' and not batch_stats:
+            a, b = a[2:], b[2:]  # mean / var rows are the running statistics themselves in eval mode (not written by the hop)
+        assert torch.equal(a, b), f'forward buffer {nm} differs'
+    for nm, a, b in zip(names_b, f_bwd, c_bwd):
+        assert (a is None) == (b is None), nm
+        if a is not None:
+            assert a.shape == b.shape and torch.equal(a, b), f'gradient {nm} differs'
+            assert torch.isfinite(a).all()
+    for a, b in zip(f_run, c_run):
+        assert torch.equal(a, b)
+    assert (SP == 0) == (f_bwd[1] is None)
