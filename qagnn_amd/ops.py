@@ -565,7 +565,20 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
 # LinearNNFn -> EdgeAttnFn -> GatMlpFn above, sequenced in C.  hop_fwd_composed / hop_bwd_composed are that same sequence
 # written against the per-kernel provider interface: the definition the native sequencing is tested against
 # (bit-identical), and what a provider without a native hop (the torch emulation in tests/) runs.
-FUSED_HOP = _os.environ.get('QAGNN_FUSED_HOP', '1') == '1'
+#
+# Which one runs (QAGNN_FUSED_HOP = 1 / 0 pins it; default "auto"): measured on MI355X (profiles/r1_run58_fused_hop_ab_*.txt),
+#   * host-bound batches (the reference's mini-batch of 10 subgraphs: the GPU work of a step is < 2 ms): native sequencing
+#     1434 / 1689 vs 1317 / 1373 QA-subgraphs/s;
+#   * GPU-bound batches (320 subgraphs, N = 64 000 rows): the composed path 26 098 / 26 113 vs 25 481 / 25 429, because only it
+#     can run the weight-gradient GEMMs of one operator under the edge backward of the next (QAGNN_WGRAD_OVERLAP above).
+# "auto" therefore takes the native hop below FUSED_HOP_MAX_ROWS node rows, where a step is bounded by the host.
+_fh = _os.environ.get('QAGNN_FUSED_HOP', 'auto')
+FUSED_HOP = {'1': True, '0': False}.get(_fh, None)  # None = auto
+FUSED_HOP_MAX_ROWS = 32768
+
+
+def use_fused_hop(n_rows):
+    return FUSED_HOP if FUSED_HOP is not None else n_rows < FUSED_HOP_MAX_ROWS
 HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta', 'W2t', 'W2', 'b2', 'run_mean_p', 'run_var_p')
 
 

@@ -109,6 +109,12 @@ fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
 fi
+if [[ "$*" == *gather* ]]; then   # row-gather rate of the memory system (tools/gather_micro.hip, prebuilt by tools/build_micro.sh)
+  timeout 120 tools/bin/gather_micro > gpurun_out/gather_micro.txt 2>&1
+fi
+if [[ "$*" == *hostfused* ]]; then
+  QAGNN_FUSED_HOP=1 timeout 300 python -m cProfile -s tottime bench.py --steps 60 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 90 > gpurun_out/hostprof_b10_fused.txt
+fi
 if [[ "$*" == *ablate* ]]; then   # prebuilt here by tools/build_micro.sh (compiling on the box would burn GPU minutes)
   run() { echo "== $*" >> gpurun_out/gemm_micro.txt; env "${@:2}" timeout 120 tools/bin/gemm_ablate_$1 >> gpurun_out/gemm_micro.txt 2>&1; }
   run BASE

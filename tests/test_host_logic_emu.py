@@ -231,7 +231,8 @@ def test_bucket_walk_covers_every_segment_once(seed, N, E, hub):
         assert sorted(flushed_at) == ends and len(ends) == N  # every node owns a segment (its self loop)
 
 
-def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch):
+@pytest.mark.parametrize('fused_hop', [False, True])
+def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch, fused_hop):
     """QAGNN_WGRAD_OVERLAP: inside the stack the weight-gradient launches are queued and issued later (on the GPU: on a side
     stream under the edge backward).  With the queued outputs poisoned (NaN until the launch runs) the gradients must still
     equal those of the immediate path -- i.e. nobody reads a deferred gradient before GatherPlan's backward joins."""
@@ -243,6 +244,7 @@ def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch):
     grads = {}
     old = ops.set_kernels(EmuKernels())
     try:
+        monkeypatch.setattr(ops, 'FUSED_HOP', fused_hop)  # False: the hops are composed from LinearNNFn / EdgeAttnFn / GatMlpFn
         for overlap in (False, True):
             monkeypatch.setattr(ops, 'WGRAD_OVERLAP', overlap)
             monkeypatch.setattr(ops, 'WGRAD_POISON', overlap)
