@@ -44,6 +44,25 @@ __device__ __forceinline__ int wave_node() {
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Per-edge head scalars (a, alpha, ga, gs, score: [E', 4] arrays) travel as LANE-HELD float4: lane i of the wave holds the 4
+// head values of edge i of the current 64-edge chunk, read or written with ONE coalesced 16-byte-per-lane instruction per
+// chunk.  Measured (profiles/r1_run59_gather_micro.txt + run 56): these kernels are bound by the number of vector-memory
+// wave-instructions they issue per edge (~21 us per instruction per edge at E' = 460 800, whether it moves 4 or 832 useful
+// bytes -- the texture addresser spends its 16 cycles per wave-instruction either way), so a 4-byte `alpha[e*4+g]` load per
+// edge costs as much as a whole feature row.  Moving a value between "lane i, component g" and "the 16 lanes of head group
+// g" is register traffic only: v_readlane + v_cndmask.
+__device__ __forceinline__ float lane_f(float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); }
+// value of edge i (wave-uniform) for this lane's head group g
+__device__ __forceinline__ float head_get(const float4 v, int i, int g) {
+  const float x = lane_f(v.x, i), y = lane_f(v.y, i), z = lane_f(v.z, i), w = lane_f(v.w, i);
+  return g == 0 ? x : (g == 1 ? y : (g == 2 ? z : w));
+}
+// lane i's float4 <- (p of head group 0, 1, 2, 3); p is uniform inside each 16-lane group
+__device__ __forceinline__ void head_put(float4& v, int i, float p, int lane) {
+  const float x = lane_f(p, 0), y = lane_f(p, 16), z = lane_f(p, 32), w = lane_f(p, 48);
+  if (lane == i) v = make_float4(x, y, z, w);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward 1/3: raw scores, one wave per SOURCE node (Q row in registers; gathers K[tgt] and Ek[cls])
 // ---------------------------------------------------------------------------------------------------------------
@@ -62,6 +81,7 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
     const int cnt = min(64, end - e0);
     const int tv = lane < cnt ? tgt_s[e0 + lane] : 0;
     const int cv = lane < cnt ? cls_s[e0 + lane] : 0;
+    float4 sc = zero4();  // lane i: the 4 head scores of edge e0 + i
     for (int i = 0; i < cnt; i += EDGE_UNROLL) {
       float4 k[EDGE_UNROLL], ek[EDGE_UNROLL];
 #pragma unroll
@@ -74,9 +94,10 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const float p = row16_sum(dot4(q, add4(k[u], ek[u]))) * qscale;
-        if (i + u < cnt && L.j == 0) score[(int64_t)(e0 + i + u) * 4 + L.g] = p;
+        if (i + u < cnt) head_put(sc, i + u, p, lane);
       }
     }
+    if (lane < cnt) st4(score + (int64_t)(e0 + lane) * 4, sc);
   }
 }
 
@@ -121,20 +142,21 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
     const int sv = lane < cnt ? src_t[e0 + lane] : 0;
     const int cv = lane < cnt ? cls_t[e0 + lane] : 0;
     const int pv = lane < cnt ? pos_t[e0 + lane] : 0;
+    const float4 al4 = lane < cnt ? ld4(alpha + (int64_t)pv * 4) : zero4();  // lane i: alpha of edge e0 + i (one gather per chunk)
     for (int i = 0; i < cnt; i += EDGE_UNROLL) {
       float4 m[EDGE_UNROLL], em[EDGE_UNROLL];
-      float wgt[EDGE_UNROLL];
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const int idx = min(i + u, cnt - 1);
         const int s = __builtin_amdgcn_readlane(sv, idx), c = __builtin_amdgcn_readlane(cv, idx);
-        const int p = __builtin_amdgcn_readlane(pv, idx);
         m[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + DP + L.off) : zero4();
         em[u] = L.act ? ld4(EkEm + (int64_t)c * lde + DP + L.off) : zero4();
-        wgt[u] = i + u < cnt ? alpha[(int64_t)p * 4 + L.g] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < EDGE_UNROLL; ++u) acc = fma4(wgt[u], add4(m[u], em[u]), acc);
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const float wgt = i + u < cnt ? head_get(al4, min(i + u, cnt - 1), L.g) : 0.f;
+        acc = fma4(wgt, add4(m[u], em[u]), acc);
+      }
     }
   }
   if (L.act) st4(aggr + (int64_t)t * lda + L.off, acc);
@@ -166,27 +188,31 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
     const int cnt = min(64, end - e0);
     const int tv = lane < cnt ? tgt_s[e0 + lane] : 0;
     const int cv = lane < cnt ? cls_s[e0 + lane] : 0;
+    // lane i: a, alpha of edge e0 + i (coalesced, once per chunk) and, on the way out, its ga
+    const float4 a4 = lane < cnt ? ld4(a + (int64_t)(e0 + lane) * 4) : zero4();
+    const float4 al4 = lane < cnt ? ld4(alpha + (int64_t)(e0 + lane) * 4) : zero4();
+    float4 ga4 = zero4();
     for (int i = 0; i < cnt; i += EDGE_UNROLL) {
       float4 g4[EDGE_UNROLL], em[EDGE_UNROLL];
-      float al[EDGE_UNROLL], av[EDGE_UNROLL];
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const int idx = min(i + u, cnt - 1);
         const int t = __builtin_amdgcn_readlane(tv, idx), c = __builtin_amdgcn_readlane(cv, idx);
         g4[u] = L.act ? ld4(G + (int64_t)t * ldg + L.off) : zero4();
         em[u] = L.act ? ld4(EkEm + (int64_t)c * lde + DP + L.off) : zero4();
-        const bool ok = i + u < cnt;
-        al[u] = ok ? alpha[(int64_t)(e0 + idx) * 4 + L.g] : 0.f;
-        av[u] = ok ? a[(int64_t)(e0 + idx) * 4 + L.g] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
-        dM = fma4(al[u], g4[u], dM);
+        const bool ok = i + u < cnt;
+        const int idx = min(i + u, cnt - 1);
+        const float al = ok ? head_get(al4, idx, L.g) : 0.f, av = ok ? head_get(a4, idx, L.g) : 0.f;
+        dM = fma4(al, g4[u], dM);
         const float gae = deg * row16_sum(dot4(add4(mrow, em[u]), g4[u]));
-        r = fmaf(av[u], gae, r);
-        if (i + u < cnt && L.j == 0) ga[(int64_t)(e0 + i + u) * 4 + L.g] = gae;
+        r = fmaf(av, gae, r);
+        if (ok) head_put(ga4, idx, gae, lane);
       }
     }
+    if (lane < cnt) st4(ga + (int64_t)(e0 + lane) * 4, ga4);
   }
   if (L.act) st4(dKMQ + (int64_t)s * ldk + DP + L.off, dM);
   if (L.j == 0) rs[(int64_t)s * 4 + L.g] = r;
@@ -202,28 +228,33 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
   const Lane L = lane_info(HP);
   const int lane = threadIdx.x & 63, DP = 4 * HP;
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
-  const float r = rs[(int64_t)s * 4 + L.g];
+  const float4 r4 = ld4(rs + (int64_t)s * 4);  // the node's 4 head values, same address in every lane
   float4 dQ = zero4();
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int cnt = min(64, end - e0);
     const int tv = lane < cnt ? tgt_s[e0 + lane] : 0;
     const int cv = lane < cnt ? cls_s[e0 + lane] : 0;
+    // lane i: gs of edge e0 + i from its a and ga (coalesced), written back in place of ga (coalesced)
+    float4 gs4 = zero4();
+    if (lane < cnt) {
+      const float4 a4 = ld4(a + (int64_t)(e0 + lane) * 4), g4 = ld4(ga + (int64_t)(e0 + lane) * 4);
+      gs4 = make_float4(qscale * a4.x * (g4.x - r4.x), qscale * a4.y * (g4.y - r4.y), qscale * a4.z * (g4.z - r4.z),
+                        qscale * a4.w * (g4.w - r4.w));
+      st4(ga + (int64_t)(e0 + lane) * 4, gs4);
+    }
     for (int i = 0; i < cnt; i += EDGE_UNROLL) {
       float4 k[EDGE_UNROLL], ek[EDGE_UNROLL];
-      float gs[EDGE_UNROLL];
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const int idx = min(i + u, cnt - 1);
         const int t = __builtin_amdgcn_readlane(tv, idx), c = __builtin_amdgcn_readlane(cv, idx);
         k[u] = L.act ? ld4(KMQ + (int64_t)t * ldk + L.off) : zero4();
         ek[u] = L.act ? ld4(EkEm + (int64_t)c * lde + L.off) : zero4();
-        const int64_t o = (int64_t)(e0 + idx) * 4 + L.g;
-        gs[u] = i + u < cnt ? qscale * a[o] * (ga[o] - r) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
-        dQ = fma4(gs[u], add4(k[u], ek[u]), dQ);
-        if (i + u < cnt && L.j == 0) ga[(int64_t)(e0 + i + u) * 4 + L.g] = gs[u];  // every lane of the group already read it
+        const float gs = i + u < cnt ? head_get(gs4, min(i + u, cnt - 1), L.g) : 0.f;
+        dQ = fma4(gs, add4(k[u], ek[u]), dQ);
       }
     }
   }
@@ -243,18 +274,20 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
     const int cnt = min(64, end - e0);
     const int sv = lane < cnt ? src_t[e0 + lane] : 0;
     const int pv = lane < cnt ? pos_t[e0 + lane] : 0;
+    const float4 gs4 = lane < cnt ? ld4(gsb + (int64_t)pv * 4) : zero4();  // lane i: gs of edge e0 + i (one gather per chunk)
     for (int i = 0; i < cnt; i += EDGE_UNROLL) {
       float4 qv[EDGE_UNROLL];
-      float gs[EDGE_UNROLL];
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const int idx = min(i + u, cnt - 1);
-        const int s = __builtin_amdgcn_readlane(sv, idx), p = __builtin_amdgcn_readlane(pv, idx);
+        const int s = __builtin_amdgcn_readlane(sv, idx);
         qv[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + 2 * DP + L.off) : zero4();
-        gs[u] = i + u < cnt ? gsb[(int64_t)p * 4 + L.g] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < EDGE_UNROLL; ++u) dK = fma4(gs[u], qv[u], dK);
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const float gs = i + u < cnt ? head_get(gs4, min(i + u, cnt - 1), L.g) : 0.f;
+        dK = fma4(gs, qv[u], dK);
+      }
     }
   }
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
@@ -275,25 +308,26 @@ __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_
   const int sv = lane < cnt ? src_c[beg + lane] : 0;
   const int tv = lane < cnt ? tgt_c[beg + lane] : 0;
   const int pv = lane < cnt ? pos_c[beg + lane] : 0;
+  // lane i: gs and alpha of the chunk's edge i (one gather each per chunk)
+  const float4 gs4 = lane < cnt ? ld4(gsb + (int64_t)pv * 4) : zero4();
+  const float4 al4 = lane < cnt ? ld4(alpha + (int64_t)pv * 4) : zero4();
   float4 dEk = zero4(), dEm = zero4();
   for (int i = 0; i < cnt; i += EDGE_UNROLL) {
     float4 qv[EDGE_UNROLL], g4[EDGE_UNROLL];
-    float gs[EDGE_UNROLL], al[EDGE_UNROLL];
 #pragma unroll
     for (int u = 0; u < EDGE_UNROLL; ++u) {
       const int idx = min(i + u, cnt - 1);
       const int s = __builtin_amdgcn_readlane(sv, idx), t = __builtin_amdgcn_readlane(tv, idx);
-      const int p = __builtin_amdgcn_readlane(pv, idx);
       qv[u] = L.act ? ld4(KMQ + (int64_t)s * ldk + 2 * DP + L.off) : zero4();
       g4[u] = L.act ? ld4(G + (int64_t)t * ldg + L.off) : zero4();
-      const bool ok = i + u < cnt;
-      gs[u] = ok ? gsb[(int64_t)p * 4 + L.g] : 0.f;
-      al[u] = ok ? alpha[(int64_t)p * 4 + L.g] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < EDGE_UNROLL; ++u) {
-      dEk = fma4(gs[u], qv[u], dEk);
-      dEm = fma4(al[u], g4[u], dEm);
+      const bool ok = i + u < cnt;
+      const int idx = min(i + u, cnt - 1);
+      const float gs = ok ? head_get(gs4, idx, L.g) : 0.f, al = ok ? head_get(al4, idx, L.g) : 0.f;
+      dEk = fma4(gs, qv[u], dEk);
+      dEm = fma4(al, g4[u], dEm);
     }
   }
   if (L.act) {
