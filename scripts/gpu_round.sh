@@ -14,7 +14,7 @@ if [[ "$*" == *poison* ]]; then   # deferred weight gradients start as NaN: any 
   QAGNN_WGRAD_POISON=1 timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q --tb=short -rf --timeout 300 -p no:cacheprovider 2>&1 | tail -n 30 > gpurun_out/test_poison.log
   echo "poison exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
-if [[ "$*" == *edgewalk* ]]; then    # the bucket-walk edge kernels stay tested behind their A/B switch
+if [[ "$*" == *edgewalk_removed* ]]; then
   QAGNN_EDGE_WALK=1 timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "edge" 2>&1 | tail -n 30 > gpurun_out/test_edge_walk.log
   echo "edgewalk exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
