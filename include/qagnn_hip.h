@@ -58,11 +58,12 @@ typedef struct qagnn_graph {
   /* grouped by TARGET (aggregation segments) */
   int32_t* rowptr_t;           /* [N+1] */
   int32_t* src_t;              /* [Ep] */
-  int32_t* tgt_t;              /* [Ep] target node of position p (segment owner, for the bucket-walk kernels) */
+  int32_t* tgt_t;              /* [Ep] target node of position p (segment owner, for edge-parallel kernels) */
   int32_t* cls_t;              /* [Ep] */
   int32_t* pos_t;              /* [Ep] position of the same edge in the source order */
-  /* grouped by CLASS, cut into chunks of <= QAGNN_CLS_CHUNK edges that never straddle a class */
-  int32_t* clsptr;             /* [C+1] */
+  /* grouped by (POSITION GROUP, CLASS): group = a run of consecutive source-order positions (the edges of a few neighbouring
+   * subgraphs; n_groups <= QAGNN_CLS_GROUPS per batch), then class; cut into chunks of <= QAGNN_CLS_CHUNK edges that never
+   * straddle a (group, class) pair.  Keeps the class pass's row gathers inside one XCD's L2. */
   int32_t* cls_count;          /* [C]   edges per class (the count-weighted BatchNorm of the edge encoder needs it) */
   int32_t* src_c;              /* [Ep] */
   int32_t* tgt_c;              /* [Ep] */
@@ -71,14 +72,16 @@ typedef struct qagnn_graph {
   int32_t* chunk_beg;          /* [max_chunks] */
   int32_t* chunk_len;          /* [max_chunks] */
   int32_t* n_chunks;           /* [1] device scalar */
-  int32_t* chunkptr;           /* [C+1] first chunk of each class */
-  int32_t max_chunks;          /* Ep / QAGNN_CLS_CHUNK + C + 1 */
+  int32_t* chunkptr;           /* [n_groups*C+1] first chunk of pair g*C + c */
+  int32_t max_chunks;          /* Ep / QAGNN_CLS_CHUNK + n_groups*C + 1 */
   int32_t* err;                /* [4] device flags: [0] = 1: an index was out of range (it was clamped);
                                   [1] = 1: some edge leaves its block of block_n consecutive node rows */
   int32_t block_n;             /* 0, or the node-block size the graph was checked against (subgraph = n consecutive rows) */
+  int32_t n_groups;            /* position groups of the class order */
 } qagnn_graph;
 
 #define QAGNN_CLS_CHUNK 64
+#define QAGNN_CLS_GROUPS 64
 
 /* int32 elements of device storage needed for all arrays of a qagnn_graph plus scratch. */
 int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T);

@@ -21,7 +21,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
-ABI_VERSION = 2  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t)
+ABI_VERSION = 3  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -29,9 +29,9 @@ _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_v
 class qagnn_graph(C.Structure):
     _fields_ = ([(n, _i32) for n in ('N', 'E', 'Ep', 'R', 'T', 'C')] +
                 [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'tgt_t', 'cls_t', 'pos_t',
-                                    'clsptr', 'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
+                                    'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
-                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32)])
+                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
 
 
 class qagnn_gemm_nn_args(C.Structure):

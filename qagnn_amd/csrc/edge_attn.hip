@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
 }
 
-// one wave per class chunk (<= QAGNN_CLS_CHUNK edges of one class)
+// one wave per class chunk (<= QAGNN_CLS_CHUNK edges of one class inside one position group)
 __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_chunks, const int* __restrict__ chunk_beg,
                                                       const int* __restrict__ chunk_len, const int* __restrict__ src_c,
                                                       const int* __restrict__ tgt_c, const int* __restrict__ pos_c,
@@ -309,8 +309,12 @@ __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_
                                                       const float* __restrict__ alpha, const float* __restrict__ gsb,
                                                       const float* __restrict__ G, int ldg, float* __restrict__ cls_part, int N) {
   __shared__ float4 slab[2][4][SLAB_ROWS];  // gs | alpha of the chunk
-  const int k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (k >= *n_chunks) return;
+  // chunks are in (position group, class) order: the remap gives every XCD a contiguous run of groups, whose node rows its L2
+  // then serves (the grid is sized for max_chunks, so the remap runs over the blocks that really have a chunk)
+  const int nch = *n_chunks, nb_real = (nch + 3) >> 2;
+  if ((int)blockIdx.x >= nb_real) return;
+  const int k = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, nb_real) * 4 + (threadIdx.x >> 6));
+  if (k >= nch) return;
   const Lane L = lane_info(HP);
   const int DP = 4 * HP;
   const uint32_t pk = (uint32_t)ldk * 4u, pg = (uint32_t)ldg * 4u, vq = L.voff + 2u * DP * 4u;
@@ -346,19 +350,26 @@ __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_
   }
 }
 
-// ordered sum of a class's chunk partials; block = one class, columns x partitions, fixed combine order
+// ordered sum of a class's chunk partials over all position groups; block = one class, columns x partitions: partition p
+// takes the class's chunks number p, p + P, ... (numbered in group order), the partitions are added in order
 __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chunkptr, const float* __restrict__ cls_part,
-                                                     float* __restrict__ dEkEm, int lde, int DP2) {
+                                                     float* __restrict__ dEkEm, int lde, int DP2, int C, int NG) {
   extern __shared__ float4 sm4[];
   const int c = blockIdx.x;
   const int ncol4 = DP2 >> 2;
   const int P = 1024 / ncol4;
   const int col4 = threadIdx.x % ncol4, part = threadIdx.x / ncol4;
-  const int kb = chunkptr[c], ke = chunkptr[c + 1];
   float4 acc = zero4();
-  if (part < P)
-    for (int k = kb + part; k < ke; k += P) acc = add4(acc, ld4(cls_part + (int64_t)k * DP2 + col4 * 4));
-  if (part < P) sm4[part * ncol4 + col4] = acc;
+  if (part < P) {
+    int seen = 0;  // chunks of this class in the groups before g
+    for (int g = 0; g < NG; ++g) {
+      const int kb = chunkptr[g * C + c], ke = chunkptr[g * C + c + 1];
+      const int first = (part - seen % P + P) % P;
+      for (int k = kb + first; k < ke; k += P) acc = add4(acc, ld4(cls_part + (int64_t)k * DP2 + col4 * 4));
+      seen += ke - kb;
+    }
+    sm4[part * ncol4 + col4] = acc;
+  }
   __syncthreads();
   if (threadIdx.x < ncol4) {
     float4 s = sm4[threadIdx.x];
@@ -556,7 +567,7 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part, g->N);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_cls");
   const int P = 1024 / (DP2 / 4);
-  k_cls_reduce<<<g->C, 1024, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, dEkEm, lde, DP2);
+  k_cls_reduce<<<g->C, 1024, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, dEkEm, lde, DP2, g->C, g->n_groups);
   QAGNN_LAUNCH_CHECK("k_cls_reduce");
   return QAGNN_OK;
 }

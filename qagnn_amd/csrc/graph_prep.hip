@@ -171,23 +171,30 @@ __global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s,
   }
 }
 
-// exclusive scan over the blocks of one class (column c of hist), one wave per class, 64 blocks per step
-__global__ __launch_bounds__(256) void k_cls_base(int* __restrict__ hist, const int* __restrict__ clsptr, int nblk, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
-  int run = clsptr[c];
-  for (int b0 = 0; b0 < nblk; b0 += 64) {
-    const int b = b0 + lane;
-    const int v = b < nblk ? hist[(int64_t)b * C + c] : 0;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (b < nblk) hist[(int64_t)b * C + c] = run + incl - v;
-    run += __shfl(incl, 63, 64);
+// The class order is (position group, class)-major: a group is `gb` consecutive 1024-position blocks of the source order
+// (<= QAGNN_CLS_GROUPS groups per batch), i.e. the edges of a few neighbouring subgraphs.  A chunk of the class pass then
+// only touches node rows of its group (~1.6 MB of Q and G rows at the CSQA batch), which one XCD's L2 keeps; with a purely
+// class-major order every chunk of a small class gathered rows from all over the batch and the pass ran at the fabric's
+// random-row rate (profiles/r1_run59_gather_micro.txt: 6.4 TB/s batch-wide vs 18 TB/s subgraph-local).
+// counts per (group, class): one thread per pair, class fastest (coalesced over the block histograms)
+__global__ __launch_bounds__(256) void k_grp_count(const int* __restrict__ hist, int* __restrict__ gc_cnt, int nblk, int C, int gb, int NG) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NG * C) return;
+  const int g = i / C, c = i - g * C;
+  int sum = 0;
+  for (int b = g * gb; b < min(nblk, (g + 1) * gb); ++b) sum += hist[(int64_t)b * C + c];
+  gc_cnt[i] = sum;
+}
+// hist[b][c] <- first class-order slot of block b's edges of class c (inside the (group, class) range that starts at gcptr)
+__global__ __launch_bounds__(256) void k_grp_base(int* __restrict__ hist, const int* __restrict__ gcptr, int nblk, int C, int gb, int NG) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NG * C) return;
+  const int g = i / C, c = i - g * C;
+  int run = gcptr[i];
+  for (int b = g * gb; b < min(nblk, (g + 1) * gb); ++b) {
+    const int v = hist[(int64_t)b * C + c];
+    hist[(int64_t)b * C + c] = run;
+    run += v;
   }
 }
 
@@ -212,24 +219,31 @@ __global__ __launch_bounds__(256) void k_cls_scatter(const int* __restrict__ cls
   }
 }
 
-// chunk table: class c owns chunks [chunkptr[c], chunkptr[c+1]), each <= QAGNN_CLS_CHUNK consecutive class-order slots
-__global__ __launch_bounds__(1024) void k_chunk_counts(const int* __restrict__ cls_count, int* __restrict__ nch, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) nch[c] = (cls_count[c] + QAGNN_CLS_CHUNK - 1) / QAGNN_CLS_CHUNK;
+// chunk table: pair i = g * C + c owns chunks [chunkptr[i], chunkptr[i+1]), each <= QAGNN_CLS_CHUNK consecutive class-order slots
+__global__ __launch_bounds__(1024) void k_chunk_counts(const int* __restrict__ gc_cnt, int* __restrict__ nch, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) nch[i] = (gc_cnt[i] + QAGNN_CLS_CHUNK - 1) / QAGNN_CLS_CHUNK;
 }
-__global__ __launch_bounds__(1024) void k_chunk_scan(const int* nch, int* chunkptr, int C) { block_exclusive_scan(nch, chunkptr, C); }
-__global__ void k_chunk_fill(const int* __restrict__ clsptr, const int* __restrict__ chunkptr, int* __restrict__ chunk_cls,
-                             int* __restrict__ chunk_beg, int* __restrict__ chunk_len, int* __restrict__ n_chunks, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0) *n_chunks = chunkptr[C];
-  if (c >= C) return;
-  const int b = clsptr[c], e = clsptr[c + 1];
-  int k = chunkptr[c];
+__global__ __launch_bounds__(1024) void k_scan1(const int* in, int* out, int n) { block_exclusive_scan(in, out, n); }
+__global__ void k_chunk_fill(const int* __restrict__ gcptr, const int* __restrict__ chunkptr, int* __restrict__ chunk_cls,
+                             int* __restrict__ chunk_beg, int* __restrict__ chunk_len, int* __restrict__ n_chunks, int C, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_chunks = chunkptr[n];
+  if (i >= n) return;
+  const int b = gcptr[i], e = gcptr[i + 1];
+  int k = chunkptr[i];
   for (int p = b; p < e; p += QAGNN_CLS_CHUNK, ++k) {
-    chunk_cls[k] = c;
+    chunk_cls[k] = i % C;
     chunk_beg[k] = p;
     chunk_len[k] = min(QAGNN_CLS_CHUNK, e - p);
   }
+}
+
+// position groups of the class order: gb blocks of CLS_BLK positions each, at most QAGNN_CLS_GROUPS groups
+static inline void cls_groups(int Ep, int* nblk, int* gb, int* NG) {
+  *nblk = cdiv(Ep, CLS_BLK);
+  *gb = cdiv(*nblk, QAGNN_CLS_GROUPS) > 1 ? cdiv(*nblk, QAGNN_CLS_GROUPS) : 1;
+  *NG = cdiv(*nblk, *gb);
 }
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
@@ -239,16 +253,19 @@ static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 using namespace qagnn;
 
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 2; }
+extern "C" int qagnn_abi_version(void) { return 3; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;
-  const int64_t maxch = Ep / QAGNN_CLS_CHUNK + C + 1;
-  const int64_t nblk = (Ep + CLS_BLK - 1) / CLS_BLK;
+  int nblk_i, gb, NG;
+  cls_groups((int)Ep, &nblk_i, &gb, &NG);
+  const int64_t pairs = (int64_t)NG * C;
+  const int64_t maxch = Ep / QAGNN_CLS_CHUNK + pairs + 1;
+  const int64_t nblk = nblk_i;
   int64_t tot = 0;
   tot += 2 * up4(N + 1);      // rowptr_s, rowptr_t
   tot += 12 * up4(Ep);        // tgt_s src_s cls_s eid_s src_t tgt_t cls_t pos_t src_c tgt_c pos_c + eid_t
-  tot += 3 * up4(C + 1);      // clsptr, chunkptr, nch scratch
+  tot += 4 * up4(pairs + 1);  // gc_cnt, gcptr, chunkptr, nch scratch
   tot += up4(C);              // cls_count
   tot += 3 * up4(maxch);      // chunk tables
   tot += 2 * up4(4);          // n_chunks, err
@@ -276,18 +293,22 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_prep: E+N=%lld too large", (long long)Ep64);
   QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_prep: %lld edge classes > 8192", (long long)C64);
   const int Ep = (int)Ep64, C = (int)C64;
-  const int maxch = Ep / QAGNN_CLS_CHUNK + C + 1;
-  const int nblk = cdiv(Ep, CLS_BLK);
+  int nblk, gb, NG;
+  cls_groups(Ep, &nblk, &gb, &NG);
+  const int pairs = NG * C;
+  const int maxch = Ep / QAGNN_CLS_CHUNK + pairs + 1;
   int32_t* p = storage;
   auto take = [&](int64_t n) { int32_t* r = p; p += up4(n); return r; };
   g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch; g->block_n = block_n;
+  g->n_groups = NG;
   g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
   g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
   g->src_t = take(Ep); g->tgt_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
   g->src_c = take(Ep); g->tgt_c = take(Ep); g->pos_c = take(Ep);
   int32_t* eid_t = take(Ep);
-  g->clsptr = take(C + 1); g->chunkptr = take(C + 1);
-  int32_t* nch = take(C + 1);
+  int32_t* gc_cnt = take(pairs + 1); int32_t* gcptr = take(pairs + 1);
+  g->chunkptr = take(pairs + 1);
+  int32_t* nch = take(pairs + 1);
   g->cls_count = take(C);
   g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
   g->n_chunks = take(4); g->err = take(4);
@@ -314,17 +335,19 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   QAGNN_LAUNCH_CHECK("k_payload");
   k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_hist");
-  k_chunk_scan<<<1, 1024, 0, stream>>>(g->cls_count, g->clsptr, C);  // clsptr = exclusive scan of the class counts
-  QAGNN_LAUNCH_CHECK("k_cls_scan");
-  k_cls_base<<<cdiv(C, 4), 256, 0, stream>>>(hist, g->clsptr, nblk, C);
-  QAGNN_LAUNCH_CHECK("k_cls_base");
+  k_grp_count<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gc_cnt, nblk, C, gb, NG);
+  QAGNN_LAUNCH_CHECK("k_grp_count");
+  k_scan1<<<1, 1024, 0, stream>>>(gc_cnt, gcptr, pairs);  // first class-order slot of every (group, class) pair
+  QAGNN_LAUNCH_CHECK("k_scan1");
+  k_grp_base<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gcptr, nblk, C, gb, NG);
+  QAGNN_LAUNCH_CHECK("k_grp_base");
   k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_scatter");
-  k_chunk_counts<<<cdiv(C, 1024), 1024, 0, stream>>>(g->cls_count, nch, C);
+  k_chunk_counts<<<cdiv(pairs, 1024), 1024, 0, stream>>>(gc_cnt, nch, pairs);
   QAGNN_LAUNCH_CHECK("k_chunk_counts");
-  k_chunk_scan<<<1, 1024, 0, stream>>>(nch, g->chunkptr, C);
+  k_scan1<<<1, 1024, 0, stream>>>(nch, g->chunkptr, pairs);
   QAGNN_LAUNCH_CHECK("k_chunk_scan");
-  k_chunk_fill<<<cdiv(C, 256), 256, 0, stream>>>(g->clsptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C);
+  k_chunk_fill<<<cdiv(pairs, 256), 256, 0, stream>>>(gcptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C, pairs);
   QAGNN_LAUNCH_CHECK("k_chunk_fill");
   return QAGNN_OK;
 }

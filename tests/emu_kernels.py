@@ -8,7 +8,7 @@ It is installed with qagnn_amd.ops.set_kernels() by tests and never imported by 
 import numpy as np
 import torch
 
-CLS_CHUNK = 64
+CLS_CHUNK, CLS_BLK, CLS_GROUPS = 64, 1024, 64  # QAGNN_CLS_CHUNK, CLS_BLK (graph_prep.hip), QAGNN_CLS_GROUPS
 
 
 class EmuGraph:
@@ -36,53 +36,28 @@ class EmuGraph:
         srcpos[eid_s] = torch.arange(self.Ep, device=dev)
         self.src_t, self.cls_t, self.pos_t = es[eid_t].int(), ec[eid_t].int(), srcpos[eid_t].int()
         self.tgt_t = et[eid_t].int()
-        pos_c = torch.sort(self.cls_s.long(), stable=True).indices
+        # class order: (position group, class)-major -- a group is gb consecutive 1024-position blocks of the source order
+        nblk = (self.Ep + CLS_BLK - 1) // CLS_BLK
+        gb = max(1, (nblk + CLS_GROUPS - 1) // CLS_GROUPS)
+        self.n_groups = (nblk + gb - 1) // gb
+        grp = (torch.arange(self.Ep, device=dev) // CLS_BLK) // gb
+        key = grp * self.C + self.cls_s.long()
+        pos_c = torch.sort(key, stable=True).indices
         self.pos_c = pos_c.int()
         self.src_c, self.tgt_c = self.src_s[pos_c], self.tgt_s[pos_c]
         self.cls_count = torch.bincount(ec, minlength=self.C).int()
-        self.clsptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), self.cls_count.long().cumsum(0)]).int()
-        nch = (self.cls_count.long() + CLS_CHUNK - 1) // CLS_CHUNK
+        pairs = self.n_groups * self.C
+        gc_cnt = torch.bincount(key, minlength=pairs)
+        gcptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), gc_cnt.cumsum(0)])
+        nch = (gc_cnt + CLS_CHUNK - 1) // CLS_CHUNK
         self.chunkptr = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), nch.cumsum(0)]).int()
         self.n_chunks = int(nch.sum())
-        self.max_chunks = self.Ep // CLS_CHUNK + self.C + 1
-        cc, cb, cl = [], [], []
-        for c in range(self.C):
-            b, e = int(self.clsptr[c]), int(self.clsptr[c + 1])
-            for p in range(b, e, CLS_CHUNK):
-                cc.append(c), cb.append(p), cl.append(min(CLS_CHUNK, e - p))
-        self.chunk_cls = torch.tensor(cc, dtype=torch.int32)
-        self.chunk_beg = torch.tensor(cb, dtype=torch.int32)
-        self.chunk_len = torch.tensor(cl, dtype=torch.int32)
-
-
-def bucket_walk(own, b):
-    """Python twin of the control flow of walk_open() + the chunk loop of the bucket-walk kernels in csrc/edge_attn.hip:
-    the positions wave `b` processes, as a list of (position, flush) pairs (flush = the segment's accumulator is stored
-    and reset after this position).  own[p] = segment owner of position p of a CSR order."""
-    Ep = len(own)
-    out = []
-    first = True
-    c0 = b * 64
-    while c0 < Ep:
-        lanes = range(c0, min(c0 + 64, Ep))
-        head = [p for p in lanes if p == 0 or own[p] != own[p - 1]]
-        last = {p for p in lanes if p + 1 >= Ep or own[p] != own[p + 1]}
-        i_lo, i_hi = c0, min(c0 + 64, Ep)
-        if first:
-            if not head:
-                return out
-            i_lo = head[0]
-        elif head:
-            i_hi = head[0]
-        if i_lo >= i_hi:
-            return out
-        first = False
-        for p in range(i_lo, i_hi):
-            out.append((p, p in last))
-        if (i_hi - 1) in last:
-            return out
-        c0 += 64
-    return out
+        self.max_chunks = self.Ep // CLS_CHUNK + pairs + 1
+        pair_of_chunk = torch.repeat_interleave(torch.arange(pairs, device=dev), nch)
+        within = torch.arange(self.n_chunks, device=dev) - self.chunkptr.long()[pair_of_chunk]
+        self.chunk_cls = (pair_of_chunk % self.C).int()
+        self.chunk_beg = (gcptr[pair_of_chunk] + within * CLS_CHUNK).int()
+        self.chunk_len = torch.minimum(torch.full_like(within, CLS_CHUNK), gcptr[pair_of_chunk + 1] - self.chunk_beg.long()).int()
 
 
 def _uniform01(seed, idx):

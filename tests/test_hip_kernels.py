@@ -66,8 +66,8 @@ def golden_graph(case):
 
 
 GRAPH_ARRAYS = [('rowptr_s', 'N+1'), ('tgt_s', 'Ep'), ('src_s', 'Ep'), ('cls_s', 'Ep'), ('eid_s', 'Ep'), ('rowptr_t', 'N+1'),
-                ('src_t', 'Ep'), ('tgt_t', 'Ep'), ('cls_t', 'Ep'), ('pos_t', 'Ep'), ('clsptr', 'C+1'), ('cls_count', 'C'), ('src_c', 'Ep'),
-                ('tgt_c', 'Ep'), ('pos_c', 'Ep'), ('chunkptr', 'C+1')]
+                ('src_t', 'Ep'), ('tgt_t', 'Ep'), ('cls_t', 'Ep'), ('pos_t', 'Ep'), ('cls_count', 'C'), ('src_c', 'Ep'),
+                ('tgt_c', 'Ep'), ('pos_c', 'Ep'), ('chunkptr', 'pairs+1')]
 
 
 @pytest.mark.gpu
@@ -79,7 +79,8 @@ def test_graph_prep_bit_exact(name):
     torch.cuda.synchronize()
     e = EmuGraph(ei, et, nt, R, T)
     assert (g.N, g.E, g.Ep, g.C, g.max_chunks) == (e.N, e.E, e.Ep, e.C, e.max_chunks)
-    sizes = {'N+1': e.N + 1, 'Ep': e.Ep, 'C+1': e.C + 1, 'C': e.C}
+    assert g.c.n_groups == e.n_groups
+    sizes = {'N+1': e.N + 1, 'Ep': e.Ep, 'C+1': e.C + 1, 'C': e.C, 'pairs+1': e.n_groups * e.C + 1}
     for arr, sz in GRAPH_ARRAYS:
         got = g.array(arr, sizes[sz]).cpu()
         assert torch.equal(got, getattr(e, arr).int()), f'{arr} differs'

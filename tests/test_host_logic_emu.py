@@ -203,34 +203,6 @@ def test_unsupported_shapes_raise():
         ops.HeadLayout(4 * 68, 'cpu')
 
 
-@pytest.mark.parametrize('seed,N,E,hub', [(0, 50, 300, False), (1, 700, 9000, True), (2, 40, 0, False), (3, 1, 5, False),
-                                          (4, 130, 64 * 5 - 130, False), (5, 3, 500, True)])
-def test_bucket_walk_covers_every_segment_once(seed, N, E, hub):
-    """Control flow of the bucket-walk edge kernels (csrc/edge_attn.hip: walk_open + chunk loop), replayed in Python:
-    over all waves every position is visited exactly once, a segment is walked by ONE wave in position order, and the
-    accumulator is flushed exactly at the last position of every segment -- including hub segments that span many
-    64-position buckets, buckets where no segment starts, and a position count that is a multiple of 64."""
-    from emu_kernels import EmuGraph, bucket_walk
-    g = torch.Generator().manual_seed(seed)
-    src, tgt = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
-    if hub and E:
-        src[: E // 3] = 0
-        tgt[E // 3: E // 2] = min(1, N - 1)
-    e = EmuGraph(torch.stack([src, tgt]), torch.randint(0, 38, (E,), generator=g), torch.randint(0, 4, (N,), generator=g), 38, 4)
-    for own in (e.src_s.tolist(), e.tgt_t.tolist()):
-        Ep = len(own)
-        seen, flushed_at, walker = [], [], {}
-        for b in range((Ep + 63) // 64):
-            for p, fl in bucket_walk(own, b):
-                seen.append(p)
-                assert walker.setdefault(own[p], b) == b, 'a segment was split between two waves'
-                if fl:
-                    flushed_at.append(p)
-        assert sorted(seen) == list(range(Ep)) and len(seen) == Ep
-        ends = [p for p in range(Ep) if p + 1 == Ep or own[p + 1] != own[p]]
-        assert sorted(flushed_at) == ends and len(ends) == N  # every node owns a segment (its self loop)
-
-
 @pytest.mark.parametrize('fused_hop', [False, True])
 def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch, fused_hop):
     """QAGNN_WGRAD_OVERLAP: inside the stack the weight-gradient launches are queued and issued later (on the GPU: on a side
