@@ -359,11 +359,18 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
   const int ncol4 = DP2 >> 2;
   const int P = 1024 / ncol4;
   const int col4 = threadIdx.x % ncol4, part = threadIdx.x / ncol4;
+  // the class's chunk ranges of all groups first (one load per thread, not 2 dependent loads per group and thread)
+  __shared__ int cp_lo[QAGNN_CLS_GROUPS], cp_hi[QAGNN_CLS_GROUPS];
+  if (threadIdx.x < NG) {
+    cp_lo[threadIdx.x] = chunkptr[threadIdx.x * C + c];
+    cp_hi[threadIdx.x] = chunkptr[threadIdx.x * C + c + 1];
+  }
+  __syncthreads();
   float4 acc = zero4();
   if (part < P) {
     int seen = 0;  // chunks of this class in the groups before g
     for (int g = 0; g < NG; ++g) {
-      const int kb = chunkptr[g * C + c], ke = chunkptr[g * C + c + 1];
+      const int kb = cp_lo[g], ke = cp_hi[g];
       const int first = (part - seen % P + P) % P;
       for (int k = kb + first; k < ke; k += P) acc = add4(acc, ld4(cls_part + (int64_t)k * DP2 + col4 * 4));
       seen += ke - kb;

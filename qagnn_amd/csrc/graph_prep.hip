@@ -59,16 +59,24 @@ __global__ void k_decode_count(const int64_t* __restrict__ edge_index, const int
 }
 
 // ---- exclusive scan of up to 3 independent arrays, one 1024-thread block each ---------------------------------
+// A thread owns SCAN_ITEMS consecutive elements per round (serial sum, then one block-wide scan of the 1024 thread totals):
+// 8192 elements per round instead of 1024, so the 64 000-entry degree arrays take 8 rounds of 3 barriers, not 63.
+constexpr int SCAN_ITEMS = 8;
 __device__ void block_exclusive_scan(const int* __restrict__ in, int* __restrict__ out, int n) {
   __shared__ int wtot[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const int v = i < n ? in[i] : 0;
-    int incl = v;
+  for (int base = 0; base < n; base += 1024 * SCAN_ITEMS) {
+    const int i0 = base + tid * SCAN_ITEMS;
+    int v[SCAN_ITEMS], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      v[k] = i0 + k < n ? in[i0 + k] : 0;
+      tsum += v[k];
+    }
+    int incl = tsum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       int u = __shfl_up(incl, o, 64);
@@ -87,8 +95,12 @@ __device__ void block_exclusive_scan(const int* __restrict__ in, int* __restrict
     }
     __syncthreads();
     const int carry = carry_s;
-    const int woff = wid ? wtot[wid - 1] : 0;
-    if (i < n) out[i] = carry + woff + incl - v;
+    int run = carry + (wid ? wtot[wid - 1] : 0) + incl - tsum;  // exclusive prefix of this thread's first element
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      if (i0 + k < n) out[i0 + k] = run;
+      run += v[k];
+    }
     __syncthreads();
     if (tid == 0) carry_s = carry + wtot[15];
     __syncthreads();
@@ -224,7 +236,11 @@ __global__ __launch_bounds__(1024) void k_chunk_counts(const int* __restrict__ g
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) nch[i] = (gc_cnt[i] + QAGNN_CLS_CHUNK - 1) / QAGNN_CLS_CHUNK;
 }
-__global__ __launch_bounds__(1024) void k_scan1(const int* in, int* out, int n) { block_exclusive_scan(in, out, n); }
+// block 0: gcptr = exclusive scan of the pair counts; block 1: chunkptr = exclusive scan of the pairs' chunk counts
+__global__ __launch_bounds__(1024) void k_scan_pairs(const int* gc_cnt, int* gcptr, const int* nch, int* chunkptr, int n) {
+  if (blockIdx.x == 0) block_exclusive_scan(gc_cnt, gcptr, n);
+  else block_exclusive_scan(nch, chunkptr, n);
+}
 __global__ void k_chunk_fill(const int* __restrict__ gcptr, const int* __restrict__ chunkptr, int* __restrict__ chunk_cls,
                              int* __restrict__ chunk_beg, int* __restrict__ chunk_len, int* __restrict__ n_chunks, int C, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,16 +353,14 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   QAGNN_LAUNCH_CHECK("k_cls_hist");
   k_grp_count<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gc_cnt, nblk, C, gb, NG);
   QAGNN_LAUNCH_CHECK("k_grp_count");
-  k_scan1<<<1, 1024, 0, stream>>>(gc_cnt, gcptr, pairs);  // first class-order slot of every (group, class) pair
-  QAGNN_LAUNCH_CHECK("k_scan1");
+  k_chunk_counts<<<cdiv(pairs, 1024), 1024, 0, stream>>>(gc_cnt, nch, pairs);
+  QAGNN_LAUNCH_CHECK("k_chunk_counts");
+  k_scan_pairs<<<2, 1024, 0, stream>>>(gc_cnt, gcptr, nch, g->chunkptr, pairs);  // first class-order slot / first chunk of every pair
+  QAGNN_LAUNCH_CHECK("k_scan_pairs");
   k_grp_base<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gcptr, nblk, C, gb, NG);
   QAGNN_LAUNCH_CHECK("k_grp_base");
   k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_scatter");
-  k_chunk_counts<<<cdiv(pairs, 1024), 1024, 0, stream>>>(gc_cnt, nch, pairs);
-  QAGNN_LAUNCH_CHECK("k_chunk_counts");
-  k_scan1<<<1, 1024, 0, stream>>>(nch, g->chunkptr, pairs);
-  QAGNN_LAUNCH_CHECK("k_chunk_scan");
   k_chunk_fill<<<cdiv(pairs, 256), 256, 0, stream>>>(gcptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C, pairs);
   QAGNN_LAUNCH_CHECK("k_chunk_fill");
   return QAGNN_OK;

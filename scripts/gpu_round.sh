@@ -49,13 +49,14 @@ if [[ " $* " == *" prof "* ]]; then
   python scripts/trace_by_shape.py /tmp/prof/r1_kernel_trace.csv > gpurun_out/prof/by_shape.txt 2>&1
   ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
 fi
-if [[ "$*" == *pmc* ]]; then
+if [[ " $* " == *" pmc "* ]]; then
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$ctr; mkdir -p /tmp/pmc_$ctr
     ( cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) 2>&1 | tail -n 5 > gpurun_out/pmc_$ctr.log
     python scripts/pmc_by_kernel.py /tmp/pmc_$ctr/p_counter_collection.csv > gpurun_out/pmc_$ctr.txt 2>&1
     ls /tmp/pmc_$ctr >> gpurun_out/pmc_$ctr.log
   done
+  python scripts/pmc_edge_traffic.py /tmp/pmc_FETCH_SIZE/p_counter_collection.csv /tmp/pmc_WRITE_SIZE/p_counter_collection.csv 64000 208 > gpurun_out/pmc_edge_fwd.json 2> gpurun_out/pmc_edge_traffic.err
 fi
 if [[ "$*" == *sqpmc* ]]; then   # SQ counters of the GEMM micro-benchmark (own pass, kernel-trace only)
   rm -rf /tmp/sqpmc; mkdir -p /tmp/sqpmc
