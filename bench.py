@@ -253,7 +253,7 @@ def main():
                                    '(LM encoder excluded: random sent_vecs), dropout 0.2, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
                        'parallelism': f'dp{world}' if world > 1 else 'single'},
-            'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores + k_edge_softmax + k_edge_aggregate), per GAT layer',
+            'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores [scores + segment softmax] + k_edge_aggregate), per GAT layer',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': traffic, 'traffic_source': 'profiles/pmc_edge_fwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)' if traffic else None,
                          'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),

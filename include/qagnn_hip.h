@@ -180,6 +180,15 @@ int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t
                             float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
+/* The two elementwise backward kernels of a hop with the column sums of their OUTPUT as a by-product (the bias gradients of
+ * the Linear behind them): one pass instead of an elementwise pass + a column-reduction pass; sums bit-identical to
+ * qagnn_colreduce_f32 mode 0 on the output.  workspace: qagnn_colreduce_workspace_elems(R, Cc, 1) floats. */
+int qagnn_gelu_dropout_bwd_colsum_f32(const float* X, const float* dY, float* dX, int32_t R, int32_t Cc, float p, uint64_t seed,
+                                      float* colsum /* [Cc] */, float* workspace, qagnn_stream_t stream);
+int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, const float* gamma, const float* sum_dy,
+                                 const float* sum_dy_hhat, float inv_rows, const float* roww, float* colsum /* [Cc] */, float* workspace,
+                                 qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

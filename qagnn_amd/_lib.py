@@ -17,6 +17,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
+           'qagnn_gelu_dropout_bwd_colsum_f32', 'qagnn_bn_relu_bwd_colsum_f32',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
@@ -81,6 +82,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    lib.qagnn_gelu_dropout_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _vp, _vp, _vp]
+    lib.qagnn_bn_relu_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
@@ -330,6 +333,31 @@ class HipKernels:
         self._check(self.lib.qagnn_gelu_dropout_bwd_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), X.numel(), float(p),
                                                         int(seed), self._stream()), 'qagnn_gelu_dropout_bwd_f32')
         return dX
+
+    def gelu_dropout_bwd_colsum(self, X, dY, p, seed):
+        """-> (dX, colsum(dX) [Cc]) in one pass."""
+        _chk2d(X, 'X'), _chk2d(dY, 'dY')
+        R, Cc = X.shape
+        dX = torch.empty_like(X)
+        cs = torch.empty(Cc, dtype=torch.float32, device=X.device)
+        ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, 1), dtype=torch.float32, device=X.device)
+        self._check(self.lib.qagnn_gelu_dropout_bwd_colsum_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), R, Cc, float(p), int(seed),
+                                                               cs.data_ptr(), ws.data_ptr(), self._stream()), 'qagnn_gelu_dropout_bwd_colsum_f32')
+        return dX, cs
+
+    def bn_relu_bwd_colsum(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
+        """bn_relu_bwd that also returns colsum(dH) [Cc]."""
+        assert red.is_contiguous() and red.shape == (2, H.size(1))
+        _chk2d(dR, 'dR'), _chk2d(H, 'H')
+        R, Cc = H.shape
+        dH = torch.empty_like(H)
+        cs = torch.empty(Cc, dtype=torch.float32, device=H.device)
+        ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, 1), dtype=torch.float32, device=H.device)
+        rc = self.lib.qagnn_bn_relu_bwd_colsum_f32(dR.data_ptr(), H.data_ptr(), dH.data_ptr(), Cc, R, Cc, mean.data_ptr(), invstd.data_ptr(),
+                                                   scale.data_ptr(), shift.data_ptr(), gamma.data_ptr(), red[0].data_ptr(), red[1].data_ptr(),
+                                                   float(inv_rows), _ptr(roww), cs.data_ptr(), ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_bn_relu_bwd_colsum_f32')
+        return dH, cs
 
     def sin_basis(self, score, js, ldo):
         assert score.is_contiguous() and js.is_contiguous() and score.dtype == js.dtype == torch.float32

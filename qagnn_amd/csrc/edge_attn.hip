@@ -70,12 +70,24 @@ __device__ __forceinline__ void slab_init(float4* slab, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward 1/3: raw scores, one wave per SOURCE node (Q row in registers; gathers K[tgt] and Ek[cls])
+// forward 1/2: scores + softmax over the out-edges, one wave per SOURCE node (Q row in registers; gathers K[tgt], Ek[cls]).
+// PyG softmax (max, exp, sum, / (sum + 1e-16)) then * out-degree.  A segment of <= 64 edges (all but the hubs) never leaves
+// the wave: its scores sit in the LDS slab, lane i takes the 4 head scores of edge i, the max / sum run over the lanes and
+// a, alpha go out as one coalesced float4 per lane.  Longer segments write their raw scores chunk by chunk and are
+// normalised by three sweeps over them afterwards (same wave; the sweeps read what other lanes of the wave stored).
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 wave_max4(float4 v) {
+  return make_float4(wave_max(v.x), wave_max(v.y), wave_max(v.z), wave_max(v.w));
+}
+__device__ __forceinline__ float4 wave_sum4(float4 v) {
+  return make_float4(wave_sum(v.x), wave_sum(v.y), wave_sum(v.z), wave_sum(v.w));
+}
+
 __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
                                                      const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale,
-                                                     float* __restrict__ score, int N, int C, const int* __restrict__ gate) {
+                                                     float* __restrict__ score, float* __restrict__ a, float* __restrict__ alpha,
+                                                     int N, int C, const int* __restrict__ gate) {
   __shared__ float4 slab[4][SLAB_ROWS];
   if (gate && *gate == 0) return;  // the LDS-resident kernel took this graph (device-side decision)
   const int s = wave_node();
@@ -86,6 +98,8 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe);
   const float4 q = buf_ld4(rK, L.voff + 2u * DP * 4u, (uint32_t)s * pk);
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+  const float deg = (float)(end - beg);
+  const bool in_wave = end - beg <= 64;
   float* const sl = reinterpret_cast<float*>(slab[L.w]) + L.g;
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int cnt = min(64, end - e0), lc = e0 + min(L.lane, cnt - 1);
@@ -101,38 +115,43 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
 #pragma unroll
       for (int u = 0; u < EDGE_UNROLL; ++u) {
         const float p = row16_sum(dot4(q, add4(k[u], ek[u]))) * qscale;
-        if (L.j == 0) sl[(i + u) * 4] = p;  // rows past cnt take the clamped duplicates: never stored
+        if (L.j == 0) sl[(i + u) * 4] = p;  // rows past cnt take the clamped duplicates: never used
       }
     }
     const float4 sc = slab[L.w][L.lane];  // lane i: the 4 head scores of edge e0 + i
-    if (L.lane < cnt) st4(score + (int64_t)(e0 + L.lane) * 4, sc);
+    if (in_wave) {
+      const bool live = L.lane < cnt;
+      const float ninf = -INFINITY;
+      const float4 m = wave_max4(live ? sc : make_float4(ninf, ninf, ninf, ninf));
+      const float4 ex = live ? make_float4(expf(sc.x - m.x), expf(sc.y - m.y), expf(sc.z - m.z), expf(sc.w - m.w)) : zero4();
+      const float4 sum = wave_sum4(ex);
+      if (live) {
+        const float4 av = make_float4(ex.x / (sum.x + 1e-16f), ex.y / (sum.y + 1e-16f), ex.z / (sum.z + 1e-16f), ex.w / (sum.w + 1e-16f));
+        st4(a + (int64_t)(e0 + L.lane) * 4, av);
+        st4(alpha + (int64_t)(e0 + L.lane) * 4, make_float4(av.x * deg, av.y * deg, av.z * deg, av.w * deg));
+      }
+    } else if (L.lane < cnt) {
+      st4(score + (int64_t)(e0 + L.lane) * 4, sc);
+    }
   }
-}
-
-// forward 2/3: softmax over each source segment (PyG softmax: max, exp, sum, / (sum + 1e-16)), then * out-degree
-__global__ __launch_bounds__(256) void k_edge_softmax(const int* __restrict__ rowptr_s, const float* __restrict__ score,
-                                                      float* __restrict__ a, float* __restrict__ alpha, int N,
-                                                      const int* __restrict__ gate) {
-  if (gate && *gate == 0) return;
-  const int s = wave_node();
-  if (s >= N) return;
-  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+  if (in_wave) return;
+  // hub segment: make the raw scores this wave stored visible to all of its lanes, then max / sum / normalise in three sweeps
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   float m = -INFINITY;
-  for (int e = beg + j; e < end; e += 16) m = fmaxf(m, score[(int64_t)e * 4 + g]);
+  for (int e = beg + L.j; e < end; e += 16) m = fmaxf(m, score[(int64_t)e * 4 + L.g]);
   m = row16_max(m);
   float sum = 0.f;
-  for (int e = beg + j; e < end; e += 16) sum += expf(score[(int64_t)e * 4 + g] - m);
+  for (int e = beg + L.j; e < end; e += 16) sum += expf(score[(int64_t)e * 4 + L.g] - m);
   sum = row16_sum(sum);
-  const float deg = (float)(end - beg);
-  for (int e = beg + j; e < end; e += 16) {
-    const float av = expf(score[(int64_t)e * 4 + g] - m) / (sum + 1e-16f);
-    a[(int64_t)e * 4 + g] = av;
-    alpha[(int64_t)e * 4 + g] = av * deg;
+  for (int e = beg + L.j; e < end; e += 16) {
+    const float av = expf(score[(int64_t)e * 4 + L.g] - m) / (sum + 1e-16f);
+    a[(int64_t)e * 4 + L.g] = av;
+    alpha[(int64_t)e * 4 + L.g] = av * deg;
   }
 }
 
-// forward 3/3: weighted sum of messages, one wave per TARGET node (gathers M[src] and Em[cls]; no atomics)
+// forward 2/2: weighted sum of messages, one wave per TARGET node (gathers M[src] and Em[cls]; no atomics)
 __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
                                                         const int* __restrict__ cls_t, const int* __restrict__ pos_t,
                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
@@ -510,10 +529,8 @@ static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
                 "edge_attn_fwd: bad output arguments");
   const int nb = cdiv(g->N, 4);
-  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, g->N, g->C, gate);
+  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C, gate);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
-  k_edge_softmax<<<nb, 256, 0, stream>>>(g->rowptr_s, score, a, alpha, g->N, gate);
-  QAGNN_LAUNCH_CHECK("k_edge_softmax");
   k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C, gate);
   QAGNN_LAUNCH_CHECK("k_edge_aggregate");
   return QAGNN_OK;

@@ -210,24 +210,43 @@ __global__ __launch_bounds__(256) void k_grp_base(int* __restrict__ hist, const 
   }
 }
 
-__global__ __launch_bounds__(256) void k_cls_scatter(const int* __restrict__ cls_s, const int* __restrict__ src_s,
-                                                     const int* __restrict__ tgt_s, const int* __restrict__ hist,
-                                                     int* __restrict__ src_c, int* __restrict__ tgt_c, int* __restrict__ pos_c,
-                                                     int Ep, int C) {
-  __shared__ int lc[CLS_BLK];
-  const int base = blockIdx.x * CLS_BLK;
-  for (int i = threadIdx.x; i < CLS_BLK; i += 256) lc[i] = base + i < Ep ? cls_s[base + i] : -1;
-  __syncthreads();
-  for (int i = threadIdx.x; i < CLS_BLK; i += 256) {
-    const int p = base + i;
-    if (p >= Ep) continue;
-    const int c = lc[i];
-    int rank = 0;
-    for (int j = 0; j < i; ++j) rank += lc[j] == c;
-    const int dst = hist[(int64_t)blockIdx.x * C + c] + rank;
-    pos_c[dst] = p;
-    src_c[dst] = src_s[p];
-    tgt_c[dst] = tgt_s[p];
+// Stable scatter of one CLS_BLK-position block into the class order, ONE wave per block: the block is walked in 16 chunks of
+// 64 positions; inside a chunk a lane's rank among the lanes of its class comes from ballots (one round per distinct class
+// of the chunk, no memory traffic), the running per-class slot counters of the block live in LDS and are read once and
+// written once per chunk.  (The first version ranked every position against all earlier positions of the block: 512 LDS
+// reads per position on average, 80 us per batch.)
+__global__ __launch_bounds__(64) void k_cls_scatter(const int* __restrict__ cls_s, const int* __restrict__ src_s,
+                                                    const int* __restrict__ tgt_s, const int* __restrict__ hist,
+                                                    int* __restrict__ src_c, int* __restrict__ tgt_c, int* __restrict__ pos_c,
+                                                    int Ep, int C) {
+  extern __shared__ int cnt[];  // [C] next class-order slot of class c for this block
+  const int lane = threadIdx.x, base = blockIdx.x * CLS_BLK;
+  for (int c = lane; c < C; c += 64) cnt[c] = hist[(int64_t)blockIdx.x * C + c];
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));  // lanes below this one
+  for (int q = 0; q < CLS_BLK / 64; ++q) {
+    const int p = base + q * 64 + lane;
+    const bool live = p < Ep;
+    if (__ballot(live) == 0) break;
+    const int c = live ? cls_s[p] : -1;
+    const int first = live ? cnt[c] : 0;  // slot of the chunk's first position of class c
+    int rank = 0, total = 0;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int cl = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
+      const unsigned long long m = __ballot(c == cl);
+      if (c == cl) {
+        rank = __builtin_popcountll(m & lt);
+        total = __builtin_popcountll(m);
+      }
+      todo &= ~m;
+    }
+    if (live) {
+      if (rank == 0) cnt[c] = first + total;  // exactly one lane per class of the chunk
+      const int dst = first + rank;
+      pos_c[dst] = p;
+      src_c[dst] = src_s[p];
+      tgt_c[dst] = tgt_s[p];
+    }
   }
 }
 
@@ -359,7 +378,7 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   QAGNN_LAUNCH_CHECK("k_scan_pairs");
   k_grp_base<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gcptr, nblk, C, gb, NG);
   QAGNN_LAUNCH_CHECK("k_grp_base");
-  k_cls_scatter<<<nblk, 256, 0, stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
+  k_cls_scatter<<<nblk, 64, C * sizeof(int), stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_scatter");
   k_chunk_fill<<<cdiv(pairs, 256), 256, 0, stream>>>(gcptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C, pairs);
   QAGNN_LAUNCH_CHECK("k_chunk_fill");

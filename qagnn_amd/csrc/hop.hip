@@ -132,27 +132,26 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
   const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
-  const int64_t nel = (int64_t)N * DP;
 
   // GELU + dropout backward
   const float* dout = h->dy;
-  if (h->apply_act) {
-    HOP_TRY(qagnn_gelu_dropout_bwd_f32(h->out, h->dy, bufA, nel, h->p_drop, h->seed, stream));
+  if (h->apply_act) {  // db2 = colsum(d out) falls out of the same pass
+    HOP_TRY(qagnn_gelu_dropout_bwd_colsum_f32(h->out, h->dy, bufA, N, DP, h->p_drop, h->seed, h->db2, crws, stream));
     dout = bufA;
+  } else {
+    HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   }
-  // second Linear: dW2^T = relu(bn(h1))^T dout, db2 = colsum(dout), d r = dout W2
+  // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
-  HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
   HOP_TRY(qagnn_gemm_nn_f32(&gr, stream));
   // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1 (overwrites d out: it is dead by now)
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
-  HOP_TRY(qagnn_bn_relu_bwd_f32(bufB, h->h1, bufA, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
-                                h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, stream));
-  // first Linear
+  HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufA, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
+                                       h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, h->db1, crws, stream));
+  // first Linear (db1 = colsum(d h1) came out of the pass above)
   HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufA, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, stream));
-  HOP_TRY(qagnn_colreduce_f32(0, bufA, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db1, crws, stream));
   qagnn_gemm_nn_args gg = {};
   gg.A1 = bufA; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
   HOP_TRY(qagnn_gemm_nn_f32(&gg, stream));

@@ -510,41 +510,34 @@ class GatMlpFn(torch.autograd.Function):
         K = kernels()
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
-        dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
-        if ctx.defer:  # weight / bias gradients of both Linears queued for the next edge backward (see defer_wgrads)
+        # the elementwise backward kernels leave the column sums of their outputs (= the bias gradients) as a by-product
+        if apply_act:
+            dout, db2 = K.gelu_dropout_bwd_colsum(out, dy.contiguous(), p, seed)
+        else:
+            dout = dy.contiguous()
+            db2 = K.colsum(dout)[0]
+        if ctx.defer:  # weight gradients of both Linears queued for the next edge backward (see defer_wgrads)
             Cc = dout.size(1)
-            dW2t, db2 = _wg_empty(dout, (h1.size(1), Cc)), _wg_empty(dout, (1, Cc))
+            dW2t = _wg_empty(dout, (h1.size(1), Cc))
             dr = K.gemm_nn(dout, W2)
             red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
-            dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
-                                roww=row_weight if training else None)
-            dW1t, db1 = _wg_empty(dout, (aggr.size(1), h1.size(1))), _wg_empty(dout, (1, h1.size(1)))
-            defer_wgrads([lambda: K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, out=dW2t), lambda: K.colsum(dout, out=db2),
-                          lambda: K.gemm_tn(aggr, dh1, out=dW1t), lambda: K.colsum(dh1, out=db1)],
+            dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
+                                            roww=row_weight if training else None)
+            dW1t = _wg_empty(dout, (aggr.size(1), h1.size(1)))
+            defer_wgrads([lambda: K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, out=dW2t), lambda: K.gemm_tn(aggr, dh1, out=dW1t)],
                          (h1, dout, scale, shift, aggr, dh1))
             daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
-            return (daggr, dW1t, None, db1[0], red[1], red[0], dW2t, None, db2[0], None, None, None, None, None, None, None, None,
-                    None)
+            return (daggr, dW1t, None, db1, red[1], red[0], dW2t, None, db2, None, None, None, None, None, None, None, None, None)
         wg = _WgradStream(dout)
         with wg:  # side stream: gradients of the second Linear
-            if FUSED_COLSUM:
-                dW2t, db2 = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, colsum_groups=1)  # relu(bn(h1))^T @ dout, colsum(dout)
-                db2 = db2[0]
-            else:
-                dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
-                db2 = K.colsum(dout)[0]
+            dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
-        dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
-                            roww=row_weight if training else None)
+        dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
+                                        roww=row_weight if training else None)
         with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
-            if FUSED_COLSUM:
-                dW1t, db1 = K.gemm_tn(aggr, dh1, colsum_groups=1)
-                db1 = db1[0]
-            else:
-                dW1t = K.gemm_tn(aggr, dh1)
-                db1 = K.colsum(dh1)[0]
+            dW1t = K.gemm_tn(aggr, dh1)
         daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
         wg.join()
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
@@ -604,14 +597,15 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     KMQ, aa, aggr, h1, out, stats = saved
     mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
     R = aggr.size(0)
-    dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
+    if apply_act:
+        dout, db2 = K.gelu_dropout_bwd_colsum(out, dy, p, seed)
+    else:
+        dout, db2 = dy, K.colsum(dy)[0]
     dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
-    db2 = K.colsum(dout)[0]
     dr = K.gemm_nn(dout, W2)
     red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
-    dh1 = K.bn_relu_bwd(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
+    dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
     dW1t = K.gemm_tn(aggr, dh1)
-    db1 = K.colsum(dh1)[0]
     daggr = K.gemm_nn(dh1, W1)
     dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
     dWx_t = K.gemm_tn(X, dKMQ)

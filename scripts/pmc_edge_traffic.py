@@ -24,7 +24,7 @@ def pick(table, needle):
 
 fetch, write = by_kernel(sys.argv[1]), by_kernel(sys.argv[2])
 N, DP = int(sys.argv[3]), int(sys.argv[4])
-names = {'k_edge_scores': 'qagnn::k_edge_scores(', 'k_edge_softmax': 'qagnn::k_edge_softmax(', 'k_edge_aggregate': 'qagnn::k_edge_aggregate('}
+names = {'k_edge_scores': 'qagnn::k_edge_scores(', 'k_edge_aggregate': 'qagnn::k_edge_aggregate('}
 per = {k: {'FETCH_SIZE': round(pick(fetch, n), 1), 'WRITE_SIZE': round(pick(write, n), 1)} for k, n in names.items()}
 bwd_names = {'k_edge_bwd_src1': 'qagnn::k_edge_bwd_src1(', 'k_edge_bwd_src2': 'qagnn::k_edge_bwd_src2(', 'k_edge_bwd_tgt': 'qagnn::k_edge_bwd_tgt(',
              'k_edge_bwd_cls': 'qagnn::k_edge_bwd_cls(', 'k_cls_reduce': 'qagnn::k_cls_reduce('}

@@ -203,6 +203,14 @@ class EmuKernels:
     def gelu_dropout_bwd(self, X, dY, p, seed):
         return dY * self._keep(X, p, seed) * _gelu_grad(X)
 
+    def gelu_dropout_bwd_colsum(self, X, dY, p, seed):
+        dX = self.gelu_dropout_bwd(X, dY, p, seed)
+        return dX, dX.sum(0)
+
+    def bn_relu_bwd_colsum(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
+        dH = self.bn_relu_bwd(dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww)
+        return dH, dH.sum(0)
+
     def sin_basis(self, score, js, ldo):
         out = torch.zeros(score.numel(), ldo, dtype=score.dtype, device=score.device)
         out[:, :js.numel()] = torch.sin(js.unsqueeze(0) * score.reshape(-1, 1))
