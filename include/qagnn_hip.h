@@ -80,7 +80,7 @@ typedef struct qagnn_graph {
   int32_t n_groups;            /* position groups of the class order */
 } qagnn_graph;
 
-#define QAGNN_CLS_CHUNK 64
+#define QAGNN_CLS_CHUNK 256
 #define QAGNN_CLS_GROUPS 64
 
 /* int32 elements of device storage needed for all arrays of a qagnn_graph plus scratch. */
@@ -180,11 +180,10 @@ int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t
                             float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
-/* The two elementwise backward kernels of a hop with the column sums of their OUTPUT as a by-product (the bias gradients of
- * the Linear behind them): one pass instead of an elementwise pass + a column-reduction pass; sums bit-identical to
- * qagnn_colreduce_f32 mode 0 on the output.  workspace: qagnn_colreduce_workspace_elems(R, Cc, 1) floats. */
-int qagnn_gelu_dropout_bwd_colsum_f32(const float* X, const float* dY, float* dX, int32_t R, int32_t Cc, float p, uint64_t seed,
-                                      float* colsum /* [Cc] */, float* workspace, qagnn_stream_t stream);
+/* qagnn_bn_relu_bwd_f32 with the column sums of its OUTPUT as a by-product (the bias gradient of the Linear in front of the
+ * BatchNorm): one pass instead of an elementwise pass + a column-reduction pass; sums bit-identical to qagnn_colreduce_f32
+ * mode 0 on the output.  workspace: qagnn_colreduce_workspace_elems(R, Cc, 1) floats.  (The same fusion for the GELU + dropout
+ * backward measured no gain: that kernel is ALU-bound and the reduction's block shape leaves it 2 blocks per CU.) */
 int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, const float* gamma, const float* sum_dy,
                                  const float* sum_dy_hhat, float inv_rows, const float* roww, float* colsum /* [Cc] */, float* workspace,

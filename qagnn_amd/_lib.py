@@ -17,7 +17,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
-           'qagnn_gelu_dropout_bwd_colsum_f32', 'qagnn_bn_relu_bwd_colsum_f32',
+           'qagnn_bn_relu_bwd_colsum_f32',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
@@ -82,7 +82,6 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
-    lib.qagnn_gelu_dropout_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _f32, _u64, _vp, _vp, _vp]
     lib.qagnn_bn_relu_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
@@ -333,17 +332,6 @@ class HipKernels:
         self._check(self.lib.qagnn_gelu_dropout_bwd_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), X.numel(), float(p),
                                                         int(seed), self._stream()), 'qagnn_gelu_dropout_bwd_f32')
         return dX
-
-    def gelu_dropout_bwd_colsum(self, X, dY, p, seed):
-        """-> (dX, colsum(dX) [Cc]) in one pass."""
-        _chk2d(X, 'X'), _chk2d(dY, 'dY')
-        R, Cc = X.shape
-        dX = torch.empty_like(X)
-        cs = torch.empty(Cc, dtype=torch.float32, device=X.device)
-        ws = torch.empty(self.lib.qagnn_colreduce_workspace_elems(R, Cc, 1), dtype=torch.float32, device=X.device)
-        self._check(self.lib.qagnn_gelu_dropout_bwd_colsum_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), R, Cc, float(p), int(seed),
-                                                               cs.data_ptr(), ws.data_ptr(), self._stream()), 'qagnn_gelu_dropout_bwd_colsum_f32')
-        return dX, cs
 
     def bn_relu_bwd_colsum(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
         """bn_relu_bwd that also returns colsum(dH) [Cc]."""

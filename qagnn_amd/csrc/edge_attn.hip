@@ -320,14 +320,16 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
 }
 
-// one wave per class chunk (<= QAGNN_CLS_CHUNK edges of one class inside one position group)
+// one wave per class chunk (<= QAGNN_CLS_CHUNK = 256 edges of one class inside one position group), walked 64 edges at a time.
+// (256 rather than 64: the few big (group, class) pairs -- the self loops of the KG nodes -- then leave 4x fewer partials,
+// and it is the largest class's partial list that bounds k_cls_reduce.)
 __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_chunks, const int* __restrict__ chunk_beg,
                                                       const int* __restrict__ chunk_len, const int* __restrict__ src_c,
                                                       const int* __restrict__ tgt_c, const int* __restrict__ pos_c,
                                                       const float* __restrict__ KMQ, int ldk, int HP,
                                                       const float* __restrict__ alpha, const float* __restrict__ gsb,
                                                       const float* __restrict__ G, int ldg, float* __restrict__ cls_part, int N) {
-  __shared__ float4 slab[2][4][SLAB_ROWS];  // gs | alpha of the chunk
+  __shared__ float4 slab[2][4][SLAB_ROWS];  // gs | alpha of the current 64 edges
   // chunks are in (position group, class) order: the remap gives every XCD a contiguous run of groups, whose node rows its L2
   // then serves (the grid is sized for max_chunks, so the remap runs over the blocks that really have a chunk)
   const int nch = *n_chunks, nb_real = (nch + 3) >> 2;
@@ -338,29 +340,31 @@ __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_
   const int DP = 4 * HP;
   const uint32_t pk = (uint32_t)ldk * 4u, pg = (uint32_t)ldg * 4u, vq = L.voff + 2u * DP * 4u;
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rG = make_rsrc(G, (uint32_t)N * pg);
-  const int beg = __builtin_amdgcn_readfirstlane(chunk_beg[k]), cnt = __builtin_amdgcn_readfirstlane(chunk_len[k]);
-  const int lc = beg + min(L.lane, cnt - 1);
-  const uint32_t sv = (uint32_t)src_c[lc] * pk, tv = (uint32_t)tgt_c[lc] * pg;
-  const int pv = pos_c[lc];
+  const int beg = __builtin_amdgcn_readfirstlane(chunk_beg[k]), len = __builtin_amdgcn_readfirstlane(chunk_len[k]);
   slab_init(slab[0][L.w], L.lane);
   slab_init(slab[1][L.w], L.lane);
-  slab[0][L.w][L.lane] = L.lane < cnt ? ld4(gsb + (int64_t)pv * 4) : zero4();
-  slab[1][L.w][L.lane] = L.lane < cnt ? ld4(alpha + (int64_t)pv * 4) : zero4();
   const float* const sl_gs = reinterpret_cast<const float*>(slab[0][L.w]) + L.g;
   const float* const sl_al = reinterpret_cast<const float*>(slab[1][L.w]) + L.g;
   float4 dEk = zero4(), dEm = zero4();
-  for (int i = 0; i < cnt; i += EDGE_UNROLL) {
-    float4 qv[EDGE_UNROLL], g4[EDGE_UNROLL];
+  for (int b0 = 0; b0 < len; b0 += 64) {
+    const int cnt = min(64, len - b0), lc = beg + b0 + min(L.lane, cnt - 1);
+    const uint32_t sv = (uint32_t)src_c[lc] * pk, tv = (uint32_t)tgt_c[lc] * pg;
+    const int pv = pos_c[lc];
+    slab[0][L.w][L.lane] = L.lane < cnt ? ld4(gsb + (int64_t)pv * 4) : zero4();
+    slab[1][L.w][L.lane] = L.lane < cnt ? ld4(alpha + (int64_t)pv * 4) : zero4();
+    for (int i = 0; i < cnt; i += EDGE_UNROLL) {
+      float4 qv[EDGE_UNROLL], g4[EDGE_UNROLL];
 #pragma unroll
-    for (int u = 0; u < EDGE_UNROLL; ++u) {
-      const int idx = min(i + u, cnt - 1);
-      qv[u] = buf_ld4(rK, vq, rl(sv, idx));
-      g4[u] = buf_ld4(rG, L.voff, rl(tv, idx));
-    }
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        const int idx = min(i + u, cnt - 1);
+        qv[u] = buf_ld4(rK, vq, rl(sv, idx));
+        g4[u] = buf_ld4(rG, L.voff, rl(tv, idx));
+      }
 #pragma unroll
-    for (int u = 0; u < EDGE_UNROLL; ++u) {
-      dEk = fma4(sl_gs[(i + u) * 4], qv[u], dEk);
-      dEm = fma4(sl_al[(i + u) * 4], g4[u], dEm);
+      for (int u = 0; u < EDGE_UNROLL; ++u) {
+        dEk = fma4(sl_gs[(i + u) * 4], qv[u], dEk);
+        dEm = fma4(sl_al[(i + u) * 4], g4[u], dEm);
+      }
     }
   }
   if (L.act) {

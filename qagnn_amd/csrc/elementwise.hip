@@ -198,19 +198,18 @@ __global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restr
   st4(out + i * 4, o);
 }
 
-// ---- elementwise backward kernels that also leave the column sums of what they write -------------------------------
-// d out = dropout'(gelu'(out)) * dy is the B operand of the second Linear's weight gradient AND its bias gradient is the
-// column sum of it; likewise d h1 (BatchNorm + ReLU backward) for the first Linear.  Taking the sums in a separate pass
-// re-reads 53 MB per layer twice.  Same block shape and the same summation order as k_colreduce<0> (32 rows per wave in
-// row order, (w0 + w1) + (w2 + w3), chunk partials summed by k_colreduce_final), so the sums are bit-identical to the
-// separate pass.  KIND 0: GELU + dropout backward (X = out, X2 = dy).  KIND 1: BatchNorm + ReLU backward (X = dR, X2 = H).
-template <int KIND>
-__global__ __launch_bounds__(256) void k_ew_colsum(const float* __restrict__ X, const float* __restrict__ X2, float* __restrict__ Y,
-                                                   int ld, int R, int Cc, float p, uint64_t seed, const float* __restrict__ mean,
-                                                   const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                   const float* __restrict__ shift, const float* __restrict__ gamma,
-                                                   const float* __restrict__ k1v, const float* __restrict__ k2v, float inv_rows,
-                                                   const float* __restrict__ roww, float* __restrict__ part) {
+// ---- BatchNorm + ReLU backward that also leaves the column sums of what it writes -------------------------------------------
+// d h1 is the B operand of the first Linear's weight gradient AND that Linear's bias gradient is its column sum; taking the
+// sum in a separate pass re-reads 53 MB per layer.  Same block shape and the same summation order as k_colreduce<0> (32 rows
+// per wave in row order, (w0 + w1) + (w2 + w3), chunk partials summed by k_colreduce_final), so the sums are bit-identical
+// to the separate pass.  (The same fusion for the GELU + dropout backward was measured and dropped: 42 us against 27 + 18 --
+// that kernel is ALU-bound and this block shape gives it only 2 blocks per CU.)
+__global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH,
+                                                            int ld, int R, int Cc, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ gamma,
+                                                            const float* __restrict__ k1v, const float* __restrict__ k2v, float inv_rows,
+                                                            const float* __restrict__ roww, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 256 + lane * 4;
@@ -218,48 +217,33 @@ __global__ __launch_bounds__(256) void k_ew_colsum(const float* __restrict__ X, 
   const int r0 = blockIdx.y * CR_ROWS + w * CR_WR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act) {
-    float4 mu = acc, is = acc, sc = acc, sh = acc, ga = acc, k1 = acc, k2 = acc;
-    if (KIND == 1) {
-      mu = ld4(mean + col); is = ld4(invstd + col); sc = ld4(scale + col); sh = ld4(shift + col);
-      ga = ld4(gamma + col); k1 = ld4(k1v + col); k2 = ld4(k2v + col);
-    }
-    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    const float4 mu = ld4(mean + col), is = ld4(invstd + col), sc = ld4(scale + col), sh = ld4(shift + col);
+    const float4 ga = ld4(gamma + col), k1 = ld4(k1v + col), k2 = ld4(k2v + col);
     const int rend = min(R, r0 + CR_WR);
     for (int rb = r0; rb < rend; rb += 8) {
       float4 xs[8], hs[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int r = min(rb + u, rend - 1);
-        xs[u] = ld4(X + (int64_t)r * ld + col);
-        hs[u] = ld4(X2 + (int64_t)r * ld + col);
+        xs[u] = ld4(dR + (int64_t)r * ld + col);
+        hs[u] = ld4(Hh + (int64_t)r * ld + col);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int r = rb + u;
         if (r >= rend) break;
         const float4 x = xs[u], h = hs[u];
+        const float ir = roww ? roww[r] : inv_rows;  // wave-uniform
         float4 o;
-        if (KIND == 0) {
-          const uint64_t e0 = (uint64_t)r * Cc + col;  // element index of the contiguous [R, Cc] tensor: the forward's mask
-#define ONE(f, k)                                                                     \
-  {                                                                                   \
-    const float keep = (p > 0.f && uniform01(seed, e0 + k) < p) ? 0.f : inv_keep;     \
-    o.f = h.f * keep * gelu_grad_f(x.f);                                              \
-  }
-          ONE(x, 0) ONE(y, 1) ONE(z, 2) ONE(w, 3)
-#undef ONE
-        } else {
-          const float ir = roww ? roww[r] : inv_rows;  // wave-uniform
 #define ONE(f)                                                          \
   {                                                                     \
     const float dy = fmaf(h.f, sc.f, sh.f) > 0.f ? x.f : 0.f;           \
     const float hh = (h.f - mu.f) * is.f;                               \
     o.f = ga.f * is.f * (dy - k1.f * ir - hh * (k2.f * ir));            \
   }
-          ONE(x) ONE(y) ONE(z) ONE(w)
+        ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
-        }
-        st4(Y + (int64_t)r * ld + col, o);
+        st4(dH + (int64_t)r * ld + col, o);
         acc = add4(acc, o);
       }
     }
@@ -374,22 +358,6 @@ extern "C" int qagnn_sin_basis_f32(const float* score, const float* js, float* o
   return QAGNN_OK;
 }
 
-// d X = dropout'(gelu'(X)) * dY  and  colsum[c] = sum_r d X[r][c]  in one pass (X, dY, dX contiguous [R, Cc])
-extern "C" int qagnn_gelu_dropout_bwd_colsum_f32(const float* X, const float* dY, float* dX, int32_t R, int32_t Cc, float p, uint64_t seed,
-                                                 float* colsum, float* workspace, qagnn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  QAGNN_REQUIRE(X && dY && dX && colsum && workspace && R > 0 && Cc > 0 && Cc % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX),
-                QAGNN_EINVAL, "gelu_dropout_bwd_colsum: bad args");
-  QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd_colsum: p=%f", p);
-  dim3 grid(cdiv(Cc, 256), cdiv(R, CR_ROWS));
-  k_ew_colsum<0><<<grid, 256, 0, stream>>>(X, dY, dX, Cc, R, Cc, p, seed, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,
-                                           nullptr, workspace);
-  QAGNN_LAUNCH_CHECK("k_ew_colsum<0>");
-  k_colreduce_final<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(workspace, colsum, grid.y, Cc, 1.0f);
-  QAGNN_LAUNCH_CHECK("k_colreduce_final");
-  return QAGNN_OK;
-}
-
 // qagnn_bn_relu_bwd_f32 that also returns colsum[c] = sum_r dH[r][c] (the bias gradient of the Linear in front of the BatchNorm)
 extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
                                             const float* invstd, const float* scale, const float* shift, const float* gamma,
@@ -400,9 +368,9 @@ extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, fl
                 "bn_relu_bwd_colsum: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd_colsum: bad sizes");
   dim3 grid(cdiv(Cc, 256), cdiv(R, CR_ROWS));
-  k_ew_colsum<1><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, 0.f, 0, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat, inv_rows, roww,
-                                           workspace);
-  QAGNN_LAUNCH_CHECK("k_ew_colsum<1>");
+  k_bn_relu_bwd_colsum<<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat, inv_rows, roww,
+                                                 workspace);
+  QAGNN_LAUNCH_CHECK("k_bn_relu_bwd_colsum");
   k_colreduce_final<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(workspace, colsum, grid.y, Cc, 1.0f);
   QAGNN_LAUNCH_CHECK("k_colreduce_final");
   return QAGNN_OK;

@@ -135,12 +135,11 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
 
   // GELU + dropout backward
   const float* dout = h->dy;
-  if (h->apply_act) {  // db2 = colsum(d out) falls out of the same pass
-    HOP_TRY(qagnn_gelu_dropout_bwd_colsum_f32(h->out, h->dy, bufA, N, DP, h->p_drop, h->seed, h->db2, crws, stream));
+  if (h->apply_act) {
+    HOP_TRY(qagnn_gelu_dropout_bwd_f32(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, stream));
     dout = bufA;
-  } else {
-    HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   }
+  HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
   qagnn_gemm_nn_args gr = {};

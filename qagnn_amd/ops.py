@@ -510,12 +510,8 @@ class GatMlpFn(torch.autograd.Function):
         K = kernels()
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
-        # the elementwise backward kernels leave the column sums of their outputs (= the bias gradients) as a by-product
-        if apply_act:
-            dout, db2 = K.gelu_dropout_bwd_colsum(out, dy.contiguous(), p, seed)
-        else:
-            dout = dy.contiguous()
-            db2 = K.colsum(dout)[0]
+        dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
+        db2 = K.colsum(dout)[0]
         if ctx.defer:  # weight gradients of both Linears queued for the next edge backward (see defer_wgrads)
             Cc = dout.size(1)
             dW2t = _wg_empty(dout, (h1.size(1), Cc))
@@ -597,10 +593,8 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     KMQ, aa, aggr, h1, out, stats = saved
     mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
     R = aggr.size(0)
-    if apply_act:
-        dout, db2 = K.gelu_dropout_bwd_colsum(out, dy, p, seed)
-    else:
-        dout, db2 = dy, K.colsum(dy)[0]
+    dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
+    db2 = K.colsum(dout)[0]
     dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
     dr = K.gemm_nn(dout, W2)
     red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)

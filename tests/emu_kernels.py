@@ -8,7 +8,7 @@ It is installed with qagnn_amd.ops.set_kernels() by tests and never imported by 
 import numpy as np
 import torch
 
-CLS_CHUNK, CLS_BLK, CLS_GROUPS = 64, 1024, 64  # QAGNN_CLS_CHUNK, CLS_BLK (graph_prep.hip), QAGNN_CLS_GROUPS
+CLS_CHUNK, CLS_BLK, CLS_GROUPS = 256, 1024, 64  # QAGNN_CLS_CHUNK, CLS_BLK (graph_prep.hip), QAGNN_CLS_GROUPS
 
 
 class EmuGraph:
@@ -202,10 +202,6 @@ class EmuKernels:
 
     def gelu_dropout_bwd(self, X, dY, p, seed):
         return dY * self._keep(X, p, seed) * _gelu_grad(X)
-
-    def gelu_dropout_bwd_colsum(self, X, dY, p, seed):
-        dX = self.gelu_dropout_bwd(X, dY, p, seed)
-        return dX, dX.sum(0)
 
     def bn_relu_bwd_colsum(self, dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww=None):
         dH = self.bn_relu_bwd(dR, H, mean, invstd, scale, shift, gamma, red, inv_rows, roww)
