@@ -80,7 +80,8 @@ typedef struct qagnn_graph {
   int32_t n_groups;            /* position groups of the class order */
 } qagnn_graph;
 
-#define QAGNN_CLS_CHUNK 256
+#define QAGNN_CLS_CHUNK 64
+#define QAGNN_CLS_SLICES 4   /* the class reduction sums a class's partials in this many independent slices first */
 #define QAGNN_CLS_GROUPS 64
 
 /* int32 elements of device storage needed for all arrays of a qagnn_graph plus scratch. */
@@ -202,7 +203,7 @@ int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t
  *   aggr[tgt] += alpha_eh * msg_e
  * forward writes a[Ep][4], alpha[Ep][4] (source order) and aggr[N][DP]; `score` is scratch [Ep][4].
  * backward takes G = d aggr [N][DP] and writes dKMQ [N][3*DP], dEkEm [C][2*DP]; scratch: ga[Ep][4] (becomes gs),
- * rs[N][4], cls_part[max_chunks][2*DP].
+ * rs[N][4], cls_part[max_chunks + QAGNN_CLS_SLICES*C][2*DP].
  * ------------------------------------------------------------------------------------------------------------ */
 int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
@@ -268,7 +269,8 @@ typedef struct qagnn_hop_args {
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
 } qagnn_hop_args;
 int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);
-int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t max_chunks);
+int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP,
+                                      int32_t cls_part_rows /* g->max_chunks + QAGNN_CLS_SLICES * g->C */);
 int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 

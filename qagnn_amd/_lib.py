@@ -22,6 +22,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
+CLS_SLICES = 4  # QAGNN_CLS_SLICES
 ABI_VERSION = 3  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
@@ -381,7 +382,7 @@ class HipKernels:
         dEkEm = torch.empty_like(EkEm)
         ga = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
         rs = torch.empty((graph.N, 4), dtype=torch.float32, device=dev)
-        cls_part = torch.empty((graph.max_chunks, 2 * DP), dtype=torch.float32, device=dev)
+        cls_part = torch.empty((graph.max_chunks + CLS_SLICES * graph.C, 2 * DP), dtype=torch.float32, device=dev)
         rc = self.lib.qagnn_edge_attn_bwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP,
                                               float(qscale), a.data_ptr(), alpha.data_ptr(), G.data_ptr(), DP,
                                               dKMQ.data_ptr(), dEkEm.data_ptr(), ga.data_ptr(), rs.data_ptr(),
@@ -466,7 +467,7 @@ class HipKernels:
             if need_dS:
                 dS = torch.empty((N, SP), dtype=torch.float32, device=dev)
                 h.dS = dS.data_ptr()
-        ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks), dtype=torch.float32, device=dev)
+        ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks + CLS_SLICES * graph.C), dtype=torch.float32, device=dev)
         h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
         self._check(self.lib.qagnn_hop_bwd_f32(C.byref(h), self._stream()), 'qagnn_hop_bwd_f32')
         return (dX, dS, dWx_t.view(DP, 3 * DP), dWs_t.view(SP, 3 * DP) if SP else None, dTT.view(T, 3 * DP), dEkEm.view(graph.C, 2 * DP),

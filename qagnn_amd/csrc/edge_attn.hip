@@ -320,9 +320,8 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
 }
 
-// one wave per class chunk (<= QAGNN_CLS_CHUNK = 256 edges of one class inside one position group), walked 64 edges at a time.
-// (256 rather than 64: the few big (group, class) pairs -- the self loops of the KG nodes -- then leave 4x fewer partials,
-// and it is the largest class's partial list that bounds k_cls_reduce.)
+// one wave per class chunk (<= QAGNN_CLS_CHUNK edges of one class inside one position group), walked 64 edges at a time
+// (chunks of 256 edges were measured: 4x fewer partials for the big classes, but the class pass itself went 65 -> 89 us).
 __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_chunks, const int* __restrict__ chunk_beg,
                                                       const int* __restrict__ chunk_len, const int* __restrict__ src_c,
                                                       const int* __restrict__ tgt_c, const int* __restrict__ pos_c,
@@ -373,26 +372,28 @@ __global__ __launch_bounds__(256) void k_edge_bwd_cls(const int* __restrict__ n_
   }
 }
 
-// ordered sum of a class's chunk partials over all position groups; block = one class, columns x partitions: partition p
-// takes the class's chunks number p, p + P, ... (numbered in group order), the partitions are added in order
+// ordered sum of a class's chunk partials over all position groups, two stages.  Stage 1: block (c, s) sums the chunks of class c
+// in the groups g = s, s + S, ... (S = QAGNN_CLS_SLICES): columns x partitions, partition p takes the slice's chunks number
+// p, p + P, ..., partitions added in order.  Stage 2 adds the S slices in order.  (One block per class left the largest class --
+// the self loops of the KG nodes, ~900 partials -- as a 100-deep chain of dependent loads: 58 of the stage's 62 us.)
 __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chunkptr, const float* __restrict__ cls_part,
-                                                     float* __restrict__ dEkEm, int lde, int DP2, int C, int NG) {
+                                                     float* __restrict__ slices, int DP2, int C, int NG) {
   extern __shared__ float4 sm4[];
-  const int c = blockIdx.x;
-  const int ncol4 = DP2 >> 2;
-  const int P = 1024 / ncol4;
-  const int col4 = threadIdx.x % ncol4, part = threadIdx.x / ncol4;
   // the class's chunk ranges of all groups first (one load per thread, not 2 dependent loads per group and thread)
   __shared__ int cp_lo[QAGNN_CLS_GROUPS], cp_hi[QAGNN_CLS_GROUPS];
+  const int c = blockIdx.x, sl = blockIdx.y;
   if (threadIdx.x < NG) {
     cp_lo[threadIdx.x] = chunkptr[threadIdx.x * C + c];
     cp_hi[threadIdx.x] = chunkptr[threadIdx.x * C + c + 1];
   }
   __syncthreads();
+  const int ncol4 = DP2 >> 2;
+  const int P = 1024 / ncol4;
+  const int col4 = threadIdx.x % ncol4, part = threadIdx.x / ncol4;
   float4 acc = zero4();
   if (part < P) {
-    int seen = 0;  // chunks of this class in the groups before g
-    for (int g = 0; g < NG; ++g) {
+    int seen = 0;  // chunks of this class in the slice's groups before g
+    for (int g = sl; g < NG; g += QAGNN_CLS_SLICES) {
       const int kb = cp_lo[g], ke = cp_hi[g];
       const int first = (part - seen % P + P) % P;
       for (int k = kb + first; k < ke; k += P) acc = add4(acc, ld4(cls_part + (int64_t)k * DP2 + col4 * 4));
@@ -404,8 +405,19 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
   if (threadIdx.x < ncol4) {
     float4 s = sm4[threadIdx.x];
     for (int q = 1; q < P; ++q) s = add4(s, sm4[q * ncol4 + threadIdx.x]);
-    st4(dEkEm + (int64_t)c * lde + threadIdx.x * 4, s);
+    st4(slices + ((int64_t)c * QAGNN_CLS_SLICES + sl) * DP2 + threadIdx.x * 4, s);
   }
+}
+__global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ slices, float* __restrict__ dEkEm, int lde, int DP2, int C) {
+  const int ncol4 = DP2 >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * ncol4) return;
+  const int c = i / ncol4, col4 = i - c * ncol4;
+  const float* p = slices + (int64_t)c * QAGNN_CLS_SLICES * DP2 + col4 * 4;
+  float4 s = ld4(p);
+#pragma unroll
+  for (int q = 1; q < QAGNN_CLS_SLICES; ++q) s = add4(s, ld4(p + (int64_t)q * DP2));
+  st4(dEkEm + (int64_t)c * lde + col4 * 4, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -595,7 +607,11 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part, g->N);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_cls");
   const int P = 1024 / (DP2 / 4);
-  k_cls_reduce<<<g->C, 1024, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, dEkEm, lde, DP2, g->C, g->n_groups);
+  float* slices = cls_part + (int64_t)g->max_chunks * DP2;  // [C][QAGNN_CLS_SLICES][DP2] behind the chunk partials
+  k_cls_reduce<<<dim3(g->C, QAGNN_CLS_SLICES), 1024, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, slices, DP2, g->C,
+                                                                                                    g->n_groups);
   QAGNN_LAUNCH_CHECK("k_cls_reduce");
+  k_cls_reduce2<<<cdiv((int64_t)g->C * (DP2 / 4), 256), 256, 0, stream>>>(slices, dEkEm, lde, DP2, g->C);
+  QAGNN_LAUNCH_CHECK("k_cls_reduce2");
   return QAGNN_OK;
 }

@@ -105,11 +105,11 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   return QAGNN_OK;
 }
 
-extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t max_chunks) {
+extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t cls_part_rows) {
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
   return 2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
-         up4((int64_t)max_chunks * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
+         up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
 }
 
 extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
@@ -124,7 +124,7 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   float* dKMQ = w.take((int64_t)N * 3 * DP);
   float* gab = w.take((int64_t)Ep * 4);
   float* rs = w.take((int64_t)N * 4);
-  float* cls_part = w.take((int64_t)h->g->max_chunks * 2 * DP);
+  float* cls_part = w.take(((int64_t)h->g->max_chunks + (int64_t)QAGNN_CLS_SLICES * h->g->C) * 2 * DP);
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
   float* tnws = w.take(tn);
