@@ -243,9 +243,11 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
   }
         ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
+        // the sums must add the ROUNDED outputs, like a separate pass over dH would: the empty asm makes o opaque, so the
+        // compiler cannot contract its last multiply into the accumulation (fp-contract is on by default in HIP)
+        asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
         st4(dH + (int64_t)r * ld + col, o);
-        // plain adds of the ROUNDED outputs (no contraction of the last multiply into the sum): what a separate pass over dH adds
-        acc = make_float4(__fadd_rn(acc.x, o.x), __fadd_rn(acc.y, o.y), __fadd_rn(acc.z, o.z), __fadd_rn(acc.w, o.w));
+        acc = add4(acc, o);
       }
     }
   }

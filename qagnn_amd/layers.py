@@ -105,10 +105,13 @@ class MultiheadAttPoolLayer(nn.Module):
         [b, l, DP] output of the GNN stack and is consumed as is (pads are zero)."""
         nh, dk, dv = self.n_head, self.d_k, self.d_v
         b, l = k.size(0), k.size(1)
-        qs = self.w_qs(q).view(b, nh, dk)
+        qs2 = self.w_qs(q)                                                         # [b, nh*dk]
+        qs = qs2.view(b, nh, dk)
         Wk = self.w_ks.weight.view(nh, dk, -1)
-        u = torch.einsum('bhk,hkd->bhd', qs, Wk)                                   # query seen from node space
-        c = torch.einsum('bhk,hk->bh', qs, self.w_ks.bias.view(nh, dk))
+        # per-head products as ONE plain matmul against the block-diagonal weight: the batched form runs (and
+        # differentiates) as batch-of-2 bmm calls, for which rocBLAS picks 48 us kernels at these sizes
+        u = torch.mm(qs2, torch.block_diag(*Wk.unbind(0))).view(b, nh, -1)          # query seen from node space [b, nh, d]
+        c = (qs * self.w_ks.bias.view(nh, dk)).sum(2)
         if layout is not None:
             u = layout.pad(u)
         from . import ops
@@ -125,7 +128,8 @@ class MultiheadAttPoolLayer(nn.Module):
         if layout is not None:
             z = layout.unpad(z)
         Wv = self.w_vs.weight.view(nh, dv, -1)
-        out = torch.einsum('bhd,hvd->bhv', z, Wv) + self.w_vs.bias.view(nh, dv) * attn.sum(2, keepdim=True)
+        out = torch.mm(z.reshape(b, -1), torch.block_diag(*Wv.transpose(1, 2).unbind(0))).view(b, nh, dv) + \
+            self.w_vs.bias.view(nh, dv) * attn.sum(2, keepdim=True)
         return self.dropout(out.reshape(b, nh * dv)), attn.transpose(0, 1).reshape(nh * b, l)
 
 

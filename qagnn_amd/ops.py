@@ -54,18 +54,16 @@ class HeadLayout:
         self.DP = H_HEADS * self.HP
         j = torch.arange(self.DP)
         h, i = j // self.HP, j % self.HP
-        src = torch.where(i < self.dh, h * self.dh + i, torch.full_like(j, -1))
-        self.pad_src = src.to(device)                      # [DP] dense index or -1
-        self.valid = (src >= 0).to(device)
-        self.dense_pos = torch.nonzero(src >= 0).flatten().to(device)  # [d] padded position of dense index k (ascending)
-        self.pad_idx = torch.where(src >= 0, src, torch.full_like(src, self.d)).to(device)  # pads read an appended zero column
+        self.dense_pos = torch.nonzero(i < self.dh).flatten().to(device)  # [d] padded position of dense index k (ascending)
 
     def pad(self, x):
-        """[*, d] -> [*, DP] (zeros in the pads).  Differentiable torch gather."""
-        return torch.nn.functional.pad(x, (0, 1)).index_select(-1, self.pad_idx).contiguous()
+        """[*, d] -> [*, DP] (zeros in the pads): one constant-pad of the [*, H, dh] view (its backward is a slice, no scatter)."""
+        lead = x.shape[:-1]
+        return torch.nn.functional.pad(x.reshape(*lead, H_HEADS, self.dh), (0, self.HP - self.dh)).reshape(*lead, self.DP)
 
     def unpad(self, xp):
-        return xp.index_select(-1, self.dense_pos)
+        lead = xp.shape[:-1]
+        return xp.reshape(*lead, H_HEADS, self.HP)[..., :self.dh].reshape(*lead, self.d)
 
 
 class _PlanGatherFn(torch.autograd.Function):
