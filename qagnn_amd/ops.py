@@ -59,7 +59,7 @@ class HeadLayout:
     def pad(self, x):
         """[*, d] -> [*, DP] (zeros in the pads): one constant-pad of the [*, H, dh] view (its backward is a slice, no scatter)."""
         lead = x.shape[:-1]
-        return torch.nn.functional.pad(x.reshape(*lead, H_HEADS, self.dh), (0, self.HP - self.dh)).reshape(*lead, self.DP)
+        return torch.nn.functional.pad(x.reshape(*lead, H_HEADS, self.dh), (0, self.HP - self.dh)).reshape(*lead, self.DP).contiguous()
 
     def unpad(self, xp):
         lead = xp.shape[:-1]

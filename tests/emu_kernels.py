@@ -60,6 +60,13 @@ class EmuGraph:
         self.chunk_len = torch.minimum(torch.full_like(within, CLS_CHUNK), gcptr[pair_of_chunk + 1] - self.chunk_beg.long()).int()
 
 
+def _chk(*tensors):
+    """What qagnn_amd._lib._chk2d enforces on the GPU: operands are contiguous 2-D matrices (host-logic tests run on this
+    emulation, so a layout slip in the packing code has to fail here, not only on the GPU box)."""
+    for t in tensors:
+        assert t is None or (t.dim() == 2 and t.is_contiguous()), f'operand must be a contiguous 2-D tensor, got {tuple(t.shape)} / {t.stride()}'
+
+
 def _uniform01(seed, idx):
     """numpy twin of uniform01() in csrc/elementwise.hip (splitmix64 finaliser)."""
     with np.errstate(over='ignore'):
@@ -94,6 +101,7 @@ class EmuKernels:
 
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
                 out=None, accumulate=False, a_rowidx=None):
+        _chk(A1, B1, A2, B2, out, rowtab)
         A1 = self._gather_rows(A1, a_rowidx)
         if a_scale is not None:
             A1 = torch.relu(A1 * a_scale + a_shift)
@@ -114,6 +122,7 @@ class EmuKernels:
 
     def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None, colsum_groups=0,
                 b_rowidx=None):
+        _chk(A, B, out)
         A = self._gather_rows(A, a_rowidx)
         if a_scale is not None:
             A = torch.relu(A * a_scale + a_shift)
