@@ -18,6 +18,7 @@
 namespace qagnn {
 
 #define EDGE_UNROLL 4
+#define TGT_UNROLL 8  // the target pass gathers ONE row per edge: 8 in flight fit the same register budget (gather_micro: -13 %)
 
 // What bounds these kernels (measured, profiles/r1_run56_*, r1_run59_gather_micro.txt, r1_run60_*): NOT the bytes.  One wave
 // handles one edge at a time, so every per-edge instruction is paid by a whole wave, and a kernel's time tracks the number
@@ -38,7 +39,7 @@ __device__ __forceinline__ float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
-constexpr int SLAB_ROWS = 68;  // 64 chunk entries + the rows an unrolled batch may touch past the chunk (always zero)
+constexpr int SLAB_ROWS = 72;  // 64 chunk entries + the rows an unrolled batch (<= 8 edges) may touch past the chunk (always zero)
 
 struct Lane {
   int lane, w, g, j;
@@ -309,12 +310,12 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
     const int cnt = min(64, end - e0), lc = e0 + min(L.lane, cnt - 1);
     const uint32_t sv = (uint32_t)src_t[lc] * pk;
     slab[L.w][L.lane] = L.lane < cnt ? ld4(gsb + (int64_t)pos_t[lc] * 4) : zero4();  // lane i: gs of edge e0 + i
-    for (int i = 0; i < cnt; i += EDGE_UNROLL) {
-      float4 qv[EDGE_UNROLL];
+    for (int i = 0; i < cnt; i += TGT_UNROLL) {
+      float4 qv[TGT_UNROLL];
 #pragma unroll
-      for (int u = 0; u < EDGE_UNROLL; ++u) qv[u] = buf_ld4(rK, vq, rl(sv, min(i + u, cnt - 1)));
+      for (int u = 0; u < TGT_UNROLL; ++u) qv[u] = buf_ld4(rK, vq, rl(sv, min(i + u, cnt - 1)));
 #pragma unroll
-      for (int u = 0; u < EDGE_UNROLL; ++u) dK = fma4(sl[(i + u) * 4], qv[u], dK);
+      for (int u = 0; u < TGT_UNROLL; ++u) dK = fma4(sl[(i + u) * 4], qv[u], dK);
     }
   }
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);

@@ -459,6 +459,12 @@ class QAGNN(nn.Module):
         ce = self.concept_emb
         fused_input = (emb_data is None and not ce.use_contextualized and hasattr(ce, 'cpt_transform') and ce.scale == 1.0
                        and not ce.emb.weight.requires_grad and ce.emb.weight.size(1) % 16 == 0)
+        graph, join_graph = None, None
+        if fused_input and self.gnn.k > 0:
+            # the graph orderings only need the integer inputs: prepared on a side stream, under the gather-GEMM below
+            edge_index, edge_type = adj
+            graph, join_graph = ops.graph_prep_async(edge_index, edge_type, node_type_ids.reshape(-1).contiguous(), self.gnn.n_etype,
+                                                     self.gnn.n_ntype, n)
         if fused_input:
             # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout
             L = head_layout(self.concept_dim, dev)
@@ -481,7 +487,9 @@ class QAGNN(nn.Module):
         node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
 
         Lh = head_layout(self.concept_dim, dev)
-        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, padded_input=fused_input, padded_output=True)
+        if join_graph is not None:
+            join_graph()
+        gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, graph=graph, padded_input=fused_input, padded_output=True)
         Z_vecs = Lh.unpad(gnn_output[:, 0])
         mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
         # never mask every node (:177).  Written without boolean-mask indexing: `mask[mask.all(1), 0] = 0` makes the host

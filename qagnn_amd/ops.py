@@ -308,6 +308,32 @@ def join_wgrads(ref=None):
     q.keep.clear()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Graph preparation under the input GEMM (QAGNN_PREP_OVERLAP).  The graph orderings depend on the batch's integer inputs
+# only; their ~13 launches are short, latency-bound integer kernels (0.28 ms per batch) while the stage in front of the stack
+# is one MFMA-bound gather-GEMM (entity table x cpt_transform, ~0.28 ms).  QAGNN.forward therefore issues the preparation on a
+# second stream first and joins it right before the stack.  No autograd node runs on that stream; the graph storage is
+# allocated there and only read elsewhere after the join (and freed after the step, i.e. before the next fork).
+PREP_OVERLAP = _os.environ.get('QAGNN_PREP_OVERLAP', '1') == '1'
+_PREP_STREAMS = {}
+
+
+def graph_prep_async(edge_index, edge_type, node_type, n_etype, n_ntype, block_n):
+    """-> (graph, join): the preparation is enqueued on the side stream; call join() on the consumer stream before using it."""
+    K = kernels()
+    if not (PREP_OVERLAP and node_type.is_cuda):
+        return K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n), (lambda: None)
+    main = torch.cuda.current_stream()
+    key = main.device_index
+    if key not in _PREP_STREAMS:
+        _PREP_STREAMS[key] = torch.cuda.Stream(device=main.device)
+    side = _PREP_STREAMS[key]
+    side.wait_stream(main)  # the inputs (and last step's readers of the recycled storage) are ordered before the fork
+    with torch.cuda.stream(side):
+        graph = K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n)
+    return graph, (lambda: torch.cuda.current_stream().wait_stream(side))
+
+
 class LinearNNFn(torch.autograd.Function):
     """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
 
