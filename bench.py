@@ -256,6 +256,8 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores [scores + segment softmax] + k_edge_aggregate), per GAT layer',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': traffic, 'traffic_source': 'profiles/pmc_edge_fwd.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note)' if traffic else None,
+                         'note': 'achieved prices every per-edge row gather as HBM bytes (SURVEY 8d); the re-reads are served by L1/L2, so it can '
+                                 'exceed the HBM peak -- `traffic` is what the fabric really moved per launch',
                          'algorithmic_bytes_per_launch': alg_fwd, 'avg_launch_ms': round(fwd_ms, 4),
                          'launches_timed': n_fwd,
                          'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
