@@ -162,50 +162,11 @@ class GatherPlan:
 # ------------------------------------------------------------------------------------------------------------------
 import os as _os
 
-# Measured on MI355X (interleaved A/B, 30 steps each, run 19): side stream ON 21 618 / 21 673 vs OFF 22 621 / 22 620
-# QA-subgraphs/s -- co-running two GEMMs costs more in L2/HBM contention than the phase overlap wins.  Default OFF.
-SIDE_STREAM_WGRAD = _os.environ.get('QAGNN_SIDE_STREAM', '0') == '1'
 _SIDE_STREAMS = {}
 # bias gradients as a by-product of the wgrad GEMM (qagnn_gemm_tn_colsum_f32).  Measured (interleaved A/B, run 21): ON 21 138 /
 # 21 156 vs OFF 21 539 / 21 538 QA-subgraphs/s -- the extra LDS sweep of the B tile inside the k-loop costs the GEMM more than
 # the three separate column-sum passes it replaces.  Default OFF; kept (and tested) for a better in-kernel schedule.
 FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '0') == '1'
-
-
-class _WgradStream:
-    """Run weight/bias-gradient kernels on a second HIP stream, forked from and joined back into the current one.
-
-    A single-round GEMM grid has every block in the same phase (operand reads, then MFMAs, then the epilogue writes), so
-    its HBM phases overlap nothing.  The weight-gradient GEMMs of a backward step are independent of
-    the data-gradient chain; issuing them on a side stream lets one kernel's streaming phases overlap the other's MFMAs.
-    Fork/join discipline (side waits for main at every entry, main waits for side in join()) keeps the caching
-    allocator's stream-ordered reuse valid without record_stream().
-    """
-
-    def __init__(self, ref):
-        self.on = SIDE_STREAM_WGRAD and ref.is_cuda
-        if self.on:
-            self.main = torch.cuda.current_stream(ref.device)
-            key = ref.device.index
-            if key not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key] = torch.cuda.Stream(device=ref.device)
-            self.side = _SIDE_STREAMS[key]
-
-    def __enter__(self):
-        if self.on:
-            self.side.wait_stream(self.main)
-            self._ctx = torch.cuda.stream(self.side)
-            self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self._ctx.__exit__(*exc)
-        return False
-
-    def join(self):
-        if self.on:
-            self.main.wait_stream(self.side)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -215,8 +176,8 @@ class _WgradStream:
 # profiles/r1_run56_*): they leave the matrix cores idle.  The weight-gradient GEMMs are MFMA-bound, independent of the
 # data-gradient chain, and per layer they take about as long as the edge backward (~430 us vs ~417 us).  So inside the
 # stack they are not launched where autograd reaches them: they are QUEUED, and the whole queue is issued on a second HIP
-# stream right before the next edge backward starts on the main stream.  Unlike QAGNN_SIDE_STREAM (fork/join inside one
-# operator: a GEMM could only ever overlap another GEMM, measured -4 %), the join is deferred to the one consumer of these
+# stream right before the next edge backward starts on the main stream.  Unlike a fork/join inside one operator (run 19: a GEMM
+# could only ever overlap another GEMM, measured -4.4 %, removed), the join is deferred to the one consumer of these
 # gradients, GatherPlan's backward (plus an end-of-backward engine callback as a safety net).  Rules that make this safe:
 #   * only operators created inside `wgrad_scope()` defer, and the stack guarantees that every weight operand there comes
 #     straight out of GatherPlan, so nothing on the main stream reads a deferred gradient before the join;
@@ -232,7 +193,7 @@ class wgrad_scope:
 
     def __enter__(self):
         self.prev = _DEFER[0]
-        _DEFER[0] = WGRAD_OVERLAP and not SIDE_STREAM_WGRAD and not FUSED_COLSUM
+        _DEFER[0] = WGRAD_OVERLAP and not FUSED_COLSUM
         return self
 
     def __exit__(self, *exc):
@@ -383,31 +344,28 @@ class LinearNNFn(torch.autograd.Function):
             if A2 is not None and need[3]:
                 dA2 = K.gemm_nn(dC, B2)
             return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
-        wg = _WgradStream(dC)
-        with wg:  # parameter gradients (optionally on a side stream)
-            cs = None
-            if FUSED_COLSUM and need[1] and (want_tab or want_bias):
-                # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
-                dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
-            else:
-                dB1t = K.gemm_tn(A1, dC) if need[1] else None
-                if want_tab or want_bias:
-                    cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
-            dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
-            if want_tab:
-                drowtab = cs
-                if want_bias:
-                    dbias = cs.sum(0)
-            elif want_bias:
-                dbias = cs[0]
+        cs = None
+        if FUSED_COLSUM and need[1] and (want_tab or want_bias):
+            # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
+            dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
+        else:
+            dB1t = K.gemm_tn(A1, dC) if need[1] else None
+            if want_tab or want_bias:
+                cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
+        dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
+        if want_tab:
+            drowtab = cs
+            if want_bias:
+                dbias = cs.sum(0)
+        elif want_bias:
+            dbias = cs[0]
         if need[0] and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
             # few rows, long reduction (the class tables: 612 x 2080): an NN launch would be 5 blocks walking 130 k-tiles one
             # after the other; the split-K weight-gradient kernel computes the same product as (dC^T)^T B1 in parallel chunks
             dA1 = K.gemm_tn(dC.t().contiguous(), B1)
         else:
-            dA1 = K.gemm_nn(dC, B1) if need[0] else None  # data gradients: the critical path stays on the main stream
+            dA1 = K.gemm_nn(dC, B1) if need[0] else None
         dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
-        wg.join()
         return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
 
 
@@ -548,18 +506,14 @@ class GatMlpFn(torch.autograd.Function):
                          (h1, dout, scale, shift, aggr, dh1))
             daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
             return (daggr, dW1t, None, db1, red[1], red[0], dW2t, None, db2, None, None, None, None, None, None, None, None, None)
-        wg = _WgradStream(dout)
-        with wg:  # side stream: gradients of the second Linear
-            dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
+        dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
         dr = K.gemm_nn(dout, W2)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
         dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
                                         roww=row_weight if training else None)
-        with wg:  # side stream again (re-forked after dh1): gradients of the first Linear
-            dW1t = K.gemm_tn(aggr, dh1)
+        dW1t = K.gemm_tn(aggr, dh1)
         daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
-        wg.join()
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
 
 

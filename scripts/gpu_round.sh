@@ -14,10 +14,6 @@ if [[ "$*" == *poison* ]]; then   # deferred weight gradients start as NaN: any 
   QAGNN_WGRAD_POISON=1 timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q --tb=short -rf --timeout 300 -p no:cacheprovider 2>&1 | tail -n 30 > gpurun_out/test_poison.log
   echo "poison exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
-if [[ "$*" == *edgewalk_removed* ]]; then
-  QAGNN_EDGE_WALK=1 timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "edge" 2>&1 | tail -n 30 > gpurun_out/test_edge_walk.log
-  echo "edgewalk exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
-fi
 if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
   echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
@@ -94,12 +90,6 @@ for arg in "$@"; do
     done; done
   fi
 done
-if [[ "$*" == *sideab* ]]; then
-  for rep in 1 2; do for v in 0 1; do
-    echo "QAGNN_SIDE_STREAM=$v" >> gpurun_out/sideab.txt
-    QAGNN_SIDE_STREAM=$v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -n 1 | cut -c1-140 >> gpurun_out/sideab.txt
-  done; done
-fi
 if [[ "$*" == *dp2* ]]; then
   QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 2>&1 | tail -n 20 > gpurun_out/bench_dp2_shared_gpu.log
   echo "dp2 exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
