@@ -260,7 +260,8 @@ typedef struct qagnn_hop_args {
   /* backward only */
   const float* dy;                 /* [N, DP] */
   float* dX;                       /* [N, DP] or NULL */
-  float* dS; int32_t accumulate_dS;/* [N, SP] or NULL; 1: dS += */
+  float* dS;                       /* [N, SP] or NULL */
+  int32_t accumulate_dS; int32_t accumulate_dX;   /* 1: the gradient is ADDED to what dS / dX hold (running total over the readers) */
   float* dWx_t; float* dWs_t;      /* [DP, 3DP], [SP, 3DP] */
   float* dTT; float* dEkEm;        /* [T, 3DP], [C, 2DP] */
   float* dW1t; float* db1;         /* [DP, DP], [DP] */

@@ -23,7 +23,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 3  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order)
+ABI_VERSION = 4  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -53,7 +53,7 @@ class qagnn_hop_args(C.Structure):
                  ('num_batches_tracked', _vp), ('dense_pos', _vp), ('d', _i32), ('momentum', _f32),
                  ('apply_act', _i32), ('p_drop', _f32), ('seed', _u64)] +
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
-                [('accumulate_dS', _i32)] +
+                [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
                 [('ws_elems', _i64)])
 
@@ -440,7 +440,8 @@ class HipKernels:
         self._check(self.lib.qagnn_hop_fwd_f32(C.byref(h), self._stream()), 'qagnn_hop_fwd_f32')
         return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats)
 
-    def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS):
+    def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
+                dX_acc=None, dS_acc=None):
         """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)"""
         h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
         KMQ, aa, aggr, h1, out, stats = saved
@@ -459,14 +460,16 @@ class HipKernels:
         h.dWx_t, h.dTT, h.dEkEm, h.dW1t, h.db1 = dWx_t.data_ptr(), dTT.data_ptr(), dEkEm.data_ptr(), dW1t.data_ptr(), db1.data_ptr()
         h.dbn, h.dW2t, h.db2 = dbn.data_ptr(), dW2t.data_ptr(), db2.data_ptr()
         dX = dS = None
-        if need_dX:
-            dX = torch.empty((N, DP), dtype=torch.float32, device=dev)
-            h.dX = dX.data_ptr()
+        if need_dX:  # *_acc: an existing running total of this gradient, added to in place (GEMM epilogue accumulate)
+            dX = dX_acc if dX_acc is not None else torch.empty((N, DP), dtype=torch.float32, device=dev)
+            assert dX.shape == (N, DP) and dX.is_contiguous()
+            h.dX, h.accumulate_dX = dX.data_ptr(), (1 if dX_acc is not None else 0)
         if SP:
             h.dWs_t = dWs_t.data_ptr()
             if need_dS:
-                dS = torch.empty((N, SP), dtype=torch.float32, device=dev)
-                h.dS = dS.data_ptr()
+                dS = dS_acc if dS_acc is not None else torch.empty((N, SP), dtype=torch.float32, device=dev)
+                assert dS.shape == (N, SP) and dS.is_contiguous()
+                h.dS, h.accumulate_dS = dS.data_ptr(), (1 if dS_acc is not None else 0)
         ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks + CLS_SLICES * graph.C), dtype=torch.float32, device=dev)
         h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
         self._check(self.lib.qagnn_hop_bwd_f32(C.byref(h), self._stream()), 'qagnn_hop_bwd_f32')

@@ -288,7 +288,7 @@ static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 using namespace qagnn;
 
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 3; }
+extern "C" int qagnn_abi_version(void) { return 4; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;

@@ -166,6 +166,7 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   if (h->dX) {
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
+    gx.accumulate = h->accumulate_dX;
     HOP_TRY(qagnn_gemm_nn_f32(&gx, stream));
   }
   if (SP > 0 && h->dS) {

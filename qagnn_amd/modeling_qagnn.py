@@ -233,7 +233,7 @@ class GATConvE(nn.Module):
 
     N_PACKED = 18
 
-    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None):
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None, acc=None):
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
@@ -267,8 +267,8 @@ class GATConvE(nn.Module):
                 return ops.gat_hop(Xp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head),
                                    (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
                                    self.training or not bn.track_running_stats, bn.eps, p_drop if self.training else 0.0, apply_act,
-                                   running)
-            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype)
+                                   running, acc=acc)
+            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc)
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
@@ -407,10 +407,14 @@ class QAGNN_Message_Passing(nn.Module):
                 tab_p = edge_class_table_padded(self.edge_encoder, graph, self.training, self.k, L, extras[14:])
                 ekem = ops.split_cols(ops.linear_nn(tab_p, We_t_all, We_all, bias=be_all), self.k)     # k x [C, 2DP]
                 TT = ops.split_cols(torch.addmm(bias_all, temb, Wtype_all), self.k)                    # k x [T, 3DP]
+            # S is read by every hop and the stack input by hop 0 and by the output GEMM: their data-gradient GEMMs accumulate into
+            # one running total each (ops.GradAcc) instead of leaving k (2) gradients for autograd to add; hop 0's backward runs
+            # last and returns the totals
+            accS, accX = (ops.GradAcc(), ops.GradAcc()) if self.k > 0 else (None, None)
             for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
                 Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
-                                  packed=pk, tables=(TT[l], ekem[l]))
-            Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx)
+                                  packed=pk, tables=(TT[l], ekem[l]), acc=(accX if l == 0 else None, True, accS, l == 0))
+            Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx, acc=(accX, False, None, False))
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
         if padded_output:
             return out.view(bs, n, L.DP)

@@ -295,17 +295,45 @@ def graph_prep_async(edge_index, edge_type, node_type, n_etype, n_ntype, block_n
     return graph, (lambda: torch.cuda.current_stream().wait_stream(side))
 
 
+class GradAcc:
+    """Running gradient of ONE tensor that several operators of the stack read (the score embedding S: every hop; the stack
+    input: hop 0 and the output GEMM).  Autograd would give each reader its own [N, .] gradient and add them with elementwise
+    kernels; here the readers' data-gradient GEMMs accumulate into one buffer in place (the GEMM epilogue's accumulate flag)
+    and only the reader whose backward runs LAST -- the one that was created first, the stack is a chain -- returns the total.
+    One instance per forward pass."""
+    __slots__ = ('buf',)
+
+    def __init__(self):
+        self.buf = None
+
+
+def _acc_grad(acc, last, compute):
+    """compute(out, accumulate) -> gradient tensor (written into `out` when given).  Returns what the operator hands to autograd."""
+    if acc is None:
+        return compute(None, False)
+    if acc.buf is None:
+        acc.buf = compute(None, False)
+    else:
+        compute(acc.buf, True)
+    if not last:
+        return None
+    total, acc.buf = acc.buf, None  # handed over: a second backward through the same graph starts a fresh total
+    return total
+
+
 class LinearNNFn(torch.autograd.Function):
-    """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K])."""
+    """C = [A1|A2] @ [B1t;B2t] + bias + rowtab[rowidx]   (B*t are [K, No] = W^T; B* are the same weights as [No, K]).
+    acc = (acc1, last1, acc2, last2) or None: GradAcc of A1 / A2 and whether this operator returns their totals."""
 
     @staticmethod
     @_fwd
-    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx):
+    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc):
         K = kernels()
         C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx)
         ctx.save_for_backward(A1, B1, A2, B2, rowidx)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
         ctx.defer = _DEFER[0]
+        ctx.acc = acc if acc is not None else (None, False, None, False)
         return C
 
     @staticmethod
@@ -335,15 +363,16 @@ class LinearNNFn(torch.autograd.Function):
                 jobs.append(lambda: K.colsum(dC, out=cs))
                 dbias = cs[0]
             defer_wgrads(jobs, (A1, A2, dC))
+            acc1, last1, acc2, last2 = ctx.acc
             dA1 = dA2 = None
             if need[0]:
-                if A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
+                if acc1 is None and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
                     dA1 = K.gemm_tn(dC.t().contiguous(), B1)  # few rows, long reduction: see below
                 else:
-                    dA1 = K.gemm_nn(dC, B1)
+                    dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu))
             if A2 is not None and need[3]:
-                dA2 = K.gemm_nn(dC, B2)
-            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
+                dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu))
+            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
         cs = None
         if FUSED_COLSUM and need[1] and (want_tab or want_bias):
             # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
@@ -359,18 +388,21 @@ class LinearNNFn(torch.autograd.Function):
                 dbias = cs.sum(0)
         elif want_bias:
             dbias = cs[0]
-        if need[0] and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
+        acc1, last1, acc2, last2 = ctx.acc
+        if need[0] and acc1 is None and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
             # few rows, long reduction (the class tables: 612 x 2080): an NN launch would be 5 blocks walking 130 k-tiles one
             # after the other; the split-K weight-gradient kernel computes the same product as (dC^T)^T B1 in parallel chunks
             dA1 = K.gemm_tn(dC.t().contiguous(), B1)
         else:
-            dA1 = K.gemm_nn(dC, B1) if need[0] else None
-        dA2 = K.gemm_nn(dC, B2) if (A2 is not None and need[3]) else None
-        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None
+            dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu)) if need[0] else None
+        dA2 = None
+        if A2 is not None and need[3]:
+            dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu))
+        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
 
 
-def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None):
-    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx)
+def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None, acc=None):
+    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc)
 
 
 class SplitColsFn(torch.autograd.Function):
@@ -566,7 +598,8 @@ def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     return y, (KMQ, torch.stack([a, alpha]), aggr, h1, out, torch.stack([mean, var, invstd, scale, shift]))
 
 
-def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS):
+def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
+                     dX_acc=None, dS_acc=None):
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
     KMQ, aa, aggr, h1, out, stats = saved
     mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
@@ -583,8 +616,8 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     dWx_t = K.gemm_tn(X, dKMQ)
     dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
     dTT = K.colsum(dKMQ, ntype, TT.size(0))
-    dX = K.gemm_nn(dKMQ, Wx) if need_dX else None
-    dS = K.gemm_nn(dKMQ, Ws) if (S is not None and need_dS) else None
+    dX = K.gemm_nn(dKMQ, Wx, out=dX_acc, accumulate=dX_acc is not None) if need_dX else None
+    dS = K.gemm_nn(dKMQ, Ws, out=dS_acc, accumulate=dS_acc is not None) if (S is not None and need_dS) else None
     return dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, red[1], red[0], dW2t, db2
 
 
@@ -593,13 +626,14 @@ class HopFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seed, apply_act, running, *prm):
+    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seed, apply_act, running, acc, *prm):
         K = kernels()
         fwd = getattr(K, 'hop_fwd', None)
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
         y, saved = fwd(*args, running) if fwd is not None else hop_fwd_composed(K, *args, running)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seed, apply_act, len(prm))
+        ctx.acc = acc if acc is not None else (None, False, None, False)  # GradAcc of X / S and whether this hop returns the totals
         a = saved[1][0]
         ctx.mark_non_differentiable(a)
         return y, a
@@ -613,18 +647,25 @@ class HopFn(torch.autograd.Function):
         X, S, ntype, prm, saved = t[0], t[1], t[2], t[3:3 + nprm], t[3 + nprm:]
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under this hop
         bwd = getattr(K, 'hop_bwd', None)
+        accX, lastX, accS, lastS = ctx.acc
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy.contiguous(),
-                ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None,
+                accS.buf if accS is not None else None)
         dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2 = bwd(*args) if bwd is not None else hop_bwd_composed(K, *args)
-        #        X   S   ntype graph HP    qscale bstats eps  p     seed  act   running | Wx_t  Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1
-        return (dX, dS, None, None, None, None, None, None, None, None, None, None, dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None, db1,
-                dgamma, dbeta, dW2t, None, db2, None, None)
+        if accX is not None and dX is not None:  # dX / dS are the running totals now (accumulated in place when a buffer existed)
+            accX.buf, dX = (None, dX) if lastX else (dX, None)
+        if accS is not None and dS is not None:
+            accS.buf, dS = (None, dS) if lastS else (dS, None)
+        #        X   S   ntype graph HP    qscale bstats eps  p     seed  act   running acc  | Wx_t  Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1
+        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None,
+                db1, dgamma, dbeta, dW2t, None, db2, None, None)
 
 
-def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act, running):
-    """prm: the 16 packed operands named in HOP_PARAMS.  `p`: dropout rate after the GELU (0 disables)."""
+def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act, running, acc=None):
+    """prm: the 16 packed operands named in HOP_PARAMS.  `p`: dropout rate after the GELU (0 disables).
+    acc = (accX, lastX, accS, lastS): GradAcc of X / S, see GradAcc."""
     p = float(p) if apply_act else 0.0
-    return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, *prm)
+    return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, acc, *prm)
 
 
 class PoolAttnFn(torch.autograd.Function):

@@ -464,6 +464,19 @@ def test_fused_hop_equals_composed_path(name, HP, mode):
     for a, b in zip(f_run, c_run):
         assert torch.equal(a, b)
     assert (SP == 0) == (f_bwd[1] is None)
+    # running totals (ops.GradAcc): dX / dS are ADDED to an existing buffer by the data-gradient GEMMs' accumulate epilogue
+    args = (g, HP, qs, X, S, ntype, prm, batch_stats, 1e-5, p, seed, apply_act)
+    base_x, base_s = rnd(N, DP, s=1.0), (rnd(N, SP, s=1.0) if SP else None)
+    tot = []
+    for fused in (True, False):
+        _, saved = K.hop_fwd(*args, None) if fused else ops.hop_fwd_composed(K, *args, None)
+        ax, as_ = base_x.clone(), (base_s.clone() if SP else None)
+        out = (K.hop_bwd if fused else lambda *a: ops.hop_bwd_composed(K, *a))(*args, saved, dy, True, True, ax, as_)
+        assert out[0] is ax and (out[1] is as_)
+        tot.append((ax, as_))
+    assert torch.equal(tot[0][0], tot[1][0]) and (not SP or torch.equal(tot[0][1], tot[1][1]))
+    err = (tot[0][0] - (base_x + f_bwd[0])).abs().max().item()
+    assert err <= 1e-5 * (f_bwd[0].abs().max().item() + base_x.abs().max().item()), err
 
 
 @pytest.mark.gpu
