@@ -239,3 +239,35 @@ def test_deferred_weight_gradients_are_joined_before_any_reader(monkeypatch, fus
     for k in grads[True]:
         assert torch.isfinite(grads[True][k]).all(), k
         assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize('k', [1, 3])
+def test_running_gradient_totals_survive_a_second_backward(k):
+    """ops.GradAcc: the readers of S / of the stack input accumulate their data gradients into one buffer and hop 0 hands the
+    total over.  The hand-over must reset the accumulator: a second backward through the same graph (retain_graph) has to
+    produce the same gradients again, not a doubled total; k = 1 is the case where the first reader is also the last."""
+    case = dict(shape='csqa', nq=2, nc=3, n=20, n_rel=17, std=0.3, train=True, seed=9,
+                cfg=helpers.model_cfg(d=32, k=k, sent_dim=24, n_concept=200, concept_in_dim=16))
+    inp = helpers.make_case_inputs(case)
+    cfg = case['cfg']
+    B, n = 6, 20
+    old = ops.set_kernels(EmuKernels())
+    try:
+        torch.manual_seed(0)
+        model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], cfg['concept_dim'], cfg['concept_in_dim'], 2,
+                         cfg['concept_dim'], 0, 0.0, 0.0, 0.0)
+        helpers.det_fill_(model, 3, 0.3)
+        model.pooler.dropout.p = model.pooler.attention.dropout.p = 0.0
+        model.train()
+        logits, _ = model(inp['sent_vecs'], inp['concept_ids'].view(B, n), inp['node_type_ids'].view(B, n),
+                          inp['node_scores'].view(B, n, 1), inp['adj_lengths'].view(B), (inp['edge_index'], inp['edge_type']))
+        loss = logits.sum()
+        names = ['svec2nvec.weight', 'gnn.emb_score.weight', 'concept_emb.cpt_transform.weight', 'gnn.Vh.weight']
+        params = dict(model.named_parameters())
+        g1 = torch.autograd.grad(loss, [params[nm] for nm in names], retain_graph=True)
+        g2 = torch.autograd.grad(loss, [params[nm] for nm in names])
+    finally:
+        ops.set_kernels(old)
+    for nm, a, b in zip(names, g1, g2):
+        assert torch.isfinite(a).all() and a.abs().max() > 0, nm
+        assert torch.equal(a, b), nm
