@@ -17,7 +17,9 @@
 
 namespace qagnn {
 
-#define EDGE_UNROLL 4
+#ifndef EDGE_UNROLL
+#define EDGE_UNROLL 4  // edges whose row gathers are in flight per wave (tools/build_micro.sh builds -DEDGE_UNROLL=6 / 8 variants for A/B)
+#endif
 #define TGT_UNROLL 8  // the target pass gathers ONE row per edge: 8 in flight fit the same register budget (gather_micro: -13 %)
 
 // What bounds these kernels (measured, profiles/r1_run56_*, r1_run59_gather_micro.txt, r1_run60_*): NOT the bytes.  One wave

@@ -100,6 +100,18 @@ fi
 if [[ "$*" == *hostprof* ]]; then
   timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt
 fi
+if [[ "$*" == *unrollab* ]]; then   # edge kernels with 4 / 6 / 8 edges in flight per wave (library variants prebuilt by tools/build_micro.sh)
+  for u in 6 8; do
+    QAGNN_LIB=$REPO/tools/bin/libqagnn_hip_u$u.so timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "edge or hop" 2>&1 | tail -n 3 >> gpurun_out/test_unroll_variants.log
+  done
+  for rep in 1; do for u in 4 6 8 4; do
+    lib=$REPO/qagnn_amd/libqagnn_hip.so; [[ $u != 4 ]] && lib=$REPO/tools/bin/libqagnn_hip_u$u.so
+    echo "EDGE_UNROLL=$u" >> gpurun_out/ab_unroll.txt
+    QAGNN_WGRAD_OVERLAP=0 QAGNN_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline 2>&1 | tail -n 1 > /tmp/ab_line.txt
+    cut -c1-140 /tmp/ab_line.txt >> gpurun_out/ab_unroll.txt
+    grep -o '"breakdown_ms_per_step.*' /tmp/ab_line.txt | cut -c1-160 >> gpurun_out/ab_unroll.txt
+  done; done
+fi
 if [[ "$*" == *gather* ]]; then   # row-gather rate of the memory system (tools/gather_micro.hip, prebuilt by tools/build_micro.sh)
   timeout 120 tools/bin/gather_micro > gpurun_out/gather_micro.txt 2>&1
 fi
