@@ -20,7 +20,8 @@ namespace qagnn {
 #ifndef EDGE_UNROLL
 #define EDGE_UNROLL 4  // edges whose row gathers are in flight per wave (tools/build_micro.sh builds -DEDGE_UNROLL=6 / 8 variants for A/B)
 #endif
-#define TGT_UNROLL 8  // the target pass gathers ONE row per edge: 8 in flight fit the same register budget (gather_micro: -13 %)
+#define TGT_UNROLL 4  // measured: 8 in flight win on balanced 64-edge chunks (gather_micro: -13 %) but lose on real segments (~7 edges: the
+                      // clamped tail of a batch is wasted gathers) -- target pass 48 us vs 45, all kernels 4 / 6 / 8: profiles/r1_run70_edge_unroll_ab.txt
 
 // What bounds these kernels (measured, profiles/r1_run56_*, r1_run59_gather_micro.txt, r1_run60_*): NOT the bytes.  One wave
 // handles one edge at a time, so every per-edge instruction is paid by a whole wave, and a kernel's time tracks the number
