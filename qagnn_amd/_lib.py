@@ -113,6 +113,50 @@ def _chk2d(t, name, dtype=torch.float32):
     return t
 
 
+VALIDATE = os.environ.get('QAGNN_VALIDATE', '0') == '1'  # synchronous input validation (debugging corrupt batches)
+
+
+class _ErrWatch:
+    """Surfaces the device-side input-validation flag of qagnn_graph_prep (err[0]: an edge endpoint, relation id or node type
+    was out of range and has been clamped) without a host synchronisation on the hot path.
+
+    The reference raises on such input in its one-hot / index ops (modeling_qagnn.py:352-367, 419-433).  Here the four flag words
+    are copied to pinned host memory right behind the preparation kernels, and looked at when the NEXT batch is prepared (or at
+    `poll(block=True)`, e.g. at the end of an epoch): a corrupt batch raises one step late instead of training silently on a
+    clamped graph.  QAGNN_VALIDATE=1 checks synchronously, in the call that saw the bad batch."""
+
+    def __init__(self):
+        self.pending = []
+
+    def watch(self, flags, what):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        host.copy_(flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host, what))
+        if VALIDATE:
+            self.poll(block=True)
+
+    def poll(self, block=False):
+        keep, bad = [], None
+        for ev, host, what in self.pending:
+            if block:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, what))
+            elif int(host[0]) != 0 and bad is None:
+                bad = what
+        self.pending = keep
+        if bad is not None:
+            raise RuntimeError(f'qagnn_graph_prep: out-of-range edge endpoint / relation id / node type in {bad} '
+                               '(the device clamped it; the results of that batch are not the reference\'s)')
+
+
+ERR_WATCH = _ErrWatch()
+
+
 class HipGraph:
     """Device-side prepared graph (see qagnn_graph in include/qagnn_hip.h)."""
 
@@ -137,8 +181,52 @@ class HipGraph:
         return self.array('eid_s', self.Ep)
 
 
-class HipKernels:
-    """Tensor-level calls into libqagnn_hip.so on the current HIP stream."""
+def _device_of(args, kwargs):
+    """Device of the first device tensor (or prepared graph) among the arguments of a kernel call."""
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, HipGraph):
+            return a.storage.device
+        elif isinstance(a, (tuple, list)):
+            for t in a:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    return t.device
+    return None
+
+
+def _on_operand_device(fn):
+    """Run a kernel call with the operands' device current, on THAT device's current stream.
+
+    The reference places the LM encoder on cuda:0 and the decoder on cuda:1 whenever two GPUs are visible
+    (reference qagnn.py:133-134, 168-169), so the process's current device is not, in general, the device that holds the
+    decoder's tensors.  A kernel launched on device 0's stream with device-1 pointers would fault or race with the torch ops
+    queued on cuda:1's stream; every entry point of the provider therefore switches to the operands' device first (a no-op
+    costing one integer compare when it already is the current one)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = _device_of(args, kwargs)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
+class _GuardedMeta(type):
+    def __new__(mcls, name, bases, ns):
+        for k, v in list(ns.items()):
+            if callable(v) and not k.startswith('_'):
+                ns[k] = _on_operand_device(v)
+        return super().__new__(mcls, name, bases, ns)
+
+
+class HipKernels(metaclass=_GuardedMeta):
+    """Tensor-level calls into libqagnn_hip.so, each on the current HIP stream of the device that holds its operands
+    (see _on_operand_device)."""
     name = 'hip'
 
     def __init__(self):
@@ -177,7 +265,10 @@ class HipKernels:
                                                _ptr(edge_type) if E else None, node_type.data_ptr(), N, E, n_etype, n_ntype,
                                                int(block_n), self._stream())
         self._check(rc, 'qagnn_graph_prep_blocked')
-        return HipGraph(storage, g, N, E, n_etype, n_ntype, int(block_n))
+        G = HipGraph(storage, g, N, E, n_etype, n_ntype, int(block_n))
+        ERR_WATCH.poll()  # flags of earlier batches that have landed since
+        ERR_WATCH.watch(G.array('err', 4), f'the batch with N={N} node rows, E={E} edges')
+        return G
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,

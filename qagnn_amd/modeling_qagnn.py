@@ -63,6 +63,14 @@ def _pad2(W, L):
 _CLASS_FEATS = {}
 
 
+def bn_momentum(bn):
+    """BatchNorm1d(momentum=None) means a cumulative moving average (factor 1 / num_batches_tracked); the running-statistics
+    update inside the BN bookkeeping kernel implements the exponential form only -- the reference never sets None."""
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm1d(momentum=None) (cumulative average) is not implemented by the HIP path')
+    return bn.momentum
+
+
 def edge_class_features(n_etype, n_ntype, device, dtype=torch.float32):
     key = (n_etype, n_ntype, str(device), dtype)
     if key not in _CLASS_FEATS:
@@ -108,7 +116,7 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
     Ep = float(graph.Ep)
     running = None
     if training and bn.track_running_stats:
-        m = bn.momentum if bn.momentum is not None else 0.1
+        m = bn_momentum(bn)
         # n identical momentum updates in closed form; the batch counter is bumped by n below (the kernel would add 1)
         running = (bn.running_mean, bn.running_var, None, L.dense_pos, 1.0 - (1.0 - m) ** n_updates, Ep / max(Ep - 1.0, 1.0))
         bn.num_batches_tracked += n_updates
@@ -136,7 +144,7 @@ def edge_class_table(edge_encoder, graph, training, n_updates=1):
         var = (w * (h - mu) ** 2).sum(0)
         if training and bn.track_running_stats:
             with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 0.1
+                m = bn_momentum(bn)
                 # n identical updates r <- (1-m) r + m x in closed form: r <- r + (1 - (1-m)^n) (x - r)
                 wgt = 1.0 - (1.0 - m) ** n_updates
                 bn.running_mean.lerp_(mu, wgt)
@@ -262,7 +270,7 @@ class GATConvE(nn.Module):
                 if self.training and bn.track_running_stats:
                     R = float(Xp.size(0))
                     running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos,
-                               bn.momentum if bn.momentum is not None else 0.1, R / max(R - 1.0, 1.0))
+                               bn_momentum(bn), R / max(R - 1.0, 1.0))
                 W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p = packed[8:]
                 return ops.gat_hop(Xp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head),
                                    (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
@@ -277,7 +285,7 @@ class GATConvE(nn.Module):
         if self.training and bn.track_running_stats:  # train-mode buffer update, done inside the BN bookkeeping kernel
             R = float(Xp.size(0))
             running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos,
-                       bn.momentum if bn.momentum is not None else 0.1, R / max(R - 1.0, 1.0))
+                       bn_momentum(bn), R / max(R - 1.0, 1.0))
         y, mean_p, var_p = ops.gat_mlp(aggr, *mlp_ops, use_batch_stats, bn.eps, p_drop if self.training else 0.0,
                                        apply_act, running)
         return y, a
@@ -373,7 +381,7 @@ class QAGNN_Message_Passing(nn.Module):
         up to 16, pad columns are exactly 0)."""
         dev = node_type_flat.device
         temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)
-        sinB = ops.kernels().sin_basis(node_score_flat.contiguous(), self._js_table(dev), Wes_t.size(0))
+        sinB = ops.sin_basis(node_score_flat.contiguous(), self._js_table(dev), Wes_t.size(0))
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
         return temb, ops.gelu_dropout(pre, 0.0, False)
 

@@ -194,6 +194,8 @@ class wgrad_scope:
     def __enter__(self):
         self.prev = _DEFER[0]
         _DEFER[0] = WGRAD_OVERLAP and not FUSED_COLSUM
+        if not self.prev:
+            reset_wgrad_queue()  # a backward that raised after defer_wgrads() must not leak its jobs into this pass
         return self
 
     def __exit__(self, *exc):
@@ -223,6 +225,21 @@ def _end_of_backward():
     join_wgrads()
 
 
+def reset_wgrad_queue():
+    """Drop whatever an aborted backward left behind (called when a new forward opens a wgrad_scope).
+
+    If a backward raises after defer_wgrads(), the engine's final callback does not run: `callback_queued` would stay True (so
+    the end-of-backward join is never re-armed) and the stale closures would be issued -- into freed outputs -- by the next
+    backward.  Work already issued on the side stream is still joined, so its buffers cannot be recycled under it."""
+    q = _WgradQueue
+    q.pending = []
+    q.callback_queued = False
+    if q.unjoined is not None:
+        q.unjoined[0].wait_stream(q.unjoined[1])
+        q.unjoined = None
+    q.keep.clear()
+
+
 def defer_wgrads(jobs, keep):
     """Queue weight-gradient launches (called from inside a backward)."""
     q = _WgradQueue
@@ -245,7 +262,7 @@ def flush_wgrads(ref=None):
         for job in jobs:
             job()
         return
-    main = torch.cuda.current_stream()
+    main = torch.cuda.current_stream(ref.device if ref is not None else None)  # the stream of the device holding the operands
     if q.unjoined is not None and q.unjoined[0] != main:
         q.unjoined[0].wait_stream(q.unjoined[1])
     key = main.device_index
@@ -284,15 +301,16 @@ def graph_prep_async(edge_index, edge_type, node_type, n_etype, n_ntype, block_n
     K = kernels()
     if not (PREP_OVERLAP and node_type.is_cuda):
         return K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n), (lambda: None)
-    main = torch.cuda.current_stream()
+    dev = node_type.device
+    main = torch.cuda.current_stream(dev)
     key = main.device_index
     if key not in _PREP_STREAMS:
-        _PREP_STREAMS[key] = torch.cuda.Stream(device=main.device)
+        _PREP_STREAMS[key] = torch.cuda.Stream(device=dev)
     side = _PREP_STREAMS[key]
     side.wait_stream(main)  # the inputs (and last step's readers of the recycled storage) are ordered before the fork
     with torch.cuda.stream(side):
         graph = K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n)
-    return graph, (lambda: torch.cuda.current_stream().wait_stream(side))
+    return graph, (lambda: torch.cuda.current_stream(dev).wait_stream(side))
 
 
 class GradAcc:
@@ -448,15 +466,55 @@ class GeluDropoutFn(torch.autograd.Function):
 _seed_counter = [0]
 
 
+_rank_salt = [None]
+
+
+def _rank():
+    """Rank of this process in the default process group (0 outside torch.distributed): ranks that were seeded identically
+    must still draw different dropout masks for their different shards."""
+    if _rank_salt[0] is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            _rank_salt[0] = dist.get_rank()
+        else:
+            return int(_os.environ.get('RANK', '0'))  # not cached: the group may be initialised later
+    return _rank_salt[0]
+
+
 def next_seed():
-    """Per-call dropout seed drawn from torch's CPU generator state (so torch.manual_seed controls it)."""
+    """Per-call dropout seed from torch's CPU seed (so torch.manual_seed controls it), a per-process call counter and the rank."""
     _seed_counter[0] += 1
-    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0] * 0x85EBCA77) % (2 ** 63)
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0] * 0x85EBCA77 + _rank() * 0xC2B2AE3D27D4EB4F) % (2 ** 63)
 
 
 def gelu_dropout(X, p, training):
     p = float(p) if training else 0.0
     return GeluDropoutFn.apply(X, p, next_seed() if p > 0 else 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class SinBasisFn(torch.autograd.Function):
+    """B[r, j] = sin(js[j] * score[r]), j < J, zero-padded to `ldo` columns (reference modeling_qagnn.py:69-71).  The reference
+    differentiates through it (node scores are data there, but a caller may learn them): dscore[r] = sum_j dB[r, j] js[j] cos(.)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, score, js, ldo):
+        ctx.save_for_backward(score, js)
+        return kernels().sin_basis(score, js, ldo)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dB):
+        score, js = ctx.saved_tensors
+        arg = score.reshape(-1, 1) * js.reshape(1, -1)
+        return (dB[:, :js.numel()] * torch.cos(arg) * js.reshape(1, -1)).sum(1).view_as(score), None, None
+
+
+def sin_basis(score, js, ldo):
+    if score.requires_grad:
+        return SinBasisFn.apply(score, js, ldo)
+    return kernels().sin_basis(score, js, ldo)  # the usual case (scores are inputs): no autograd node
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -271,3 +271,104 @@ def test_running_gradient_totals_survive_a_second_backward(k):
     for nm, a, b in zip(names, g1, g2):
         assert torch.isfinite(a).all() and a.abs().max() > 0, nm
         assert torch.equal(a, b), nm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round-2 advisor findings
+# ---------------------------------------------------------------------------------------------------------------------
+def test_sin_basis_propagates_gradient_to_scores():
+    """The reference differentiates through sin(1.1^j * score) (modeling_qagnn.py:69-71); so does ops.sin_basis."""
+    score = (torch.randn(37) * 2).requires_grad_(True)
+    js = torch.pow(1.1, torch.arange(10).float())
+    out = ops.sin_basis(score, js, 16)
+    assert out.shape == (37, 16) and bool((out[:, 10:] == 0).all())
+    w = torch.randn(37, 16)
+    (out * w).sum().backward()
+    s2 = score.detach().clone().requires_grad_(True)
+    (torch.sin(js.unsqueeze(0) * s2.reshape(-1, 1)) * w[:, :10]).sum().backward()
+    assert torch.allclose(score.grad, s2.grad, rtol=1e-5, atol=1e-5)
+    # scores that are plain inputs (the QAGNN.forward case) create no autograd node
+    assert not ops.sin_basis(score.detach(), js, 16).requires_grad
+
+
+def test_batchnorm_cumulative_average_is_rejected():
+    model = build('small_train')
+    model.gnn.gnn_layers[0].mlp[1].momentum = None
+    fix = helpers.load_golden('small_train')
+    sv, cids, nt, ns, al, ei, et = golden_inputs('small_train', fix)
+    with pytest.raises(NotImplementedError):
+        model(sv, cids, nt, ns, al, (ei, et))
+
+
+def test_wgrad_queue_survives_an_aborted_backward():
+    """A backward that raises after defer_wgrads() leaves jobs + the callback latch behind; the next forward drops them."""
+    q = ops._WgradQueue
+    ran = []
+    q.pending.append(lambda: ran.append('stale'))
+    q.keep.append(torch.zeros(1))
+    q.callback_queued = True  # what an aborted backward leaves: the engine never ran _end_of_backward
+    old = ops.WGRAD_OVERLAP
+    ops.WGRAD_OVERLAP = True
+    try:
+        model = build('small_train')
+        fix = helpers.load_golden('small_train')
+        sv, cids, nt, ns, al, ei, et = golden_inputs('small_train', fix)
+        n0 = q.n_deferred
+        logits, _ = model(sv, cids, nt, ns, al, (ei, et))
+        assert not q.pending and not q.keep and not q.callback_queued
+        logits.sum().backward()
+        assert q.n_deferred > n0 and not q.pending and not q.callback_queued and ran == []
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        ops.WGRAD_OVERLAP = old
+
+
+def test_dropout_seed_depends_on_rank(monkeypatch):
+    ops._rank_salt[0] = None
+    ops._seed_counter[0] = 0
+    monkeypatch.setenv('RANK', '0')
+    a = ops.next_seed()
+    ops._seed_counter[0] = 0
+    monkeypatch.setenv('RANK', '3')
+    b = ops.next_seed()
+    assert a != b
+
+
+def test_kernel_calls_run_on_the_operands_device(monkeypatch):
+    """_lib._on_operand_device: a call whose operands live on a non-current device runs under torch.cuda.device(that device)
+    (the reference keeps the decoder on cuda:1 when two GPUs are visible, qagnn.py:133-134).  Host logic only: the device
+    switch is observed through a stub, no GPU needed."""
+    from qagnn_amd import _lib
+
+    class FakeDev:
+        def __init__(self, index):
+            self.index = index
+
+    class FakeTensor(torch.Tensor):
+        pass
+
+    seen = []
+
+    class Probe(metaclass=_lib._GuardedMeta):
+        def launch(self, t):
+            seen.append(('ran', _lib.torch.cuda.current_device()))
+            return 7
+
+    state = {'cur': 0}
+
+    class Ctx:
+        def __init__(self, dev):
+            self.dev = dev
+
+        def __enter__(self):
+            self.prev, state['cur'] = state['cur'], self.dev.index
+
+        def __exit__(self, *a):
+            state['cur'] = self.prev
+
+    monkeypatch.setattr(_lib.torch.cuda, 'current_device', lambda: state['cur'])
+    monkeypatch.setattr(_lib.torch.cuda, 'device', Ctx)
+    monkeypatch.setattr(_lib, '_device_of', lambda a, k: FakeDev(a[0]))
+    p = Probe()
+    assert p.launch(0) == 7 and seen[-1] == ('ran', 0)
+    assert p.launch(1) == 7 and seen[-1] == ('ran', 1) and state['cur'] == 0
