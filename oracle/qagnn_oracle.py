@@ -38,6 +38,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+# Float64 yardstick runs (tests only).  The reference feeds sin(1.1^j * score), 1.1^j up to 1.2e4, from a score
+# normalisation that ends in a division: run in float64, the quotient -- and with it every high-frequency basis feature --
+# differs from any fp32 run by ~1e-3, which says nothing about the arithmetic downstream.  With this switch on, a float64
+# model computes the normalisation and the products 1.1^j * score in fp32 (exactly what the reference does in its fp32 run,
+# modeling_qagnn.py:160-167, 70-71) and everything else, including sin() of those arguments, in float64: "exact arithmetic
+# downstream of the reference's own fp32 sin arguments".  |fp32 run - this run| is then the reference's genuine fp32 rounding
+# error, the yardstick the parity tests hold the HIP path to (tests/helpers.py: f64_yardstick).
+PIN_FP32_SCORES = False
+
+
 # --------------------------------------------------------------------------------------
 # utils/layers.py restatements
 # --------------------------------------------------------------------------------------
@@ -285,7 +295,10 @@ class QAGNN_Message_Passing(nn.Module):
         node_type_emb = self.activation(self.emb_node_type(T))  # :65-66
         js = torch.arange(self.hidden_size // 2).unsqueeze(0).unsqueeze(0).float()
         js = torch.pow(1.1, js)  # :70-71
-        B = torch.sin(js * node_score)
+        if PIN_FP32_SCORES:  # float64 yardstick runs: the sin ARGUMENTS are the fp32 ones (see PIN_FP32_SCORES)
+            B = torch.sin((js * node_score.float()).to(H.dtype))
+        else:
+            B = torch.sin(js * node_score)
         node_score_emb = self.activation(self.emb_score(B))  # :73
         X = H
         edge_index, edge_type = A
@@ -337,11 +350,14 @@ class QAGNN(nn.Module):
         gnn_input = self.dropout_e(torch.cat([gnn_input0, gnn_input1], dim=1))
         # :160-167 node-score normalisation
         _mask = (torch.arange(node_scores.size(1)) < adj_lengths.unsqueeze(1)).float()
+        work_dtype = node_scores.dtype
+        if PIN_FP32_SCORES:
+            node_scores = node_scores.float()
         node_scores = -node_scores
         node_scores = node_scores - node_scores[:, 0:1, :]
         node_scores = node_scores.squeeze(2) * _mask
         mean_norm = torch.abs(node_scores).sum(dim=1) / adj_lengths
-        node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
+        node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2).to(work_dtype)
 
         gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores)  # :170
         Z_vecs = gnn_output[:, 0]

@@ -24,14 +24,80 @@ def shard_questions(n_questions, rank, world):
     return a, a + base + (1 if rank < rem else 0)
 
 
+def balance_questions(question_cost, world):
+    """Assign the questions of a global batch to ranks so that the per-rank sums of `question_cost` are as equal as a greedy
+    longest-processing-time pass makes them ("balance ranks by sum E'_g rather than by question count").
+
+    question_cost[q] = sum over the question's nc subgraphs of E'_g = edges + node rows (the self loops): the edge kernels'
+    time is proportional to it and subgraph edge counts vary by more than 10x (400 ... 5 800).  Every rank computes the same
+    assignment from the same costs (deterministic: ties broken by question index), so no communication is needed.
+    Returns a list of `world` ascending index lists; every rank gets at least one question when n_questions >= world (a rank
+    with no subgraph would have no BatchNorm batch).  A step's time is the slowest rank's, so what matters is the maximum."""
+    cost = [float(c) for c in question_cost]
+    nq = len(cost)
+    order = sorted(range(nq), key=lambda q: (-cost[q], q))
+    load, out = [0.0] * world, [[] for _ in range(world)]
+    for i, q in enumerate(order):
+        left = nq - i                                  # questions still to place, this one included
+        empty = [r for r in range(world) if not out[r]]
+        # when only as many questions remain as there are empty ranks, they must go to the empty ranks
+        cand = empty if empty and left <= len(empty) else range(world)
+        r = min(cand, key=lambda r: (load[r], r))
+        out[r].append(q)
+        load[r] += cost[q]
+    return [sorted(v) for v in out]
+
+
+def question_costs(edge_counts, n_nodes, num_choice):
+    """E'_g summed over each question's choices, from the per-subgraph edge counts of a batch ([bs * nc] ints)."""
+    ec = torch.as_tensor(edge_counts, dtype=torch.float64).view(-1, num_choice)
+    return (ec.sum(1) + float(n_nodes * num_choice)).tolist()
+
+
 def shard_loss_weight(n_local, n_global):
     """(b - a) / bs, the reference's mini-batch loss weight (qagnn.py:261)."""
     return n_local / float(n_global)
 
 
+class GradBucket:
+    """ONE persistent flat fp32 buffer for the gradient all-reduce of `params` (the ~2.85 M decoder parameters: 11.4 MB).
+
+    allreduce() packs the current p.grad tensors into the buffer with one multi-tensor copy, sums the buffer across ranks with
+    a single RCCL call on memory that never moves, and copies the sums back INTO the existing p.grad tensors with one more
+    multi-tensor copy: no allocation per step, and p.grad keeps its identity (an optimiser or hook holding on to a gradient
+    tensor sees the reduced values).  Gradients may be reset with p.grad = None (optimizer.zero_grad(set_to_none=True)), which
+    lets autograd hand its buffers over instead of adding into zeros with one kernel per parameter."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, 'no trainable parameters'
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        assert all(p.device == dev and p.dtype == dtype for p in self.params), 'one bucket = one device, one dtype'
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dtype, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            self.views.append(self.flat[off:off + n].view_as(p))
+            off += n
+
+    def allreduce(self, group=None):
+        """Sum the gradients across ranks in place; returns the number of elements reduced.  A parameter without a gradient on
+        this rank contributes zeros (and receives the other ranks' sum only if it has a gradient tensor to receive it)."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if have:
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+        return self.flat.numel()
+
+
 def allreduce_gradients(params, group=None):
-    """Sum the gradients of `params` across ranks through one flat bucket (in place).  Parameters whose grad is None on
-    this rank (e.g. frozen) must be excluded by the caller consistently on all ranks."""
+    """Sum the gradients of `params` across ranks through one flat bucket (in place) without a persistent bucket: the
+    gradients are copied into a temporary flat buffer and back (p.grad keeps its identity).  Prefer GradBucket in a training
+    loop.  Parameters whose grad is None on this rank (e.g. frozen) must be excluded consistently on all ranks."""
     params = [p for p in params if p.grad is not None]
     if not params:
         return 0
@@ -40,7 +106,7 @@ def allreduce_gradients(params, group=None):
     off = 0
     for p in params:
         n = p.numel()
-        p.grad = flat[off:off + n].view_as(p)  # re-point the gradient at its slice of the bucket: no copy-back kernels
+        p.grad.copy_(flat[off:off + n].view_as(p))
         off += n
     return flat.numel()
 
@@ -50,9 +116,9 @@ def allgather_logits(logits, group=None, equal_shards=False):
     `equal_shards=True` (every rank has the same bs_local) skips the size exchange and its host synchronisation."""
     world = dist.get_world_size(group)
     if equal_shards:
-        out = [torch.empty_like(logits) for _ in range(world)]
-        dist.all_gather(out, logits.detach().contiguous(), group=group)
-        return torch.cat(out, dim=0)
+        out = torch.empty((world * logits.size(0), logits.size(1)), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, logits.detach().contiguous(), group=group)  # one output tensor, rank-major
+        return out
     n_local = torch.tensor([logits.size(0)], device=logits.device, dtype=torch.long)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
@@ -63,3 +129,11 @@ def allgather_logits(logits, group=None, equal_shards=False):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def scatter_logits_by_assignment(gathered, assignment):
+    """Undo balance_questions(): rank-ordered logits (rank 0's questions, then rank 1's, ...) -> original question order."""
+    order = torch.tensor([q for part in assignment for q in part], dtype=torch.long, device=gathered.device)
+    out = torch.empty_like(gathered)
+    out[order] = gathered
+    return out

@@ -52,7 +52,11 @@ def make_record(rng, n_concepts, n_q, n_a, n_kg_edges, n_rel=17, n_concept_vocab
     adj = coo_matrix((np.ones(len(row), dtype=bool), (row, col)), shape=(n_rel * m, m))
     if with_scores:
         # LM scores are negative MLM losses; the extra (non Q/A) concepts are stored from high to low score
-        sc = -(20.0 + 40.0 * rng.random(m))
+        # ... stored as multiples of 1/64: the reference's score normalisation (modeling_qagnn.py:160-167) divides by a row sum
+        # of |score|, and sin(1.1^j * score) with 1.1^j up to 1.2e4 amplifies a 1-ulp difference of that sum (summation order:
+        # CPU vs GPU, fp32 vs fp64) into 1e-3-level feature changes.  Sums of <= 200 such values are exact in fp32 in ANY
+        # order, so every implementation sees bit-identical normalised scores and parity can be stated tightly.
+        sc = -np.round((20.0 + 40.0 * rng.random(m)) * 64.0) / 64.0
         sc[n_q + n_a:] = np.sort(sc[n_q + n_a:])[::-1]
         cid2score = OrderedDict()
         cid2score[-1] = float(max(sc.max(), -20.0) + 1.0)  # context node = the highest score

@@ -239,14 +239,11 @@ def main():
         edge_index, edge_type = ref_mq.LM_QAGNN.batch_graph(None, ei_flat, et_flat, n)
         fix['batched_edge_index'] = edge_index.numpy().astype(np.int32)
         # ---- reference model: run 1 = caller edge order (the fixtures); run 2 = permuted edge order, only used to
-        #      record the reference's own fp32 re-ordering noise per tensor ('noise::<key>') ----------------------
+        #      record the reference's own fp32 re-ordering noise per tensor ('noise::<key>', used for FORWARD values;
+        #      gradients are held to the float64 yardstick of helpers.f64_yardstick instead) ---------------------
         fix.update(run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens, edge_index, edge_type))
         perm = torch.randperm(edge_index.size(1), generator=torch.Generator().manual_seed(c['seed'] + 5))
         alt = run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens, edge_index[:, perm], edge_type[perm])
-        # run 3 = raw node scores moved by one fp32 ulp: the score normalisation (modeling_qagnn.py:160-167) feeds
-        # sin(1.1**j * score) with 1.1**j up to 1.2e4, so a 1-ulp change of a score (e.g. a different summation order of
-        # the mean-|score| reduction on another device) moves the high-frequency basis features by ~1e-3
-        alt2 = run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores * (1 + 2.0 ** -23), alens, edge_index, edge_type)
         for key in list(fix.keys()):
             if key.endswith('::sum') or key.startswith('noise::') or key not in alt:
                 continue
@@ -255,8 +252,7 @@ def main():
                 continue
             dn = 0.0
             if fix[key].size:
-                dn = max(float(np.abs(fix[key].astype(np.float64) - alt[key].astype(np.float64)).max()),
-                         float(np.abs(fix[key].astype(np.float64) - alt2[key].astype(np.float64)).max()))
+                dn = float(np.abs(fix[key].astype(np.float64) - alt[key].astype(np.float64)).max())
             fix['noise::' + base] = np.array(max(dn, float(fix.get('noise::' + base, 0.0))))
         path = os.path.join(HERE, name + '.npz')
         np.savez_compressed(path, **fix)

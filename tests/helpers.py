@@ -86,6 +86,12 @@ GOLDEN_CASES = {
                      cfg=model_cfg(d=200, k=5, n_etype=34, sent_dim=48, n_concept=2000, concept_in_dim=24)),
     'trunc_eval': dict(shape='csqa', nq=1, nc=4, n=60, n_rel=17, std=0.7, train=False, seed=17,
                        cfg=model_cfg(d=64, k=3, sent_dim=32, n_concept=2000, concept_in_dim=16)),
+    # the real entity-table widths: SapBERT 768-d (MedQA-USMLE, DDB graph: 34 relations, no node scores) and the 1024-d
+    # CSQA table -- these take the fused gather-GEMM input stage (concept_in_dim % 16 == 0), medqa_b8 (24) the stock path
+    'sapbert_b4': dict(shape='medqa', nq=1, nc=4, n=200, n_rel=15, std=0.6, train=True, seed=18,
+                       cfg=model_cfg(d=200, k=5, n_etype=34, sent_dim=768, n_concept=3000, concept_in_dim=768)),
+    'roberta_b5': dict(shape='csqa', nq=1, nc=5, n=200, n_rel=17, std=0.6, train=True, seed=19,
+                       cfg=model_cfg(d=200, k=5, sent_dim=1024, n_concept=2000, concept_in_dim=1024)),
 }
 
 
@@ -145,11 +151,11 @@ NOISE_MULT = 6.0
 def _close(t, ref, rtol, atol, what, noise=0.0):
     """Elementwise |t - ref| <= atol + rtol * max(|ref| elementwise, max|ref| of the tensor) + NOISE_MULT * noise.
 
-    `noise` is the reference's OWN fp32 re-ordering noise for this tensor: make_golden.py runs the reference twice,
-    the second time with the edge list permuted (a mathematically neutral change that only re-orders its float
-    sums), and stores max|run1 - run2| per tensor.  The train-mode cases are visibly ill-conditioned in fp32 (the
-    reference moves its own gradients by up to 1e-3..3e-2 of their scale under that permutation), so the bar for
-    "identical within fp32" is stated relative to that floor.
+    Used for FORWARD values against the reference's fixtures, and for the oracle against the fixtures (same ATen kernels in
+    the same order: agreement at the 1e-6 level).  `noise` is the reference's OWN fp32 re-ordering noise for this tensor:
+    make_golden.py runs the reference twice, the second time with the edge list permuted (a mathematically neutral change
+    that only re-orders its float sums), and stores max|run1 - run2| per tensor.  Gradients of the package are NOT compared
+    this way: they are held to the float64 yardstick (F64Ref below).
 
     The tensor-level term is the usual backward-error yardstick for fp32 sums of mixed-sign terms: an element
     that is a near-cancellation of O(max|ref|) contributions cannot be reproduced to a relative 1e-4.
@@ -158,11 +164,6 @@ def _close(t, ref, rtol, atol, what, noise=0.0):
     err = (t - ref).abs()
     bound = atol + rtol * torch.clamp(ref.abs(), min=scale) + NOISE_MULT * float(noise)
     bad = err > bound
-    if bool(bad.any()) and what.split('::')[0] in ('grad', 'mpgrad', 'layergrad'):
-        # ReLU-flip outliers (see tests/test_host_logic_emu.py docstring): a handful of gradient elements may sit
-        # outside the bound, but never by more than 20x and never more than max(2, 0.2 %) of a tensor
-        if int(bad.sum()) <= max(2, int(0.002 * ref.numel())) and bool((err <= 20 * bound).all()):
-            return err.max().item()
     assert not bool(bad.any()), (f'{what}: {int(bad.sum())}/{ref.numel()} elements off, worst |d|={err.max().item():.3e} '
                                  f'(tensor scale {scale:.3e}, rtol {rtol}, atol {atol}, ref noise {float(noise):.3e})')
     return err.max().item() if ref.numel() else 0.0
@@ -173,30 +174,10 @@ def _stored_scale(fix, base):
     return max((float(np.abs(a).max()) for a in arrs if a.size), default=0.0)
 
 
-def section_rel_noise(fix, section):
-    """max over the tensors of a gradient section ('grad', 'mpgrad', 'layergrad') of reference-noise / tensor scale.
-
-    A single permuted re-run is a noisy estimate of one tensor's noise, but all gradients of one backward pass share
-    the same conditioning, so the section-wide maximum is the robust floor (most sections: 1e-6..3e-5; two chaotic
-    ones, config1_refinit/grad and csqa_b10/mpgrad, reach 6e-3 in the reference itself)."""
-    cache = fix.setdefault('_relnoise', {})
-    if section not in cache:
-        worst = 0.0
-        pre = 'noise::' + section + '::'
-        for k in list(fix.keys()):
-            if isinstance(k, str) and k.startswith(pre) and not re.search(r'(linear_key|pooler\.w_ks)\.bias$|(edge_encoder|mlp)\.0\.bias$', k):
-                worst = max(worst, float(fix[k]) / (_stored_scale(fix, k[len('noise::'):]) + 1e-30))
-        cache[section] = worst
-    return cache[section]
-
-
 def check_stored(fix, key, t, rtol, atol):
     """Compare tensor `t` with whatever `store` kept under `key`; returns max abs error seen."""
     t = t.detach().cpu().float()
     noise = float(fix['noise::' + key]) if ('noise::' + key) in fix else 0.0
-    section = key.split('::')[0]
-    if section in ('grad', 'mpgrad', 'layergrad'):
-        noise = max(noise, section_rel_noise(fix, section) * _stored_scale(fix, key))
     if key in fix:
         ref = torch.from_numpy(fix[key])
         worst = _close(t, ref.view_as(t), rtol, atol, key, noise)
@@ -244,3 +225,281 @@ def load_golden(name):
     path = os.path.join(GOLDEN_DIR, name + '.npz')
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float64 yardstick for gradients
+# ---------------------------------------------------------------------------------------------------------------------
+def build_oracle(case):
+    from oracle import qagnn_oracle as O
+    c = GOLDEN_CASES[case] if isinstance(case, str) else case
+    torch.manual_seed(0)
+    model = O.build_qagnn(c['cfg'])
+    det_fill_(model, c['seed'], c['std'])
+    model.pooler.dropout.p = 0.0
+    model.pooler.attention.dropout.p = 0.0
+    model.train(c['train'])
+    return model
+
+
+def golden_inputs(case, fix):
+    c = GOLDEN_CASES[case]
+    B, n = c['nq'] * c['nc'], c['n']
+    cids = torch.from_numpy(fix['concept_ids']).view(B, n)
+    nt = torch.from_numpy(fix['node_type_ids']).view(B, n)
+    ns = torch.from_numpy(fix['node_scores']).view(B, n, 1)
+    al = torch.from_numpy(fix['adj_lengths']).view(B)
+    ei = torch.from_numpy(fix['batched_edge_index'].astype(np.int64))
+    et = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
+    sv = torch.from_numpy(fix['sent_vecs'])
+    return sv, cids, nt, ns, al, ei, et
+
+
+# How gradients are compared (tests/test_host_logic_emu.py on CPU, tests/test_hip_parity.py on the GPU) -------------------------
+#
+#   |g - g64| <= YARD_MULT * |g_ref32 - g64| + 1e-6 * scale      per tensor, max norm, scale = max|g64|
+#
+# g64 is the oracle in float64 with the fp32 sin arguments pinned (oracle.PIN_FP32_SCORES), g_ref32 the fp32 oracle (itself pinned
+# to the reference's own fp32 run by tests/test_oracle_golden.py).  Two refinements keep the bar both tight and deterministic:
+#
+#  * ReLU kinks.  Every GATConvE.mlp is Linear -> BatchNorm -> ReLU -> Linear; of the ~1e6..1e8 BatchNorm outputs of a case a few
+#    lie within fp32 rounding of 0 (measured: |x| up to 6e-6 where the fp32 and float64 oracle disagree about x > 0), and each
+#    fp32 implementation rounds a different handful to the other side.  That is a different SUBGRADIENT choice at a kink, not
+#    an arithmetic error, but a single flipped mask moves the BatchNorm-bias gradient (a mixed-sign sum over rows) by up to
+#    1 %.  The float64 reference therefore lets the masks of its near-zero elements (|x| < KINK_TAU) be overridden: the
+#    gradient of the BatchNorm bias in front of a ReLU changes by exactly +-(upstream gradient at the element) per flip, so the
+#    flips a candidate made can be READ OFF its BatchNorm-bias gradients; one more float64 backward with those masks gives the
+#    reference the candidate is held to, for every tensor.  The fp32 oracle gets the same treatment before its distance
+#    becomes the yard.
+#  * The per-tensor yard is floored by the section's median relative yard: one tensor on which the fp32 oracle happened to
+#    land within 1e-9 of float64 must not set a bar no fp32 run can meet.
+#
+# Whatever is allowed must stay below MAX_ALLOWED of the tensor's scale, asserted per tensor.
+KINK_TAU = 2e-5
+YARD_MULT = 3.0
+MAX_ALLOWED = 1e-2
+
+
+class _KinkState:
+    def __init__(self):
+        self.groups = {}    # module idx -> list of LongTensors: flat positions (in the ReLU input) that flip together
+        self.natural = {}   # module idx -> list of bools: mask bit of each group as float64 sees it (x > 0)
+        self.override = {}  # module idx -> {group number: bit}
+        self.gsum = {}      # module idx -> float64 tensor [n_groups]: upstream gradient summed over the group (and over calls)
+
+
+class _KinkReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        ctx.mod = mod
+        ctx.save_for_backward(x)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        mod, st = ctx.mod, ctx.mod.state
+        mask = x > 0  # relu'(0) = 0, as in torch
+        groups = st.groups.get(mod.idx, [])
+        if groups:
+            gf = g.reshape(-1)
+            st.gsum[mod.idx] += torch.stack([gf[p].sum() for p in groups])
+            ov = st.override.get(mod.idx)
+            if ov:
+                mask = mask.clone()
+                for k, bit in ov.items():
+                    mask.view(-1)[groups[k]] = bool(bit)
+        return g * mask, None
+
+
+class _KinkReLU(torch.nn.Module):
+    """nn.ReLU whose backward mask can be overridden on the elements within KINK_TAU of the kink."""
+
+    def __init__(self, state, idx):
+        super().__init__()
+        self.state, self.idx = state, idx
+
+    def forward(self, x):
+        st = self.state
+        if self.idx not in st.groups:  # a shared module (the edge encoder) sees the same input on every call
+            near = (x.detach().abs() < KINK_TAU)
+            pos = near.reshape(-1).nonzero().flatten()
+            groups = []
+            if pos.numel():
+                col = pos % x.size(-1)
+                val = x.detach().reshape(-1)[pos]
+                key = col.double() * 4.0 + torch.round(val / 1e-10) * 1e-3  # identical rows (edges of one class) flip together
+                for kv in torch.unique(key):
+                    groups.append(pos[key == kv])
+            st.groups[self.idx] = groups
+            st.natural[self.idx] = [bool(x.detach().reshape(-1)[p[0]] > 0) for p in groups]
+            st.gsum[self.idx] = torch.zeros(len(groups), dtype=torch.float64)
+        return _KinkReLUFn.apply(x, self)
+
+
+def relu_sites(model_gnn, prefix):
+    """[(Sequential holding Linear-BN-ReLU-Linear, name of its BatchNorm bias)] of a QAGNN_Message_Passing-like module."""
+    sites = [(model_gnn.edge_encoder, prefix + 'edge_encoder.1.bias')]
+    for l, layer in enumerate(model_gnn.gnn_layers):
+        sites.append((layer.mlp, f'{prefix}gnn_layers.{l}.mlp.1.bias'))
+    return sites
+
+
+class F64Ref:
+    """Float64 reference gradients of one (case, section) with overridable ReLU kinks; see the comment block above.
+
+    section: 'grad' (QAGNN.forward, loss = sum(logits * linspace(0.5, 1.5))), 'mpgrad' (the message-passing stack on
+    mp_inputs, loss = sum(out * cos(0.37 i))), 'layergrad' (GATConvE layer 0, loss = sum(out * sin(0.11 i))).
+    `case`: a GOLDEN_CASES name, or a case dict with `inputs` = (sent_vecs, concept_ids, node_type_ids, node_scores,
+    adj_lengths, edge_index, edge_type)."""
+
+    def __init__(self, case, section, inputs=None):
+        from oracle import qagnn_oracle as O
+        self.c = c = GOLDEN_CASES[case] if isinstance(case, str) else case
+        self.section = section
+        if inputs is None:
+            inputs = golden_inputs(case, load_golden(case))
+        self.inputs = inputs
+        self.mp_in = mp_inputs(c)  # drawn under the fp32 default dtype: the same numbers for every run
+        self.state = _KinkState()
+        model = build_oracle(c).double()  # weights are drawn in fp32, then widened
+        if section == 'layergrad':
+            layer = model.gnn.gnn_layers[0]
+            self.sites = [(layer.edge_encoder, 'edge_encoder.1.bias'), (layer.mlp, 'mlp.1.bias')]
+        else:
+            self.sites = relu_sites(model.gnn, 'gnn.' if section == 'grad' else '')
+        for idx, (seq, _) in enumerate(self.sites):
+            assert isinstance(seq[2], torch.nn.ReLU)
+            seq[2] = _KinkReLU(self.state, idx)
+        torch.set_default_dtype(torch.float64)
+        O.PIN_FP32_SCORES = True
+        try:
+            self.loss, self.params, self.extra = self._forward(model, torch.float64)
+        finally:
+            torch.set_default_dtype(torch.float32)
+            O.PIN_FP32_SCORES = False
+        self.n_kinks = sum(len(g) for g in self.state.groups.values())
+        self.g0 = self.backward({})
+        self.g0_gsum = {k: v.clone() for k, v in self.state.gsum.items()}
+        self.yard = None
+
+    def _forward(self, model, dtype):
+        c, section = self.c, self.section
+        B, n = c['nq'] * c['nc'], c['n']
+        sv, cids, nt, ns, al, ei, et = self.inputs
+        H, nsc, x, extra = self.mp_in
+        if section == 'grad':
+            logits, attn = model(sv.to(dtype), cids, nt, ns.to(dtype), al, (ei, et))
+            loss = (logits * torch.linspace(0.5, 1.5, B).view(B, 1).to(dtype)).sum()
+            params = {k: p for k, p in model.named_parameters() if p.requires_grad}
+            return loss, params, {'::logits': logits.detach(), '::pool_attn': attn.detach()}
+        if section == 'mpgrad':
+            nsc = nsc * (torch.arange(n) < al.unsqueeze(1)).float().unsqueeze(2)
+            Hg = H.detach().to(dtype).clone().requires_grad_(True)
+            out = model.gnn(Hg, (ei, et), nt, nsc.to(dtype))
+            wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out).to(dtype)
+            params = {k: p for k, p in model.gnn.named_parameters() if p.requires_grad}
+            params['::mp_dH'] = Hg
+            return (out * wg).sum(), params, {'::mp_out': out.detach()}
+        if section == 'layergrad':
+            layer = model.gnn.gnn_layers[0]
+            xg = x.detach().to(dtype).clone().requires_grad_(True)
+            out = layer(xg, ei, et, nt.view(-1), extra.to(dtype))
+            wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out).to(dtype)
+            params = {k: p for k, p in layer.named_parameters() if p.requires_grad}
+            params['::layer_dx'] = xg
+            return (out * wl).sum(), params, {'::layer_out': out.detach()}
+        raise ValueError(section)
+
+    def backward(self, override):
+        st = self.state
+        st.override = override
+        for k in st.gsum:
+            st.gsum[k].zero_()
+        names = list(self.params.keys())
+        gs = torch.autograd.grad(self.loss, [self.params[k] for k in names], retain_graph=True, allow_unused=True)
+        st.override = {}
+        return {k: g.detach() for k, g in zip(names, gs) if g is not None}
+
+    def oracle32(self):
+        """Gradients (and forward outputs) of the fp32 oracle on the same inputs."""
+        model = build_oracle(self.c)
+        loss, params, extra = self._forward(model, torch.float32)
+        names = list(params.keys())
+        gs = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)
+        out = {k: g.detach() for k, g in zip(names, gs) if g is not None}
+        out.update(extra)
+        return out
+
+    def read_flips(self, grads):
+        """Which kink groups did the run that produced `grads` put on the other side?  Read off the BatchNorm-bias gradients."""
+        import itertools
+        override = {}
+        for idx, (_, bias_name) in enumerate(self.sites):
+            groups = self.state.groups.get(idx, [])
+            if not groups or bias_name not in grads:
+                continue
+            width = self.g0[bias_name].numel()
+            resid = grads[bias_name].detach().cpu().double().reshape(-1) - self.g0[bias_name].reshape(-1)
+            by_col = {}
+            for k, p in enumerate(groups):
+                by_col.setdefault(int(p[0]) % width, []).append(k)
+            for col, ks in by_col.items():
+                ks = ks[:8]  # 2^8 combinations at most; more near-zero elements in one column do not occur at these sizes
+                # flipping group k moves this bias gradient by +g (mask 0 -> 1) or -g (mask 1 -> 0)
+                delta = [(-1.0 if self.state.natural[idx][k] else 1.0) * float(self.g0_gsum[idx][k]) for k in ks]
+                best, best_err = None, None
+                for bits in itertools.product((0, 1), repeat=len(ks)):
+                    err = abs(float(resid[col]) - sum(b * d for b, d in zip(bits, delta)))
+                    if best_err is None or err < best_err - 1e-300:
+                        best, best_err = bits, err
+                for k, b in zip(ks, best):
+                    if b:
+                        override.setdefault(idx, {})[k] = not self.state.natural[idx][k]
+        return override
+
+    def reference_for(self, grads):
+        """Float64 gradients under the ReLU masks the candidate run chose at the kinks -> (dict, number of flips)."""
+        override = self.read_flips(grads)
+        n = sum(len(v) for v in override.values())
+        return (self.backward(override) if n else self.g0), n
+
+    def compute_yard(self):
+        if self.yard is not None:
+            return self.yard
+        g32 = self.oracle32()
+        ref, self.flips32 = self.reference_for(g32)
+        self.yard, rels = {}, []
+        for k, r in ref.items():
+            scale = r.abs().max().item() if r.numel() else 0.0
+            y = (g32[k].double() - r).abs().max().item() if r.numel() else 0.0
+            self.yard[k] = (y, scale)
+            if not k.startswith('::') and not has_null_gradient(k, self.c['train']) and scale > 0:
+                rels.append(y / scale)
+        self.median_rel = float(np.median(rels)) if rels else 0.0
+        self.forward32 = {k: v for k, v in g32.items() if k in self.extra}
+        return self.yard
+
+    def check_all(self, grads, what='', min_checked=1):
+        """Hold every gradient tensor of `grads` (name -> tensor; null-gradient parameters skipped) to the bar above.
+        Returns {name: error / scale}."""
+        self.compute_yard()
+        ref, n_flips = self.reference_for(grads)
+        report, fails = {}, []
+        for k, t in grads.items():
+            if k not in ref or has_null_gradient(k, self.c['train']):
+                continue
+            r = ref[k]
+            yard, scale = self.yard[k]
+            err = (t.detach().cpu().double().reshape(r.shape) - r).abs().max().item() if r.numel() else 0.0
+            allowed = YARD_MULT * max(yard, self.median_rel * scale) + 1e-6 * scale
+            assert allowed <= MAX_ALLOWED * scale + 1e-30, f'{what}{k}: the bar itself ({allowed / scale:.2e} of scale) is too loose'
+            report[k] = err / (scale + 1e-300)
+            if err > allowed:
+                fails.append(f'{k}: max|d| = {err:.3e} = {err / (scale + 1e-300):.2e} of scale, allowed {allowed / (scale + 1e-300):.2e} '
+                             f'(fp32 oracle: {yard / (scale + 1e-300):.2e})')
+        assert len(report) >= min_checked, f'{what}only {len(report)} gradient tensors compared'
+        assert not fails, (f'{what}{len(fails)}/{len(report)} gradient tensors off (section median yard {self.median_rel:.1e}, '
+                           f'{self.n_kinks} kink groups, {n_flips} flips read for this run, {self.flips32} for the fp32 oracle):\n  '
+                           + '\n  '.join(fails[:12]))
+        return report

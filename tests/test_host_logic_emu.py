@@ -70,13 +70,8 @@ def test_qagnn_matches_reference(case):
     helpers.check_plain(fix, 'pool_attn', pool_attn, **FWD)
     w = torch.linspace(0.5, 1.5, B).view(B, 1)
     (logits * w).sum().backward()
-    n_checked = 0
-    for pname, p in model.named_parameters():
-        if p.grad is None or helpers.has_null_gradient(pname, c['train']):
-            continue
-        helpers.check_stored(fix, 'grad::' + pname, p.grad, **BWD)
-        n_checked += 1
-    assert n_checked > 20
+    ref = helpers.F64Ref(case, 'grad')
+    ref.check_all({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, what=case + ' grad::', min_checked=20)
     for bname, b in model.named_buffers():
         helpers.check_plain(fix, 'buf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -95,10 +90,9 @@ def test_message_passing_stack_matches_reference(case):
     helpers.check_stored(fix, 'mp_out', out, **FWD)
     wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out)
     (out * wg).sum().backward()
-    helpers.check_stored(fix, 'mp_dH', Hg.grad, **BWD)
-    for pname, p in model.gnn.named_parameters():
-        if p.grad is not None and not helpers.has_null_gradient(pname, c['train']):
-            helpers.check_stored(fix, 'mpgrad::' + pname, p.grad, **BWD)
+    grads = {k: p.grad for k, p in model.gnn.named_parameters() if p.grad is not None}
+    grads['::mp_dH'] = Hg.grad
+    helpers.F64Ref(case, 'mpgrad').check_all(grads, what=case + ' mpgrad::', min_checked=20)
     for bname, b in model.gnn.named_buffers():
         helpers.check_plain(fix, 'mpbuf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -118,10 +112,9 @@ def test_single_gatconve_layer_matches_reference(case):
     helpers.check_stored(fix, 'layer_alpha', alpha, rtol=1e-4, atol=1e-7)
     wl = torch.sin(torch.arange(out.numel(), dtype=torch.float32) * 0.11).view_as(out)
     (out * wl).sum().backward()
-    helpers.check_stored(fix, 'layer_dx', xg.grad, **BWD)
-    for pname, p in layer.named_parameters():
-        if p.grad is not None and not helpers.has_null_gradient(pname, c['train']):
-            helpers.check_stored(fix, 'layergrad::' + pname, p.grad, **BWD)
+    grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
+    grads['::layer_dx'] = xg.grad
+    helpers.F64Ref(case, 'layergrad').check_all(grads, what=case + ' layergrad::', min_checked=10)
 
 
 @pytest.mark.parametrize('case', ['config1_train', 'small_eval', 'medqa_b8'])
@@ -372,3 +365,14 @@ def test_kernel_calls_run_on_the_operands_device(monkeypatch):
     p = Probe()
     assert p.launch(0) == 7 and seen[-1] == ('ran', 0)
     assert p.launch(1) == 7 and seen[-1] == ('ran', 1) and state['cur'] == 0
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_gpu_parity_harness_on_cpu(train):
+    """The oracle-vs-package harness of tests/test_hip_parity.py (forward at FWD, gradients on the float64 yardstick), run here
+    with the torch emulation of the kernels: checks the harness and the host logic on an odd-sized case outside the fixtures."""
+    import test_hip_parity as T
+    case = dict(shape='tiny', nq=3, nc=4, n=37, n_rel=17, std=0.6, train=train, seed=31,
+                cfg=helpers.model_cfg(d=100, k=3, sent_dim=40, n_concept=500, concept_in_dim=24))
+    report = T.oracle_vs_package(case, device='cpu')
+    assert len(report) > 20 and max(report.values()) < 1e-3

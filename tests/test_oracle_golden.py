@@ -14,28 +14,8 @@ from oracle import qagnn_oracle as O
 CASES = list(helpers.GOLDEN_CASES.keys())
 
 
-def build_oracle(case):
-    c = helpers.GOLDEN_CASES[case]
-    torch.manual_seed(0)
-    model = O.build_qagnn(c['cfg'])
-    helpers.det_fill_(model, c['seed'], c['std'])
-    model.pooler.dropout.p = 0.0
-    model.pooler.attention.dropout.p = 0.0
-    model.train(c['train'])
-    return model
-
-
-def golden_inputs(case, fix):
-    c = helpers.GOLDEN_CASES[case]
-    B, n = c['nq'] * c['nc'], c['n']
-    cids = torch.from_numpy(fix['concept_ids']).view(B, n)
-    nt = torch.from_numpy(fix['node_type_ids']).view(B, n)
-    ns = torch.from_numpy(fix['node_scores']).view(B, n, 1)
-    al = torch.from_numpy(fix['adj_lengths']).view(B)
-    ei = torch.from_numpy(fix['batched_edge_index'].astype(np.int64))
-    et = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
-    sv = torch.from_numpy(fix['sent_vecs'])
-    return sv, cids, nt, ns, al, ei, et
+build_oracle = helpers.build_oracle
+golden_inputs = helpers.golden_inputs
 
 
 @pytest.mark.parametrize('case', CASES)

@@ -51,8 +51,18 @@ def _worker(rank, world, port, q):
     a, b = parallel.shard_questions(CASE['nq'], rank, world)
     logits = _run_questions(model, inp, a, b, CASE['nq'])
     params = [p for p in model.parameters() if p.requires_grad]
-    n = parallel.allreduce_gradients(params)
+    held = {id(p): p.grad for p in params if p.grad is not None}  # an optimiser holding on to the gradient tensors ...
+    bucket = parallel.GradBucket(params)
+    n = bucket.allreduce()
+    assert all(p.grad is held[id(p)] for p in params if id(p) in held)  # ... still sees them after the all-reduce
+    n2 = bucket.allreduce()  # the bucket is persistent: a second reduction (of the already summed values) doubles them
+    for p in params:
+        if p.grad is not None:
+            p.grad.mul_(1.0 / world)
+    assert n2 == n
     allz = parallel.allgather_logits(logits)
+    same = parallel.allgather_logits(logits[:2], equal_shards=True)  # the no-sync path (every rank contributes 2 rows)
+    assert same.shape == (2 * world, logits.size(1)) and torch.equal(same[2 * rank:2 * rank + 2], logits[:2])
     if rank == 0:
         q.put((n, allz.numpy(), {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}))
     dist.barrier()
@@ -98,8 +108,34 @@ def test_two_rank_gloo_matches_gradient_accumulation():
     assert allz.shape == (CASE['nq'], CASE['nc'])
     assert torch.allclose(allz, torch.cat(zs), rtol=1e-5, atol=1e-6)
     ref = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
-    assert set(ref) == set(grads) and n == sum(v.numel() for v in ref.values())
+    assert set(ref) == set(grads) and n == sum(p.numel() for p in model.parameters() if p.requires_grad)
     for k in ref:
         if helpers.has_null_gradient(k, True):
             continue
         assert torch.allclose(grads[k], ref[k], rtol=1e-4, atol=1e-6 + 1e-4 * ref[k].abs().max().item()), k
+
+
+def test_balance_questions_by_edge_count():
+    """ranks are balanced by the sum of E'_g, not by question count -- skewed edge counts."""
+    from qagnn_amd import parallel
+    g = torch.Generator().manual_seed(3)
+    nc, n = 5, 200
+    for nq, world in ((64, 8), (64, 2), (13, 4), (8, 8)):
+        # Zipf-like skew: a few questions carry 10x the edges of the rest (400 ... 5 800 per subgraph)
+        ec = (400 + 5400 * torch.rand(nq * nc, generator=g) ** 4).long()
+        cost = parallel.question_costs(ec, n, nc)
+        assert len(cost) == nq and abs(sum(cost) - (int(ec.sum()) + nq * nc * n)) < 1e-6
+        parts = parallel.balance_questions(cost, world)
+        assert sorted(q for p in parts for q in p) == list(range(nq))       # a partition
+        assert all(len(p) >= 1 for p in parts)                               # no rank without a BatchNorm batch
+        assert parts == parallel.balance_questions(cost, world)              # deterministic: every rank derives the same one
+        load = [sum(cost[q] for q in p) for p in parts]
+        naive = [sum(cost[slice(*parallel.shard_questions(nq, r, world))]) for r in range(world)]
+        assert max(load) <= max(naive) + 1e-9
+        if nq >= 4 * world:
+            assert max(load) <= 1.05 * sum(load) / world                     # within 5 % of perfect on realistic batches
+    # rank-ordered logits go back to question order
+    parts = parallel.balance_questions([5.0, 1.0, 4.0, 2.0, 3.0], 2)
+    order = [q for p in parts for q in p]
+    gathered = torch.tensor(order, dtype=torch.float32).view(-1, 1)
+    assert parallel.scatter_logits_by_assignment(gathered, parts).flatten().tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
