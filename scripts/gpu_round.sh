@@ -32,17 +32,17 @@ if [[ "$*" == *smoke* ]]; then
   echo "smoke exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
 fi
 if [[ "$*" == *bench* ]]; then
-  timeout 600 python bench.py --steps 10 --warmup 3 2>&1 | tail -n 50 > gpurun_out/bench.log
+  timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -n 50 > gpurun_out/bench.log
   echo "bench exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   timeout 300 python bench.py --steps 30 --warmup 5 --questions 2 --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/bench_b10.log
 fi
 if [[ " $* " == *" prof "* ]]; then
   rm -rf /tmp/prof; mkdir -p /tmp/prof
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r1 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r2 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
   echo "prof exit $?" >> gpurun_out/summary.txt
   mkdir -p gpurun_out/prof
   find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
-  python scripts/trace_by_shape.py /tmp/prof/r1_kernel_trace.csv > gpurun_out/prof/by_shape.txt 2>&1
+  python scripts/trace_by_shape.py /tmp/prof/r2_kernel_trace.csv > gpurun_out/prof/by_shape.txt 2>&1
   ls -la /tmp/prof/* | head -20 >> gpurun_out/prof.log
 fi
 if [[ " $* " == *" pmc "* ]]; then

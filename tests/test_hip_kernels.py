@@ -95,8 +95,18 @@ def test_graph_prep_bit_exact(name):
 def test_graph_prep_flags_out_of_range_indices():
     ei, et, nt, R, T = rand_graph(7, 30, 100)
     ei[0, 5] = 1000
+    from qagnn_amd import _lib
+    _lib.ERR_WATCH.poll(block=True)  # nothing pending from earlier batches
     g = hip().graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
     assert int(g.array('err', 1).item()) == 1
+    # ... and the flag does not stay on the device: the binding raises when it looks at the batch's flags (at the next
+    # graph_prep, or on an explicit blocking poll; QAGNN_VALIDATE=1 would have raised inside the call above)
+    with pytest.raises(RuntimeError, match='out-of-range'):
+        _lib.ERR_WATCH.poll(block=True)
+    assert not _lib.ERR_WATCH.pending
+    ei[0, 5] = 3
+    hip().graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    _lib.ERR_WATCH.poll(block=True)  # a clean batch raises nothing
 
 
 def _bound(absA, absB, extra=0.0):
