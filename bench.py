@@ -55,7 +55,11 @@ def make_batch(n_questions, seed, n_concept):
     g = torch.Generator().manual_seed(seed + 1)
     sent = torch.randn(n_questions * NC, SENT_DIM, generator=g)
     labels = torch.randint(0, NC, (n_questions,), generator=g)
-    return dict(sent=sent, cids=cids, nt=nt, ns=ns, al=al, ei=bei, et=bet, labels=labels)
+    # the same graph as load-time blobs (qagnn_amd.data_utils.GraphBlobStore): what the batch generator ships to the device
+    store = data_utils.GraphBlobStore.build(ei, et, nt, N_ETYPE, N_NTYPE)
+    ids = list(range(len(store)))
+    buf, B, E = store.pack(ids)
+    return dict(sent=sent, cids=cids, nt=nt, ns=ns, al=al, ei=bei, et=bet, labels=labels, blobs=buf, blob_meta=(B, E, store, ids))
 
 
 def build_model(cls_module, n_concept, p=0.2, seed=0):
@@ -119,7 +123,7 @@ def _tn_flops(A, B, **kw):
 def step(model, b, world, flat_grad_params, bucket=None):
     for p in flat_grad_params:
         p.grad = None
-    logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], (b['ei'], b['et']))
+    logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'])
     logits = logits.view(-1, NC)
     # the reference's mini-batch loss weight (b - a) / bs with bs = all questions of the global batch (qagnn.py:261)
     loss = torch.nn.functional.cross_entropy(logits, b['labels']) * parallel.shard_loss_weight(1, world)
@@ -153,7 +157,8 @@ def measure_edge_traffic(args, N, DP):
         td = tempfile.mkdtemp(prefix=f'qagnn_pmc_{ctr}_', dir='/tmp')
         cmd = [rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', td, '-o', 'p', '--', sys.executable,
                os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-pmc', '--pmc-child',
-               '--questions', str(args.questions), '--n-concept', str(args.n_concept), '--dropout', str(args.dropout)]
+               '--questions', str(args.questions), '--n-concept', str(args.n_concept), '--dropout', str(args.dropout)] + \
+              (['--edge-lists'] if args.edge_lists else [])
         try:
             subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=240, check=True)
@@ -184,9 +189,20 @@ def measure_edge_traffic(args, N, DP):
                                                '128-B reads at 64 B)' + cal)
 
 
+def to_device(batch, dev, use_blobs):
+    """Inputs resident in HBM: either the reference's (edge_index, edge_type) int64 pair or the packed blob buffer."""
+    b = {k: v.to(dev) for k, v in batch.items() if torch.is_tensor(v)}
+    if use_blobs:
+        B, E, store, ids = batch['blob_meta']
+        b['adj'] = data_utils.PackedGraphBatch(b['blobs'], B, E, store, ids, NC)
+    else:
+        b['adj'] = (b['ei'], b['et'])
+    return b
+
+
 def small_batch_line(args, dev, questions=2, steps=30, warmup=5):
     """The same step at the reference's own mini-batch (2 questions x 5 choices = 10 subgraphs, run_qagnn__csqa.sh:17)."""
-    b = {k: v.to(dev) for k, v in make_batch(questions, seed=123, n_concept=args.n_concept).items()}
+    b = to_device(make_batch(questions, seed=123, n_concept=args.n_concept), dev, not args.edge_lists)
     model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
@@ -243,6 +259,8 @@ def main():
     ap.add_argument('--n-concept', type=int, default=100000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', type=float, default=0.2)
+    ap.add_argument('--edge-lists', action='store_true', help='feed the graph as int64 (edge_index, edge_type) (the reference protocol; the '
+                    'graph orderings are then re-derived per batch) instead of the load-time blobs of qagnn_amd.data_utils')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -278,12 +296,12 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    b = {k: v.to(dev) for k, v in make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept).items()}
+    b = to_device(make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept), dev, not args.edge_lists)
     model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     bucket = parallel.GradBucket(params) if world > 1 else None
-    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'gemm_nn', 'gemm_tn'],
+    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn'],
                          work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
     ops.set_kernels(timed)
 
@@ -298,7 +316,7 @@ def main():
         step(model, b, world, params, bucket)
     sync()
     timed.enabled = True
-    timed.active = {'edge_attn_fwd', 'graph_prep'}  # 6 event pairs per step inside the timed region
+    timed.active = {'edge_attn_fwd', 'graph_prep', 'graph_from_blobs'}  # 6 event pairs per step inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(model, b, world, params, bucket)
@@ -328,10 +346,11 @@ def main():
         B = args.questions * NC
         N = B * N_NODE
         E = b['ei'].size(1)
+        h2d = b['blobs'].numel() * 4 if not args.edge_lists else (b['ei'].numel() + b['et'].numel()) * 8
         Ep = E + N
         fwd_ms, n_fwd = timed.mean_ms('edge_attn_fwd')
         bwd_ms, n_bwd = timed.mean_ms('edge_attn_bwd')
-        prep_ms, _ = timed.mean_ms('graph_prep')
+        prep_ms, _ = timed.mean_ms('graph_prep' if args.edge_lists else 'graph_from_blobs')
         gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn')
         gemm_flops = timed.work['gemm_nn'] + timed.work['gemm_tn']
         alg_fwd = Ep * 2410 + N * 800
@@ -362,6 +381,8 @@ def main():
                                    '400..2000 edges/subgraph, 5-layer GAT d=200 H=4, 38 relations, QAGNN decoder fwd+bwd '
                                    '(LM encoder excluded: random sent_vecs), dropout 0.2, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
+                       'graph_input': ('int64 (edge_index, edge_type), orderings derived per batch' if args.edge_lists else
+                                       'load-time int32 blobs (qagnn_graph_from_blobs)') + f', {h2d / max(E, 1):.1f} B/edge on the wire',
                        'parallelism': f'dp{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores [scores + segment softmax] + k_edge_aggregate), per GAT layer',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(min(achieved / HBM_PEAK_GBS, 1.0), 4),

@@ -96,6 +96,22 @@ int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const int64_t* ed
                              const int64_t* node_type, int32_t N, int32_t E, int32_t R, int32_t T, int32_t block_n,
                              qagnn_stream_t stream);
 
+/* The same graph from per-sample blobs built once at LOAD time.  Replaces the per-batch work of
+ *   utils/data_utils.py:53-76   2*bs*nc individual .to(device) copies of int64 edge lists
+ *   modeling_qagnn.py:244-251   LM_QAGNN.batch_graph (offsets + cat), and the five sorting launches of qagnn_graph_prep.
+ * `blobs` is the concatenation of the batch's B sample blobs, blob_off[g] the int32-word offset of sample g in it, edge_off[g]
+ * the number of real edges of the samples before g (edge_off[B] = E).  One blob = cnt_s[n] | cnt_t[n] | w0[E_g] | w1[E_g] | w2[E_g]:
+ *   cnt_s, cnt_t   out- / in-degree of each of the sample's n node slots, real edges only
+ *   w0[i] = tgt | cls << 16     edge i of the sample's SOURCE order (sorted by (src, local edge id)): local target, edge class
+ *   w1[i] = eid | src << 16     eid: local edge id of source-order edge i;   src: local source of TARGET-order edge i
+ *   w2[i]                       position in the local source order of TARGET-order edge i (sorted by (tgt, local edge id))
+ * i.e. 12 bytes per edge + 8 per node slot; self loops are not stored (inserted here, one per node row, last in their segments).
+ * node_type is the batch's [B*n] int64 tensor (the self loops' classes).  Produces arrays bit-identical to
+ * qagnn_graph_prep_blocked(edge_index = batch_graph(...), block_n = n); err[0] is set if a blob field is out of range. */
+int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const int32_t* blobs, const int32_t* blob_off /* [B+1] */,
+                           const int32_t* edge_off /* [B+1] */, const int64_t* node_type /* [B*n] */, int32_t B, int32_t n, int32_t E,
+                           int32_t R, int32_t T, qagnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Dense fp32 MFMA GEMMs (v_mfma_f32_16x16x4_f32).  Replace the cuBLAS SGEMMs of
  *   modeling_qagnn.py:464-466 (linear_key/msg/query, after the project-then-gather rewrite: N rows, not E'),

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')  # QAGNN_LIB: an alternate build (kernel A/B runs)
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
+           'qagnn_graph_from_blobs',
            'qagnn_edge_attn_fwd_blocked_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
@@ -23,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 4  # bumped when a struct of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX)
+ABI_VERSION = 5  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -69,6 +70,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_storage_elems.argtypes = [_i32, _i32, _i32, _i32]
     lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
+    lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
@@ -268,6 +270,25 @@ class HipKernels(metaclass=_GuardedMeta):
         G = HipGraph(storage, g, N, E, n_etype, n_ntype, int(block_n))
         ERR_WATCH.poll()  # flags of earlier batches that have landed since
         ERR_WATCH.watch(G.array('err', 4), f'the batch with N={N} node rows, E={E} edges')
+        return G
+
+    def graph_from_blobs(self, packed, node_type):
+        """packed: data_utils.PackedGraphBatch on the device (the batch's load-time blobs); node_type [B*n] int64."""
+        assert packed.buf.is_cuda and packed.buf.dtype == torch.int32 and node_type.dtype == torch.long and node_type.is_contiguous()
+        B, n, E, R, T = packed.B, packed.n, packed.E, packed.n_etype, packed.n_ntype
+        N = B * n
+        assert node_type.numel() == N
+        elems = self.lib.qagnn_graph_storage_elems(N, E, R, T)
+        storage = torch.empty(elems, dtype=torch.int32, device=node_type.device)
+        g = qagnn_graph()
+        base = packed.buf.data_ptr()
+        rc = self.lib.qagnn_graph_from_blobs(C.byref(g), storage.data_ptr(), base + 4 * packed.head, base, base + 4 * (B + 1),
+                                             node_type.data_ptr(), B, n, E, R, T, self._stream())
+        self._check(rc, 'qagnn_graph_from_blobs')
+        G = HipGraph(storage, g, N, E, R, T, n)
+        G.keep = packed.buf  # the blobs are read by the kernel just enqueued
+        ERR_WATCH.poll()
+        ERR_WATCH.watch(G.array('err', 4), f'the blob batch with B={B} samples, E={E} edges')
         return G
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------

@@ -166,6 +166,99 @@ __global__ void k_payload(const int* __restrict__ es, const int* __restrict__ et
   pos_t[p] = srcpos[e2];
 }
 
+
+// ---- graph orderings from per-sample blobs built at LOAD time ----------------------------------
+// Everything graph_prep derives per batch with five sorting launches -- source order, target order, the position of every edge in
+// the source order, class ids, degrees -- is static per dataset sample (the reference re-slices the same lists every
+// epoch, utils/data_utils.py:53-76, and offsets them per batch, modeling_qagnn.py:244-251).  The loader therefore stores, per
+// (question, choice) sample, a blob of int32 words
+//     cnt_s[n] | cnt_t[n] | w0[E_g] | w1[E_g] | w2[E_g]
+//     cnt_s / cnt_t   out- / in-degree of the n node slots (real edges only)
+//     w0[i] = tgt | cls << 16          edge i of the SOURCE order (by (src, local edge id)): local target, edge class
+//     w1[i] = eid | src << 16          eid = local id of source-order edge i;  src = local source of TARGET-order edge i
+//     w2[i] = position, in the local source order, of TARGET-order edge i
+// = 12 bytes per edge + 8 per node slot on the wire (the int64 edge lists were 24 bytes per edge).  A batch is the plain
+// concatenation of its samples' blobs; one workgroup per sample adds the offsets batch_graph would add (node rows g*n, edge ids,
+// positions) and inserts the self loops (last in both of a node's segments: their edge id E + v is the largest).  The result is
+// bit-identical to qagnn_graph_prep_blocked on the same batch (tests/test_hip_kernels.py).
+__device__ __forceinline__ int seg_owner(const int* __restrict__ rp, int n, int i) {  // largest v with rp[v] <= i
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rp[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict__ blobs, const int32_t* __restrict__ blob_off,
+                                                       const int32_t* __restrict__ edge_off, const int64_t* __restrict__ node_type,
+                                                       int n, int B, int E, int R, int T, int* __restrict__ rowptr_s,
+                                                       int* __restrict__ tgt_s, int* __restrict__ src_s, int* __restrict__ cls_s,
+                                                       int* __restrict__ eid_s, int* __restrict__ rowptr_t, int* __restrict__ src_t,
+                                                       int* __restrict__ tgt_t, int* __restrict__ cls_t, int* __restrict__ pos_t,
+                                                       int* __restrict__ err) {
+  extern __shared__ int rp[];  // rp_s[n+1] | rp_t[n+1]: local exclusive scans of the degrees
+  __shared__ int wsum[2][4];
+  int* const rp_s = rp;
+  int* const rp_t = rp + n + 1;
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int32_t* blob = blobs + blob_off[g];
+  const int Eoff = edge_off[g], Eg = edge_off[g + 1] - Eoff, node0 = g * n, Epoff = Eoff + node0;
+  const int32_t *cnt_s = blob, *cnt_t = blob + n;
+  const uint32_t* w0 = reinterpret_cast<const uint32_t*>(blob + 2 * n);
+  const uint32_t* w1 = w0 + Eg;
+  const int32_t* w2 = reinterpret_cast<const int32_t*>(w1 + Eg);
+  // exclusive scans: a thread owns `per` consecutive slots
+  const int per = (n + 255) >> 8, v0 = tid * per;
+  int sum_s = 0, sum_t = 0;
+  for (int k = 0; k < per; ++k)
+    if (v0 + k < n) { sum_s += cnt_s[v0 + k]; sum_t += cnt_t[v0 + k]; }
+  int inc_s = sum_s, inc_t = sum_t;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int us = __shfl_up(inc_s, o, 64), ut = __shfl_up(inc_t, o, 64);
+    if (lane >= o) { inc_s += us; inc_t += ut; }
+  }
+  if (lane == 63) { wsum[0][wid] = inc_s; wsum[1][wid] = inc_t; }
+  __syncthreads();
+  int run_s = inc_s - sum_s, run_t = inc_t - sum_t;
+  for (int w = 0; w < wid; ++w) { run_s += wsum[0][w]; run_t += wsum[1][w]; }
+  for (int k = 0; k < per; ++k)
+    if (v0 + k < n) {
+      rp_s[v0 + k] = run_s; rp_t[v0 + k] = run_t;
+      run_s += cnt_s[v0 + k]; run_t += cnt_t[v0 + k];
+    }
+  if (tid == 255) { rp_s[n] = run_s; rp_t[n] = run_t; }
+  __syncthreads();
+  bool bad = rp_s[n] != Eg || rp_t[n] != Eg;
+  // node rows: segment starts and the self loops
+  for (int v = tid; v < n; v += 256) {
+    rowptr_s[node0 + v] = Epoff + rp_s[v] + v;
+    rowptr_t[node0 + v] = Epoff + rp_t[v] + v;
+    const int64_t ty = node_type[node0 + v];
+    bad = bad || ty < 0 || ty >= T;
+    const int c = R * T * T + (int)min(max(ty, (int64_t)0), (int64_t)T - 1);
+    const int ps = Epoff + rp_s[v + 1] + v, pt = Epoff + rp_t[v + 1] + v;
+    tgt_s[ps] = node0 + v; src_s[ps] = node0 + v; cls_s[ps] = c; eid_s[ps] = E + node0 + v;
+    src_t[pt] = node0 + v; tgt_t[pt] = node0 + v; cls_t[pt] = c; pos_t[pt] = ps;
+  }
+  if (g == B - 1 && tid == 0) { rowptr_s[(int64_t)B * n] = E + B * n; rowptr_t[(int64_t)B * n] = E + B * n; }
+  const int C_real = R * T * T;
+  for (int i = tid; i < Eg; i += 256) {
+    const uint32_t a = w0[i], b = w1[i];
+    const int pos = w2[i];
+    const int tl = (int)(a & 0xFFFFu), cl = (int)(a >> 16), el = (int)(b & 0xFFFFu), sl = (int)(b >> 16);
+    bad = bad || tl >= n || cl >= C_real || el >= Eg || sl >= n || pos < 0 || pos >= Eg;
+    const int s = seg_owner(rp_s, n, i), t = seg_owner(rp_t, n, i);
+    const int p = Epoff + i + s;
+    tgt_s[p] = node0 + min(tl, n - 1); src_s[p] = node0 + s; cls_s[p] = min(cl, C_real - 1); eid_s[p] = Eoff + el;
+    const int q = Epoff + i + t, posc = min(max(pos, 0), max(Eg - 1, 0)), slc = min(sl, n - 1);
+    src_t[q] = node0 + slc; tgt_t[q] = node0 + t; pos_t[q] = Epoff + posc + slc;
+    cls_t[q] = min((int)(w0[posc] >> 16), C_real - 1);
+  }
+  if (bad) *err = 1;
+}
+
 // ---- stable counting sort of the source-ordered positions by class -------------------------------------------
 #define CLS_BLK 1024
 __global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s, int* __restrict__ hist,
@@ -287,8 +380,62 @@ static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
 using namespace qagnn;
 
+// carve `storage` into the arrays of *g plus scratch (layout shared by qagnn_graph_prep_blocked and qagnn_graph_from_blobs)
+struct carved {
+  int32_t *eid_t, *gc_cnt, *gcptr, *nch, *cnt_s, *cnt_t, *es, *et, *ec, *tmp_s, *tmp_t, *srcpos, *hist;
+  int nblk, gb, NG, pairs;
+};
+static carved carve(qagnn_graph* g, int32_t* storage, int N, int E, int R, int T, int block_n) {
+  carved cv;
+  const int Ep = E + N, C = R * T * T + T;
+  cls_groups(Ep, &cv.nblk, &cv.gb, &cv.NG);
+  cv.pairs = cv.NG * C;
+  const int maxch = Ep / QAGNN_CLS_CHUNK + cv.pairs + 1;
+  int32_t* p = storage;
+  auto take = [&](int64_t n) { int32_t* r = p; p += up4(n); return r; };
+  g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch; g->block_n = block_n;
+  g->n_groups = cv.NG;
+  g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
+  g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
+  g->src_t = take(Ep); g->tgt_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
+  g->src_c = take(Ep); g->tgt_c = take(Ep); g->pos_c = take(Ep);
+  cv.eid_t = take(Ep);
+  cv.gc_cnt = take(cv.pairs + 1); cv.gcptr = take(cv.pairs + 1);
+  g->chunkptr = take(cv.pairs + 1);
+  cv.nch = take(cv.pairs + 1);
+  g->cls_count = take(C);
+  g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
+  g->n_chunks = take(4); g->err = take(4);
+  // ---- scratch; the zero-initialised region comes first (cls_count, which sits just before it, must be zero too) ----
+  cv.cnt_s = take(N); cv.cnt_t = take(N);
+  cv.es = take(Ep); cv.et = take(Ep); cv.ec = take(Ep);
+  cv.tmp_s = take(Ep); cv.tmp_t = take(Ep); cv.srcpos = take(Ep);
+  cv.hist = take((int64_t)cv.nblk * C);
+  return cv;
+}
+
+static int class_pass(qagnn_graph* g, int32_t* hist, int32_t* gc_cnt, int32_t* gcptr, int32_t* nch, int nblk, int gb, int NG, int pairs,
+                      hipStream_t stream) {
+  const int TB = 256, Ep = g->Ep, C = g->C;
+  k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
+  QAGNN_LAUNCH_CHECK("k_cls_hist");
+  k_grp_count<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gc_cnt, nblk, C, gb, NG);
+  QAGNN_LAUNCH_CHECK("k_grp_count");
+  k_chunk_counts<<<cdiv(pairs, 1024), 1024, 0, stream>>>(gc_cnt, nch, pairs);
+  QAGNN_LAUNCH_CHECK("k_chunk_counts");
+  k_scan_pairs<<<2, 1024, 0, stream>>>(gc_cnt, gcptr, nch, g->chunkptr, pairs);  // first class-order slot / first chunk of every pair
+  QAGNN_LAUNCH_CHECK("k_scan_pairs");
+  k_grp_base<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gcptr, nblk, C, gb, NG);
+  QAGNN_LAUNCH_CHECK("k_grp_base");
+  k_cls_scatter<<<nblk, 64, C * sizeof(int), stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
+  QAGNN_LAUNCH_CHECK("k_cls_scatter");
+  k_chunk_fill<<<cdiv(pairs, 256), 256, 0, stream>>>(gcptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C, pairs);
+  QAGNN_LAUNCH_CHECK("k_chunk_fill");
+  return QAGNN_OK;
+}
+
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 4; }
+extern "C" int qagnn_abi_version(void) { return 5; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;
@@ -327,31 +474,11 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   const int64_t Ep64 = (int64_t)E + N, C64 = (int64_t)R * T * T + T;
   QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_prep: E+N=%lld too large", (long long)Ep64);
   QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_prep: %lld edge classes > 8192", (long long)C64);
-  const int Ep = (int)Ep64, C = (int)C64;
-  int nblk, gb, NG;
-  cls_groups(Ep, &nblk, &gb, &NG);
-  const int pairs = NG * C;
-  const int maxch = Ep / QAGNN_CLS_CHUNK + pairs + 1;
-  int32_t* p = storage;
-  auto take = [&](int64_t n) { int32_t* r = p; p += up4(n); return r; };
-  g->N = N; g->E = E; g->Ep = Ep; g->R = R; g->T = T; g->C = C; g->max_chunks = maxch; g->block_n = block_n;
-  g->n_groups = NG;
-  g->rowptr_s = take(N + 1); g->rowptr_t = take(N + 1);
-  g->tgt_s = take(Ep); g->src_s = take(Ep); g->cls_s = take(Ep); g->eid_s = take(Ep);
-  g->src_t = take(Ep); g->tgt_t = take(Ep); g->cls_t = take(Ep); g->pos_t = take(Ep);
-  g->src_c = take(Ep); g->tgt_c = take(Ep); g->pos_c = take(Ep);
-  int32_t* eid_t = take(Ep);
-  int32_t* gc_cnt = take(pairs + 1); int32_t* gcptr = take(pairs + 1);
-  g->chunkptr = take(pairs + 1);
-  int32_t* nch = take(pairs + 1);
-  g->cls_count = take(C);
-  g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
-  g->n_chunks = take(4); g->err = take(4);
-  // ---- scratch; zero-initialised region first (cls_count must be zero too, it sits just before) ----
-  int32_t* cnt_s = take(N); int32_t* cnt_t = take(N);
-  int32_t* es = take(Ep); int32_t* et = take(Ep); int32_t* ec = take(Ep);
-  int32_t* tmp_s = take(Ep); int32_t* tmp_t = take(Ep); int32_t* srcpos = take(Ep);
-  int32_t* hist = take((int64_t)nblk * C);
+  const int Ep = (int)Ep64;
+  carved cv = carve(g, storage, N, E, R, T, block_n);
+  int32_t *cnt_s = cv.cnt_s, *cnt_t = cv.cnt_t, *es = cv.es, *et = cv.et, *ec = cv.ec, *tmp_s = cv.tmp_s, *tmp_t = cv.tmp_t;
+  int32_t *srcpos = cv.srcpos, *eid_t = cv.eid_t, *hist = cv.hist, *gc_cnt = cv.gc_cnt, *gcptr = cv.gcptr, *nch = cv.nch;
+  const int nblk = cv.nblk, gb = cv.gb, NG = cv.NG, pairs = cv.pairs;
 
   hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)es - (char*)g->cls_count), stream);
   if (he != hipSuccess) { set_error("graph_prep: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
@@ -368,19 +495,27 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   k_payload<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, ec, g->eid_s, eid_t, srcpos, g->tgt_s, g->src_s, g->cls_s, g->src_t,
                                               g->tgt_t, g->cls_t, g->pos_t, Ep);
   QAGNN_LAUNCH_CHECK("k_payload");
-  k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
-  QAGNN_LAUNCH_CHECK("k_cls_hist");
-  k_grp_count<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gc_cnt, nblk, C, gb, NG);
-  QAGNN_LAUNCH_CHECK("k_grp_count");
-  k_chunk_counts<<<cdiv(pairs, 1024), 1024, 0, stream>>>(gc_cnt, nch, pairs);
-  QAGNN_LAUNCH_CHECK("k_chunk_counts");
-  k_scan_pairs<<<2, 1024, 0, stream>>>(gc_cnt, gcptr, nch, g->chunkptr, pairs);  // first class-order slot / first chunk of every pair
-  QAGNN_LAUNCH_CHECK("k_scan_pairs");
-  k_grp_base<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gcptr, nblk, C, gb, NG);
-  QAGNN_LAUNCH_CHECK("k_grp_base");
-  k_cls_scatter<<<nblk, 64, C * sizeof(int), stream>>>(g->cls_s, g->src_s, g->tgt_s, hist, g->src_c, g->tgt_c, g->pos_c, Ep, C);
-  QAGNN_LAUNCH_CHECK("k_cls_scatter");
-  k_chunk_fill<<<cdiv(pairs, 256), 256, 0, stream>>>(gcptr, g->chunkptr, g->chunk_cls, g->chunk_beg, g->chunk_len, g->n_chunks, C, pairs);
-  QAGNN_LAUNCH_CHECK("k_chunk_fill");
-  return QAGNN_OK;
+  return class_pass(g, hist, gc_cnt, gcptr, nch, nblk, gb, NG, pairs, stream);
+}
+
+extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const int32_t* blobs, const int32_t* blob_off,
+                                      const int32_t* edge_off, const int64_t* node_type, int32_t B, int32_t n, int32_t E, int32_t R,
+                                      int32_t T, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(g && storage && blobs && blob_off && edge_off && node_type, QAGNN_EINVAL, "graph_from_blobs: null pointer");
+  QAGNN_REQUIRE(B > 0 && n > 0 && E >= 0 && R > 0 && T > 0, QAGNN_EINVAL, "graph_from_blobs: bad sizes B=%d n=%d E=%d R=%d T=%d", B, n, E, R, T);
+  QAGNN_REQUIRE(n < 65536 && (int64_t)R * T * T < 65536, QAGNN_EUNSUPPORTED, "graph_from_blobs: n=%d or R*T*T=%d does not fit the 16-bit blob fields", n, R * T * T);
+  QAGNN_REQUIRE((size_t)(2 * (n + 1)) * sizeof(int) <= 64 * 1024, QAGNN_EUNSUPPORTED, "graph_from_blobs: n=%d node slots per sample exceed the LDS scan", n);
+  QAGNN_REQUIRE(aligned16(storage), QAGNN_EINVAL, "graph_from_blobs: storage must be 16-byte aligned");
+  const int64_t N64 = (int64_t)B * n, Ep64 = (int64_t)E + N64, C64 = (int64_t)R * T * T + T;
+  QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_from_blobs: E+N=%lld too large", (long long)Ep64);
+  QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_from_blobs: %lld edge classes > 8192", (long long)C64);
+  carved cv = carve(g, storage, (int)N64, E, R, T, n);
+  hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)cv.es - (char*)g->cls_count), stream);
+  if (he != hipSuccess) { set_error("graph_from_blobs: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1)) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, E, R, T, g->rowptr_s,
+                                                                            g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t,
+                                                                            g->tgt_t, g->cls_t, g->pos_t, g->err);
+  QAGNN_LAUNCH_CHECK("k_blob_assemble");
+  return class_pass(g, cv.hist, cv.gc_cnt, cv.gcptr, cv.nch, cv.nblk, cv.gb, cv.NG, cv.pairs, stream);
 }

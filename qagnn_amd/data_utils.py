@@ -164,6 +164,152 @@ def load_flat_cache(path, num_choice):
     return concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Load-time graph blobs.  Source / target orderings, the position of every edge in the source
+# order, edge classes and degrees are static per dataset sample, so they are derived ONCE here, in numpy, and
+# stored as int32 words: 12 bytes per edge + 8 per node slot (the int64 edge lists are 24 bytes per edge).  A batch is the
+# concatenation of its samples' blobs in ONE pinned buffer = one host-to-device copy; libqagnn_hip's qagnn_graph_from_blobs
+# adds the offsets LM_QAGNN.batch_graph would add and inserts the self loops.  Layout: see include/qagnn_hip.h.
+# ---------------------------------------------------------------------------------------------------------------------
+def build_graph_blob(edge_index, edge_type, node_type, n_etype, n_ntype):
+    """One sample -> int32 blob  cnt_s[n] | cnt_t[n] | w0[E] | w1[E] | w2[E].
+
+    edge_index [2, E] local node ids, edge_type [E], node_type [n] (numpy or torch, any integer dtype).  Raises on input the
+    reference's one-hot / index ops would raise on (modeling_qagnn.py:352-367, 419-433)."""
+    ei = np.asarray(edge_index, dtype=np.int64).reshape(2, -1)
+    et = np.asarray(edge_type, dtype=np.int64).reshape(-1)
+    nt = np.asarray(node_type, dtype=np.int64).reshape(-1)
+    n, E, T = nt.size, et.size, int(n_ntype)
+    if E >= 65536 or n >= 65536 or n_etype * T * T >= 65536:
+        raise ValueError(f'graph blob fields are 16 bits wide: E={E}, n={n}, classes={n_etype * T * T}')
+    if (nt < 0).any() or (nt >= T).any():
+        raise IndexError('node type id out of range')
+    if E and ((ei < 0).any() or (ei >= n).any() or (et < 0).any() or (et >= n_etype).any()):
+        raise IndexError('edge endpoint or relation id out of range')
+    s, t = ei[0], ei[1]
+    cls = et * (T * T) + nt[s] * T + nt[t]
+    order_s = np.argsort(s, kind='stable')   # by (src, local edge id)
+    order_t = np.argsort(t, kind='stable')   # by (tgt, local edge id)
+    inv_s = np.empty(E, dtype=np.int64)
+    inv_s[order_s] = np.arange(E)
+    w0 = (t[order_s] | (cls[order_s] << 16)).astype(np.uint32)
+    w1 = (order_s | (s[order_t] << 16)).astype(np.uint32)
+    w2 = inv_s[order_t].astype(np.int32)
+    return np.concatenate([np.bincount(s, minlength=n).astype(np.int32), np.bincount(t, minlength=n).astype(np.int32),
+                           w0.view(np.int32), w1.view(np.int32), w2])
+
+
+def decode_graph_blob(blob, n, n_ntype):
+    """Inverse of build_graph_blob: -> (edge_index [2, E] int64, edge_type [E] int64) in the caller's original edge order."""
+    blob = np.asarray(blob)
+    E = (blob.size - 2 * n) // 3
+    cnt_s = blob[:n].astype(np.int64)
+    w0 = blob[2 * n:2 * n + E].view(np.uint32).astype(np.int64)
+    w1 = blob[2 * n + E:2 * n + 2 * E].view(np.uint32).astype(np.int64)
+    src_sorted = np.repeat(np.arange(n, dtype=np.int64), cnt_s)
+    eid = w1 & 0xFFFF
+    ei = np.empty((2, E), dtype=np.int64)
+    et = np.empty(E, dtype=np.int64)
+    ei[0, eid] = src_sorted
+    ei[1, eid] = w0 & 0xFFFF
+    et[eid] = (w0 >> 16) // (n_ntype * n_ntype)
+    return ei, et
+
+
+class GraphBlobStore:
+    """All samples' blobs in one int32 array (`data`, possibly an np.memmap) + word offsets.  `edge_count[i]` = E of sample i."""
+
+    def __init__(self, data, off, edge_count, n, n_etype, n_ntype):
+        self.data, self.off, self.edge_count = data, np.asarray(off, dtype=np.int64), np.asarray(edge_count, dtype=np.int64)
+        self.n, self.n_etype, self.n_ntype = int(n), int(n_etype), int(n_ntype)
+
+    def __len__(self):
+        return self.edge_count.size
+
+    @classmethod
+    def build(cls, edge_index_list, edge_type_list, node_type_ids, n_etype, n_ntype=4):
+        """edge_index_list / edge_type_list: FLAT lists (one entry per sample, as records_to_tensors() returns them);
+        node_type_ids [S, n]."""
+        nt = np.asarray(node_type_ids).reshape(len(edge_index_list), -1)
+        blobs = [build_graph_blob(ei, et, nt[i], n_etype, n_ntype) for i, (ei, et) in enumerate(zip(edge_index_list, edge_type_list))]
+        off = np.zeros(len(blobs) + 1, dtype=np.int64)
+        np.cumsum([b.size for b in blobs], out=off[1:])
+        data = np.concatenate(blobs) if blobs else np.zeros(0, np.int32)
+        return cls(data, off, [(b.size - 2 * nt.shape[1]) // 3 for b in blobs], nt.shape[1], n_etype, n_ntype)
+
+    def sample(self, i):
+        return self.data[self.off[i]:self.off[i + 1]]
+
+    def edge_lists(self, i):
+        """(edge_index [2, E] int64, edge_type [E] int64) torch tensors of sample i, caller order (the reference's per-graph lists)."""
+        ei, et = decode_graph_blob(self.sample(i), self.n, self.n_ntype)
+        return torch.from_numpy(ei), torch.from_numpy(et)
+
+    def pack(self, sample_ids, pin=False):
+        """The batch's blobs + offset tables in ONE int32 host tensor:  blob_off[B+1] | edge_off[B+1] | pad | blobs ...
+        (blobs start 16-byte aligned).  Returns (host tensor, B, E)."""
+        ids = [int(i) for i in sample_ids]
+        B = len(ids)
+        sizes = self.off[[i + 1 for i in ids]] - self.off[ids] if B else np.zeros(0, np.int64)
+        head = (2 * (B + 1) + 3) // 4 * 4
+        total = head + int(sizes.sum())
+        buf = torch.empty(total, dtype=torch.int32)
+        if pin:
+            buf = buf.pin_memory()
+        a = buf.numpy()
+        a[0] = 0
+        np.cumsum(sizes, out=a[1:B + 1])
+        a[B + 1] = 0
+        np.cumsum(self.edge_count[ids], out=a[B + 2:2 * B + 2])
+        pos = head
+        for i, sz in zip(ids, sizes):
+            a[pos:pos + sz] = self.data[self.off[i]:self.off[i + 1]]
+            pos += int(sz)
+        return buf, B, int(a[2 * B + 1]) if B else 0
+
+    def save(self, prefix):
+        np.save(prefix + '.blobs.npy', np.ascontiguousarray(self.data))
+        np.save(prefix + '.blobmeta.npy', np.concatenate([[self.n, self.n_etype, self.n_ntype, len(self)], self.off, self.edge_count]).astype(np.int64))
+
+    @classmethod
+    def load(cls, prefix, mmap=True):
+        meta = np.load(prefix + '.blobmeta.npy')
+        n, R, T, S = (int(v) for v in meta[:4])
+        return cls(np.load(prefix + '.blobs.npy', mmap_mode='r' if mmap else None), meta[4:4 + S + 1], meta[4 + S + 1:4 + 2 * S + 1], n, R, T)
+
+
+class PackedGraphBatch:
+    """A batch's graph on the device as ONE buffer of sample blobs (see GraphBlobStore.pack): what the batch generator yields
+    in place of the nested edge lists when it was given a blob store, and what LM_QAGNN / QAGNN accept as `adj`.  The
+    reference's nested per-graph lists are recovered lazily (host side) for the callers that want them."""
+
+    def __init__(self, buf, B, E, store, sample_ids, num_choice):
+        self.buf, self.B, self.E, self.store = buf, B, E, store
+        self.sample_ids, self.num_choice = list(sample_ids), num_choice
+        self.n, self.n_etype, self.n_ntype = store.n, store.n_etype, store.n_ntype
+        self.head = (2 * (B + 1) + 3) // 4 * 4
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def nested_lists(self, device=None):
+        """(edge_index, edge_type) as nested lists [bs][nc] of int64 tensors: the reference generator's protocol."""
+        ei, et = [], []
+        for q in range(0, self.B, self.num_choice):
+            pairs = [self.store.edge_lists(i) for i in self.sample_ids[q:q + self.num_choice]]
+            ei.append([p[0].to(device) if device is not None else p[0] for p in pairs])
+            et.append([p[1].to(device) if device is not None else p[1] for p in pairs])
+        return ei, et
+
+    def batched(self, device=None):
+        """(edge_index [2, E], edge_type [E]) as LM_QAGNN.batch_graph would return them."""
+        ei, et = self.nested_lists()
+        bei, bet = batch_graph([g for row in ei for g in row], [g for row in et for g in row], self.n)
+        dev = device if device is not None else self.buf.device
+        return bei.to(dev), bet.to(dev)
+
+
 def batch_graph(edge_index_init, edge_type_init, n_nodes):
     """LM_QAGNN.batch_graph (reference modeling_qagnn.py:244-251): offset subgraph i by i*n and concatenate.
 
@@ -188,7 +334,10 @@ class MultiGPUSparseAdjDataBatchGenerator(object):
     """
 
     def __init__(self, args, mode, device0, device1, batch_size, indexes, qids, labels,
-                 tensors0=[], lists0=[], tensors1=[], lists1=[], adj_data=None):
+                 tensors0=[], lists0=[], tensors1=[], lists1=[], adj_data=None, graph_blobs=None, num_choice=None):
+        """graph_blobs (GraphBlobStore, optional): the batch's graph then travels as ONE int32 buffer of load-time blobs
+        (12 B/edge) and is yielded as (PackedGraphBatch, None) in place of (edge_index, edge_type); `adj_data` may be None."""
+        self.graph_blobs, self.num_choice = graph_blobs, num_choice
         self.args, self.mode = args, mode
         self.device0, self.device1 = device0, device1
         self.batch_size = batch_size
@@ -251,8 +400,16 @@ class MultiGPUSparseAdjDataBatchGenerator(object):
             batch_tensors1 = [self._to_device(x[batch_indexes], self.device1) for x in self.tensors1]
             batch_lists0 = [self._to_device([x[i] for i in batch_indexes], self.device0) for x in self.lists0]
             batch_lists1 = [self._to_device([x[i] for i in batch_indexes], self.device1) for x in self.lists1]
-            edge_index_all, edge_type_all = self.adj_data
-            edge_index, edge_type = self._graphs_to_device([edge_index_all[i] for i in batch_indexes],
-                                                           [edge_type_all[i] for i in batch_indexes], self.device1)
+            if self.graph_blobs is not None:
+                nc = self.num_choice or (self.tensors1[0].size(1) if self.tensors1 else 1)
+                ids = [int(q) * nc + c for q in batch_indexes for c in range(nc)]
+                on_gpu = torch.device(self.device1).type == 'cuda'
+                buf, B, E = self.graph_blobs.pack(ids, pin=on_gpu)
+                edge_index = PackedGraphBatch(buf.to(self.device1, non_blocking=True), B, E, self.graph_blobs, ids, nc)
+                edge_type = None
+            else:
+                edge_index_all, edge_type_all = self.adj_data
+                edge_index, edge_type = self._graphs_to_device([edge_index_all[i] for i in batch_indexes],
+                                                               [edge_type_all[i] for i in batch_indexes], self.device1)
             yield tuple([batch_qids, batch_labels, *batch_tensors0, *batch_lists0, *batch_tensors1,
                          *batch_lists1, edge_index, edge_type])

@@ -397,11 +397,11 @@ class QAGNN_Message_Passing(nn.Module):
         bs, n = node_type.size()
         d = self.hidden_size
         L = head_layout(d, H.device)
-        edge_index, edge_type = A
         ntype = node_type.reshape(-1).contiguous()
         if graph is None:
-            # subgraph i owns node rows [i*n, (i+1)*n) (LM_QAGNN.batch_graph): lets the edge forward run out of LDS
-            graph = ops.kernels().graph_prep(edge_index, edge_type, ntype, self.n_etype, self.n_ntype, block_n=n)
+            # subgraph i owns node rows [i*n, (i+1)*n) (LM_QAGNN.batch_graph): lets the edge forward run out of LDS.
+            # A = (edge_index, edge_type) like the reference, or a data_utils.PackedGraphBatch of load-time blobs
+            graph = ops.build_graph(A, ntype, self.n_etype, self.n_ntype, n)
         per_layer, extras = self.pack_all(L)
         Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes, We_t_all, We_all, be_all, Wtype_all, bias_all = extras[:14]
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
@@ -474,9 +474,7 @@ class QAGNN(nn.Module):
         graph, join_graph = None, None
         if fused_input and self.gnn.k > 0:
             # the graph orderings only need the integer inputs: prepared on a side stream, under the gather-GEMM below
-            edge_index, edge_type = adj
-            graph, join_graph = ops.graph_prep_async(edge_index, edge_type, node_type_ids.reshape(-1).contiguous(), self.gnn.n_etype,
-                                                     self.gnn.n_ntype, n)
+            graph, join_graph = ops.graph_prep_async(adj, node_type_ids.reshape(-1).contiguous(), self.gnn.n_etype, self.gnn.n_ntype, n)
         if fused_input:
             # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout
             L = head_layout(self.concept_dim, dev)
@@ -549,17 +547,24 @@ class LM_QAGNN(nn.Module):
         edge_index_orig, edge_type_orig = inputs[-2:]
         flat = [x.reshape(bs * nc, *x.shape[2:]) for x in inputs[:-2]]
         *lm_inputs, concept_ids, node_type_ids, node_scores, adj_lengths = flat
-        edge_index = [g for row in edge_index_orig for g in row]  # (:224) nested [bs][nc] -> flat [bs*nc]
-        edge_type = [g for row in edge_type_orig for g in row]
-        edge_index, edge_type = batch_graph(edge_index, edge_type, concept_ids.size(1))
         dev = node_type_ids.device
-        adj = (edge_index.to(dev), edge_type.to(dev))
+        from .data_utils import PackedGraphBatch
+        if isinstance(edge_index_orig, PackedGraphBatch):
+            # the batch generator shipped the graph as one buffer of load-time blobs: batch_graph's offsets are applied in-kernel
+            adj = edge_index_orig
+        else:
+            edge_index = [g for row in edge_index_orig for g in row]  # (:224) nested [bs][nc] -> flat [bs*nc]
+            edge_type = [g for row in edge_type_orig for g in row]
+            edge_index, edge_type = batch_graph(edge_index, edge_type, concept_ids.size(1))
+            adj = (edge_index.to(dev), edge_type.to(dev))
         sent_vecs, all_hidden_states = self.encoder(*lm_inputs, layer_id=layer_id)
         logits, attn = self.decoder(sent_vecs.to(dev), concept_ids, node_type_ids, node_scores, adj_lengths, adj,
                                     emb_data=None, cache_output=cache_output)
         logits = logits.view(bs, nc)
         if not detail:
             return logits, attn
+        if isinstance(edge_index_orig, PackedGraphBatch):
+            edge_index_orig, edge_type_orig = edge_index_orig.nested_lists()  # what the reference returns here (:237-239)
         return logits, attn, concept_ids.view(bs, nc, -1), node_type_ids.view(bs, nc, -1), edge_index_orig, edge_type_orig
 
     batch_graph = staticmethod(batch_graph)

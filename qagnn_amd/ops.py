@@ -296,11 +296,22 @@ PREP_OVERLAP = _os.environ.get('QAGNN_PREP_OVERLAP', '1') == '1'
 _PREP_STREAMS = {}
 
 
-def graph_prep_async(edge_index, edge_type, node_type, n_etype, n_ntype, block_n):
-    """-> (graph, join): the preparation is enqueued on the side stream; call join() on the consumer stream before using it."""
+def build_graph(adj, node_type, n_etype, n_ntype, block_n):
+    """The batch's graph orderings from whatever the caller handed over as `adj`: a data_utils.PackedGraphBatch (load-time
+    blobs, one device buffer) or the reference's (edge_index [2, E], edge_type [E]) int64 pair."""
     K = kernels()
+    from .data_utils import PackedGraphBatch
+    packed = adj if isinstance(adj, PackedGraphBatch) else (adj[0] if isinstance(adj[0], PackedGraphBatch) else None)
+    if packed is not None:
+        assert packed.n == block_n and packed.n_etype == n_etype and packed.n_ntype == n_ntype, 'blob store built for another model shape'
+        return K.graph_from_blobs(packed, node_type)
+    return K.graph_prep(adj[0], adj[1], node_type, n_etype, n_ntype, block_n=block_n)
+
+
+def graph_prep_async(adj, node_type, n_etype, n_ntype, block_n):
+    """-> (graph, join): the preparation is enqueued on the side stream; call join() on the consumer stream before using it."""
     if not (PREP_OVERLAP and node_type.is_cuda):
-        return K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n), (lambda: None)
+        return build_graph(adj, node_type, n_etype, n_ntype, block_n), (lambda: None)
     dev = node_type.device
     main = torch.cuda.current_stream(dev)
     key = main.device_index
@@ -309,7 +320,7 @@ def graph_prep_async(edge_index, edge_type, node_type, n_etype, n_ntype, block_n
     side = _PREP_STREAMS[key]
     side.wait_stream(main)  # the inputs (and last step's readers of the recycled storage) are ordered before the fork
     with torch.cuda.stream(side):
-        graph = K.graph_prep(edge_index, edge_type, node_type, n_etype, n_ntype, block_n=block_n)
+        graph = build_graph(adj, node_type, n_etype, n_ntype, block_n)
     return graph, (lambda: torch.cuda.current_stream(dev).wait_stream(side))
 
 

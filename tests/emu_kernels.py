@@ -93,6 +93,10 @@ class EmuKernels:
     def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype, block_n=0):
         return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype, block_n)
 
+    def graph_from_blobs(self, packed, node_type):
+        ei, et = packed.batched(device=node_type.device)
+        return EmuGraph(ei, et, node_type, packed.n_etype, packed.n_ntype, packed.n)
+
     @staticmethod
     def _gather_rows(A, idx):
         if idx is None:

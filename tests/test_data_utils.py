@@ -142,3 +142,89 @@ def test_batch_generator_protocol():
     for q in range(3):
         for ch in range(3):
             assert torch.equal(bei[q][ch], nested_ei[q][ch]) and torch.equal(bet[q][ch], nested_et[q][ch])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# load-time graph blobs
+# ---------------------------------------------------------------------------------------------------------------------
+def _case_store(case):
+    c = helpers.GOLDEN_CASES[case]
+    inp = helpers.make_case_inputs(case)
+    store = data_utils.GraphBlobStore.build(inp['edge_index_list'], inp['edge_type_list'], inp['node_type_ids'].view(-1, c['n']),
+                                            c['cfg']['n_etype'], c['cfg']['n_ntype'])
+    return c, inp, store
+
+
+@pytest.mark.parametrize('case', ['small_train', 'csqa_b10', 'medqa_b8', 'trunc_eval'])
+def test_graph_blobs_are_a_lossless_encoding(case):
+    """decode(build(graph)) gives back the reference loader's per-graph edge lists, element for element (incl. empty graphs)."""
+    c, inp, store = _case_store(case)
+    assert len(store) == c['nq'] * c['nc']
+    for i, (ei, et) in enumerate(zip(inp['edge_index_list'], inp['edge_type_list'])):
+        dei, det = store.edge_lists(i)
+        assert torch.equal(dei, ei) and torch.equal(det, et)
+        assert store.sample(i).size == 2 * c['n'] + 3 * ei.size(1)       # 12 bytes per edge + 8 per node slot
+    # the orderings inside a blob: source order sorted by (src, id), target order by (tgt, id), w2 = inverse permutation
+    n, T = c['n'], c['cfg']['n_ntype']
+    i = max(range(len(store)), key=lambda k: store.edge_count[k])
+    b, E = store.sample(i), int(store.edge_count[i])
+    ei, et = inp['edge_index_list'][i].numpy(), inp['edge_type_list'][i].numpy()
+    nt = inp['node_type_ids'].view(-1, n)[i].numpy()
+    w0, w1, w2 = b[2 * n:2 * n + E].view(np.uint32), b[2 * n + E:2 * n + 2 * E].view(np.uint32), b[2 * n + 2 * E:]
+    eid = (w1 & 0xFFFF).astype(np.int64)
+    src_sorted = ei[0][eid]
+    assert (np.diff(src_sorted) >= 0).all() and all((np.diff(eid[src_sorted == v]) > 0).all() for v in np.unique(src_sorted))
+    assert np.array_equal(w0 & 0xFFFF, ei[1][eid])
+    assert np.array_equal(w0 >> 16, et[eid] * T * T + nt[ei[0][eid]] * T + nt[ei[1][eid]])
+    order_t = eid[w2]                                                   # local ids of the target-ordered edges
+    assert (np.diff(ei[1][order_t]) >= 0).all() and np.array_equal(w1 >> 16, ei[0][order_t])
+    assert np.array_equal(b[:n], np.bincount(ei[0], minlength=n)) and np.array_equal(b[n:2 * n], np.bincount(ei[1], minlength=n))
+
+
+def test_graph_blob_rejects_what_the_reference_rejects():
+    nt = np.array([3, 0, 2, 2])
+    ok = data_utils.build_graph_blob(np.array([[0, 1], [1, 2]]), np.array([0, 5]), nt, 38, 4)
+    assert ok.size == 2 * 4 + 3 * 2
+    with pytest.raises(IndexError):
+        data_utils.build_graph_blob(np.array([[0, 9], [1, 2]]), np.array([0, 5]), nt, 38, 4)       # endpoint >= n
+    with pytest.raises(IndexError):
+        data_utils.build_graph_blob(np.array([[0, 1], [1, 2]]), np.array([0, 38]), nt, 38, 4)      # relation >= n_etype
+    with pytest.raises(IndexError):
+        data_utils.build_graph_blob(np.array([[0, 1], [1, 2]]), np.array([0, 5]), np.array([3, 0, 4, 2]), 38, 4)  # node type >= T
+
+
+def test_graph_blob_store_pack_save_load(tmp_path):
+    c, inp, store = _case_store('csqa_b10')
+    prefix = str(tmp_path / 'train.graph')
+    store.save(prefix)
+    mm = data_utils.GraphBlobStore.load(prefix, mmap=True)
+    assert isinstance(mm.data, np.memmap) and (mm.n, mm.n_etype, mm.n_ntype) == (store.n, store.n_etype, store.n_ntype)
+    ids = [7, 2, 3]
+    buf, B, E = mm.pack(ids)
+    a = buf.numpy()
+    head = (2 * (B + 1) + 3) // 4 * 4
+    assert B == 3 and E == int(store.edge_count[ids].sum()) and a[B] == buf.numel() - head and a[2 * B + 1] == E
+    for k, i in enumerate(ids):
+        assert np.array_equal(a[head + a[k]:head + a[k + 1]], store.sample(i))
+        assert a[B + 1 + k + 1] - a[B + 1 + k] == store.edge_count[i]
+    assert buf.numel() * 4 <= 12 * E + 8 * c['n'] * B + 16 * (B + 2)    # <= 12 B/edge + 8 B/node slot + the offset tables
+
+
+def test_batch_generator_with_blobs_follows_the_reference_protocol():
+    """Same batches, same order as the list-based generator; the graph arrives as ONE packed buffer whose lazily decoded
+    nested lists equal what the reference protocol yields."""
+    c, inp, store = _case_store('csqa_b10')
+    nq, nc, n = c['nq'], c['nc'], c['n']
+    nested = lambda flat: [flat[q * nc:(q + 1) * nc] for q in range(nq)]  # noqa: E731
+    tensors1 = [inp['concept_ids'].view(nq, nc, n), inp['node_type_ids'].view(nq, nc, n)]
+    common = dict(args=None, mode='eval', device0='cpu', device1='cpu', batch_size=1, indexes=torch.arange(nq), qids=list(range(nq)),
+                  labels=torch.zeros(nq, dtype=torch.long), tensors1=tensors1)
+    ref_gen = data_utils.MultiGPUSparseAdjDataBatchGenerator(adj_data=(nested(inp['edge_index_list']), nested(inp['edge_type_list'])), **common)
+    blob_gen = data_utils.MultiGPUSparseAdjDataBatchGenerator(graph_blobs=store, num_choice=nc, **common)
+    for ref_b, blob_b in zip(ref_gen, blob_gen):
+        assert ref_b[0] == blob_b[0] and torch.equal(ref_b[2], blob_b[2]) and torch.equal(ref_b[3], blob_b[3])
+        packed = blob_b[-2]
+        assert isinstance(packed, data_utils.PackedGraphBatch) and blob_b[-1] is None and packed.B == nc
+        ei, et = packed.nested_lists()
+        assert all(torch.equal(a, b) for ra, rb in zip(ei, ref_b[-2]) for a, b in zip(ra, rb))
+        assert all(torch.equal(a, b) for ra, rb in zip(et, ref_b[-1]) for a, b in zip(ra, rb))

@@ -506,3 +506,81 @@ def test_bn_relu_backward_with_colsum_by_product(R, C):
         dH2 = K.bn_relu_bwd(dY, H, mean, invstd, scale, shift, gamma, red, 1.0 / R, roww)
         assert torch.equal(cs, K.colsum(dH)[0])
         assert (dH - dH2).abs().max().item() <= 1e-6 * dH2.abs().max().item()  # same formula; FMA contraction may differ by an ulp
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# load-time graph blobs: qagnn_graph_from_blobs == qagnn_graph_prep_blocked, bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+def _blob_batch(case, device='cuda'):
+    import helpers
+    from qagnn_amd import data_utils
+    c = helpers.GOLDEN_CASES[case]
+    inp = helpers.make_case_inputs(case)
+    n = c['n']
+    store = data_utils.GraphBlobStore.build(inp['edge_index_list'], inp['edge_type_list'], inp['node_type_ids'].view(-1, n),
+                                            c['cfg']['n_etype'], c['cfg']['n_ntype'])
+    ids = list(range(len(store)))
+    buf, B, E = store.pack(ids, pin=device == 'cuda')
+    return c, inp, data_utils.PackedGraphBatch(buf.to(device), B, E, store, ids, c['nc'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['small_train', 'csqa_b10', 'medqa_b8', 'trunc_eval', 'config1_train'])
+def test_graph_from_blobs_bit_identical_to_graph_prep(case):
+    c, inp, packed = _blob_batch(case)
+    K = hip()
+    nt = inp['node_type_ids'].view(-1).cuda()
+    g1 = K.graph_prep(inp['edge_index'].cuda(), inp['edge_type'].cuda(), nt, c['cfg']['n_etype'], c['cfg']['n_ntype'], block_n=c['n'])
+    g2 = K.graph_from_blobs(packed, nt)
+    torch.cuda.synchronize()
+    assert (g1.N, g1.E, g1.Ep, g1.C, g1.max_chunks, g1.c.n_groups, g1.c.block_n) == (g2.N, g2.E, g2.Ep, g2.C, g2.max_chunks, g2.c.n_groups, g2.c.block_n)
+    sizes = {'N+1': g1.N + 1, 'Ep': g1.Ep, 'C': g1.C, 'pairs+1': g1.c.n_groups * g1.C + 1}
+    for arr, sz in GRAPH_ARRAYS:
+        assert torch.equal(g1.array(arr, sizes[sz]), g2.array(arr, sizes[sz])), f'{arr} differs'
+    nch = int(g1.array('n_chunks', 1).item())
+    assert nch == int(g2.array('n_chunks', 1).item())
+    for arr in ('chunk_cls', 'chunk_beg', 'chunk_len'):
+        assert torch.equal(g1.array(arr, nch), g2.array(arr, nch)), f'{arr} differs'
+    assert g2.array('err', 2).tolist() == [0, 0]
+
+
+@pytest.mark.gpu
+def test_blob_batch_through_the_model_and_the_generator():
+    """The packed pinned single copy (data_utils generator on cuda) feeds QAGNN.forward to the bit-identical logits and
+    gradients of the reference protocol (per-graph int64 lists -> batch_graph -> graph_prep)."""
+    import helpers
+    from qagnn_amd import data_utils
+    from test_host_logic_emu import build
+    from qagnn_amd import ops
+    ops.set_kernels(None)
+    case = 'csqa_b10'
+    c, inp, _ = _blob_batch(case, device='cpu')
+    nq, nc, n = c['nq'], c['nc'], c['n']
+    store = data_utils.GraphBlobStore.build(inp['edge_index_list'], inp['edge_type_list'], inp['node_type_ids'].view(-1, n),
+                                            c['cfg']['n_etype'], c['cfg']['n_ntype'])
+    nest = lambda flat: [flat[q * nc:(q + 1) * nc] for q in range(nq)]  # noqa: E731
+    tensors1 = [inp['concept_ids'].view(nq, nc, n), inp['node_type_ids'].view(nq, nc, n), inp['node_scores'].view(nq, nc, n, 1),
+                inp['adj_lengths'].view(nq, nc)]
+    common = dict(args=None, mode='eval', device0='cuda', device1='cuda', batch_size=nq, indexes=torch.arange(nq), qids=list(range(nq)),
+                  labels=torch.zeros(nq, dtype=torch.long), tensors0=[inp['sent_vecs'].view(nq, nc, -1)], tensors1=tensors1)
+    gens = [data_utils.MultiGPUSparseAdjDataBatchGenerator(adj_data=(nest(inp['edge_index_list']), nest(inp['edge_type_list'])), **common),
+            data_utils.MultiGPUSparseAdjDataBatchGenerator(graph_blobs=store, num_choice=nc, **common)]
+    outs = []
+    for gen in gens:
+        (batch,) = list(gen)
+        qids, labels, sent, cids, ntypes, nscores, alens, ei, et = batch
+        assert sent.is_cuda and cids.is_cuda
+        B = nq * nc
+        if isinstance(ei, data_utils.PackedGraphBatch):
+            assert ei.buf.is_cuda and ei.buf.dtype == torch.int32 and ei.buf.numel() * 4 <= 12 * ei.E + 8 * n * B + 16 * (B + 2)
+            adj = ei
+        else:
+            bei, bet = data_utils.batch_graph([g for row in ei for g in row], [g for row in et for g in row], n)
+            assert bei.is_cuda
+            adj = (bei, bet)
+        model = build(case).cuda()
+        logits, attn = model(sent.view(B, -1), cids.view(B, n), ntypes.view(B, n), nscores.view(B, n, 1), alens.view(B), adj)
+        logits.sum().backward()
+        outs.append([logits.detach(), attn.detach()] + [p.grad for p in model.parameters() if p.grad is not None])
+    assert len(outs[0]) == len(outs[1]) > 40
+    assert all(torch.equal(a, b) for a, b in zip(*outs))

@@ -376,3 +376,45 @@ def test_gpu_parity_harness_on_cpu(train):
                 cfg=helpers.model_cfg(d=100, k=3, sent_dim=40, n_concept=500, concept_in_dim=24))
     report = T.oracle_vs_package(case, device='cpu')
     assert len(report) > 20 and max(report.values()) < 1e-3
+
+
+def test_model_accepts_a_packed_blob_batch():
+    """QAGNN.forward / LM_QAGNN.forward with the graph as a PackedGraphBatch of load-time blobs == with (edge_index, edge_type)."""
+    from qagnn_amd import data_utils
+    case = 'small_train'
+    c = helpers.GOLDEN_CASES[case]
+    inp = helpers.make_case_inputs(case)
+    nq, nc, n = c['nq'], c['nc'], c['n']
+    store = data_utils.GraphBlobStore.build(inp['edge_index_list'], inp['edge_type_list'], inp['node_type_ids'].view(-1, n),
+                                            c['cfg']['n_etype'], c['cfg']['n_ntype'])
+    ids = list(range(nq * nc))
+    buf, B, E = store.pack(ids)
+    packed = data_utils.PackedGraphBatch(buf, B, E, store, ids, nc)
+    args = (inp['sent_vecs'], inp['concept_ids'].view(B, n), inp['node_type_ids'].view(B, n), inp['node_scores'].view(B, n, 1),
+            inp['adj_lengths'].view(B))
+    outs = []
+    for adj in ((inp['edge_index'], inp['edge_type']), packed):
+        model = build(case)
+        logits, attn = model(*args, adj)
+        logits.sum().backward()
+        outs.append((logits.detach(), attn.detach(), model.gnn.Vx.weight.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+    class Enc(torch.nn.Module):
+        sent_dim = c['cfg']['sent_dim']
+
+        def forward(self, x, layer_id=-1):
+            return x, None
+    cfg = c['cfg']
+    lm = MQ.LM_QAGNN(None, 'none', cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['n_concept'], cfg['concept_dim'], cfg['concept_in_dim'],
+                     cfg['n_attention_head'], cfg['fc_dim'], cfg['n_fc_layer'], 0.0, 0.0, 0.0, init_range=0.02, encoder=Enc())
+    lm.decoder.load_state_dict(build(case).state_dict())
+    lm.train(c['train'])
+    lm.decoder.pooler.dropout.p = lm.decoder.pooler.attention.dropout.p = 0.0
+    nest = lambda flat: [flat[q * nc:(q + 1) * nc] for q in range(nq)]  # noqa: E731
+    shaped = [inp['sent_vecs'].view(nq, nc, -1), inp['concept_ids'].view(nq, nc, n), inp['node_type_ids'].view(nq, nc, n),
+              inp['node_scores'].view(nq, nc, n, 1), inp['adj_lengths'].view(nq, nc)]
+    a, _ = lm(*shaped, nest(inp['edge_index_list']), nest(inp['edge_type_list']))
+    b, _, _, _, ei_back, et_back = lm(*shaped, packed, None, detail=True)
+    assert torch.equal(a, b) and torch.equal(a.view(-1, 1), outs[0][0])
+    assert all(torch.equal(x, y) for rx, ry in zip(ei_back, nest(inp['edge_index_list'])) for x, y in zip(rx, ry))
