@@ -291,6 +291,18 @@ int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t
 int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused multi-tensor RAdam step.  Replaces the per-parameter Python loop of
+ *   utils/optimization_utils.py:31-97  (RAdam.step: ~10 elementwise kernels per tensor, ~70 decoder tensors)
+ * p, g, m, v: HOST arrays of n_tensors DEVICE pointers (parameter, gradient, exp_avg, exp_avg_sq; fp32, contiguous, any
+ * alignment), numel: host array of element counts.  All tensors share one step count, i.e. one (step_size, mode):
+ *   mode 2: N_sma >= 5 (:83-87)   mode 1: SGD-like branch (:89-92)   mode 0: moments only (step_size < 0)
+ * Per element:  v = beta2 v + (1-beta2) g g;  m = beta1 m + (1-beta1) g;  p -= weight_decay lr p;  p -= step_size lr m / (sqrt(v)+eps)
+ * (or  p -= step_size lr m  in mode 1).  Pointer tables travel in the kernel arguments: nothing to allocate, capture safe. */
+int qagnn_radam_step_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                         const int64_t* numel, float beta1, float beta2, float eps, float lr, float weight_decay, float step_size,
+                         int32_t mode, qagnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

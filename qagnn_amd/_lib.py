@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')  # QAGNN_LIB: an alternate build (kernel A/B runs)
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
-           'qagnn_graph_from_blobs',
+           'qagnn_graph_from_blobs', 'qagnn_radam_step_f32',
            'qagnn_edge_attn_fwd_blocked_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
@@ -71,6 +71,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
+    lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
@@ -290,6 +291,18 @@ class HipKernels(metaclass=_GuardedMeta):
         ERR_WATCH.poll()
         ERR_WATCH.watch(G.array('err', 4), f'the blob batch with B={B} samples, E={E} edges')
         return G
+
+    def radam_step(self, params, grads, exp_avgs, exp_avg_sqs, beta1, beta2, eps, lr, weight_decay, step_size, mode):
+        """One fused RAdam update of a list of fp32 device tensors that share a step count (qagnn_radam_step_f32)."""
+        n = len(params)
+        for group in (params, grads, exp_avgs, exp_avg_sqs):
+            assert len(group) == n and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in group)
+        assert all(p.numel() == g.numel() == m.numel() == v.numel() for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs))
+        tab = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+        numel = (C.c_int64 * n)(*[t.numel() for t in params])
+        rc = self.lib.qagnn_radam_step_f32(n, tab(params), tab(grads), tab(exp_avgs), tab(exp_avg_sqs), numel, float(beta1), float(beta2),
+                                           float(eps), float(lr), float(weight_decay), float(step_size), int(mode), self._stream())
+        self._check(rc, 'qagnn_radam_step_f32')
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,

@@ -131,37 +131,61 @@ def load_sparse_adj_data_with_contextnode(adj_pk_path, max_node_num, num_choice,
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Flat binary cache.  The reference's `.loaded_cache` is a pickle of Python lists holding tens of
-# thousands of tiny tensors (slow to load, 2 objects per subgraph).  The flat form is ONE .npz with CSR offsets + int32
-# edges + uint8 edge types + the four dense arrays; it can be np.load()-ed with mmap_mode='r' and sliced per batch without
-# touching Python objects per graph.
+# thousands of tiny tensors (reference utils/data_utils.py:80-88, 178-179: 2 objects per subgraph, all unpickled and kept as
+# Python objects).  The flat form is a handful of UNCOMPRESSED .npy files next to each other -- the four dense arrays in their
+# narrowest integer types + the graph blob store (below) -- which np.load(mmap_mode='r') maps without reading: a batch touches
+# only the pages of its own samples, and no per-graph Python object exists until somebody asks for the reference's lists.
 # ---------------------------------------------------------------------------------------------------------------------
-def save_flat_cache(path, concept_ids, node_type_ids, node_scores, adj_lengths, edge_index, edge_type, half_n_rel):
-    """`edge_index` / `edge_type`: flat lists (one entry per subgraph) as produced by records_to_tensors()."""
-    counts = np.array([e.size(1) for e in edge_index], dtype=np.int64)
-    ptr = np.concatenate([[0], np.cumsum(counts)])
-    ei = torch.cat(edge_index, dim=1).numpy().astype(np.int32) if len(edge_index) else np.zeros((2, 0), np.int32)
-    et = torch.cat(edge_type, dim=0).numpy()
-    assert et.max(initial=0) < 256
-    np.savez(path, concept_ids=concept_ids.numpy().astype(np.int32), node_type_ids=node_type_ids.numpy().astype(np.uint8),
-             node_scores=node_scores.numpy(), adj_lengths=adj_lengths.numpy().astype(np.int32), edge_ptr=ptr, edge_index=ei,
-             edge_type=et.astype(np.uint8), half_n_rel=np.array(half_n_rel))
+def save_flat_cache(prefix, concept_ids, node_type_ids, node_scores, adj_lengths, edge_index, edge_type, half_n_rel, n_ntype=4):
+    """`edge_index` / `edge_type`: FLAT lists (one entry per subgraph) as produced by records_to_tensors(); the dense tensors
+    are [S, n(, 1)] / [S].  n_etype = 2 * half_n_rel (the loader mirrors every relation, reference utils/data_utils.py:173)."""
+    cids, nts = concept_ids.numpy(), node_type_ids.numpy()
+    assert cids.max(initial=0) < 2 ** 31 and nts.max(initial=0) < 256
+    np.save(prefix + '.concept_ids.npy', cids.astype(np.int32))
+    np.save(prefix + '.node_type_ids.npy', nts.astype(np.uint8))
+    np.save(prefix + '.node_scores.npy', node_scores.numpy().astype(np.float32))
+    np.save(prefix + '.adj_lengths.npy', adj_lengths.numpy().astype(np.int32))
+    np.save(prefix + '.meta.npy', np.array([half_n_rel, n_ntype], dtype=np.int64))
+    GraphBlobStore.build(edge_index, edge_type, nts.reshape(len(edge_index), -1), 2 * int(half_n_rel), n_ntype).save(prefix)
 
 
-def load_flat_cache(path, num_choice):
-    """Inverse of save_flat_cache(): returns exactly what load_sparse_adj_data_with_contextnode() returns."""
-    z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
-    ptr = z['edge_ptr']
-    ei_all = torch.from_numpy(z['edge_index'].astype(np.int64))
-    et_all = torch.from_numpy(z['edge_type'].astype(np.int64))
-    n_samples = len(ptr) - 1
-    ei = [ei_all[:, ptr[i]:ptr[i + 1]] for i in range(n_samples)]
-    et = [et_all[ptr[i]:ptr[i + 1]] for i in range(n_samples)]
-    edge_index = [ei[q:q + num_choice] for q in range(0, n_samples, num_choice)]
-    edge_type = [et[q:q + num_choice] for q in range(0, n_samples, num_choice)]
-    dense = [torch.from_numpy(z['concept_ids'].astype(np.int64)), torch.from_numpy(z['node_type_ids'].astype(np.int64)),
-             torch.from_numpy(z['node_scores']), torch.from_numpy(z['adj_lengths'].astype(np.int64))]
+class LazyNestedGraphs:
+    """What load_sparse_adj_data_with_contextnode returns as `edge_index` (which=0) / `edge_type` (which=1): a sequence over
+    questions whose items are lists of num_choice int64 tensors -- decoded from the blob store on access, nothing is
+    materialised up front.  The batch generator recognises `.store` and ships the blobs themselves instead."""
+
+    def __init__(self, store, num_choice, which):
+        self.store, self.num_choice, self.which = store, num_choice, which
+
+    def __len__(self):
+        return len(self.store) // self.num_choice
+
+    def __getitem__(self, q):
+        if isinstance(q, slice):
+            return [self[i] for i in range(*q.indices(len(self)))]
+        q = int(q)
+        if q < 0:
+            q += len(self)
+        if not 0 <= q < len(self):
+            raise IndexError(q)
+        return [self.store.edge_lists(q * self.num_choice + c)[self.which] for c in range(self.num_choice)]
+
+    def __iter__(self):
+        return (self[q] for q in range(len(self)))
+
+
+def load_flat_cache(prefix, num_choice, mmap=True):
+    """Inverse of save_flat_cache(): the same 5-tuple load_sparse_adj_data_with_contextnode() returns -- dense int64 / fp32
+    tensors [nq, nc, ...] (one vectorised widening pass over the mapped arrays) and adj_data = (edge_index, edge_type) as
+    LazyNestedGraphs over the memory-mapped blob store."""
+    mode = 'r' if mmap else None
+    dense = [torch.from_numpy(np.asarray(np.load(prefix + '.concept_ids.npy', mmap_mode=mode), dtype=np.int64)),
+             torch.from_numpy(np.asarray(np.load(prefix + '.node_type_ids.npy', mmap_mode=mode), dtype=np.int64)),
+             torch.from_numpy(np.array(np.load(prefix + '.node_scores.npy', mmap_mode=mode), dtype=np.float32)),
+             torch.from_numpy(np.asarray(np.load(prefix + '.adj_lengths.npy', mmap_mode=mode), dtype=np.int64))]
     concept_ids, node_type_ids, node_scores, adj_lengths = [x.view(-1, num_choice, *x.size()[1:]) for x in dense]
-    return concept_ids, node_type_ids, node_scores, adj_lengths, (edge_index, edge_type)
+    store = GraphBlobStore.load(prefix, mmap=mmap)
+    return concept_ids, node_type_ids, node_scores, adj_lengths, (LazyNestedGraphs(store, num_choice, 0), LazyNestedGraphs(store, num_choice, 1))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -337,6 +361,8 @@ class MultiGPUSparseAdjDataBatchGenerator(object):
                  tensors0=[], lists0=[], tensors1=[], lists1=[], adj_data=None, graph_blobs=None, num_choice=None):
         """graph_blobs (GraphBlobStore, optional): the batch's graph then travels as ONE int32 buffer of load-time blobs
         (12 B/edge) and is yielded as (PackedGraphBatch, None) in place of (edge_index, edge_type); `adj_data` may be None."""
+        if graph_blobs is None and adj_data is not None and getattr(adj_data[0], 'store', None) is not None:
+            graph_blobs, num_choice = adj_data[0].store, adj_data[0].num_choice  # adj_data from load_flat_cache()
         self.graph_blobs, self.num_choice = graph_blobs, num_choice
         self.args, self.mode = args, mode
         self.device0, self.device1 = device0, device1

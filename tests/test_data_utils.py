@@ -86,6 +86,19 @@ def test_flat_cache_round_trip(tmp_path):
     flat_et = [t for r in et for t in r]
     assert all(torch.equal(a, b) for a, b in zip(flat_ei, out[5])) and all(torch.equal(a, b) for a, b in zip(flat_et, out[6]))
     assert flat_ei[0].dtype == torch.long and len(ei) == 3 and len(ei[0]) == 4
+    # nothing was materialised up front: the graph side is a lazy view over memory-mapped blobs, the dense side came from
+    # uncompressed, mappable .npy files in their narrowest integer types
+    assert isinstance(ei, data_utils.LazyNestedGraphs) and isinstance(ei.store.data, np.memmap) and ei.store is et.store
+    assert np.load(p + '.concept_ids.npy', mmap_mode='r').dtype == np.int32 and np.load(p + '.node_type_ids.npy', mmap_mode='r').dtype == np.uint8
+    assert torch.equal(ei[-1][0], out[5][8]) and [len(x) for x in ei[1:3]] == [4, 4]
+    # handed to the batch generator as adj_data, the blobs themselves are shipped (one packed buffer per batch)
+    gen = data_utils.MultiGPUSparseAdjDataBatchGenerator(None, 'eval', 'cpu', 'cpu', 2, torch.arange(3), list(range(3)), torch.zeros(3, dtype=torch.long),
+                                                         tensors1=[cids, nt], adj_data=(ei, et))
+    batches = list(gen)
+    assert len(batches) == 2 and isinstance(batches[0][-2], data_utils.PackedGraphBatch) and batches[0][-2].B == 8 and batches[1][-2].B == 4
+    bei, bet = batches[1][-2].batched()
+    rei, ret = data_utils.batch_graph(out[5][8:12], out[6][8:12], 200)
+    assert torch.equal(bei, rei) and torch.equal(bet, ret)
 
 
 def test_loader_invariants():
