@@ -224,15 +224,17 @@ int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t
 int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                             qagnn_stream_t stream);
-/* Forward for block-structured batches (g->block_n = n > 0): one workgroup per (subgraph, head) stages that head's K, M and Q
- * rows of the subgraph in LDS (3 * n * HP floats: 125 KB at n = 200, d = 200) plus the subgraph's alpha values, computes
- * scores / segment softmax / aggregation entirely out of LDS and touches HBM only for the compulsory bytes (each K|M|Q row
- * once, indices, outputs).  If the device flag says the graph is NOT block-structured the workgroups exit at once and the
- * generic three kernels run instead (and vice versa), so the result is always right and the host never synchronises.
- * Returns QAGNN_EUNSUPPORTED when 3 * n * HP floats do not fit the 160 KB LDS (callers then use qagnn_edge_attn_fwd_f32). */
-int qagnn_edge_attn_fwd_blocked_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
-                                    float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
-                                    qagnn_stream_t stream);
+/* Forward for block-structured batches (g->block_n = n > 0, e.g. from qagnn_graph_from_blobs), LDS-resident: one workgroup per
+ * (subgraph, head) stages that head's slice of the subgraph's K rows (then M rows) in LDS -- n * HP floats, 41.6 KB at n = 200,
+ * d = 200 -- together with the subgraph's packed edge indices and its scores / alpha values, and computes scores, segment softmax
+ * and aggregation out of LDS; HBM sees each K | M | Q slice once.  `max_sub_ep` must bound E_g + n over the batch's subgraphs (the
+ * host knows it from the blob store); qagnn_edge_attn_fwd_lds_bytes() is the dynamic LDS per workgroup, QAGNN_EUNSUPPORTED above
+ * 160 KB (callers then use qagnn_edge_attn_fwd_f32).  Same outputs as qagnn_edge_attn_fwd_f32 up to the summation order of the
+ * softmax denominator (a, alpha agree to 1 ulp; aggr to the usual fp32 bound); deterministic. */
+int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep);
+int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
+                                float qscale, float* a, float* alpha, float* aggr, int32_t lda, int32_t max_sub_ep,
+                                qagnn_stream_t stream);
 int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ,
                             float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32',
-           'qagnn_edge_attn_fwd_blocked_f32',
+           'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 5  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs)
+ABI_VERSION = 6  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -90,7 +90,9 @@ def load_library(path=LIB_PATH):
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
-    lib.qagnn_edge_attn_fwd_blocked_f32.argtypes = lib.qagnn_edge_attn_fwd_f32.argtypes
+    lib.qagnn_edge_attn_fwd_lds_bytes.restype = _i64
+    lib.qagnn_edge_attn_fwd_lds_bytes.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_edge_attn_fwd_lds_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
     lib.qagnn_hop_fwd_workspace_elems.restype = _i64
@@ -238,10 +240,9 @@ class HipKernels(metaclass=_GuardedMeta):
         self.lib = load_library()
         if self.lib.qagnn_abi_version() != ABI_VERSION:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
-        # LDS-resident edge forward (qagnn_edge_attn_fwd_blocked_f32).  Correct, but in its first form 5x slower than the generic
-        # gather kernels (interleaved A/B, run 26: 17 786 / 17 751 vs 21 449 / 21 452 QA-subgraphs/s): one 157 KB workgroup per CU
-        # leaves 8 waves to hide the latency of the per-edge index and class-table loads, the generic path has 32.  Default OFF.
-        self.edge_blocked = os.environ.get('QAGNN_EDGE_BLOCKED', '0') == '1'
+        # LDS-resident edge forward (qagnn_edge_attn_fwd_lds_f32) for block-structured batches whose largest subgraph is known on
+        # the host (graphs built from load-time blobs).  QAGNN_EDGE_LDS=0 pins the generic L2-gather kernels.
+        self.edge_lds = os.environ.get('QAGNN_EDGE_LDS', '1') == '1'
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -288,6 +289,7 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(rc, 'qagnn_graph_from_blobs')
         G = HipGraph(storage, g, N, E, R, T, n)
         G.keep = packed.buf  # the blobs are read by the kernel just enqueued
+        G.max_sub_ep = packed.max_sub_ep  # host-side bound on E_g + n per subgraph: sizes the LDS of the edge kernels
         ERR_WATCH.poll()
         ERR_WATCH.watch(G.array('err', 4), f'the blob batch with B={B} samples, E={E} edges')
         return G
@@ -487,16 +489,21 @@ class HipKernels(metaclass=_GuardedMeta):
         DP = 4 * HP
         assert KMQ.shape == (graph.N, 3 * DP) and EkEm.shape == (graph.C, 2 * DP)
         dev = KMQ.device
-        score = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
-        a = torch.empty_like(score)
-        alpha = torch.empty_like(score)
+        a = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
+        alpha = torch.empty_like(a)
         aggr = torch.empty((graph.N, DP), dtype=torch.float32, device=dev)
-        # block-structured batch whose per-head K|M|Q slabs fit the LDS: LDS-resident kernel (decided again on the device)
-        blocked = (self.edge_blocked and graph.block_n > 0 and 3 * graph.block_n * HP * 4 + 4096 <= 160 * 1024)
-        fn = self.lib.qagnn_edge_attn_fwd_blocked_f32 if blocked else self.lib.qagnn_edge_attn_fwd_f32
-        rc = fn(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale), score.data_ptr(),
-                a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, self._stream())
-        self._check(rc, 'qagnn_edge_attn_fwd_blocked_f32' if blocked else 'qagnn_edge_attn_fwd_f32')
+        max_sub_ep = getattr(graph, 'max_sub_ep', 0)
+        if (self.edge_lds and graph.block_n > 0 and max_sub_ep > 0 and graph.block_n < 65536 and graph.C < 65536 and
+                self.lib.qagnn_edge_attn_fwd_lds_bytes(graph.block_n, HP, max_sub_ep) <= 80 * 1024):
+            # block-structured batch, largest subgraph known: two LDS-resident workgroups per CU
+            rc = self.lib.qagnn_edge_attn_fwd_lds_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale),
+                                                      a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, int(max_sub_ep), self._stream())
+            self._check(rc, 'qagnn_edge_attn_fwd_lds_f32')
+            return aggr, a, alpha
+        score = torch.empty_like(a)  # scratch of the generic kernels (raw scores of hub segments)
+        rc = self.lib.qagnn_edge_attn_fwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale), score.data_ptr(),
+                                              a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, self._stream())
+        self._check(rc, 'qagnn_edge_attn_fwd_f32')
         return aggr, a, alpha
 
     def edge_attn_bwd(self, graph, KMQ, EkEm, HP, qscale, a, alpha, G):

@@ -91,9 +91,8 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
                                                      const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale,
                                                      float* __restrict__ score, float* __restrict__ a, float* __restrict__ alpha,
-                                                     int N, int C, const int* __restrict__ gate) {
+                                                     int N, int C) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  if (gate && *gate == 0) return;  // the LDS-resident kernel took this graph (device-side decision)
   const int s = wave_node();
   if (s >= N) return;
   const Lane L = lane_info(HP);
@@ -160,9 +159,8 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
                                                         const int* __restrict__ cls_t, const int* __restrict__ pos_t,
                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
                                                         int lde, int HP, const float* __restrict__ alpha,
-                                                        float* __restrict__ aggr, int lda, int N, int C, const int* __restrict__ gate) {
+                                                        float* __restrict__ aggr, int lda, int N, int C) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  if (gate && *gate == 0) return;
   const int t = wave_node();
   if (t >= N) return;
   const Lane L = lane_info(HP);
@@ -425,103 +423,130 @@ __global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ s
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward, LDS-resident: one workgroup per (subgraph, head).  A QA subgraph is n consecutive node rows and its edges never
-// leave it (LM_QAGNN.batch_graph), so the head's K, M and Q rows of the subgraph -- 3 x n x HP floats, 125 KB at n = 200,
-// d = 200 -- fit the 160 KB LDS of a CU.  All per-edge gathers then hit LDS; HBM sees each K|M|Q row once.
-// 16 lanes own one edge (13 of them carry the head's 52 floats as float4), so a wave works on 4 edges at a time.
-// The softmax is three sweeps over the segment (max, sum, normalise), each recomputing the score from LDS: no per-edge state.
+// forward, LDS-resident (the shape north_star names: destination rows staged in LDS, segmented reductions over the CSR-sorted
+// edge list).  One workgroup per (subgraph, head): a QA subgraph is n consecutive node rows and its edges never leave it
+// (LM_QAGNN.batch_graph), so ONE head's slice of the subgraph's K rows -- n x HP floats, 41.6 KB at n = 200, d = 200 -- fits
+// the LDS with room for two workgroups per CU.  The two phases need different matrices and share the buffer:
+//   phase 1  rows <- K slice;  a 16-lane group (13 lanes carry the head's 52 floats as float4 = one DPP row) owns a SOURCE node:
+//            Q slice in registers, per out-edge K[tgt] from LDS + Ek[cls] through L1, 16-lane DPP dot product, raw score into
+//            the LDS score array; then the group normalises its own segment (max, sum, divide: three strided sweeps over LDS)
+//            and leaves alpha = deg * a in place of the score
+//   phase 2  rows <- M slice;  a group owns a TARGET node: sum of alpha[pos] * (M[src] + Em[cls]) over its in-edges.
+// Per-edge indices are packed into LDS words once per phase (tgt | cls << 16; src | cls << 16, pos), so the inner loops issue
+// no dependent global index loads.  HBM sees every K | M | Q slice exactly once (the compulsory bytes); what still goes through
+// L1/L2 per edge is the class-table row (612 rows in all; ~120 distinct ones per subgraph).
+// Node order = node index, round-robin over the 32 groups: real nodes (index < adj_len) come first, PAD rows (one self loop
+// each) last, which balances the groups without a sort.  Every reduction has a fixed order: deterministic.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float grp4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float grp4_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+constexpr int LDS_UNROLL = 4;
 
-__global__ __launch_bounds__(512) void k_edge_fwd_blocked(const int* __restrict__ cross_block, const int* __restrict__ rowptr_s,
-                                                          const int* __restrict__ tgt_s, const int* __restrict__ cls_s,
-                                                          const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
-                                                          const int* __restrict__ cls_t, const int* __restrict__ pos_t,
-                                                          const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
-                                                          int lde, int HP, float qscale, int n, int alpha_cap,
-                                                          float* __restrict__ a, float* __restrict__ alpha,
-                                                          float* __restrict__ aggr, int lda) {
-  if (*cross_block != 0) return;  // not block-structured: the generic kernels handle this graph
-  extern __shared__ __attribute__((aligned(16))) float sm_blk[];
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // the 4 heads of a subgraph stay on one XCD (shared indices, tables)
+__global__ __launch_bounds__(512) void k_edge_fwd_lds(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
+                                                      const int* __restrict__ cls_s, const int* __restrict__ rowptr_t,
+                                                      const int* __restrict__ src_t, const int* __restrict__ cls_t,
+                                                      const int* __restrict__ pos_t, const float* __restrict__ KMQ, int ldk,
+                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale, int n, int ecap,
+                                                      float* __restrict__ a, float* __restrict__ alpha, float* __restrict__ aggr,
+                                                      int lda, int N, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm_lds[];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // the 4 heads of a subgraph run on one XCD (shared indices, class rows)
   const int gph = tile >> 2, h = tile & 3, node0 = gph * n;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, j = lane & 15;
+  const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
   const int DP = 4 * HP, f4 = HP >> 2;
   const bool act = j < f4;
-  float* const Ks = sm_blk;
-  float* const Ms = Ks + n * HP;
-  float* const Qs = Ms + n * HP;
-  float* const alphaL = Qs + n * HP;
-  for (int idx = tid; idx < n * f4; idx += 512) {  // stage the head's K, M, Q slices: 208-byte runs, each read once
-    const int row = idx / f4, c4 = idx - row * f4;
-    const float* src = KMQ + (int64_t)(node0 + row) * ldk + h * HP + c4 * 4;
-    st4(Ks + row * HP + c4 * 4, ld4(src));
-    st4(Ms + row * HP + c4 * 4, ld4(src + DP));
-    st4(Qs + row * HP + c4 * 4, ld4(src + 2 * DP));
+  float* const rows = sm_lds;                                     // [n][HP]   K slice, then M slice
+  float* const sc = rows + n * HP;                                // [ecap]    raw score -> alpha, local source-order position
+  uint32_t* const idx = reinterpret_cast<uint32_t*>(sc + ecap);   // [2*ecap]  packed per-edge indices of the current phase
+  int* const rp = reinterpret_cast<int*>(idx + 2 * ecap);         // [n+1]     local segment starts of the current phase
+  const int ebase = rowptr_s[node0], Eg = rowptr_s[node0 + n] - ebase;  // same range in the target order (block structure)
+  const uint32_t pe = (uint32_t)lde * 4u;
+  const rsrc_t rE = make_rsrc(EkEm, (uint32_t)C * pe);
+  const uint32_t voffE = act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF;  // this lane's float4 of the head inside Ek; Em is DP floats on
+
+  // ---- stage K slice, source-order indices, local rowptr ----
+  for (int i = tid; i < n * f4; i += 512) {
+    const int row = i / f4, c4 = i - row * f4;
+    st4(rows + row * HP + c4 * 4, ld4(KMQ + (int64_t)(node0 + row) * ldk + h * HP + c4 * 4));
   }
-  const int ebase = rowptr_s[node0], Eg = rowptr_s[node0 + n] - ebase;
-  const bool in_lds = Eg <= alpha_cap;
+  for (int e = tid; e < Eg; e += 512) idx[e] = (uint32_t)(tgt_s[ebase + e] - node0) | ((uint32_t)cls_s[ebase + e] << 16);
+  for (int v = tid; v <= n; v += 512) rp[v] = rowptr_s[node0 + v] - ebase;
   __syncthreads();
 
-  // phase 1: scores + softmax over the out-edges of every source node of the subgraph
-  for (int sl = w; sl < n; sl += 8) {
-    const int s = node0 + sl;
-    const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
-    const float4 q4 = act ? ld4(Qs + sl * HP + j * 4) : zero4();
-    const float deg = (float)(end - beg);
-    auto score_at = [&](int e) {  // all 64 lanes call this (shuffles inside); e is clamped by the caller
-      const int t = tgt_s[e] - node0, c = cls_s[e];
-      const float4 k4 = act ? ld4(Ks + t * HP + j * 4) : zero4();
-      const float4 ek = act ? ld4(EkEm + (int64_t)c * lde + h * HP + j * 4) : zero4();
-      return row16_sum(dot4(q4, add4(k4, ek))) * qscale;
-    };
-    float m = -INFINITY;
-    for (int e0 = beg; e0 < end; e0 += 4) {
-      const int e = e0 + grp;
-      const float p = score_at(min(e, end - 1));
-      if (e < end) m = fmaxf(m, p);
-    }
-    m = grp4_max(m);
-    float sum = 0.f;
-    for (int e0 = beg; e0 < end; e0 += 4) {
-      const int e = e0 + grp;
-      const float p = score_at(min(e, end - 1));
-      if (e < end) sum += expf(p - m);
-    }
-    sum = grp4_sum(sum);
-    for (int e0 = beg; e0 < end; e0 += 4) {
-      const int e = e0 + grp;
-      const float p = score_at(min(e, end - 1));
-      if (e < end && j == 0) {
-        const float av = expf(p - m) / (sum + 1e-16f), al = av * deg;
-        a[(int64_t)e * 4 + h] = av;
-        alpha[(int64_t)e * 4 + h] = al;
-        if (in_lds) alphaL[e - ebase] = al;
+  // ---- phase 1: scores + segment softmax, one group per source node ----
+  {
+    const float* qp = KMQ + 2 * DP + h * HP + j * 4;
+    float4 qn = (grp < n && act) ? ld4(qp + (int64_t)(node0 + grp) * ldk) : zero4();
+    for (int v = grp; v < n; v += 32) {
+      const float4 q = qn;
+      if (v + 32 < n && act) qn = ld4(qp + (int64_t)(node0 + v + 32) * ldk);  // next node's Q slice flies under this segment
+      const int beg = rp[v], end = rp[v + 1];
+      for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
+        float4 ek[LDS_UNROLL];
+        uint32_t w[LDS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < LDS_UNROLL; ++u) {
+          w[u] = idx[min(e0 + u, end - 1)];
+          ek[u] = buf_ld4(rE, voffE, (w[u] >> 16) * pe);
+        }
+#pragma unroll
+        for (int u = 0; u < LDS_UNROLL; ++u) {
+          const float4 k4 = act ? ld4(rows + (w[u] & 0xFFFFu) * HP + j * 4) : zero4();
+          const float p = row16_sum(dot4(q, add4(k4, ek[u]))) * qscale;
+          if (j == 0 && e0 + u < end) sc[e0 + u] = p;
+        }
+      }
+      // the group's own segment: its scores were written by its lane 0 (LDS operations of one wave retire in order)
+      float m = -INFINITY;
+      for (int e = beg + j; e < end; e += 16) m = fmaxf(m, sc[e]);
+      m = row16_max(m);
+      float sum = 0.f;
+      for (int e = beg + j; e < end; e += 16) sum += expf(sc[e] - m);
+      sum = row16_sum(sum);
+      const float deg = (float)(end - beg), inv = 1.0f / (sum + 1e-16f);
+      for (int e = beg + j; e < end; e += 16) {
+        const float av = expf(sc[e] - m) * inv, al = av * deg;
+        a[(int64_t)(ebase + e) * 4 + h] = av;
+        alpha[(int64_t)(ebase + e) * 4 + h] = al;
+        sc[e] = al;
       }
     }
   }
-  if (!in_lds) __threadfence();  // oversized subgraph: phase 2 reads alpha back from global memory
   __syncthreads();
 
-  // phase 2: weighted sum of messages into every target node of the subgraph
-  for (int tl = w; tl < n; tl += 8) {
-    const int t = node0 + tl;
-    const int beg = __builtin_amdgcn_readfirstlane(rowptr_t[t]), end = __builtin_amdgcn_readfirstlane(rowptr_t[t + 1]);
+  // ---- stage M slice, target-order indices ----
+  for (int i = tid; i < n * f4; i += 512) {
+    const int row = i / f4, c4 = i - row * f4;
+    st4(rows + row * HP + c4 * 4, ld4(KMQ + (int64_t)(node0 + row) * ldk + DP + h * HP + c4 * 4));
+  }
+  for (int e = tid; e < Eg; e += 512) {
+    idx[2 * e] = (uint32_t)(src_t[ebase + e] - node0) | ((uint32_t)cls_t[ebase + e] << 16);
+    idx[2 * e + 1] = (uint32_t)(pos_t[ebase + e] - ebase);
+  }
+  for (int v = tid; v <= n; v += 512) rp[v] = rowptr_t[node0 + v] - ebase;
+  __syncthreads();
+
+  // ---- phase 2: weighted sum of messages, one group per target node ----
+  const uint32_t voffEm = act ? voffE + (uint32_t)DP * 4u : OOB_OFF;
+  for (int v = grp; v < n; v += 32) {
+    const int beg = rp[v], end = rp[v + 1];
     float4 acc = zero4();
-    for (int e0 = beg; e0 < end; e0 += 4) {
-      const int e = e0 + grp, ec = min(e, end - 1);
-      const int sl = src_t[ec] - node0, c = cls_t[ec], p = pos_t[ec];
-      const float al = e < end ? (in_lds ? alphaL[p - ebase] : alpha[(int64_t)p * 4 + h]) : 0.f;
-      const float4 m4 = act ? ld4(Ms + sl * HP + j * 4) : zero4();
-      const float4 em = act ? ld4(EkEm + (int64_t)c * lde + DP + h * HP + j * 4) : zero4();
-      acc = fma4(al, add4(m4, em), acc);
+    for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
+      float4 em[LDS_UNROLL];
+      uint32_t w[LDS_UNROLL];
+      float al[LDS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < LDS_UNROLL; ++u) {
+        const int e = min(e0 + u, end - 1);
+        w[u] = idx[2 * e];
+        em[u] = buf_ld4(rE, voffEm, (w[u] >> 16) * pe);
+        al[u] = e0 + u < end ? sc[idx[2 * e + 1]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < LDS_UNROLL; ++u) {
+        const float4 m4 = act ? ld4(rows + (w[u] & 0xFFFFu) * HP + j * 4) : zero4();
+        acc = fma4(al[u], add4(m4, em[u]), acc);
+      }
     }
-    acc.x = grp4_sum(acc.x);
-    acc.y = grp4_sum(acc.y);
-    acc.z = grp4_sum(acc.z);
-    acc.w = grp4_sum(acc.w);
-    if (grp == 0 && act) st4(aggr + (int64_t)t * lda + h * HP + j * 4, acc);
+    if (act) st4(aggr + (int64_t)(node0 + v) * lda + h * HP + j * 4, acc);
   }
 }
 
@@ -542,16 +567,16 @@ static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const f
 using namespace qagnn;
 
 static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
-                                 float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda, const int* gate,
+                                 float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                                  hipStream_t stream) {
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
                 "edge_attn_fwd: bad output arguments");
   const int nb = cdiv(g->N, 4);
-  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C, gate);
+  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
-  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C, gate);
+  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C);
   QAGNN_LAUNCH_CHECK("k_edge_aggregate");
   return QAGNN_OK;
 }
@@ -559,33 +584,37 @@ static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t
 extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
                                        int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                                        qagnn_stream_t stream_) {
-  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, nullptr, (hipStream_t)stream_);
+  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, (hipStream_t)stream_);
 }
 
-extern "C" int qagnn_edge_attn_fwd_blocked_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
-                                               int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr,
-                                               int32_t lda, qagnn_stream_t stream_) {
+extern "C" int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep) {
+  const int64_t ecap = (max_sub_ep + 3) & ~3;
+  return ((int64_t)n * HP + 3 * ecap + (n + 1 + 3)) * (int64_t)sizeof(float);
+}
+
+extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
+                                           int32_t HP, float qscale, float* a, float* alpha, float* aggr, int32_t lda,
+                                           int32_t max_sub_ep, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd_blocked");
+  int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd_lds");
   if (rc != QAGNN_OK) return rc;
-  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0, QAGNN_EINVAL, "edge_attn_fwd_blocked: graph was not prepared with a block size");
+  QAGNN_REQUIRE(a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL, "edge_attn_fwd_lds: bad output arguments");
+  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0, QAGNN_EINVAL, "edge_attn_fwd_lds: the graph has no block structure (block_n = %d)", g->block_n);
   const int n = g->block_n;
-  const size_t lds_max = 160 * 1024, slabs = (size_t)3 * n * HP * sizeof(float);
-  QAGNN_REQUIRE(slabs + 4096 <= lds_max, QAGNN_EUNSUPPORTED, "edge_attn_fwd_blocked: 3 x %d x %d floats do not fit the LDS", n, HP);
-  const int alpha_cap = (int)((lds_max - slabs) / sizeof(float)) & ~3;
+  QAGNN_REQUIRE(max_sub_ep >= n && n < 65536 && g->C < 65536, QAGNN_EINVAL, "edge_attn_fwd_lds: max_sub_ep=%d must bound every subgraph's E_g + n", max_sub_ep);
+  const int64_t bytes = qagnn_edge_attn_fwd_lds_bytes(n, HP, max_sub_ep);
+  QAGNN_REQUIRE(bytes <= 160 * 1024, QAGNN_EUNSUPPORTED, "edge_attn_fwd_lds: %lld bytes of LDS per workgroup (n=%d, %d edges)", (long long)bytes, n, max_sub_ep);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_blocked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    if (e != hipSuccess) { set_error("edge_attn_fwd_blocked: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
+    hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("edge_attn_fwd_lds: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     attr_set = true;
   }
-  const int* cross = g->err + 1;
-  k_edge_fwd_blocked<<<(g->N / n) * 4, 512, slabs + (size_t)alpha_cap * sizeof(float), stream>>>(
-      cross, g->rowptr_s, g->tgt_s, g->cls_s, g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, qscale, n,
-      alpha_cap, a, alpha, aggr, lda);
-  QAGNN_LAUNCH_CHECK("k_edge_fwd_blocked");
-  // graphs that are not block-structured fall through to the generic kernels (gated on the same device flag)
-  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, cross, stream);
+  const int ecap = (max_sub_ep + 3) & ~3;
+  k_edge_fwd_lds<<<(g->N / n) * 4, 512, (size_t)bytes, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ,
+                                                                ldk, EkEm, lde, HP, qscale, n, ecap, a, alpha, aggr, lda, g->N, g->C);
+  QAGNN_LAUNCH_CHECK("k_edge_fwd_lds");
+  return QAGNN_OK;
 }
 
 extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,

@@ -263,7 +263,7 @@ class GATConvE(nn.Module):
             else:
                 TT = torch.addmm(bias, temb, Wtype)                  # [T, 3DP] type-embedding half of the projection + bq
                 ekem = torch.addmm(be_p, tab, We_p.t())              # [C, 2DP]: Ek | Em, pads exactly 0
-            if ops.use_fused_hop(Xp.size(0)) and not getattr(ops.kernels(), 'edge_blocked', False):
+            if ops.use_fused_hop(Xp.size(0)):
                 # the whole hop (projection, attention, mlp, GELU + dropout, and its backward) as one native call each way
                 bn = self.mlp[1]
                 running = None
