@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 6  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel)
+ABI_VERSION = 7  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -34,7 +34,8 @@ class qagnn_graph(C.Structure):
                 [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'tgt_t', 'cls_t', 'pos_t',
                                     'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
-                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
+                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)] +
+                [(n, _vp) for n in ('pk_s', 'pk_t', 'sub_ncls', 'sub_cls')])
 
 
 class qagnn_gemm_nn_args(C.Structure):
@@ -91,7 +92,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_fwd_lds_bytes.restype = _i64
-    lib.qagnn_edge_attn_fwd_lds_bytes.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_edge_attn_fwd_lds_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.qagnn_edge_attn_fwd_lds_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
@@ -494,8 +495,8 @@ class HipKernels(metaclass=_GuardedMeta):
         aggr = torch.empty((graph.N, DP), dtype=torch.float32, device=dev)
         max_sub_ep = getattr(graph, 'max_sub_ep', 0)
         if (self.edge_lds and graph.block_n > 0 and max_sub_ep > 0 and graph.block_n < 65536 and graph.C < 65536 and
-                self.lib.qagnn_edge_attn_fwd_lds_bytes(graph.block_n, HP, max_sub_ep) <= 80 * 1024):
-            # block-structured batch, largest subgraph known: two LDS-resident workgroups per CU
+                self.lib.qagnn_edge_attn_fwd_lds_bytes(graph.block_n, HP, max_sub_ep, graph.C) <= 160 * 1024):
+            # block-structured batch, largest subgraph known: one LDS-resident workgroup (16 waves) per CU
             rc = self.lib.qagnn_edge_attn_fwd_lds_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale),
                                                       a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, int(max_sub_ep), self._stream())
             self._check(rc, 'qagnn_edge_attn_fwd_lds_f32')

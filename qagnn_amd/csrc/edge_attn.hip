@@ -439,58 +439,91 @@ __global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ s
 // each) last, which balances the groups without a sort.  Every reduction has a fixed order: deterministic.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LDS_UNROLL = 4;
+constexpr int LDS_THREADS = 1024;                 // 16 waves = 64 groups of 16 lanes
+constexpr int LDS_GROUPS = LDS_THREADS / 16;
+constexpr int LDS_PF = 8;                         // float4 registers per thread that carry phase 2's slabs under phase 1
 
-__global__ __launch_bounds__(512) void k_edge_fwd_lds(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
-                                                      const int* __restrict__ cls_s, const int* __restrict__ rowptr_t,
-                                                      const int* __restrict__ src_t, const int* __restrict__ cls_t,
-                                                      const int* __restrict__ pos_t, const float* __restrict__ KMQ, int ldk,
-                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale, int n, int ecap,
-                                                      float* __restrict__ a, float* __restrict__ alpha, float* __restrict__ aggr,
-                                                      int lda, int N, int C) {
+// rows <- one head's slice of n node rows (matrix `part` of K|M|Q), crow <- the head's slice of the subgraph's class rows (half
+// `half` of Ek|Em); item i of the combined list is handled by thread i % LDS_THREADS in round i / LDS_THREADS
+__device__ __forceinline__ const float* slab_src(int i, int n, int f4, int nc, const float* __restrict__ KMQ, int ldk, int node0,
+                                                 int part_off, const float* __restrict__ EkEm, int lde, const int* __restrict__ cls_list,
+                                                 int half_off, int* dst_off, int HP) {
+  const int nrow = n * f4;
+  if (i < nrow) {
+    const int row = i / f4, c4 = i - row * f4;
+    *dst_off = row * HP + c4 * 4;
+    return KMQ + (int64_t)(node0 + row) * ldk + part_off + c4 * 4;
+  }
+  const int k = i - nrow, r = k / f4, c4 = k - r * f4;
+  if (r >= nc) { *dst_off = -1; return nullptr; }
+  *dst_off = (n + r) * HP + c4 * 4;   // crow sits right behind rows
+  return EkEm + (int64_t)cls_list[r] * lde + half_off + c4 * 4;
+}
+
+__global__ __launch_bounds__(LDS_THREADS) void k_edge_fwd_lds(const int* __restrict__ rowptr_s, const int* __restrict__ rowptr_t,
+                                                              const int* __restrict__ pk_s, const int* __restrict__ pk_t,
+                                                              const int* __restrict__ pos_t, const int* __restrict__ sub_ncls,
+                                                              const int* __restrict__ sub_cls, const float* __restrict__ KMQ, int ldk,
+                                                              const float* __restrict__ EkEm, int lde, int HP, float qscale, int n,
+                                                              int ecap, int ccap, float* __restrict__ a, float* __restrict__ alpha,
+                                                              float* __restrict__ aggr, int lda, int N, int C) {
   extern __shared__ __attribute__((aligned(16))) float sm_lds[];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);  // the 4 heads of a subgraph run on one XCD (shared indices, class rows)
   const int gph = tile >> 2, h = tile & 3, node0 = gph * n;
   const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
   const int DP = 4 * HP, f4 = HP >> 2;
   const bool act = j < f4;
-  float* const rows = sm_lds;                                     // [n][HP]   K slice, then M slice
-  float* const sc = rows + n * HP;                                // [ecap]    raw score -> alpha, local source-order position
-  uint32_t* const idx = reinterpret_cast<uint32_t*>(sc + ecap);   // [2*ecap]  packed per-edge indices of the current phase
-  int* const rp = reinterpret_cast<int*>(idx + 2 * ecap);         // [n+1]     local segment starts of the current phase
+  float* const rows = sm_lds;                                     // [n][HP]     K slice, then M slice
+  float* const crow = rows + n * HP;                              // [ccap][HP]  Ek rows of the subgraph's classes, then Em rows
+  float* const sc = crow + ccap * HP;                             // [ecap]      raw score -> alpha, local source-order position
+  uint32_t* const idx = reinterpret_cast<uint32_t*>(sc + ecap);   // [2*ecap]    packed per-edge words of the current phase
+  int* const rp = reinterpret_cast<int*>(idx + 2 * ecap);         // [n+1]       local segment starts of the current phase
   const int ebase = rowptr_s[node0], Eg = rowptr_s[node0 + n] - ebase;  // same range in the target order (block structure)
+  const int* const cls_list = sub_cls + (int64_t)gph * C;
+  const int nc = min(sub_ncls[gph], ccap);   // classes with local id >= ccap (none at these sizes) are read through L1 instead
   const uint32_t pe = (uint32_t)lde * 4u;
   const rsrc_t rE = make_rsrc(EkEm, (uint32_t)C * pe);
-  const uint32_t voffE = act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF;  // this lane's float4 of the head inside Ek; Em is DP floats on
+  const int items = n * f4 + nc * f4;
 
-  // ---- stage K slice, source-order indices, local rowptr ----
-  for (int i = tid; i < n * f4; i += 512) {
-    const int row = i / f4, c4 = i - row * f4;
-    st4(rows + row * HP + c4 * 4, ld4(KMQ + (int64_t)(node0 + row) * ldk + h * HP + c4 * 4));
+  // ---- stage phase 1: K slice + Ek rows, source-order words, local rowptr ----
+  for (int i = tid; i < items; i += LDS_THREADS) {
+    int d;
+    const float* src = slab_src(i, n, f4, nc, KMQ, ldk, node0, h * HP, EkEm, lde, cls_list, h * HP, &d, HP);
+    if (d >= 0) st4(rows + d, ld4(src));
   }
-  for (int e = tid; e < Eg; e += 512) idx[e] = (uint32_t)(tgt_s[ebase + e] - node0) | ((uint32_t)cls_s[ebase + e] << 16);
-  for (int v = tid; v <= n; v += 512) rp[v] = rowptr_s[node0 + v] - ebase;
+  for (int e = tid; e < Eg; e += LDS_THREADS) idx[e] = (uint32_t)pk_s[ebase + e];
+  for (int v = tid; v <= n; v += LDS_THREADS) rp[v] = rowptr_s[node0 + v] - ebase;
+  // ---- phase 2's slabs (M slice + Em rows) start flying now and land in registers under phase 1 ----
+  float4 pf[LDS_PF];
+#pragma unroll
+  for (int r = 0; r < LDS_PF; ++r) {
+    int d;
+    const float* src = slab_src(tid + r * LDS_THREADS, n, f4, nc, KMQ, ldk, node0, DP + h * HP, EkEm, lde, cls_list, DP + h * HP, &d, HP);
+    pf[r] = (tid + r * LDS_THREADS < items && d >= 0) ? ld4(src) : zero4();
+  }
   __syncthreads();
 
-  // ---- phase 1: scores + segment softmax, one group per source node ----
+  // ---- phase 1: scores + segment softmax, one 16-lane group per source node ----
   {
     const float* qp = KMQ + 2 * DP + h * HP + j * 4;
     float4 qn = (grp < n && act) ? ld4(qp + (int64_t)(node0 + grp) * ldk) : zero4();
-    for (int v = grp; v < n; v += 32) {
+    for (int v = grp; v < n; v += LDS_GROUPS) {
       const float4 q = qn;
-      if (v + 32 < n && act) qn = ld4(qp + (int64_t)(node0 + v + 32) * ldk);  // next node's Q slice flies under this segment
+      if (v + LDS_GROUPS < n && act) qn = ld4(qp + (int64_t)(node0 + v + LDS_GROUPS) * ldk);  // next node's Q slice flies under this segment
       const int beg = rp[v], end = rp[v + 1];
       for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-        float4 ek[LDS_UNROLL];
-        uint32_t w[LDS_UNROLL];
+        float4 k4[LDS_UNROLL], ek[LDS_UNROLL];
 #pragma unroll
         for (int u = 0; u < LDS_UNROLL; ++u) {
-          w[u] = idx[min(e0 + u, end - 1)];
-          ek[u] = buf_ld4(rE, voffE, (w[u] >> 16) * pe);
+          const uint32_t w = idx[min(e0 + u, end - 1)];
+          const uint32_t lc = w >> 16;
+          k4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
+          if (lc < (uint32_t)ccap) ek[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
+          else ek[u] = buf_ld4(rE, act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)cls_list[lc] * pe);
         }
 #pragma unroll
         for (int u = 0; u < LDS_UNROLL; ++u) {
-          const float4 k4 = act ? ld4(rows + (w[u] & 0xFFFFu) * HP + j * 4) : zero4();
-          const float p = row16_sum(dot4(q, add4(k4, ek[u]))) * qscale;
+          const float p = row16_sum(dot4(q, add4(k4[u], ek[u]))) * qscale;
           if (j == 0 && e0 + u < end) sc[e0 + u] = p;
         }
       }
@@ -512,39 +545,47 @@ __global__ __launch_bounds__(512) void k_edge_fwd_lds(const int* __restrict__ ro
   }
   __syncthreads();
 
-  // ---- stage M slice, target-order indices ----
-  for (int i = tid; i < n * f4; i += 512) {
-    const int row = i / f4, c4 = i - row * f4;
-    st4(rows + row * HP + c4 * 4, ld4(KMQ + (int64_t)(node0 + row) * ldk + DP + h * HP + c4 * 4));
+  // ---- phase 2's slabs: registers -> LDS; target-order words ----
+#pragma unroll
+  for (int r = 0; r < LDS_PF; ++r) {
+    const int i = tid + r * LDS_THREADS;
+    if (i < items) {
+      int d;
+      (void)slab_src(i, n, f4, nc, KMQ, ldk, node0, 0, EkEm, lde, cls_list, 0, &d, HP);
+      if (d >= 0) st4(rows + d, pf[r]);
+    }
   }
-  for (int e = tid; e < Eg; e += 512) {
-    idx[2 * e] = (uint32_t)(src_t[ebase + e] - node0) | ((uint32_t)cls_t[ebase + e] << 16);
+  for (int i = tid + LDS_PF * LDS_THREADS; i < items; i += LDS_THREADS) {  // (larger subgraph blocks than the registers cover)
+    int d;
+    const float* src = slab_src(i, n, f4, nc, KMQ, ldk, node0, DP + h * HP, EkEm, lde, cls_list, DP + h * HP, &d, HP);
+    if (d >= 0) st4(rows + d, ld4(src));
+  }
+  for (int e = tid; e < Eg; e += LDS_THREADS) {
+    idx[2 * e] = (uint32_t)pk_t[ebase + e];
     idx[2 * e + 1] = (uint32_t)(pos_t[ebase + e] - ebase);
   }
-  for (int v = tid; v <= n; v += 512) rp[v] = rowptr_t[node0 + v] - ebase;
+  for (int v = tid; v <= n; v += LDS_THREADS) rp[v] = rowptr_t[node0 + v] - ebase;
   __syncthreads();
 
   // ---- phase 2: weighted sum of messages, one group per target node ----
-  const uint32_t voffEm = act ? voffE + (uint32_t)DP * 4u : OOB_OFF;
-  for (int v = grp; v < n; v += 32) {
+  for (int v = grp; v < n; v += LDS_GROUPS) {
     const int beg = rp[v], end = rp[v + 1];
     float4 acc = zero4();
     for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-      float4 em[LDS_UNROLL];
-      uint32_t w[LDS_UNROLL];
+      float4 m4[LDS_UNROLL], em[LDS_UNROLL];
       float al[LDS_UNROLL];
 #pragma unroll
       for (int u = 0; u < LDS_UNROLL; ++u) {
         const int e = min(e0 + u, end - 1);
-        w[u] = idx[2 * e];
-        em[u] = buf_ld4(rE, voffEm, (w[u] >> 16) * pe);
+        const uint32_t w = idx[2 * e];
+        const uint32_t lc = w >> 16;
+        m4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
+        if (lc < (uint32_t)ccap) em[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
+        else em[u] = buf_ld4(rE, act ? (uint32_t)(DP + h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)cls_list[lc] * pe);
         al[u] = e0 + u < end ? sc[idx[2 * e + 1]] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < LDS_UNROLL; ++u) {
-        const float4 m4 = act ? ld4(rows + (w[u] & 0xFFFFu) * HP + j * 4) : zero4();
-        acc = fma4(al[u], add4(m4, em[u]), acc);
-      }
+      for (int u = 0; u < LDS_UNROLL; ++u) acc = fma4(al[u], add4(m4[u], em[u]), acc);
     }
     if (act) st4(aggr + (int64_t)(node0 + v) * lda + h * HP + j * 4, acc);
   }
@@ -587,9 +628,20 @@ extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, i
   return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, (hipStream_t)stream_);
 }
 
-extern "C" int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep) {
-  const int64_t ecap = (max_sub_ep + 3) & ~3;
-  return ((int64_t)n * HP + 3 * ecap + (n + 1 + 3)) * (int64_t)sizeof(float);
+// class rows a workgroup keeps in LDS: everything the 160 KB allow next to the node rows and the per-edge arrays, at most C
+static int lds_class_cap(int n, int HP, int ecap, int C) {
+  const int64_t fixed = ((int64_t)n * HP + 3 * (int64_t)ecap + (n + 1 + 3)) * 4;
+  const int64_t room = 156 * 1024 - fixed;
+  if (room < (int64_t)HP * 4 * 16) return 0;
+  const int64_t cap = room / (HP * 4);
+  return (int)(cap < C ? cap : C);
+}
+
+extern "C" int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep, int32_t C) {
+  const int ecap = (max_sub_ep + 3) & ~3;
+  const int ccap = lds_class_cap(n, HP, ecap, C);
+  if (ccap <= 0) return (int64_t)1 << 40;
+  return ((int64_t)n * HP + (int64_t)ccap * HP + 3 * (int64_t)ecap + (n + 1 + 3)) * (int64_t)sizeof(float);
 }
 
 extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
@@ -599,20 +651,23 @@ extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KM
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd_lds");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL, "edge_attn_fwd_lds: bad output arguments");
-  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0, QAGNN_EINVAL, "edge_attn_fwd_lds: the graph has no block structure (block_n = %d)", g->block_n);
+  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0 && g->pk_s && g->pk_t && g->sub_ncls && g->sub_cls, QAGNN_EINVAL,
+                "edge_attn_fwd_lds: the graph has no per-subgraph views (build it with qagnn_graph_from_blobs)");
   const int n = g->block_n;
   QAGNN_REQUIRE(max_sub_ep >= n && n < 65536 && g->C < 65536, QAGNN_EINVAL, "edge_attn_fwd_lds: max_sub_ep=%d must bound every subgraph's E_g + n", max_sub_ep);
-  const int64_t bytes = qagnn_edge_attn_fwd_lds_bytes(n, HP, max_sub_ep);
-  QAGNN_REQUIRE(bytes <= 160 * 1024, QAGNN_EUNSUPPORTED, "edge_attn_fwd_lds: %lld bytes of LDS per workgroup (n=%d, %d edges)", (long long)bytes, n, max_sub_ep);
+  const int ecap = (max_sub_ep + 3) & ~3;
+  const int ccap = lds_class_cap(n, HP, ecap, g->C);
+  const int64_t bytes = qagnn_edge_attn_fwd_lds_bytes(n, HP, max_sub_ep, g->C);
+  QAGNN_REQUIRE(ccap > 0 && bytes <= 160 * 1024, QAGNN_EUNSUPPORTED, "edge_attn_fwd_lds: n=%d, %d edges per subgraph do not fit the LDS", n, max_sub_ep);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("edge_attn_fwd_lds: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     attr_set = true;
   }
-  const int ecap = (max_sub_ep + 3) & ~3;
-  k_edge_fwd_lds<<<(g->N / n) * 4, 512, (size_t)bytes, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ,
-                                                                ldk, EkEm, lde, HP, qscale, n, ecap, a, alpha, aggr, lda, g->N, g->C);
+  k_edge_fwd_lds<<<(g->N / n) * 4, LDS_THREADS, (size_t)bytes, stream>>>(g->rowptr_s, g->rowptr_t, g->pk_s, g->pk_t, g->pos_t, g->sub_ncls,
+                                                                        g->sub_cls, KMQ, ldk, EkEm, lde, HP, qscale, n, ecap, ccap, a, alpha,
+                                                                        aggr, lda, g->N, g->C);
   QAGNN_LAUNCH_CHECK("k_edge_fwd_lds");
   return QAGNN_OK;
 }

@@ -369,7 +369,7 @@ def test_edge_attention_forward_lds_resident(case):
     KMQ = torch.randn(g.N, 12 * HP, generator=gen)
     EkEm = torch.randn(g.C, 8 * HP, generator=gen)
     qs = 1.0 / (c['cfg']['concept_dim'] // 4) ** 0.5
-    assert K.edge_lds and K.lib.qagnn_edge_attn_fwd_lds_bytes(g.block_n, HP, g.max_sub_ep) <= 80 * 1024
+    assert K.edge_lds and K.lib.qagnn_edge_attn_fwd_lds_bytes(g.block_n, HP, g.max_sub_ep, g.C) <= 160 * 1024
     aggr, a, alpha = K.edge_attn_fwd(g, KMQ.cuda(), EkEm.cuda(), HP, qs)
     K.edge_lds = False
     try:
@@ -546,6 +546,19 @@ def test_graph_from_blobs_bit_identical_to_graph_prep(case):
     for arr in ('chunk_cls', 'chunk_beg', 'chunk_len'):
         assert torch.equal(g1.array(arr, nch), g2.array(arr, nch)), f'{arr} differs'
     assert g2.array('err', 2).tolist() == [0, 0]
+    # per-subgraph views of the LDS-resident edge kernels: distinct classes in ascending order, local (node, class) words
+    B, n, C = g2.N // c['n'], c['n'], g2.C
+    ncls, scls = g2.array('sub_ncls', B).cpu(), g2.array('sub_cls', B * C).cpu().view(B, C)
+    cls_s, tgt_s, rp_s = g2.array('cls_s', g2.Ep).cpu(), g2.array('tgt_s', g2.Ep).cpu(), g2.array('rowptr_s', g2.N + 1).cpu()
+    cls_t, src_t = g2.array('cls_t', g2.Ep).cpu(), g2.array('src_t', g2.Ep).cpu()
+    pk_s, pk_t = g2.array('pk_s', g2.Ep).cpu(), g2.array('pk_t', g2.Ep).cpu()
+    for b in range(B):
+        lo, hi = int(rp_s[b * n]), int(rp_s[(b + 1) * n])
+        uniq = torch.unique(cls_s[lo:hi])
+        assert int(ncls[b]) == uniq.numel() and torch.equal(scls[b, :uniq.numel()], uniq)
+        assert torch.equal(pk_s[lo:hi] & 0xFFFF, tgt_s[lo:hi] - b * n) and torch.equal(scls[b][(pk_s[lo:hi] >> 16).long()], cls_s[lo:hi])
+        assert torch.equal(pk_t[lo:hi] & 0xFFFF, src_t[lo:hi] - b * n) and torch.equal(scls[b][(pk_t[lo:hi] >> 16).long()], cls_t[lo:hi])
+    assert g1.c.pk_s is None and g2.c.pk_s is not None
 
 
 @pytest.mark.gpu
