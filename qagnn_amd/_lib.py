@@ -242,8 +242,9 @@ class HipKernels(metaclass=_GuardedMeta):
         if self.lib.qagnn_abi_version() != ABI_VERSION:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
         # LDS-resident edge forward (qagnn_edge_attn_fwd_lds_f32) for block-structured batches whose largest subgraph is known on
-        # the host (graphs built from load-time blobs).  QAGNN_EDGE_LDS=0 pins the generic L2-gather kernels.
-        self.edge_lds = os.environ.get('QAGNN_EDGE_LDS', '1') == '1'
+        # the host (graphs built from load-time blobs).  Measured 0.177 ms per layer against 0.126 ms for the generic L2-gather kernels at the
+        # CSQA batch (profiles/r2_run8_edge_lds_variants.txt: bound by VALU issue, 120 wave-instructions per edge): off by default, QAGNN_EDGE_LDS=1.
+        self.edge_lds = os.environ.get('QAGNN_EDGE_LDS', '0') == '1'
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):

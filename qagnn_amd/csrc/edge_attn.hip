@@ -438,27 +438,31 @@ __global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ s
 // Node order = node index, round-robin over the 32 groups: real nodes (index < adj_len) come first, PAD rows (one self loop
 // each) last, which balances the groups without a sort.  Every reduction has a fixed order: deterministic.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LDS_UNROLL = 4;
-constexpr int LDS_THREADS = 1024;                 // 16 waves = 64 groups of 16 lanes
+#ifndef LDS_UNROLL_N
+#define LDS_UNROLL_N 2
+#endif
+#ifndef LDS_PF_N
+#define LDS_PF_N 6
+#endif
+#ifndef LDS_THREADS_N
+#define LDS_THREADS_N 1024
+#endif
+constexpr int LDS_UNROLL = LDS_UNROLL_N;
+constexpr int LDS_THREADS = LDS_THREADS_N;      // 16 waves = 64 groups of 16 lanes
 constexpr int LDS_GROUPS = LDS_THREADS / 16;
-constexpr int LDS_PF = 8;                         // float4 registers per thread that carry phase 2's slabs under phase 1
+constexpr int LDS_PF = LDS_PF_N;                  // float4 registers per thread that carry the next phase's slabs under the current one
 
-// rows <- one head's slice of n node rows (matrix `part` of K|M|Q), crow <- the head's slice of the subgraph's class rows (half
-// `half` of Ek|Em); item i of the combined list is handled by thread i % LDS_THREADS in round i / LDS_THREADS
-__device__ __forceinline__ const float* slab_src(int i, int n, int f4, int nc, const float* __restrict__ KMQ, int ldk, int node0,
-                                                 int part_off, const float* __restrict__ EkEm, int lde, const int* __restrict__ cls_list,
-                                                 int half_off, int* dst_off, int HP) {
-  const int nrow = n * f4;
-  if (i < nrow) {
-    const int row = i / f4, c4 = i - row * f4;
-    *dst_off = row * HP + c4 * 4;
-    return KMQ + (int64_t)(node0 + row) * ldk + part_off + c4 * 4;
-  }
-  const int k = i - nrow, r = k / f4, c4 = k - r * f4;
-  if (r >= nc) { *dst_off = -1; return nullptr; }
-  *dst_off = (n + r) * HP + c4 * 4;   // crow sits right behind rows
-  return EkEm + (int64_t)cls_list[r] * lde + half_off + c4 * 4;
-}
+constexpr int LDS_IW = 4;  // per-thread registers for a phase's per-edge words (covers subgraphs of <= 4096 edges without a reload loop)
+
+// One tile = (subgraph, head).  The kernel is PERSISTENT -- one 16-wave workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... --
+// and software-pipelined: everything a phase reads from LDS (a node-row slab, the class-row slab, the per-edge words, the segment
+// starts) is fetched from global memory into REGISTERS one phase ahead and only copied into LDS at the phase boundary:
+//     phase 1 of tile i   runs while   phase 2's slabs of tile i     are in flight
+//     phase 2 of tile i   runs while   phase 1's slabs of tile i + 1 are in flight
+// so a workgroup never waits on HBM except for its very first tile (with one workgroup per CU there is nobody else to hide it).
+struct lds_tile {
+  int node0, h, ebase, Eg, nc;
+};
 
 __global__ __launch_bounds__(LDS_THREADS) void k_edge_fwd_lds(const int* __restrict__ rowptr_s, const int* __restrict__ rowptr_t,
                                                               const int* __restrict__ pk_s, const int* __restrict__ pk_t,
@@ -466,10 +470,8 @@ __global__ __launch_bounds__(LDS_THREADS) void k_edge_fwd_lds(const int* __restr
                                                               const int* __restrict__ sub_cls, const float* __restrict__ KMQ, int ldk,
                                                               const float* __restrict__ EkEm, int lde, int HP, float qscale, int n,
                                                               int ecap, int ccap, float* __restrict__ a, float* __restrict__ alpha,
-                                                              float* __restrict__ aggr, int lda, int N, int C) {
+                                                              float* __restrict__ aggr, int lda, int N, int C, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float sm_lds[];
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);  // the 4 heads of a subgraph run on one XCD (shared indices, class rows)
-  const int gph = tile >> 2, h = tile & 3, node0 = gph * n;
   const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
   const int DP = 4 * HP, f4 = HP >> 2;
   const bool act = j < f4;
@@ -478,116 +480,165 @@ __global__ __launch_bounds__(LDS_THREADS) void k_edge_fwd_lds(const int* __restr
   float* const sc = crow + ccap * HP;                             // [ecap]      raw score -> alpha, local source-order position
   uint32_t* const idx = reinterpret_cast<uint32_t*>(sc + ecap);   // [2*ecap]    packed per-edge words of the current phase
   int* const rp = reinterpret_cast<int*>(idx + 2 * ecap);         // [n+1]       local segment starts of the current phase
-  const int ebase = rowptr_s[node0], Eg = rowptr_s[node0 + n] - ebase;  // same range in the target order (block structure)
-  const int* const cls_list = sub_cls + (int64_t)gph * C;
-  const int nc = min(sub_ncls[gph], ccap);   // classes with local id >= ccap (none at these sizes) are read through L1 instead
   const uint32_t pe = (uint32_t)lde * 4u;
   const rsrc_t rE = make_rsrc(EkEm, (uint32_t)C * pe);
-  const int items = n * f4 + nc * f4;
 
-  // ---- stage phase 1: K slice + Ek rows, source-order words, local rowptr ----
-  for (int i = tid; i < items; i += LDS_THREADS) {
-    int d;
-    const float* src = slab_src(i, n, f4, nc, KMQ, ldk, node0, h * HP, EkEm, lde, cls_list, h * HP, &d, HP);
-    if (d >= 0) st4(rows + d, ld4(src));
-  }
-  for (int e = tid; e < Eg; e += LDS_THREADS) idx[e] = (uint32_t)pk_s[ebase + e];
-  for (int v = tid; v <= n; v += LDS_THREADS) rp[v] = rowptr_s[node0 + v] - ebase;
-  // ---- phase 2's slabs (M slice + Em rows) start flying now and land in registers under phase 1 ----
+  auto tile_of = [&](int t) {
+    lds_tile T;
+    const int gph = t >> 2;
+    T.h = t & 3;
+    T.node0 = gph * n;
+    T.ebase = rowptr_s[T.node0];
+    T.Eg = rowptr_s[T.node0 + n] - T.ebase;  // same range in the target order (block structure)
+    T.nc = min(sub_ncls[gph], ccap);         // classes with local id >= ccap (none at these sizes) are read through L1 instead
+    return T;
+  };
+  // Slab rows: LDS row r < n is node row node0 + r (matrix `part_off` of K|M|Q), LDS row n + k is the subgraph's k-th class row
+  // (half `half_off` of Ek|Em); a 16-lane group moves one row per round (lane j < f4 carries float4 j of the head's slice), so the
+  // row of round k is grp + k * LDS_GROUPS and both the LDS offset and the global address are one multiply-add away.
+  auto slab_ptr = [&](const lds_tile& T, int r, int part_off, int half_off) -> const float* {
+    if (r < n) return KMQ + (int64_t)(T.node0 + r) * ldk + part_off + T.h * HP + j * 4;
+    return EkEm + (int64_t)sub_cls[(int64_t)(T.node0 / n) * C + (r - n)] * lde + half_off + T.h * HP + j * 4;
+  };
+  auto fetch_slab = [&](const lds_tile& T, int part_off, int half_off, float4 (&pf)[LDS_PF]) {
+#pragma unroll
+    for (int k = 0; k < LDS_PF; ++k) {
+      const int r = grp + k * LDS_GROUPS;
+      pf[k] = (act && r < n + T.nc) ? ld4(slab_ptr(T, r, part_off, half_off)) : zero4();
+    }
+  };
+  auto store_slab = [&](const lds_tile& T, int part_off, int half_off, const float4 (&pf)[LDS_PF]) {
+#pragma unroll
+    for (int k = 0; k < LDS_PF; ++k) {
+      const int r = grp + k * LDS_GROUPS;
+      if (act && r < n + T.nc) st4(rows + r * HP + j * 4, pf[k]);
+    }
+    for (int r = grp + LDS_PF * LDS_GROUPS; r < n + T.nc; r += LDS_GROUPS)  // more rows than the registers cover: plain reload
+      if (act) st4(rows + r * HP + j * 4, ld4(slab_ptr(T, r, part_off, half_off)));
+  };
+
+  if ((int)blockIdx.x >= ntiles) return;
+  lds_tile T = tile_of(blockIdx.x);
   float4 pf[LDS_PF];
+  uint32_t iw[LDS_IW], iw2[LDS_IW];
+  int rpr;
+  // prologue: phase-1 data of the first tile
+  fetch_slab(T, 0, 0, pf);
 #pragma unroll
-  for (int r = 0; r < LDS_PF; ++r) {
-    int d;
-    const float* src = slab_src(tid + r * LDS_THREADS, n, f4, nc, KMQ, ldk, node0, DP + h * HP, EkEm, lde, cls_list, DP + h * HP, &d, HP);
-    pf[r] = (tid + r * LDS_THREADS < items && d >= 0) ? ld4(src) : zero4();
-  }
-  __syncthreads();
+  for (int r = 0; r < LDS_IW; ++r) iw[r] = (uint32_t)pk_s[T.ebase + min(tid + r * LDS_THREADS, max(T.Eg - 1, 0))];
+  rpr = tid <= n ? rowptr_s[T.node0 + tid] - T.ebase : 0;
 
-  // ---- phase 1: scores + segment softmax, one 16-lane group per source node ----
-  {
-    const float* qp = KMQ + 2 * DP + h * HP + j * 4;
-    float4 qn = (grp < n && act) ? ld4(qp + (int64_t)(node0 + grp) * ldk) : zero4();
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int node0 = T.node0, h = T.h, ebase = T.ebase, Eg = T.Eg;
+    // ---- phase-1 registers -> LDS ----
+    store_slab(T, 0, 0, pf);
+#pragma unroll
+    for (int r = 0; r < LDS_IW; ++r)
+      if (tid + r * LDS_THREADS < Eg) idx[tid + r * LDS_THREADS] = iw[r];
+    for (int e = tid + LDS_IW * LDS_THREADS; e < Eg; e += LDS_THREADS) idx[e] = (uint32_t)pk_s[ebase + e];
+    if (tid <= n) rp[tid] = rpr;
+    for (int v = tid + LDS_THREADS; v <= n; v += LDS_THREADS) rp[v] = rowptr_s[node0 + v] - ebase;
+    // ---- phase-2 data of this tile starts flying ----
+    fetch_slab(T, DP, DP, pf);
+#pragma unroll
+    for (int r = 0; r < LDS_IW; ++r) {
+      const int e = ebase + min(tid + r * LDS_THREADS, max(Eg - 1, 0));
+      iw[r] = (uint32_t)pk_t[e];
+      iw2[r] = (uint32_t)(pos_t[e] - ebase);
+    }
+    rpr = tid <= n ? rowptr_t[node0 + tid] - ebase : 0;
+    __syncthreads();
+
+    // ---- phase 1: scores + segment softmax, one 16-lane group per source node ----
+    {
+      const float* qp = KMQ + 2 * DP + h * HP + j * 4;
+      float4 qn = (grp < n && act) ? ld4(qp + (int64_t)(node0 + grp) * ldk) : zero4();
+      for (int v = grp; v < n; v += LDS_GROUPS) {
+        const float4 q = qn;
+        if (v + LDS_GROUPS < n && act) qn = ld4(qp + (int64_t)(node0 + v + LDS_GROUPS) * ldk);  // next node's Q slice flies under this segment
+        const int beg = rp[v], end = rp[v + 1];
+        for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
+          float4 k4[LDS_UNROLL], ek[LDS_UNROLL];
+#pragma unroll
+          for (int u = 0; u < LDS_UNROLL; ++u) {
+            const uint32_t w = idx[min(e0 + u, end - 1)];
+            const uint32_t lc = w >> 16;
+            k4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
+            if (lc < (uint32_t)ccap) ek[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
+            else ek[u] = buf_ld4(rE, act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)sub_cls[(int64_t)(node0 / n) * C + lc] * pe);
+          }
+#pragma unroll
+          for (int u = 0; u < LDS_UNROLL; ++u) {
+            const float p = row16_sum(dot4(q, add4(k4[u], ek[u]))) * qscale;
+            if (j == 0 && e0 + u < end) sc[e0 + u] = p;
+          }
+        }
+        // the group's own segment: its scores were written by its lane 0 (LDS operations of one wave retire in order)
+        float m = -INFINITY;
+        for (int e = beg + j; e < end; e += 16) m = fmaxf(m, sc[e]);
+        m = row16_max(m);
+        float sum = 0.f;
+        for (int e = beg + j; e < end; e += 16) sum += expf(sc[e] - m);
+        sum = row16_sum(sum);
+        const float deg = (float)(end - beg), inv = 1.0f / (sum + 1e-16f);
+        for (int e = beg + j; e < end; e += 16) {
+          const float av = expf(sc[e] - m) * inv, al = av * deg;
+          a[(int64_t)(ebase + e) * 4 + h] = av;
+          alpha[(int64_t)(ebase + e) * 4 + h] = al;
+          sc[e] = al;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase-2 registers -> LDS ----
+    store_slab(T, DP, DP, pf);
+#pragma unroll
+    for (int r = 0; r < LDS_IW; ++r)
+      if (tid + r * LDS_THREADS < Eg) {
+        idx[2 * (tid + r * LDS_THREADS)] = iw[r];
+        idx[2 * (tid + r * LDS_THREADS) + 1] = iw2[r];
+      }
+    for (int e = tid + LDS_IW * LDS_THREADS; e < Eg; e += LDS_THREADS) {
+      idx[2 * e] = (uint32_t)pk_t[ebase + e];
+      idx[2 * e + 1] = (uint32_t)(pos_t[ebase + e] - ebase);
+    }
+    if (tid <= n) rp[tid] = rpr;
+    for (int v = tid + LDS_THREADS; v <= n; v += LDS_THREADS) rp[v] = rowptr_t[node0 + v] - ebase;
+    // ---- phase-1 data of the NEXT tile starts flying ----
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) {
+      T = tile_of(tn);
+      fetch_slab(T, 0, 0, pf);
+#pragma unroll
+      for (int r = 0; r < LDS_IW; ++r) iw[r] = (uint32_t)pk_s[T.ebase + min(tid + r * LDS_THREADS, max(T.Eg - 1, 0))];
+      rpr = tid <= n ? rowptr_s[T.node0 + tid] - T.ebase : 0;
+    }
+    __syncthreads();
+
+    // ---- phase 2: weighted sum of messages, one group per target node ----
     for (int v = grp; v < n; v += LDS_GROUPS) {
-      const float4 q = qn;
-      if (v + LDS_GROUPS < n && act) qn = ld4(qp + (int64_t)(node0 + v + LDS_GROUPS) * ldk);  // next node's Q slice flies under this segment
       const int beg = rp[v], end = rp[v + 1];
+      float4 acc = zero4();
       for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-        float4 k4[LDS_UNROLL], ek[LDS_UNROLL];
+        float4 m4[LDS_UNROLL], em[LDS_UNROLL];
+        float al[LDS_UNROLL];
 #pragma unroll
         for (int u = 0; u < LDS_UNROLL; ++u) {
-          const uint32_t w = idx[min(e0 + u, end - 1)];
+          const int e = min(e0 + u, end - 1);
+          const uint32_t w = idx[2 * e];
           const uint32_t lc = w >> 16;
-          k4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
-          if (lc < (uint32_t)ccap) ek[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
-          else ek[u] = buf_ld4(rE, act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)cls_list[lc] * pe);
+          m4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
+          if (lc < (uint32_t)ccap) em[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
+          else em[u] = buf_ld4(rE, act ? (uint32_t)(DP + h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)sub_cls[(int64_t)(node0 / n) * C + lc] * pe);
+          al[u] = e0 + u < end ? sc[idx[2 * e + 1]] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < LDS_UNROLL; ++u) {
-          const float p = row16_sum(dot4(q, add4(k4[u], ek[u]))) * qscale;
-          if (j == 0 && e0 + u < end) sc[e0 + u] = p;
-        }
+        for (int u = 0; u < LDS_UNROLL; ++u) acc = fma4(al[u], add4(m4[u], em[u]), acc);
       }
-      // the group's own segment: its scores were written by its lane 0 (LDS operations of one wave retire in order)
-      float m = -INFINITY;
-      for (int e = beg + j; e < end; e += 16) m = fmaxf(m, sc[e]);
-      m = row16_max(m);
-      float sum = 0.f;
-      for (int e = beg + j; e < end; e += 16) sum += expf(sc[e] - m);
-      sum = row16_sum(sum);
-      const float deg = (float)(end - beg), inv = 1.0f / (sum + 1e-16f);
-      for (int e = beg + j; e < end; e += 16) {
-        const float av = expf(sc[e] - m) * inv, al = av * deg;
-        a[(int64_t)(ebase + e) * 4 + h] = av;
-        alpha[(int64_t)(ebase + e) * 4 + h] = al;
-        sc[e] = al;
-      }
+      if (act) st4(aggr + (int64_t)(node0 + v) * lda + h * HP + j * 4, acc);
     }
-  }
-  __syncthreads();
-
-  // ---- phase 2's slabs: registers -> LDS; target-order words ----
-#pragma unroll
-  for (int r = 0; r < LDS_PF; ++r) {
-    const int i = tid + r * LDS_THREADS;
-    if (i < items) {
-      int d;
-      (void)slab_src(i, n, f4, nc, KMQ, ldk, node0, 0, EkEm, lde, cls_list, 0, &d, HP);
-      if (d >= 0) st4(rows + d, pf[r]);
-    }
-  }
-  for (int i = tid + LDS_PF * LDS_THREADS; i < items; i += LDS_THREADS) {  // (larger subgraph blocks than the registers cover)
-    int d;
-    const float* src = slab_src(i, n, f4, nc, KMQ, ldk, node0, DP + h * HP, EkEm, lde, cls_list, DP + h * HP, &d, HP);
-    if (d >= 0) st4(rows + d, ld4(src));
-  }
-  for (int e = tid; e < Eg; e += LDS_THREADS) {
-    idx[2 * e] = (uint32_t)pk_t[ebase + e];
-    idx[2 * e + 1] = (uint32_t)(pos_t[ebase + e] - ebase);
-  }
-  for (int v = tid; v <= n; v += LDS_THREADS) rp[v] = rowptr_t[node0 + v] - ebase;
-  __syncthreads();
-
-  // ---- phase 2: weighted sum of messages, one group per target node ----
-  for (int v = grp; v < n; v += LDS_GROUPS) {
-    const int beg = rp[v], end = rp[v + 1];
-    float4 acc = zero4();
-    for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-      float4 m4[LDS_UNROLL], em[LDS_UNROLL];
-      float al[LDS_UNROLL];
-#pragma unroll
-      for (int u = 0; u < LDS_UNROLL; ++u) {
-        const int e = min(e0 + u, end - 1);
-        const uint32_t w = idx[2 * e];
-        const uint32_t lc = w >> 16;
-        m4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
-        if (lc < (uint32_t)ccap) em[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
-        else em[u] = buf_ld4(rE, act ? (uint32_t)(DP + h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)cls_list[lc] * pe);
-        al[u] = e0 + u < end ? sc[idx[2 * e + 1]] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < LDS_UNROLL; ++u) acc = fma4(al[u], add4(m4[u], em[u]), acc);
-    }
-    if (act) st4(aggr + (int64_t)(node0 + v) * lda + h * HP + j * 4, acc);
+    __syncthreads();  // every read of this tile's LDS is done before the next tile's phase-1 registers are stored
   }
 }
 
@@ -665,9 +716,17 @@ extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KM
     if (e != hipSuccess) { set_error("edge_attn_fwd_lds: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     attr_set = true;
   }
-  k_edge_fwd_lds<<<(g->N / n) * 4, LDS_THREADS, (size_t)bytes, stream>>>(g->rowptr_s, g->rowptr_t, g->pk_s, g->pk_t, g->pos_t, g->sub_ncls,
-                                                                        g->sub_cls, KMQ, ldk, EkEm, lde, HP, qscale, n, ecap, ccap, a, alpha,
-                                                                        aggr, lda, g->N, g->C);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("edge_attn_fwd_lds: cannot query the device"); return QAGNN_EHIP; }
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int ntiles = (g->N / n) * 4;
+  const int grid = ntiles < n_cu ? ntiles : n_cu;  // persistent: one 16-wave workgroup per CU (the LDS allows no second one)
+  k_edge_fwd_lds<<<grid, LDS_THREADS, (size_t)bytes, stream>>>(g->rowptr_s, g->rowptr_t, g->pk_s, g->pk_t, g->pos_t, g->sub_ncls, g->sub_cls, KMQ,
+                                                              ldk, EkEm, lde, HP, qscale, n, ecap, ccap, a, alpha, aggr, lda, g->N, g->C, ntiles);
   QAGNN_LAUNCH_CHECK("k_edge_fwd_lds");
   return QAGNN_OK;
 }
