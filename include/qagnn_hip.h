@@ -301,6 +301,16 @@ int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t
 int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 
+/* Per-batch node bookkeeping of QAGNN.forward in one launch.  Replaces ~15 elementwise / reduction kernels of
+ *   modeling_qagnn.py:154      concept_ids[:, 1:] - 1            -> ridx [B][n] (int64; -1 on the context node, slot 0)
+ *   modeling_qagnn.py:160-167  node-score normalisation          -> score [B][n] (negate, subtract the context node's, mask PAD,
+ *                                                                   divide by the mean |.| over the adj_len real nodes + 1e-5)
+ *   modeling_qagnn.py:173-177  pooling mask                      -> mask [B][n] (uint8: PAD or context node; slot 0 cleared when
+ *                                                                   every slot would be masked)
+ * raw_scores [B][n] fp32, adj_len [B], node_type [B][n], concept_ids [B][n] int64 as the reference holds them. */
+int qagnn_node_prep_f32(const float* raw_scores, const int64_t* adj_len, const int64_t* node_type, const int64_t* concept_ids,
+                        int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, qagnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused multi-tensor RAdam step.  Replaces the per-parameter Python loop of
  *   utils/optimization_utils.py:31-97  (RAdam.step: ~10 elementwise kernels per tensor, ~70 decoder tensors)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')  # QAGNN_LIB: an alternate build (kernel A/B runs)
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
-           'qagnn_graph_from_blobs', 'qagnn_radam_step_f32',
+           'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32',
            'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
@@ -72,6 +72,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
+    lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]
     lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
@@ -295,6 +296,21 @@ class HipKernels(metaclass=_GuardedMeta):
         ERR_WATCH.poll()
         ERR_WATCH.watch(G.array('err', 4), f'the blob batch with B={B} samples, E={E} edges')
         return G
+
+    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids):
+        """-> (normalised scores [B, n] fp32, pooling mask [B, n] bool, entity-table row ids [B*n] int64); qagnn_node_prep_f32."""
+        B, n = node_type_ids.shape
+        raw = node_scores.reshape(B, n).float().contiguous()  # the reference computes the normalisation in fp32 (qagnn.py: fp32 inputs)
+        assert raw.dtype == torch.float32 and raw.is_contiguous() and adj_lengths.dtype == torch.long and adj_lengths.is_contiguous()
+        assert node_type_ids.dtype == torch.long and node_type_ids.is_contiguous() and concept_ids.dtype == torch.long and concept_ids.is_contiguous()
+        dev = node_type_ids.device
+        score = torch.empty((B, n), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, n), dtype=torch.bool, device=dev)
+        ridx = torch.empty(B * n, dtype=torch.long, device=dev)
+        rc = self.lib.qagnn_node_prep_f32(raw.data_ptr(), adj_lengths.data_ptr(), node_type_ids.data_ptr(), concept_ids.data_ptr(), B, n,
+                                          score.data_ptr(), mask.data_ptr(), ridx.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_node_prep_f32')
+        return score, mask, ridx
 
     def radam_step(self, params, grads, exp_avgs, exp_avg_sqs, beta1, beta2, eps, lr, weight_decay, step_size, mode):
         """One fused RAdam update of a list of fp32 device tensors that share a step count (qagnn_radam_step_f32)."""

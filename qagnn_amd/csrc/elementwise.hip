@@ -378,3 +378,54 @@ extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, fl
   QAGNN_LAUNCH_CHECK("k_colreduce_final");
   return QAGNN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-batch node bookkeeping of QAGNN.forward in one launch (reference modeling_qagnn.py:154, 160-167, 173-177):
+//   ridx[g][v]   = concept_ids[g][v] - 1, and -1 for the context node v = 0 (its feature comes from svec2nvec, :153)
+//   score[g][v]  = (-(s[g][v]) - (-(s[g][0]))) * [v < adj_len[g]]  /  (sum_v |.| / adj_len[g] + 1e-5)          (:160-167)
+//   mask[g][v]   = v >= adj_len[g]  or  node_type[g][v] == 3;   mask[g][0] cleared when every slot of g is masked   (:173-177)
+// One workgroup per subgraph.  The row sum of |score| is taken in float64 and rounded once: the correctly rounded fp32 sum, which is
+// what ANY summation order gives when the sum is exactly representable (the reference's own order is a CPU / GPU library detail,
+// and sin(1.1^j * score) downstream amplifies a 1-ulp difference by 1e4) -- and within 1 ulp of every fp32 order otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+namespace qagnn {
+__global__ __launch_bounds__(256) void k_node_prep(const float* __restrict__ raw, const int64_t* __restrict__ adj_len,
+                                                   const int64_t* __restrict__ node_type, const int64_t* __restrict__ concept_ids, int n,
+                                                   float* __restrict__ score, uint8_t* __restrict__ mask, int64_t* __restrict__ ridx) {
+  __shared__ double wsum[4];
+  __shared__ int wall[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int64_t len = adj_len[g];
+  const float s0 = -raw[(int64_t)g * n];
+  double part = 0.0;
+  int unmasked = 0;
+  for (int v = tid; v < n; v += 256) {
+    const float d = (-raw[(int64_t)g * n + v] - s0) * (v < len ? 1.0f : 0.0f);
+    part += (double)fabsf(d);
+    unmasked |= !(v >= len || node_type[(int64_t)g * n + v] == 3);
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  unmasked = __any(unmasked);
+  if ((tid & 63) == 0) { wsum[tid >> 6] = part; wall[tid >> 6] = unmasked; }
+  __syncthreads();
+  const float total = (float)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  const bool all_masked = !(wall[0] | wall[1] | wall[2] | wall[3]);
+  const float denom = total / (float)len + 1e-05f;
+  for (int v = tid; v < n; v += 256) {
+    const int64_t i = (int64_t)g * n + v;
+    const float d = (-raw[i] - s0) * (v < len ? 1.0f : 0.0f);
+    score[i] = d / denom;
+    const bool m = v >= len || node_type[i] == 3;
+    mask[i] = (v == 0 && all_masked) ? 0 : (m ? 1 : 0);
+    ridx[i] = v == 0 ? -1 : concept_ids[i] - 1;
+  }
+}
+}  // namespace qagnn
+
+extern "C" int qagnn_node_prep_f32(const float* raw_scores, const int64_t* adj_len, const int64_t* node_type, const int64_t* concept_ids,
+                                   int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(raw_scores && adj_len && node_type && concept_ids && score && mask && ridx && B > 0 && n > 0, QAGNN_EINVAL, "node_prep: bad arguments");
+  qagnn::k_node_prep<<<B, 256, 0, (hipStream_t)stream_>>>(raw_scores, adj_len, node_type, concept_ids, n, score, mask, ridx);
+  QAGNN_LAUNCH_CHECK("k_node_prep");
+  return QAGNN_OK;
+}

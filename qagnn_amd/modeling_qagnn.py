@@ -472,15 +472,21 @@ class QAGNN(nn.Module):
         fused_input = (emb_data is None and not ce.use_contextualized and hasattr(ce, 'cpt_transform') and ce.scale == 1.0
                        and not ce.emb.weight.requires_grad and ce.emb.weight.size(1) % 16 == 0)
         graph, join_graph = None, None
+        node_type_ids = node_type_ids.contiguous()
         if fused_input and self.gnn.k > 0:
             # the graph orderings only need the integer inputs: prepared on a side stream, under the gather-GEMM below
-            graph, join_graph = ops.graph_prep_async(adj, node_type_ids.reshape(-1).contiguous(), self.gnn.n_etype, self.gnn.n_ntype, n)
+            graph, join_graph = ops.graph_prep_async(adj, node_type_ids.reshape(-1), self.gnn.n_etype, self.gnn.n_ntype, n)
+        # node-score normalisation (:160-167), pooling mask (:173-177) and the entity-table row ids (:154) in ONE launch.  The mask is
+        # built without boolean-mask indexing: `mask[mask.all(1), 0] = 0` makes the host wait for the whole GNN forward (nonzero()
+        # synchronises) and lets the GPU idle while the backward is launched.
+        node_scores, mask, ridx = ops.kernels().node_prep(node_scores.contiguous(), adj_lengths.contiguous(), node_type_ids,
+                                                          concept_ids.contiguous())
+        node_scores = node_scores.unsqueeze(2)
         if fused_input:
-            # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout
+            # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout; context-node rows
+            # (ridx = -1) take svec2nvec(sent_vecs) instead of an entity embedding
             L = head_layout(self.concept_dim, dev)
-            ridx = concept_ids - 1
-            ridx[:, 0] = -1  # context-node rows take svec2nvec(sent_vecs) instead of an entity embedding
-            gnn_input = ops.concept_input(ce.emb.weight, ridx.reshape(-1).contiguous(), L.pad(ce.cpt_transform.weight.t()),
+            gnn_input = ops.concept_input(ce.emb.weight, ridx, L.pad(ce.cpt_transform.weight.t()),
                                           L.pad(ce.cpt_transform.bias), L.pad(self.svec2nvec(sent_vecs)), n,
                                           self.dropout_e.p, self.training)
         else:
@@ -488,23 +494,11 @@ class QAGNN(nn.Module):
             gnn_input1 = self.concept_emb(concept_ids[:, 1:] - 1, emb_data).to(dev)
             gnn_input = self.dropout_e(torch.cat([gnn_input0, gnn_input1], dim=1))
 
-        # node-score normalisation (:160-167): negate, subtract the context node's score, mask PAD, / mean |.|
-        ar = torch.arange(n, device=dev)
-        _mask = (ar < adj_lengths.unsqueeze(1)).float()
-        node_scores = -node_scores
-        node_scores = (node_scores - node_scores[:, 0:1, :]).squeeze(2) * _mask
-        mean_norm = node_scores.abs().sum(dim=1) / adj_lengths
-        node_scores = (node_scores / (mean_norm.unsqueeze(1) + 1e-05)).unsqueeze(2)
-
         Lh = head_layout(self.concept_dim, dev)
         if join_graph is not None:
             join_graph()
         gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, graph=graph, padded_input=fused_input, padded_output=True)
         Z_vecs = Lh.unpad(gnn_output[:, 0])
-        mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)  # pool over KG nodes only
-        # never mask every node (:177).  Written without boolean-mask indexing: `mask[mask.all(1), 0] = 0` makes the host
-        # wait for the whole GNN forward (nonzero() synchronises) and lets the GPU idle while the backward is launched.
-        mask[:, 0] = mask[:, 0] & ~mask.all(1)
         graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask, layout=Lh)
         if cache_output:
             self.concept_ids, self.adj, self.pool_attn = concept_ids, adj, pool_attn

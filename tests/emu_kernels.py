@@ -93,6 +93,19 @@ class EmuKernels:
     def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype, block_n=0):
         return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype, block_n)
 
+    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids):
+        B, n = node_type_ids.shape
+        ar = torch.arange(n, device=node_type_ids.device)
+        real = (ar < adj_lengths.unsqueeze(1)).to(node_scores.dtype)
+        s = -node_scores.reshape(B, n)
+        s = (s - s[:, 0:1]) * real
+        mean_norm = s.abs().sum(dim=1) / adj_lengths
+        mask = (ar >= adj_lengths.unsqueeze(1)) | (node_type_ids == 3)
+        mask[:, 0] = mask[:, 0] & ~mask.all(1)
+        ridx = concept_ids - 1
+        ridx[:, 0] = -1
+        return s / (mean_norm.unsqueeze(1) + 1e-05), mask, ridx.reshape(-1)
+
     def graph_from_blobs(self, packed, node_type):
         ei, et = packed.batched(device=node_type.device)
         return EmuGraph(ei, et, node_type, packed.n_etype, packed.n_ntype, packed.n)

@@ -601,3 +601,22 @@ def test_blob_batch_through_the_model_and_the_generator():
         outs.append([logits.detach(), attn.detach()] + [p.grad for p in model.parameters() if p.grad is not None])
     assert len(outs[0]) == len(outs[1]) > 40
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['csqa_b10', 'medqa_b8', 'small_train'])
+def test_node_prep_matches_the_reference_ops(case):
+    """qagnn_node_prep_f32 == the reference's elementwise ops (modeling_qagnn.py:154, 160-167, 173-177) on the loader's tensors:
+    bit-identical scores (the synthetic raw scores have order-exact row sums), identical mask and row ids; plus an all-PAD corner."""
+    import helpers
+    c = helpers.GOLDEN_CASES[case]
+    inp = helpers.make_case_inputs(case)
+    B, n = c['nq'] * c['nc'], c['n']
+    ns, al = inp['node_scores'].view(B, n, 1).clone(), inp['adj_lengths'].view(B).clone()
+    nt, cids = inp['node_type_ids'].view(B, n).clone(), inp['concept_ids'].view(B, n).clone()
+    al[0] = 1          # only the context node is real: every slot would be masked -> slot 0 is un-masked (:177)
+    nt[0, 1:] = 2
+    score_e, mask_e, ridx_e = EMU.node_prep(ns, al, nt, cids)
+    score, mask, ridx = hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), cids.cuda())
+    assert torch.equal(mask.cpu(), mask_e) and torch.equal(ridx.cpu(), ridx_e) and not bool(mask_e[0, 0]) and bool(mask_e[0, 1:].all())
+    assert torch.equal(score.cpu(), score_e), (score.cpu() - score_e).abs().max()
