@@ -318,9 +318,11 @@ int qagnn_node_prep_f32(const float* raw_scores, const int64_t* adj_len, const i
  * alignment), numel: host array of element counts.  All tensors share one step count, i.e. one (step_size, mode):
  *   mode 2: N_sma >= 5 (:83-87)   mode 1: SGD-like branch (:89-92)   mode 0: moments only (step_size < 0)
  * Per element:  v = beta2 v + (1-beta2) g g;  m = beta1 m + (1-beta1) g;  p -= weight_decay lr p;  p -= step_size lr m / (sqrt(v)+eps)
- * (or  p -= step_size lr m  in mode 1).  Pointer tables travel in the kernel arguments: nothing to allocate, capture safe. */
+ * (or  p -= step_size lr m  in mode 1).  The hyper-parameters are doubles: 1 - beta, weight_decay lr and step_size lr are formed in
+ * double and rounded to fp32 once, like the reference's Python scalars.  Pointer tables travel in the kernel arguments: nothing to
+ * allocate, capture safe. */
 int qagnn_radam_step_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                         const int64_t* numel, float beta1, float beta2, float eps, float lr, float weight_decay, float step_size,
+                         const int64_t* numel, double beta1, double beta2, double eps, double lr, double weight_decay, double step_size,
                          int32_t mode, qagnn_stream_t stream);
 
 #ifdef __cplusplus

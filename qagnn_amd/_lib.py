@@ -73,7 +73,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]
-    lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]
+    lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp] + [C.c_double] * 6 + [_i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]

@@ -26,8 +26,8 @@ struct radam_pack {
   int numel[RADAM_MAX_TENSORS];
   int block_chunk[RADAM_MAX_BLOCKS];
   unsigned char block_tensor[RADAM_MAX_BLOCKS];
-  float beta1, beta2, eps, lr, wd, step_size;
-  int mode;
+  float beta1, beta2, ob1, ob2, eps, decay, s;  // ob = 1 - beta, decay = -wd * lr, s = -step_size * lr: derived in DOUBLE on the host,
+  int mode;                                     // like the reference's Python scalars (1 - 0.999 in fp32 is off by 1.3e-5 relative)
 };
 
 __global__ __launch_bounds__(256) void k_radam_multi(const radam_pack a) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_radam_multi(const radam_pack a) {
   const float* __restrict__ g = a.g[t] + base;
   float* __restrict__ m = a.m[t] + base;
   float* __restrict__ v = a.v[t] + base;
-  const float ob1 = 1.0f - a.beta1, ob2 = 1.0f - a.beta2, decay = -a.wd * a.lr, s = -a.step_size * a.lr;
+  const float ob1 = a.ob1, ob2 = a.ob2, decay = a.decay, s = a.s;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float gi = g[i];
     const float vi = v[i] * a.beta2 + ob2 * gi * gi;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_radam_multi(const radam_pack a) {
     m[i] = mi;
     if (a.mode) {
       float pi = p[i];
-      if (a.wd != 0.0f) pi += decay * pi;
+      if (decay != 0.0f) pi += decay * pi;
       pi += a.mode == 2 ? s * (mi / (sqrtf(vi) + a.eps)) : s * mi;
       p[i] = pi;
     }
@@ -59,13 +59,14 @@ __global__ __launch_bounds__(256) void k_radam_multi(const radam_pack a) {
 using namespace qagnn;
 
 extern "C" int qagnn_radam_step_f32(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                    const int64_t* numel, float beta1, float beta2, float eps, float lr, float weight_decay,
-                                    float step_size, int32_t mode, qagnn_stream_t stream_) {
+                                    const int64_t* numel, double beta1, double beta2, double eps, double lr, double weight_decay,
+                                    double step_size, int32_t mode, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (p && g && m && v && numel)), QAGNN_EINVAL, "radam_step: null table");
   QAGNN_REQUIRE(mode >= 0 && mode <= 2, QAGNN_EINVAL, "radam_step: mode %d", mode);
   radam_pack a;
-  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.lr = lr; a.wd = weight_decay; a.step_size = step_size; a.mode = mode;
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.ob1 = (float)(1.0 - beta1); a.ob2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  a.decay = (float)(-weight_decay * lr); a.s = (float)(-step_size * lr); a.mode = mode;
   int nt = 0, nb = 0;
   auto flush = [&]() -> int {
     if (nb == 0) { nt = 0; return QAGNN_OK; }

@@ -126,6 +126,6 @@ def test_fused_radam_decoder_tensor_list_vs_float64(step, wd):
         rp, rm, rv = RO.radam_step(pb, p.grad.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), step, 1e-3, weight_decay=wd)
         st = opt.state[p]
         assert st['step'] == step
-        np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), rm, rtol=2e-6, atol=1e-9)
-        np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), rv, rtol=2e-6, atol=1e-12)
-        np.testing.assert_allclose(p.detach().cpu().numpy(), rp, rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), rm, rtol=2e-6, atol=3e-8)   # two O(0.1) terms may cancel
+        np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), rv, rtol=2e-6, atol=1e-10)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), rp, rtol=2e-6, atol=1e-7)
