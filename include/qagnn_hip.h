@@ -142,6 +142,13 @@ typedef struct qagnn_gemm_nn_args {
   int32_t xcd_remap;                 /* set by the library (XCD-contiguous tile order); callers leave it 0 */
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
+/* The same product on the bf16 matrix cores by EXACT operand splitting (csrc/gemm_split.hip): every fp32 operand is the exact sum
+ * of three bf16 numbers; the six partial products of order >= 2^-16 are accumulated in fp32 (six v_mfma_f32_16x16x32_bf16 per
+ * tile pair at 16x the fp32-MFMA rate).  Relative error <= 2^-23 per product -- one fp32 rounding -- so the result agrees with
+ * qagnn_gemm_nn_f32 to fp32 round-off but not bit for bit.  B is passed in its [No][K] layout (B1n / B2n, pitches ldn1 / ldn2:
+ * row j = column j of B1 / B2); a->B1 / a->B2 are ignored.  K1, K2 multiples of 4 (any length; tiles are zero-filled). */
+int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
+                            qagnn_stream_t stream);
 
 /* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) (includes room for the optional column sums of B) */
 int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);

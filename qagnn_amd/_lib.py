@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32',
            'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
@@ -75,6 +75,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]
     lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp] + [C.c_double] * 6 + [_i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
+    lib.qagnn_gemm_nn_split_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
@@ -246,6 +247,9 @@ class HipKernels(metaclass=_GuardedMeta):
         # the host (graphs built from load-time blobs).  Measured 0.177 ms per layer against 0.126 ms for the generic L2-gather kernels at the
         # CSQA batch (profiles/r2_run8_edge_lds_variants.txt: bound by VALU issue, 120 wave-instructions per edge): off by default, QAGNN_EDGE_LDS=1.
         self.edge_lds = os.environ.get('QAGNN_EDGE_LDS', '0') == '1'
+        # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
+        # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
+        self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -326,7 +330,9 @@ class HipKernels(metaclass=_GuardedMeta):
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False, a_rowidx=None):
+                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None):
+        """B1n / B2n: the same weights as B1 / B2 in their [No, K] layout (optional); with them the product runs on the bf16 matrix
+        cores by exact operand splitting (see gemm_split.hip), else on the fp32-input MFMAs."""
         _chk2d(A1, 'A1'), _chk2d(B1, 'B1')
         K1 = A1.size(1)
         M = A1.size(0) if a_rowidx is None else a_rowidx.numel()
@@ -359,6 +365,17 @@ class HipKernels(metaclass=_GuardedMeta):
         if a_rowidx is not None:
             assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
             a.a_rowidx = a_rowidx.data_ptr()
+        if self.gemm_split and B1n is not None and (A2 is None or B2n is not None) and K1 % 4 == 0 and (A2 is None or A2.size(1) % 4 == 0):
+            _chk2d(B1n, 'B1n')
+            assert B1n.shape == (No, K1)
+            n2, ld2 = None, 0
+            if A2 is not None:
+                _chk2d(B2n, 'B2n')
+                assert B2n.shape == (No, A2.size(1))
+                n2, ld2 = B2n.data_ptr(), B2n.size(1)
+            self._check(self.lib.qagnn_gemm_nn_split_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, self._stream()), 'qagnn_gemm_nn_split_f32')
+            return out
+        assert K1 % 16 == 0 and (A2 is None or A2.size(1) % 16 == 0), 'the fp32-MFMA kernel needs K to be a multiple of 16'
         self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')
         return out
 

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libqagnn_hip.so')
-SOURCES = ['graph_prep.hip', 'gemm.hip', 'elementwise.hip', 'edge_attn.hip', 'pool.hip', 'hop.hip', 'optim.hip']
+SOURCES = ['graph_prep.hip', 'gemm.hip', 'elementwise.hip', 'edge_attn.hip', 'pool.hip', 'hop.hip', 'optim.hip', 'gemm_split.hip']
 
 
 def _newest_source_mtime():

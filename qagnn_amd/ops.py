@@ -358,8 +358,8 @@ class LinearNNFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc):
         K = kernels()
-        C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx)
-        ctx.save_for_backward(A1, B1, A2, B2, rowidx)
+        C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx, B1n=B1, B2n=B2)
+        ctx.save_for_backward(A1, B1, A2, B2, rowidx, B1t, B2t)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
         ctx.defer = _DEFER[0]
         ctx.acc = acc if acc is not None else (None, False, None, False)
@@ -369,7 +369,7 @@ class LinearNNFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, dC):
         K = kernels()
-        A1, B1, A2, B2, rowidx = ctx.saved_tensors
+        A1, B1, A2, B2, rowidx, B1t, B2t = ctx.saved_tensors
         dC = dC.contiguous()
         need = ctx.needs_input_grad
         has_bias, has_tab, G = ctx.has
@@ -398,9 +398,9 @@ class LinearNNFn(torch.autograd.Function):
                 if acc1 is None and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
                     dA1 = K.gemm_tn(dC.t().contiguous(), B1)  # few rows, long reduction: see below
                 else:
-                    dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu))
+                    dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t))
             if A2 is not None and need[3]:
-                dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu))
+                dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
             return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
         cs = None
         if FUSED_COLSUM and need[1] and (want_tab or want_bias):
@@ -423,10 +423,10 @@ class LinearNNFn(torch.autograd.Function):
             # after the other; the split-K weight-gradient kernel computes the same product as (dC^T)^T B1 in parallel chunks
             dA1 = K.gemm_tn(dC.t().contiguous(), B1)
         else:
-            dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu)) if need[0] else None
+            dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t)) if need[0] else None
         dA2 = None
         if A2 is not None and need[3]:
-            dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu))
+            dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
         return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
 
 
@@ -570,7 +570,7 @@ class GatMlpFn(torch.autograd.Function):
                 row_weight):
         K = kernels()
         R = aggr.size(0)
-        h1 = K.gemm_nn(aggr, W1t, bias=b1)
+        h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
         if training:
             sc = 1.0 / R if row_weight is None else 1.0  # row_weight [R] (sums to 1): weighted statistics
             mean = K.colsum(h1, scale=sc, roww=row_weight)[0]
@@ -579,9 +579,9 @@ class GatMlpFn(torch.autograd.Function):
             mean, var = run_mean, run_var
         # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
         invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
-        out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
+        out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift, B1n=W2)
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
-        ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight)
+        ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t)
         ctx.cfg = (training, p, seed, R, apply_act)
         ctx.defer = _DEFER[0]
         ctx.mark_non_differentiable(mean, var)
@@ -591,30 +591,30 @@ class GatMlpFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, dy, _dm, _dv):
         K = kernels()
-        aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight = ctx.saved_tensors
+        aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
         db2 = K.colsum(dout)[0]
         if ctx.defer:  # weight gradients of both Linears queued for the next edge backward (see defer_wgrads)
             Cc = dout.size(1)
             dW2t = _wg_empty(dout, (h1.size(1), Cc))
-            dr = K.gemm_nn(dout, W2)
+            dr = K.gemm_nn(dout, W2, B1n=W2t)
             red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
             dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
                                             roww=row_weight if training else None)
             dW1t = _wg_empty(dout, (aggr.size(1), h1.size(1)))
             defer_wgrads([lambda: K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, out=dW2t), lambda: K.gemm_tn(aggr, dh1, out=dW1t)],
                          (h1, dout, scale, shift, aggr, dh1))
-            daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
+            daggr = K.gemm_nn(dh1, W1, B1n=W1t) if ctx.needs_input_grad[0] else None
             return (daggr, dW1t, None, db1, red[1], red[0], dW2t, None, db2, None, None, None, None, None, None, None, None, None)
         dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
-        dr = K.gemm_nn(dout, W2)
+        dr = K.gemm_nn(dout, W2, B1n=W2t)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
         dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
                                         roww=row_weight if training else None)
         dW1t = K.gemm_tn(aggr, dh1)
-        daggr = K.gemm_nn(dh1, W1) if ctx.needs_input_grad[0] else None
+        daggr = K.gemm_nn(dh1, W1, B1n=W1t) if ctx.needs_input_grad[0] else None
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
 
 
@@ -652,9 +652,9 @@ HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamm
 
 def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
-    KMQ = K.gemm_nn(X, Wx_t, S, Ws_t, rowtab=TT, rowidx=ntype)
+    KMQ = K.gemm_nn(X, Wx_t, S, Ws_t, rowtab=TT, rowidx=ntype, B1n=Wx, B2n=Ws)
     aggr, a, alpha = K.edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
-    h1 = K.gemm_nn(aggr, W1t, bias=b1)
+    h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
     if batch_stats:
         sc = 1.0 / aggr.size(0)
         mean = K.colsum(h1, scale=sc)[0]
@@ -662,7 +662,7 @@ def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     else:
         mean, var = run_mean_p, run_var_p
     invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
-    out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift)
+    out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift, B1n=W2)
     y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
     return y, (KMQ, torch.stack([a, alpha]), aggr, h1, out, torch.stack([mean, var, invstd, scale, shift]))
 
@@ -676,17 +676,17 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
     db2 = K.colsum(dout)[0]
     dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
-    dr = K.gemm_nn(dout, W2)
+    dr = K.gemm_nn(dout, W2, B1n=W2t)
     red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
     dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
     dW1t = K.gemm_tn(aggr, dh1)
-    daggr = K.gemm_nn(dh1, W1)
+    daggr = K.gemm_nn(dh1, W1, B1n=W1t)
     dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
     dWx_t = K.gemm_tn(X, dKMQ)
     dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
     dTT = K.colsum(dKMQ, ntype, TT.size(0))
-    dX = K.gemm_nn(dKMQ, Wx, out=dX_acc, accumulate=dX_acc is not None) if need_dX else None
-    dS = K.gemm_nn(dKMQ, Ws, out=dS_acc, accumulate=dS_acc is not None) if (S is not None and need_dS) else None
+    dX = K.gemm_nn(dKMQ, Wx, out=dX_acc, accumulate=dX_acc is not None, B1n=Wx_t) if need_dX else None
+    dS = K.gemm_nn(dKMQ, Ws, out=dS_acc, accumulate=dS_acc is not None, B1n=Ws_t) if (S is not None and need_dS) else None
     return dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, red[1], red[0], dW2t, db2
 
 
@@ -789,7 +789,7 @@ class ConceptInputFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed):
         K = kernels()
-        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx)
+        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx, B1n=Wc_t.t().contiguous())
         B = ctx_pre.size(0)
         pre.view(B, n, -1)[:, 0] = ctx_pre
         ctx.save_for_backward(emb_w, rowidx, pre)

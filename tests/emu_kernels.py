@@ -117,8 +117,10 @@ class EmuKernels:
         return A[idx.clamp(min=0)] * (idx >= 0).to(A.dtype).unsqueeze(1)
 
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False, a_rowidx=None):
-        _chk(A1, B1, A2, B2, out, rowtab)
+                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None):
+        _chk(A1, B1, A2, B2, out, rowtab, B1n, B2n)
+        assert B1n is None or (B1n.shape == (B1.size(1), B1.size(0)) and torch.equal(B1n, B1.t())), 'B1n must be B1 transposed'
+        assert B2n is None or (B2n.shape == (B2.size(1), B2.size(0)) and torch.equal(B2n, B2.t())), 'B2n must be B2 transposed'
         A1 = self._gather_rows(A1, a_rowidx)
         if a_scale is not None:
             A1 = torch.relu(A1 * a_scale + a_shift)

@@ -120,7 +120,10 @@ GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,K1,K2,No', GEMM_SHAPES)
 @pytest.mark.parametrize('variant', ['plain', 'bias_tab', 'affine', 'accumulate'])
-def test_gemm_nn(M, K1, K2, No, variant):
+@pytest.mark.parametrize('split', [False, True])
+def test_gemm_nn(M, K1, K2, No, variant, split):
+    """split=True: the same product through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way operand splitting, B handed
+    over in its [No, K] layout as well) -- held to the SAME fp32 backward-error bound as the fp32-MFMA kernel."""
     g = torch.Generator().manual_seed(M + K1 + No)
     A1, B1 = torch.randn(M, K1, generator=g), torch.randn(K1, No, generator=g)
     A2 = torch.randn(M, K2, generator=g) if K2 else None
@@ -133,7 +136,10 @@ def test_gemm_nn(M, K1, K2, No, variant):
     out0 = torch.randn(M, No, generator=g) if variant == 'accumulate' else None
     K = hip()
     cu = lambda t: None if t is None else t.cuda()  # noqa: E731
-    got = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), out=cu(out0), accumulate=out0 is not None, **{k: cu(v) for k, v in kw.items()}).cpu()
+    K.gemm_split = split
+    nk = dict(B1n=cu(B1.t().contiguous()), B2n=cu(B2.t().contiguous()) if K2 else None) if split else {}
+    got = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), out=cu(out0), accumulate=out0 is not None, **{k: cu(v) for k, v in kw.items()}, **nk).cpu()
+    K.gemm_split = True
     d = lambda t: None if t is None else (t.double() if t.is_floating_point() else t)  # noqa: E731
     ref = EMU.gemm_nn(d(A1), d(B1), d(A2), d(B2), **{k: d(v) for k, v in kw.items()})
     if out0 is not None:

@@ -30,7 +30,7 @@ label(MQ.QAGNN_Message_Passing, 'forward', 'mp_other')
 label(MQ.QAGNN, 'forward', 'qagnn_other')
 
 dev = torch.device('cuda', 0)
-b = {k: v.to(dev) for k, v in bench.make_batch(64, seed=1000, n_concept=100000).items()}
+b = bench.to_device(bench.make_batch(64, seed=1000, n_concept=100000), dev, True)
 model = bench.build_model(MQ, 100000, p=0.2).to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
 for _ in range(3):
