@@ -38,7 +38,7 @@ if [[ "$*" == *bench* ]]; then
 fi
 if [[ " $* " == *" prof "* ]]; then
   rm -rf /tmp/prof; mkdir -p /tmp/prof
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r2 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) 2>&1 | tail -n 30 > gpurun_out/prof.log
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r2 -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc ) 2>&1 | tail -n 30 > gpurun_out/prof.log
   echo "prof exit $?" >> gpurun_out/summary.txt
   mkdir -p gpurun_out/prof
   find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
