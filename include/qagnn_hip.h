@@ -301,6 +301,7 @@ typedef struct qagnn_hop_args {
   float* dbn;                      /* [2, DP]: d beta, d gamma */
   float* dW2t; float* db2;         /* [DP, DP], [DP] */
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
+  int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split) */
 } qagnn_hop_args;
 int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);
 int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP,

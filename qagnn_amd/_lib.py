@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 7  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls)
+ABI_VERSION = 8  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -57,7 +57,7 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64)])
+                [('ws_elems', _i64), ('gemm_split', _i32)])
 
 
 def load_library(path=LIB_PATH):
@@ -583,6 +583,7 @@ class HipKernels(metaclass=_GuardedMeta):
         h.batch_stats, h.eps = (1 if batch_stats else 0), float(eps)
         h.run_mean_p, h.run_var_p = run_mean_p.data_ptr(), run_var_p.data_ptr()
         h.apply_act, h.p_drop, h.seed = (1 if apply_act else 0), float(p), int(seed)
+        h.gemm_split = 1 if self.gemm_split else 0
         return h
 
     def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):

@@ -59,6 +59,14 @@ extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t 
   return up4((int64_t)Ep * 4) + up4(qagnn_colreduce_workspace_elems(N, DP, 1));
 }
 
+// NN product through the kernel family the caller asked for (qagnn_hop_args.gemm_split): the bf16-split kernel takes B in its
+// [No][K] layout, which the hop holds for every weight (W and W^T both arrive packed)
+static int hop_nn(const qagnn_hop_args* h, const qagnn_gemm_nn_args* a, const float* B1n, int ldn1, const float* B2n, int ldn2,
+                  qagnn_stream_t stream) {
+  if (h->gemm_split && a->K1 % 4 == 0 && a->K2 % 4 == 0) return qagnn_gemm_nn_split_f32(a, B1n, ldn1, B2n, ldn2, stream);
+  return qagnn_gemm_nn_f32(a, stream);
+}
+
 extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
   HOP_TRY(check_hop(h, "hop_fwd"));
   const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
@@ -74,13 +82,13 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   if (SP > 0) { ga.A2 = h->S; ga.lda2 = SP; ga.K2 = SP; ga.B2 = h->Ws_t; ga.ldb2 = 3 * DP; }
   ga.C = h->KMQ; ga.ldc = 3 * DP; ga.M = N; ga.No = 3 * DP;
   ga.rowtab = h->TT; ga.ldt = 3 * DP; ga.rowidx = h->ntype;
-  HOP_TRY(qagnn_gemm_nn_f32(&ga, stream));
+  HOP_TRY(hop_nn(h, &ga, h->Wx, DP, SP > 0 ? h->Ws : nullptr, SP, stream));
   // attention + aggregation (:442, 455-484)
   HOP_TRY(qagnn_edge_attn_fwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP, stream));
   // mlp: Linear -> BatchNorm1d -> ReLU -> Linear (:443, 408); BN + ReLU are folded into the second GEMM's operand load
   qagnn_gemm_nn_args g1 = {};
   g1.A1 = h->aggr; g1.lda1 = DP; g1.K1 = DP; g1.B1 = h->W1t; g1.ldb1 = DP; g1.C = h->h1; g1.ldc = DP; g1.M = N; g1.No = DP; g1.bias = h->b1;
-  HOP_TRY(qagnn_gemm_nn_f32(&g1, stream));
+  HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, stream));
   const float* mean_u = mean;
   const float* var_u = var;
   if (h->batch_stats) {
@@ -99,7 +107,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
   g2.a_scale = scale; g2.a_shift = shift;
-  HOP_TRY(qagnn_gemm_nn_f32(&g2, stream));
+  HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, stream));
   if (h->apply_act)  // X' = dropout(GELU(out))  (:48-49)
     HOP_TRY(qagnn_gelu_dropout_fwd_f32(h->out, h->y, (int64_t)N * DP, h->p_drop, h->seed, stream));
   return QAGNN_OK;
@@ -144,7 +152,7 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
-  HOP_TRY(qagnn_gemm_nn_f32(&gr, stream));
+  HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, stream));
   // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1 (overwrites d out: it is dead by now)
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
   HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufA, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
@@ -153,7 +161,7 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufA, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, stream));
   qagnn_gemm_nn_args gg = {};
   gg.A1 = bufA; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
-  HOP_TRY(qagnn_gemm_nn_f32(&gg, stream));
+  HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, stream));
   // attention backward
   HOP_TRY(qagnn_edge_attn_bwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs,
                                   cls_part, stream));
@@ -167,13 +175,13 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
     gx.accumulate = h->accumulate_dX;
-    HOP_TRY(qagnn_gemm_nn_f32(&gx, stream));
+    HOP_TRY(hop_nn(h, &gx, h->Wx_t, 3 * DP, nullptr, 0, stream));
   }
   if (SP > 0 && h->dS) {
     qagnn_gemm_nn_args gs = {};
     gs.A1 = dKMQ; gs.lda1 = 3 * DP; gs.K1 = 3 * DP; gs.B1 = h->Ws; gs.ldb1 = SP; gs.C = h->dS; gs.ldc = SP; gs.M = N; gs.No = SP;
     gs.accumulate = h->accumulate_dS;
-    HOP_TRY(qagnn_gemm_nn_f32(&gs, stream));
+    HOP_TRY(hop_nn(h, &gs, h->Ws_t, 3 * DP, nullptr, 0, stream));
   }
   return QAGNN_OK;
 }
