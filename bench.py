@@ -376,7 +376,7 @@ def main():
             'metric': 'QA-subgraphs/sec (batch x num_choice) fwd+bwd', 'value': round(B * world * args.steps / dt, 1),
             'unit': 'QA-subgraphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic',  # fp32 storage and fp32-accurate arithmetic everywhere (see roofline_mfma.note)
             'config': {'workload': 'configs[1]: CSQA-shaped batch 64 questions x 5 choices = 320 subgraphs per GPU, n=200 node slots, '
                                    '400..2000 edges/subgraph, 5-layer GAT d=200 H=4, 38 relations, QAGNN decoder fwd+bwd '
                                    '(LM encoder excluded: random sent_vecs), dropout 0.2, train-mode BN',
@@ -407,7 +407,10 @@ def main():
                               'frac': round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if gemm_ms > 0 else 0.0,
                               'gflop_per_step': round(gemm_flops / GEMM_STEPS / 1e9, 1), 'ms_per_step': round(gemm_ms / GEMM_STEPS, 3),
                               'launches_per_step': (len(timed.events['gemm_nn']) + len(timed.events['gemm_tn'])) // GEMM_STEPS,
-                              'timed_in': f'{GEMM_STEPS} extra steps after the timed region (HIP events around every launch)'},
+                              'timed_in': f'{GEMM_STEPS} extra steps after the timed region (HIP events around every launch)',
+                              'note': 'fp32-equivalent FLOPs of all GEMM launches against the fp32-input MFMA peak.  The NN products run as six '
+                                      'bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per product = one fp32 rounding; fp32-equivalent '
+                                      'ceiling 2500 / 6 = 417 TFLOP/s) unless QAGNN_GEMM_SPLIT=0; the weight-gradient products on fp32-input MFMAs'},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
                                       'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms / GEMM_STEPS, 3)},
         }
