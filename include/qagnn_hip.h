@@ -308,6 +308,11 @@ int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t
                                       int32_t cls_part_rows /* g->max_chunks + QAGNN_CLS_SLICES * g->C */);
 int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
+/* The whole k-hop stack per call (QAGNN_Message_Passing.mp_helper, modeling_qagnn.py:45-50, and its backward): hops[l] is a complete
+ * qagnn_hop_args, chained by the caller (hops[l+1].X = hops[l].y; hops[l].dy = hops[l+1].dX; one shared dS with accumulate_dS = 1 on
+ * every hop but the last).  Same launches in the same order as k single-hop calls; one FFI crossing for host-bound batches. */
+int qagnn_stack_fwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream);
+int qagnn_stack_bwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream);
 
 /* Per-batch node bookkeeping of QAGNN.forward in one launch.  Replaces ~15 elementwise / reduction kernels of
  *   modeling_qagnn.py:154      concept_ids[:, 1:] - 1            -> ridx [B][n] (int64; -1 on the context node, slot 0)

@@ -21,10 +21,11 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_bn_relu_bwd_colsum_f32',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
-           'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32']
+           'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
+           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 8  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split)
+ABI_VERSION = 9  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -104,6 +105,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_hop_bwd_workspace_elems.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.qagnn_hop_fwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _vp]
     lib.qagnn_hop_bwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _vp]
+    lib.qagnn_stack_fwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _i32, _vp]
+    lib.qagnn_stack_bwd_f32.argtypes = [C.POINTER(qagnn_hop_args), _i32, _vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('qagnn_abi_version',):
@@ -253,7 +256,9 @@ class HipKernels(metaclass=_GuardedMeta):
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
-        return torch.cuda.current_stream().cuda_stream
+        # raw handle of the current device's current stream (torch.cuda.current_stream() builds a Stream object: ~10 us per call,
+        # 25 calls per step); the entry points run under _on_operand_device, so "current device" is the operands' device
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
     def _check(self, rc, what):
         if rc != 0:
@@ -643,3 +648,79 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(self.lib.qagnn_hop_bwd_f32(C.byref(h), self._stream()), 'qagnn_hop_bwd_f32')
         return (dX, dS, dWx_t.view(DP, 3 * DP), dWs_t.view(SP, 3 * DP) if SP else None, dTT.view(T, 3 * DP), dEkEm.view(graph.C, 2 * DP),
                 dW1t.view(DP, DP), db1, dbn[DP:], dbn[:DP], dW2t.view(DP, DP), db2)
+
+    # -- the whole k-hop stack per call (csrc/hop.hip: qagnn_stack_{fwd,bwd}_f32) -------------------------------------------------------
+    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings):
+        """k hops with GELU + dropout after each; prms / seeds / runnings: per-layer lists.  -> (y [N, DP], saved)."""
+        k = len(prms)
+        N, DP, dev = graph.N, 4 * HP, X.device
+        KMQ = torch.empty((k, N, 3 * DP), dtype=torch.float32, device=dev)
+        aa = torch.empty((k, 2, graph.Ep, 4), dtype=torch.float32, device=dev)
+        rows = torch.empty((k, 4, N, DP), dtype=torch.float32, device=dev)  # per hop: aggr, h1, out, y
+        stats = torch.empty((k, 5, DP), dtype=torch.float32, device=dev)
+        ws = torch.empty(self.lib.qagnn_hop_fwd_workspace_elems(N, graph.Ep, DP), dtype=torch.float32, device=dev)
+        hops = (qagnn_hop_args * k)()
+        x = X
+        for l in range(k):
+            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
+            h.KMQ, h.a, h.alpha, h.stats = KMQ[l].data_ptr(), aa[l, 0].data_ptr(), aa[l, 1].data_ptr(), stats[l].data_ptr()
+            h.aggr, h.h1, h.out, h.y = rows[l, 0].data_ptr(), rows[l, 1].data_ptr(), rows[l, 2].data_ptr(), rows[l, 3].data_ptr()
+            if runnings[l] is not None:
+                rm, rv, nbt, pos, mom, _unb = runnings[l]
+                assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
+                h.run_mean, h.run_var, h.num_batches_tracked, h.dense_pos = rm.data_ptr(), rv.data_ptr(), _ptr(nbt), pos.data_ptr()
+                h.d, h.momentum = rm.numel(), float(mom)
+            h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
+            hops[l] = h
+            x = rows[l, 3]
+        self._check(self.lib.qagnn_stack_fwd_f32(hops, k, self._stream()), 'qagnn_stack_fwd_f32')
+        return rows[k - 1, 3], (KMQ, aa, rows, stats)
+
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None):
+        """-> (dX, dS, [per layer: (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)]); dX_acc: an existing running total of
+        the stack input's gradient (the output GEMM's share), added to in place."""
+        k = len(prms)
+        KMQ, aa, rows, stats = saved
+        N, DP, dev = graph.N, 4 * HP, X.device
+        SP = S.size(1) if S is not None else 0
+        T = prms[0][4].size(0)
+        _chk2d(dy, 'dy')
+        sizes = [DP * 3 * DP, SP * 3 * DP, T * 3 * DP, graph.C * 2 * DP, DP * DP, DP, 2 * DP, DP * DP, DP]
+        per = sum(sizes)
+        flat = torch.empty(k * per, dtype=torch.float32, device=dev)  # every size is a multiple of 4: 16-byte aligned views
+        dxs = torch.empty((max(k - 1, 1), N, DP), dtype=torch.float32, device=dev)  # gradient handed from hop l to hop l-1
+        dS = torch.empty((N, SP), dtype=torch.float32, device=dev) if (SP and need_dS) else None
+        dX = None
+        if need_dX:
+            dX = dX_acc if dX_acc is not None else torch.empty((N, DP), dtype=torch.float32, device=dev)
+            assert dX.shape == (N, DP) and dX.is_contiguous()
+        ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks + CLS_SLICES * graph.C), dtype=torch.float32, device=dev)
+        hops = (qagnn_hop_args * k)()
+        grads = []
+        for l in range(k):
+            x = X if l == 0 else rows[l - 1, 3]
+            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
+            h.KMQ, h.a, h.alpha, h.stats = KMQ[l].data_ptr(), aa[l, 0].data_ptr(), aa[l, 1].data_ptr(), stats[l].data_ptr()
+            h.aggr, h.h1, h.out, h.y = rows[l, 0].data_ptr(), rows[l, 1].data_ptr(), rows[l, 2].data_ptr(), rows[l, 2].data_ptr()
+            h.dy = dy.data_ptr() if l == k - 1 else dxs[l].data_ptr()
+            parts, off = [], l * per
+            for n in sizes:
+                parts.append(flat[off:off + n])
+                off += n
+            dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = parts
+            h.dWx_t, h.dTT, h.dEkEm, h.dW1t, h.db1 = dWx_t.data_ptr(), dTT.data_ptr(), dEkEm.data_ptr(), dW1t.data_ptr(), db1.data_ptr()
+            h.dbn, h.dW2t, h.db2 = dbn.data_ptr(), dW2t.data_ptr(), db2.data_ptr()
+            if l > 0:
+                h.dX, h.accumulate_dX = dxs[l - 1].data_ptr(), 0
+            elif dX is not None:
+                h.dX, h.accumulate_dX = dX.data_ptr(), (1 if dX_acc is not None else 0)
+            if SP:
+                h.dWs_t = dWs_t.data_ptr()
+                if dS is not None:
+                    h.dS, h.accumulate_dS = dS.data_ptr(), (0 if l == k - 1 else 1)  # hop k-1's backward runs first
+            h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
+            hops[l] = h
+            grads.append((dWx_t.view(DP, 3 * DP), dWs_t.view(SP, 3 * DP) if SP else None, dTT.view(T, 3 * DP), dEkEm.view(graph.C, 2 * DP),
+                          dW1t.view(DP, DP), db1, dbn[DP:], dbn[:DP], dW2t.view(DP, DP), db2))
+        self._check(self.lib.qagnn_stack_bwd_f32(hops, k, self._stream()), 'qagnn_stack_bwd_f32')
+        return dX, dS, grads

@@ -185,3 +185,19 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   }
   return QAGNN_OK;
 }
+
+// ---- the whole k-hop stack per call (qagnn_mp_forward / qagnn_mp_backward) -------------------------------------
+// hops[l] is a complete qagnn_hop_args; the caller chains them (hops[l+1].X = hops[l].y, hops[l].dy = hops[l+1].dX, shared dS
+// with accumulate_dS = 1 on all but the hop whose backward runs first).  Pure sequencing: the same launches, in the same order,
+// as k calls of qagnn_hop_fwd_f32 / qagnn_hop_bwd_f32 -- one FFI crossing and one autograd node instead of k for host-bound batches.
+extern "C" int qagnn_stack_fwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream) {
+  QAGNN_REQUIRE(hops && k > 0, QAGNN_EINVAL, "stack_fwd: no hops");
+  for (int l = 0; l < k; ++l) HOP_TRY(qagnn_hop_fwd_f32(&hops[l], stream));
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_stack_bwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream) {
+  QAGNN_REQUIRE(hops && k > 0, QAGNN_EINVAL, "stack_bwd: no hops");
+  for (int l = k - 1; l >= 0; --l) HOP_TRY(qagnn_hop_bwd_f32(&hops[l], stream));
+  return QAGNN_OK;
+}

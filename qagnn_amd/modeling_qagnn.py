@@ -419,6 +419,22 @@ class QAGNN_Message_Passing(nn.Module):
             # one running total each (ops.GradAcc) instead of leaving k (2) gradients for autograd to add; hop 0's backward runs
             # last and returns the totals
             accS, accX = (ops.GradAcc(), ops.GradAcc()) if self.k > 0 else (None, None)
+            if self.k > 0 and ops.use_fused_hop(Hp.size(0)) and hasattr(ops.kernels(), 'stack_fwd') and ops.FUSED_STACK:
+                # host-bound batches: all k hops as ONE native call and one autograd node each way (csrc/hop.hip)
+                prms, runnings = [], []
+                for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):
+                    bn = layer.mlp[1]
+                    Wx_t, Wx, Ws_t, Ws = pk[:4]
+                    W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p = pk[8:]
+                    prms.append((Wx_t, Wx, Ws_t, Ws, TT[l], ekem[l], W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p))
+                    R = float(Hp.size(0))
+                    runnings.append((bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos, bn_momentum(bn),
+                                     R / max(R - 1.0, 1.0)) if (self.training and bn.track_running_stats) else None)
+                bn0 = self.gnn_layers[0].mlp[1]
+                Xp = ops.gat_stack(Hp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.gnn_layers[0].dim_per_head), prms,
+                                   self.training or not bn0.track_running_stats, bn0.eps, self.dropout_rate if self.training else 0.0,
+                                   runnings, accX=accX)
+                per_layer = []
             for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
                 Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
                                   packed=pk, tables=(TT[l], ekem[l]), acc=(accX if l == 0 else None, True, accS, l == 0))

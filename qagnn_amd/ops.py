@@ -643,6 +643,7 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
 _fh = _os.environ.get('QAGNN_FUSED_HOP', 'auto')
 FUSED_HOP = {'1': True, '0': False}.get(_fh, None)  # None = auto
 FUSED_HOP_MAX_ROWS = 32768
+FUSED_STACK = _os.environ.get('QAGNN_FUSED_STACK', '1') == '1'  # where the native hop is taken, take all k hops in one call
 
 
 def use_fused_hop(n_rows):
@@ -735,6 +736,52 @@ def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act,
     acc = (accX, lastX, accS, lastS): GradAcc of X / S, see GradAcc."""
     p = float(p) if apply_act else 0.0
     return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, acc, *prm)
+
+
+class StackFn(torch.autograd.Function):
+    """All k GATConvE hops of QAGNN_Message_Passing.mp_helper (GELU + dropout after each) as ONE autograd node over
+    qagnn_stack_{fwd,bwd}_f32: for host-bound batches (the reference's mini-batch of 10 subgraphs) the per-hop Python, ctypes and
+    autograd bookkeeping is most of a step.  Same launches, in the same order, as k HopFn nodes."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seeds, runnings, accX, k, *prm):
+        K = kernels()
+        npk = len(prm) // k
+        prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
+        y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings)
+        ctx.save_for_backward(X, S, ntype, *prm, *saved)
+        ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seeds, k, npk)
+        ctx.accX = accX
+        return y
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dy):
+        K = kernels()
+        graph, HP, qscale, batch_stats, eps, p, seeds, k, npk = ctx.cfg
+        t = ctx.saved_tensors
+        X, S, ntype, prm, saved = t[0], t[1], t[2], t[3:3 + k * npk], t[3 + k * npk:]
+        prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
+        flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under the hops
+        accX = ctx.accX
+        dX, dS, grads = K.stack_bwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy.contiguous(),
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None)
+        if accX is not None:
+            accX.buf = None  # handed over: this node is the last reader of the stack input (it was created first)
+        out = []
+        for (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2) in grads:
+            #       Wx_t   Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1   gamma   beta   W2t   W2   b2  run_mean run_var
+            out += [dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None]
+        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, *out)
+
+
+def gat_stack(X, S, ntype, graph, HP, qscale, prms, batch_stats, eps, p, runnings, accX=None):
+    """prms: per-layer lists of the 16 packed operands named in HOP_PARAMS."""
+    k = len(prms)
+    seeds = [next_seed() if p > 0 else 0 for _ in range(k)]
+    flat = [t for prm in prms for t in prm]
+    return StackFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, float(p), seeds, runnings, accX, k, *flat)
 
 
 class PoolAttnFn(torch.autograd.Function):

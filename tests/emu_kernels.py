@@ -93,6 +93,29 @@ class EmuKernels:
     def graph_prep(self, edge_index, edge_type, node_type, n_etype, n_ntype, block_n=0):
         return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype, block_n)
 
+    # whole-stack sequencing, defined by the composed per-kernel path (what qagnn_stack_{fwd,bwd}_f32 must equal launch for launch)
+    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings):
+        from qagnn_amd import ops
+        x, saved = X, []
+        for l, prm in enumerate(prms):
+            y, sv = ops.hop_fwd_composed(self, graph, HP, qscale, x, S, ntype, prm, batch_stats, eps, p, seeds[l], True, runnings[l])
+            saved.append((x, sv))
+            x = y
+        return x, tuple(t for _, sv in saved for t in sv) + tuple(xi for xi, _ in saved)
+
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None):
+        from qagnn_amd import ops
+        k = len(prms)
+        svs, xs = [saved[6 * l:6 * l + 6] for l in range(k)], saved[6 * k:]
+        dS, grads = None, [None] * k
+        for l in range(k - 1, -1, -1):
+            r = ops.hop_bwd_composed(self, graph, HP, qscale, xs[l], S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, svs[l], dy,
+                                     True if l else need_dX, need_dS, dX_acc if l == 0 else None, dS)
+            dy = r[0]
+            dS = r[1] if r[1] is not None else dS
+            grads[l] = r[2:]
+        return dy, dS, grads
+
     def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids):
         B, n = node_type_ids.shape
         ar = torch.arange(n, device=node_type_ids.device)

@@ -311,3 +311,33 @@ def test_model_on_a_non_current_device():
     logits.sum().backward()
     assert torch.cuda.current_device() == 0 and logits.device.index == 1
     helpers.check_plain(fix, 'logits', logits, **FWD)
+
+
+@pytest.mark.parametrize('case', ['csqa_b10', 'small_train'])
+def test_whole_stack_native_call_equals_per_hop_path(case):
+    """qagnn_stack_{fwd,bwd}_f32 (all k hops per C call, ops.StackFn) == k native hop calls == the composed per-kernel path, bit for
+    bit, dropout on: logits, every gradient, every BatchNorm buffer."""
+    fix = helpers.load_golden(case)
+    inputs = cu(*golden_inputs(case, fix))
+    res = []
+    for stack, hop in ((True, True), (False, True), (False, False)):
+        old = ops.FUSED_STACK, ops.FUSED_HOP
+        ops.FUSED_STACK, ops.FUSED_HOP = stack, hop
+        try:
+            model = build(case)
+            model.gnn.dropout_rate = 0.2
+            model = model.cuda()
+            torch.manual_seed(5)
+            ops._seed_counter[0] = 0
+            logits, _ = model(*inputs[:5], (inputs[5], inputs[6]))
+            logits.sum().backward()
+            res.append((logits.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                        {k: b.clone() for k, b in model.named_buffers()}))
+        finally:
+            ops.FUSED_STACK, ops.FUSED_HOP = old
+    (l0, g0, b0), (l1, g1, b1), (l2, g2, b2) = res
+    assert torch.equal(l0, l1) and torch.equal(l0, l2)
+    assert set(g0) == set(g1) == set(g2)
+    assert all(torch.equal(g0[k], g1[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g1[k])][:5]
+    assert all(torch.equal(g0[k], g2[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g2[k])][:5]
+    assert all(torch.equal(b0[k], b1[k]) and torch.equal(b0[k], b2[k]) for k in b0)

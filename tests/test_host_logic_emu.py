@@ -418,3 +418,30 @@ def test_model_accepts_a_packed_blob_batch():
     b, _, _, _, ei_back, et_back = lm(*shaped, packed, None, detail=True)
     assert torch.equal(a, b) and torch.equal(a.view(-1, 1), outs[0][0])
     assert all(torch.equal(x, y) for rx, ry in zip(ei_back, nest(inp['edge_index_list'])) for x, y in zip(rx, ry))
+
+
+@pytest.mark.parametrize('case', ['small_train', 'config1_train'])
+def test_whole_stack_operator_equals_per_hop_path(case):
+    """ops.StackFn (all k hops as one autograd node; the form taken for host-bound batches) against the per-hop operators:
+    same logits, same gradients, same BatchNorm buffers -- bit for bit (both run the same kernel sequence)."""
+    fix = helpers.load_golden(case)
+    inputs = golden_inputs(case, fix)
+    res = []
+    for stack, hop in ((True, True), (False, True), (False, False)):
+        old = ops.FUSED_STACK, ops.FUSED_HOP
+        ops.FUSED_STACK, ops.FUSED_HOP = stack, hop
+        try:
+            model = build(case)
+            model.gnn.dropout_rate = 0.2
+            torch.manual_seed(5)
+            ops._seed_counter[0] = 0
+            logits, _ = model(*inputs[:5], (inputs[5], inputs[6]))
+            logits.sum().backward()
+            res.append((logits.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                        {k: b.clone() for k, b in model.named_buffers()}))
+        finally:
+            ops.FUSED_STACK, ops.FUSED_HOP = old
+    (l0, g0, b0), (l1, g1, b1), (l2, g2, b2) = res
+    assert torch.equal(l0, l1) and torch.equal(l0, l2)
+    assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0) and all(torch.equal(g0[k], g2[k]) for k in g0)
+    assert all(torch.equal(b0[k], b1[k]) for k in b0)

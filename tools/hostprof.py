@@ -40,4 +40,5 @@ for _ in range(steps):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(45)
+st.sort_stats('tottime').print_stats(30)
+st.sort_stats('cumulative').print_stats(70)
