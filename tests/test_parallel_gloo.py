@@ -139,3 +139,18 @@ def test_balance_questions_by_edge_count():
     order = [q for p in parts for q in p]
     gathered = torch.tensor(order, dtype=torch.float32).view(-1, 1)
     assert parallel.scatter_logits_by_assignment(gathered, parts).flatten().tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher spawns its own N ranks -- and says so loudly when fewer than N GPUs are visible
+    (here: none) instead of silently running one rank."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and '--gpus 2 requested but only' in (r.stderr + r.stdout)
+    # under a launcher whose world size disagrees with --gpus the mismatch is reported as well
+    env2 = dict(env, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(helpers.ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=240, env=env2)
+    assert r.returncode != 0 and 'WORLD_SIZE=3' in (r.stderr + r.stdout)
