@@ -225,6 +225,258 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
   return QAGNN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// TN (weight gradients): P[chunk][Ka][No] = sum_{r in chunk} A[r][ka] * B[r][no], the same exact 3 x bf16 products.
+//
+// Both operands arrive with the reduction index r as the SLOW index, while the MFMA wants 8 consecutive r per lane, so the tiles are
+// transposed on their way into LDS: a task = 8 rows x one float4 column (buffer loads: 16-lane row segments of 256 B, rows past R
+// and columns past the operand come back as zeros from the descriptor's bounds check -- no clamps, no selects); the 32 numbers are
+// split and written, per column, as one 16-byte chunk per piece.  LDS holds [piece][column][32 rows] bf16 with a column pitch of
+// 80 B (32 rows + 8 pad) and the 16-byte slot of row group g stored at g ^ s(column), s = bit 2 ^ bit 3 of the column: with that,
+// the 8-lane groups of ds_write_b128 (2 float4 columns x 4 row groups) and the four 16-lane groups of the ds_read_b128 fragment
+// reads (MI355X_MICROARCH.md, LDS) each touch every bank once (searched exhaustively; pitch 80 B alone left 34 % of the LDS
+// cycles as conflicts).
+//
+// Block = 4 waves, one chunk of rows, KT*16 x NT*16 outputs with (KT, NT) = (13, 7) or (7, 13): 77 KB of LDS and <= 256 VGPRs, so
+// TWO blocks per CU -- one block's split/transpose (VALU) runs under the other's MFMAs, which a single block with its
+// barrier-separated phases cannot do (v1: 208 x 208 per block, one block per CU, 26 % MFMA-busy).  The 320 tasks of a k-tile are
+// six task-waves: the four of the wide operand stay with their wave, the two of the narrow one rotate over the waves tile by tile.
+// Wave w owns the 16-row output strips w, w+4, ... of the first 4*(KT/4) strips with all NT column tiles (A fragments stay in
+// registers across the column loop); the tiles of the KT%4 leftover strips are dealt out one by one (tile q -> wave q % 4).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TKR = 32, TCP = 40, TTHR = 256;
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
+
+// 8 rows of one column -> three 16-byte chunks
+__device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_elems, const float (&x)[8]) {
+  uint32_t h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(x[i], h1[i], h2[i], h3[i]);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]), pack_hi(h1[4], h1[5]), pack_hi(h1[6], h1[7]));
+  *reinterpret_cast<uint4*>(dst + img_elems) = make_uint4(pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]), pack_hi(h2[4], h2[5]), pack_hi(h2[6], h2[7]));
+  *reinterpret_cast<uint4*>(dst + 2 * img_elems) = make_uint4(pack_hi(h3[0], h3[1]), pack_hi(h3[2], h3[3]), pack_hi(h3[4], h3[5]), pack_hi(h3[6], h3[7]));
+}
+
+// a task's 8 x 4 numbers -> LDS (4 columns); AFF: relu(x * sc + sh) per column first
+template <bool AFF>
+__device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w;
+      if (AFF) {
+        const float s = j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w, h = j == 0 ? sh.x : j == 1 ? sh.y : j == 2 ? sh.z : sh.w;
+        v = fmaxf(fmaf(v, s, h), 0.f);
+      }
+      x[i] = v;
+    }
+    store_col8(img + off + j * TCP, img_elems, x);
+  }
+}
+
+template <int KT, int NT, bool AFFINE>
+__global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_split(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
+  constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
+  constexpr int MT = KT / 4, REM = KT % 4, RS = (REM * NT + 3) / 4;  // full strips per wave; leftover strips, shared tile by tile
+  constexpr int A_TW = (AC + 63) / 64, B_TW = (BC + 63) / 64;
+  constexpr bool A_MAJOR = A_TW >= B_TW;                              // the wide operand: one task-wave per wave, every tile
+  constexpr int MAJ_TW = A_MAJOR ? A_TW : B_TW, MIN_TW = A_MAJOR ? B_TW : A_TW;
+  constexpr int MAJ_C = A_MAJOR ? AC : BC, MIN_C = A_MAJOR ? BC : AC, MAJ_EL = A_MAJOR ? A_EL : B_EL, MIN_EL = A_MAJOR ? B_EL : A_EL;
+  static_assert(MAJ_TW <= 4 && MIN_TW <= 4, "task-waves per operand");
+  uint16_t* const As = reinterpret_cast<uint16_t*>(smem_tn);
+  uint16_t* const Bs = As + 3 * A_EL;
+  uint16_t* const Maj = A_MAJOR ? As : Bs;
+  uint16_t* const Min = A_MAJOR ? Bs : As;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * BC, m0 = blockIdx.y * AC, chunk = blockIdx.z;
+  const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
+  const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, R * lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, R * ldb * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsMaj = A_MAJOR ? rsA : rsB, rsMin = A_MAJOR ? rsB : rsA;
+  const int maj0 = A_MAJOR ? m0 : n0, min0 = A_MAJOR ? n0 : m0, majDim = A_MAJOR ? Ka : No, minDim = A_MAJOR ? No : Ka;
+  const uint32_t ldMaj4 = (uint32_t)(A_MAJOR ? lda : ldb) * 4u, ldMin4 = (uint32_t)(A_MAJOR ? ldb : lda) * 4u;
+  constexpr uint32_t OOB = 0x80000000u;  // beyond any operand this kernel is launched on: the load returns zeros
+
+  const int g = lane & 3;                                   // row group (8 rows) of this thread's tasks
+  const int c4j = w * 16 + (lane >> 2);                     // float4 column of the major task
+  const bool maj_act = w < MAJ_TW && c4j * 4 < MAJ_C;
+  const bool maj_in = maj_act && maj0 + c4j * 4 < majDim;
+  uint32_t maj_voff = maj_in ? ((uint32_t)(r_beg + g * 8) * ldMaj4 + (uint32_t)(maj0 + c4j * 4) * 4u) : OOB;
+  const int maj_off = c4j * 4 * TCP + ((g ^ ((c4j ^ (c4j >> 1)) & 1)) << 3);
+  float4 scj = make_float4(1.f, 1.f, 1.f, 1.f), shj = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (AFFINE && A_MAJOR) {
+    const int cc = min(maj0 + c4j * 4, Ka - 4);
+    scj = ld4(a_scale + cc);
+    shj = ld4(a_shift + cc);
+  }
+
+  f32x4s acc[MT > 0 ? MT : 1][NT], accr[RS > 0 ? RS : 1];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < RS; ++q) accr[q] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+
+  float4 rj[8], rn[8];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rj[i] = bload4(rsMaj, maj_voff + (uint32_t)i * ldMaj4);
+    maj_voff += maj_in ? (uint32_t)TKR * ldMaj4 : 0u;
+    const int mk = (w - t) & 3;  // this tile's minor task-wave of this wave (wave-uniform)
+    if (mk < MIN_TW) {
+      const int c4 = mk * 16 + (lane >> 2);
+      const bool in = c4 * 4 < MIN_C && min0 + c4 * 4 < minDim;
+      const uint32_t voff = in ? ((uint32_t)(r_beg + t * TKR + g * 8) * ldMin4 + (uint32_t)(min0 + c4 * 4) * 4u) : OOB;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rn[i] = bload4(rsMin, voff + (uint32_t)i * ldMin4);
+    }
+  };
+  auto lstore = [&](int t) {
+    if (maj_act) store_task<AFFINE && A_MAJOR>(Maj, MAJ_EL, maj_off, rj, scj, shj);
+    const int mk = (w - t) & 3;
+    if (mk < MIN_TW) {
+      const int c4 = mk * 16 + (lane >> 2);
+      if (c4 * 4 < MIN_C) {
+        const int off = c4 * 4 * TCP + ((g ^ ((c4 ^ (c4 >> 1)) & 1)) << 3);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AFFINE && !A_MAJOR) {
+          const int cc = min(min0 + c4 * 4, Ka - 4);
+          sc = ld4(a_scale + cc);
+          sh = ld4(a_shift + cc);
+        }
+        store_task<AFFINE && !A_MAJOR>(Min, MIN_EL, off, rn, sc, sh);
+      }
+    }
+  };
+
+  const int rd_off = (lane & 15) * TCP + (((lane >> 4) ^ ((((lane & 15) >> 2) ^ ((lane & 15) >> 3)) & 1)) << 3);
+#define QAGNN_SIX(C, AF, BF)                                              \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
+
+  gload(0);
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    lstore(t);
+    __syncthreads();
+    gload(t + 1);  // in flight under the MFMAs; past the last tile: rows of the next chunk (or zeros), never stored
+    bf16x8 af[MT > 0 ? MT : 1][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (w + 4 * i) * 16 * TCP + rd_off);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + j * 16 * TCP + rd_off);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {  // small terms first
+        f32x4s c = acc[i][j];
+        QAGNN_SIX(c, af[i], bf)
+        acc[i][j] = c;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      const int q = w + 4 * s;  // wave-uniform
+      if (q < REM * NT) {
+        const int ir = q / NT, jr = q % NT;
+        bf16x8 ar[3], br[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          ar[p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (4 * MT + ir) * 16 * TCP + rd_off);
+          br[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + jr * 16 * TCP + rd_off);
+        }
+        f32x4s c = accr[s];
+        QAGNN_SIX(c, ar, br)
+        accr[s] = c;
+      }
+    }
+  }
+#undef QAGNN_SIX
+
+  float* const Pc = P + (int64_t)chunk * Ka * No;
+  auto put = [&](int strip, int j, const f32x4s& c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + strip * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
+      if (row < Ka && col < No) Pc[(int64_t)row * No + col] = c[r];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) put(w + 4 * i, j, acc[i][j]);
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    const int q = w + 4 * s;
+    if (q < REM * NT) put(4 * MT + q / NT, q % NT, accr[s]);
+  }
+}
+
+template <int KT, int NT, bool AFFINE>
+static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
+                             const float* sc, const float* sh, int chunk_rows) {
+  constexpr size_t lds = (size_t)3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t);
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (lds > 64 * 1024 && !raised[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KT, NT, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("gemm_tn_split: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
+    raised[dev & 63] = true;
+  }
+  k_gemm_tn_split<KT, NT, AFFINE><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
+  QAGNN_LAUNCH_CHECK("k_gemm_tn_split");
+  return QAGNN_OK;
+}
+
+// QAGNN_TN_SPLIT=0 pins the fp32-MFMA weight-gradient kernels of gemm.hip
+bool tn_split_ok(int R, int Ka, int No, int lda, int ldb) {
+  static const int v = getenv("QAGNN_TN_SPLIT") ? atoi(getenv("QAGNN_TN_SPLIT")) : 1;
+  const int64_t big = (int64_t)R * (lda > ldb ? lda : ldb) * 4;
+  return v != 0 && Ka >= 64 && No >= 104 && R >= 1024 && big < (int64_t)0x7FFFFFFF;  // 32-bit buffer offsets
+}
+static bool tn_split_wide_b(int Ka) { return Ka <= 112; }  // (KT, NT) = (7, 13), else (13, 7)
+// rows per split-K chunk: two blocks per CU, a multiple of the 32-row k-tile, never below `lo` (the workspace's sizing)
+int tn_split_chunk_rows(int R, int Ka, int No, int lo) {
+  const int ac = tn_split_wide_b(Ka) ? 112 : 208, bc = tn_split_wide_b(Ka) ? 208 : 112;
+  const int blocks_per_chunk = cdiv(No, bc) * cdiv(Ka, ac);
+  const int target = 2 * split_num_cus() / blocks_per_chunk;
+  const int rows = (cdiv(R, target > 0 ? target : 1) + TKR - 1) / TKR * TKR;
+  const int lo32 = (lo + TKR - 1) / TKR * TKR;
+  return rows > lo32 ? rows : lo32;
+}
+int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
+                    int chunk_rows, hipStream_t stream) {
+  if (tn_split_wide_b(Ka)) {
+    dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
+    return sc ? launch_tn_split_i<7, 13, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
+              : launch_tn_split_i<7, 13, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
+  }
+  dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
+  return sc ? launch_tn_split_i<13, 7, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
+            : launch_tn_split_i<13, 7, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
+}
+
 }  // namespace qagnn
 
 using namespace qagnn;

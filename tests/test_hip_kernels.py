@@ -154,7 +154,8 @@ def test_gemm_nn(M, K1, K2, No, variant, split):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('R,Ka,No', [(5000, 208, 208), (1030, 624, 208), (2049, 208, 624), (100, 112, 112), (64000, 208, 208), (7, 32, 96)])
+@pytest.mark.parametrize('R,Ka,No', [(5000, 208, 208), (1030, 624, 208), (2049, 208, 624), (100, 112, 112), (64000, 208, 208), (7, 32, 96),
+                                     (4100, 112, 624), (3000, 200, 204), (2080, 612, 208), (1500, 64, 104)])
 @pytest.mark.parametrize('affine', [False, True])
 def test_gemm_tn(R, Ka, No, affine):
     g = torch.Generator().manual_seed(R + Ka)
@@ -171,7 +172,9 @@ def test_gemm_tn(R, Ka, No, affine):
     for groups, ridx in ((1, None), (4, idx)):
         got2, cs = hip().gemm_tn(A.cuda(), B.cuda(), colsum_groups=groups, b_rowidx=None if ridx is None else ridx.cuda(),
                                  **{k: v.cuda() for k, v in kw.items()})
-        assert torch.equal(got2.cpu(), got), 'the by-product must not change the product'
+        # (the plain product may take the bf16-split kernel, the by-product variant always takes the fp32-MFMA one)
+        err2 = (got2.cpu().double() - ref).abs()
+        assert bool((err2 <= bound).all()), 'the by-product must not change the product'
         ref_cs = EMU.colsum(B.double(), ridx, groups)
         assert (cs.cpu().double() - ref_cs).abs().max().item() <= 8 * EPS * B.abs().sum(0).max().item() + 1e-6
 
