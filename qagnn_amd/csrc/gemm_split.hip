@@ -34,7 +34,7 @@ __device__ __forceinline__ void split3(float x, uint32_t& h1, uint32_t& h2, uint
   const float r1 = x - __builtin_bit_cast(float, h1);  // exact
   h2 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
   const float r2 = r1 - __builtin_bit_cast(float, h2);  // exact, <= 8 significant bits
-  h3 = __builtin_bit_cast(uint32_t, r2) & 0xFFFF0000u;
+  h3 = __builtin_bit_cast(uint32_t, r2);  // <= 8 significant bits: the low half is already zero
 }
 // two fp32 bit patterns whose low halves are zero -> one dword of two bf16 (element 0 = lo, in the low half)
 __device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
@@ -450,8 +450,12 @@ static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int 
 }
 
 // QAGNN_TN_SPLIT=0 pins the fp32-MFMA weight-gradient kernels of gemm.hip
-bool tn_split_ok(int R, int Ka, int No, int lda, int ldb) {
+static int tn_split_mode() {
   static const int v = getenv("QAGNN_TN_SPLIT") ? atoi(getenv("QAGNN_TN_SPLIT")) : 1;
+  return v;
+}
+bool tn_split_ok(int R, int Ka, int No, int lda, int ldb) {
+  const int v = tn_split_mode();
   const int64_t big = (int64_t)R * (lda > ldb ? lda : ldb) * 4;
   return v != 0 && Ka >= 64 && No >= 104 && R >= 1024 && big < (int64_t)0x7FFFFFFF;  // 32-bit buffer offsets
 }
