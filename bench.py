@@ -288,6 +288,11 @@ def main():
     share = os.environ.get('QAGNN_BENCH_SHARE_GPU') == '1'
     dev = torch.device('cuda', 0 if share else local_rank)
     torch.cuda.set_device(dev)
+    if share and world > 1:
+        # several processes time-slicing ONE GPU, each with its side streams, plus gloo's host-side waits: measured 1.5-4.8 s per
+        # collective after a step (profiles/r2_run50_mg_probe.txt); with one queue per process the rig behaves (12.6 ms per step)
+        ops.WGRAD_OVERLAP = False
+        ops.PREP_OVERLAP = False
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
