@@ -661,10 +661,13 @@ class HipKernels(metaclass=_GuardedMeta):
         ws = torch.empty(self.lib.qagnn_hop_fwd_workspace_elems(N, graph.Ep, DP), dtype=torch.float32, device=dev)
         hops = (qagnn_hop_args * k)()
         x = X
+        # addresses by arithmetic: a view tensor per pointer costs the host-bound batches ~0.3 ms per step
+        p_kmq, p_aa, p_rows, p_stats, row_b = KMQ.data_ptr(), aa.data_ptr(), rows.data_ptr(), stats.data_ptr(), N * DP * 4
         for l in range(k):
             h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
-            h.KMQ, h.a, h.alpha, h.stats = KMQ[l].data_ptr(), aa[l, 0].data_ptr(), aa[l, 1].data_ptr(), stats[l].data_ptr()
-            h.aggr, h.h1, h.out, h.y = rows[l, 0].data_ptr(), rows[l, 1].data_ptr(), rows[l, 2].data_ptr(), rows[l, 3].data_ptr()
+            h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
+            h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
+            h.aggr, h.h1, h.out, h.y = (p_rows + (4 * l + i) * row_b for i in range(4))
             if runnings[l] is not None:
                 rm, rv, nbt, pos, mom, _unb = runnings[l]
                 assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
@@ -697,25 +700,29 @@ class HipKernels(metaclass=_GuardedMeta):
         ws = torch.empty(self.lib.qagnn_hop_bwd_workspace_elems(N, graph.Ep, DP, SP, graph.max_chunks + CLS_SLICES * graph.C), dtype=torch.float32, device=dev)
         hops = (qagnn_hop_args * k)()
         grads = []
+        p_kmq, p_aa, p_rows, p_stats, row_b = KMQ.data_ptr(), aa.data_ptr(), rows.data_ptr(), stats.data_ptr(), N * DP * 4
+        p_flat, p_dxs = flat.data_ptr(), dxs.data_ptr()
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
         for l in range(k):
             x = X if l == 0 else rows[l - 1, 3]
             h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
-            h.KMQ, h.a, h.alpha, h.stats = KMQ[l].data_ptr(), aa[l, 0].data_ptr(), aa[l, 1].data_ptr(), stats[l].data_ptr()
-            h.aggr, h.h1, h.out, h.y = rows[l, 0].data_ptr(), rows[l, 1].data_ptr(), rows[l, 2].data_ptr(), rows[l, 2].data_ptr()
-            h.dy = dy.data_ptr() if l == k - 1 else dxs[l].data_ptr()
-            parts, off = [], l * per
-            for n in sizes:
-                parts.append(flat[off:off + n])
-                off += n
-            dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = parts
-            h.dWx_t, h.dTT, h.dEkEm, h.dW1t, h.db1 = dWx_t.data_ptr(), dTT.data_ptr(), dEkEm.data_ptr(), dW1t.data_ptr(), db1.data_ptr()
-            h.dbn, h.dW2t, h.db2 = dbn.data_ptr(), dW2t.data_ptr(), db2.data_ptr()
+            h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
+            h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
+            h.aggr, h.h1, h.out = (p_rows + (4 * l + i) * row_b for i in range(3))
+            h.y = h.out
+            h.dy = dy.data_ptr() if l == k - 1 else p_dxs + l * row_b
+            base = p_flat + l * per * 4
+            h.dWx_t, pdWs_t, h.dTT, h.dEkEm, h.dW1t, h.db1, h.dbn, h.dW2t, h.db2 = (base + o * 4 for o in offs[:9])
+            fl = flat[l * per:(l + 1) * per]
+            dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = fl.split(sizes)
             if l > 0:
-                h.dX, h.accumulate_dX = dxs[l - 1].data_ptr(), 0
+                h.dX, h.accumulate_dX = p_dxs + (l - 1) * row_b, 0
             elif dX is not None:
                 h.dX, h.accumulate_dX = dX.data_ptr(), (1 if dX_acc is not None else 0)
             if SP:
-                h.dWs_t = dWs_t.data_ptr()
+                h.dWs_t = pdWs_t
                 if dS is not None:
                     h.dS, h.accumulate_dS = dS.data_ptr(), (0 if l == k - 1 else 1)  # hop k-1's backward runs first
             h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
