@@ -18,7 +18,7 @@ if [[ "$*" == *kernels* ]]; then
   timeout 900 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider 2>&1 | tail -n 300 > gpurun_out/test_kernels.log
   echo "kernels exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   # the non-default GEMM launch shapes go through the same tests
-  for cfg in "QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0" "QAGNN_NN_PERSIST=2 QAGNN_TN_CHUNK=256" "QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=1"; do
+  for cfg in "QAGNN_NN_PERSIST=0 QAGNN_TN_STRIP=0 QAGNN_TN_SPLIT=0" "QAGNN_NN_PERSIST=2 QAGNN_TN_CHUNK=256 QAGNN_TN_SPLIT=0" "QAGNN_NN_PERSIST=1 QAGNN_NN_BLOCKS_PER_CU=1" "QAGNN_TN_SPLIT=0"; do
     env $cfg timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q --tb=short -rf --timeout 180 -p no:cacheprovider -k "gemm" 2>&1 | tail -n 40 >> gpurun_out/test_kernels_variants.log
     echo "kernels[$cfg] exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt
   done
