@@ -88,8 +88,12 @@ typedef struct qagnn_graph {
 } qagnn_graph;
 
 #define QAGNN_CLS_CHUNK 64
-#define QAGNN_CLS_SLICES 4   /* the class reduction sums a class's partials in this many independent slices first */
-#define QAGNN_CLS_GROUPS 64
+#ifndef QAGNN_CLS_SLICES
+#define QAGNN_CLS_SLICES 4   /* the class reduction sums a class's partials in this many independent slices first (1 / 2 / 4 / 8 / 16 measured: 0.318 / 0.298 / 0.293 / 0.296 / 0.306 ms) */
+#endif
+#ifndef QAGNN_CLS_GROUPS
+#define QAGNN_CLS_GROUPS 32 /* measured 16 / 32 / 64 / 128: backward edge stage 0.286 / 0.288 / 0.302 / 0.329 ms per layer at B = 320 */
+#endif
 
 /* int32 elements of device storage needed for all arrays of a qagnn_graph plus scratch. */
 int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T);

@@ -8,7 +8,7 @@ It is installed with qagnn_amd.ops.set_kernels() by tests and never imported by 
 import numpy as np
 import torch
 
-CLS_CHUNK, CLS_BLK, CLS_GROUPS = 64, 1024, 64  # QAGNN_CLS_CHUNK, CLS_BLK (graph_prep.hip), QAGNN_CLS_GROUPS
+CLS_CHUNK, CLS_BLK, CLS_GROUPS = 64, 1024, 32  # QAGNN_CLS_CHUNK, CLS_BLK (graph_prep.hip), QAGNN_CLS_GROUPS
 
 
 class EmuGraph:
