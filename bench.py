@@ -415,8 +415,7 @@ def main():
                               'timed_in': f'{GEMM_STEPS} extra steps after the timed region (HIP events around every launch)',
                               'note': 'fp32-equivalent FLOPs of all GEMM launches against the fp32-input MFMA peak.  The NN products run as six '
                                       'bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per product = one fp32 rounding; fp32-equivalent '
-                                      'ceiling 2500 / 6 = 417 TFLOP/s) unless QAGNN_GEMM_SPLIT=0, the weight-gradient (TN) products the same way with the tiles transposed into LDS unless QAGNN_TN_SPLIT=0 '
-                                      '(the 1024-wide gathered entity-table gradient stays on fp32-input MFMAs)'},
+                                      'ceiling 2500 / 6 = 417 TFLOP/s) unless QAGNN_GEMM_SPLIT=0, the weight-gradient (TN) products the same way with the tiles transposed into LDS unless QAGNN_TN_SPLIT=0'},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
                                       'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms / GEMM_STEPS, 3)},
         }

@@ -11,10 +11,10 @@ namespace qagnn {
 void set_error(const char* fmt, ...);
 
 // weight-gradient products on the bf16 matrix cores (gemm_split.hip), used by qagnn_gemm_tn_f32's dispatch in gemm.hip
-bool tn_split_ok(int R, int Ka, int No, int lda, int ldb);
+bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affine);
 int tn_split_chunk_rows(int R, int Ka, int No, int lo);
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    int chunk_rows, hipStream_t stream);
+                    const int64_t* a_rowidx, int chunk_rows, hipStream_t stream);
 
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \

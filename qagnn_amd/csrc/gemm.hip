@@ -777,13 +777,13 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
                 "gemm_tn: a_scale/a_shift must both be given and 16-byte aligned");
   QAGNN_REQUIRE(!bsum || (groups >= 1 && groups <= 4 && (groups == 1 || b_rowidx)), QAGNN_EINVAL, "gemm_tn: colsum groups=%d (1..4)", groups);
   const int nt = pick_nt(No);
-  const bool split = !bsum && !a_rowidx && tn_split_ok(R, Ka, No, lda, ldb);
+  const bool split = !bsum && tn_split_ok(R, Ka, No, lda, ldb, a_rowidx != nullptr, a_scale != nullptr);
   const bool strip = nt == 13 && tn_strip_enabled() && tn_strip_ok(Ka);
   const int crows = split ? tn_split_chunk_rows(R, Ka, No, tn_min_chunk(R)) : pick_tn_chunk_rows(R, Ka, No, nt);
   const int nchunks = cdiv(R, crows);
   float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;
-  if (split) rc = launch_tn_split(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, crows, stream);
+  if (split) rc = launch_tn_split(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, stream);
   else if (strip) rc = launch_tn_strip(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream);
   else switch (nt) {
     case 13: rc = launch_tn<13>(A, lda, B, ldb, workspace, R, Ka, No, a_scale, a_shift, a_rowidx, crows, Pcs, b_rowidx, groups, stream); break;

@@ -281,10 +281,12 @@ __device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_e
   }
 }
 
-template <int KT, int NT, bool AFFINE>
+// GATHER: row r of A is A[a_rowidx[r]] (negative = zero row): the frozen entity table under cpt_transform's weight gradient.  The
+// table can exceed 2 GB, so these rows come through 64-bit flat loads; their indices are fetched one tile ahead, behind the stores.
+template <int KT, int NT, bool AFFINE, bool GATHER>
 __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_split(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
-    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows) {
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const int64_t* __restrict__ a_rowidx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
   constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
   constexpr int MT = KT / 4, REM = KT % 4, RS = (REM * NT + 3) / 4;  // full strips per wave; leftover strips, shared tile by tile
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
 
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, R * lda * 4, 0x00020000);
+  static_assert(!GATHER || A_MAJOR, "the gathered operand is handled as the wide one");
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, GATHER ? 0 : R * lda * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, R * ldb * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsMaj = A_MAJOR ? rsA : rsB, rsMin = A_MAJOR ? rsB : rsA;
   const int maj0 = A_MAJOR ? m0 : n0, min0 = A_MAJOR ? n0 : m0, majDim = A_MAJOR ? Ka : No, minDim = A_MAJOR ? No : Ka;
@@ -331,10 +334,30 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   for (int q = 0; q < RS; ++q) accr[q] = (f32x4s){0.f, 0.f, 0.f, 0.f};
 
   float4 rj[8], rn[8];
-  auto gload = [&](int t) {
+  int gi[GATHER ? 8 : 1];  // table rows of this thread's 8 rows of the NEXT tile to load (-1: zero row / past R / idle lane)
+  const float* const Acol = A + min(maj0 + c4j * 4, Ka - 4);
+  auto gidx = [&](int t) {
+    if constexpr (GATHER) {
+      const int r0 = r_beg + t * TKR + g * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rj[i] = bload4(rsMaj, maj_voff + (uint32_t)i * ldMaj4);
-    maj_voff += maj_in ? (uint32_t)TKR * ldMaj4 : 0u;
+      for (int i = 0; i < 8; ++i) {
+        const int64_t v = a_rowidx[min(r0 + i, R - 1)];
+        gi[i] = (maj_in && r0 + i < R && v >= 0) ? (int)v : -1;
+      }
+    }
+  };
+  auto gload = [&](int t) {
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = ld4(Acol + (int64_t)max(gi[i], 0) * lda);
+        rj[i] = gi[i] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rj[i] = bload4(rsMaj, maj_voff + (uint32_t)i * ldMaj4);
+      maj_voff += maj_in ? (uint32_t)TKR * ldMaj4 : 0u;
+    }
     const int mk = (w - t) & 3;  // this tile's minor task-wave of this wave (wave-uniform)
     if (mk < MIN_TW) {
       const int c4 = mk * 16 + (lane >> 2);
@@ -371,10 +394,12 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
 
+  gidx(0);
   gload(0);
   for (int t = 0; t < ntile; ++t) {
     __syncthreads();  // the previous tile's fragment reads are done
     lstore(t);
+    gidx(t + 1);
     __syncthreads();
     gload(t + 1);  // in flight under the MFMAs; past the last tile: rows of the next chunk (or zeros), never stored
     bf16x8 af[MT > 0 ? MT : 1][3];
@@ -432,19 +457,19 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 }
 
-template <int KT, int NT, bool AFFINE>
+template <int KT, int NT, bool AFFINE, bool GATHER = false>
 static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
-                             const float* sc, const float* sh, int chunk_rows) {
+                             const float* sc, const float* sh, int chunk_rows, const int64_t* ridx = nullptr) {
   constexpr size_t lds = (size_t)3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t);
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (lds > 64 * 1024 && !raised[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KT, NT, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KT, NT, AFFINE, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("gemm_tn_split: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_split<KT, NT, AFFINE><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
+  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_split");
   return QAGNN_OK;
 }
@@ -454,9 +479,10 @@ static int tn_split_mode() {
   static const int v = getenv("QAGNN_TN_SPLIT") ? atoi(getenv("QAGNN_TN_SPLIT")) : 1;
   return v;
 }
-bool tn_split_ok(int R, int Ka, int No, int lda, int ldb) {
+bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affine) {
   const int v = tn_split_mode();
-  const int64_t big = (int64_t)R * (lda > ldb ? lda : ldb) * 4;
+  const int64_t big = (int64_t)R * ((lda > ldb && !gather) ? lda : ldb) * 4;  // (a gathered A goes through flat loads)
+  if (gather && (Ka <= 112 || affine)) return false;
   return v != 0 && Ka >= 64 && No >= 104 && R >= 1024 && big < (int64_t)0x7FFFFFFF;  // 32-bit buffer offsets
 }
 static bool tn_split_wide_b(int Ka) { return Ka <= 112; }  // (KT, NT) = (7, 13), else (13, 7)
@@ -470,7 +496,11 @@ int tn_split_chunk_rows(int R, int Ka, int No, int lo) {
   return rows > lo32 ? rows : lo32;
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    int chunk_rows, hipStream_t stream) {
+                    const int64_t* ridx, int chunk_rows, hipStream_t stream) {
+  if (ridx) {
+    dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
+    return launch_tn_split_i<13, 7, false, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
+  }
   if (tn_split_wide_b(Ka)) {
     dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
     return sc ? launch_tn_split_i<7, 13, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
