@@ -61,6 +61,17 @@ __device__ __forceinline__ int swz(int row, int k) {
   return row * SBK + ((((k >> 3) ^ g) & 3) << 3) + (k & 7);
 }
 
+// QAGNN_NN_TRACE (tools/nn_trace.hip only): cycle stamps of one block's waves at the phase boundaries of every k-tile
+#ifdef QAGNN_NN_TRACE
+__device__ unsigned long long g_nn_trace[4][40][7];
+#define NN_STAMP(kt, ph)                                                                                                   \
+  do {                                                                                                                     \
+    if (blockIdx.x == QAGNN_NN_TRACE && vb == (int)blockIdx.x && lane == 0 && (kt) < 40) g_nn_trace[w][kt][ph] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define NN_STAMP(kt, ph)
+#endif
+
 template <int NT, bool AFFINE>
 __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn_split(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
                                                                                            int ldn1, const float* __restrict__ B2n,
@@ -144,10 +155,19 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
     gload(0);
     for (int kt = 0; kt < nkt; ++kt) {
+      NN_STAMP(kt, 0);
       __syncthreads();  // the previous tile's fragment reads (or the previous output tile's slab reads) are done
+      NN_STAMP(kt, 1);
+#ifdef QAGNN_NN_TRACE
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tile's global loads have landed (separates their latency from the split)
+      NN_STAMP(kt, 6);
+#endif
       lstore(kt);
+      NN_STAMP(kt, 2);
       __syncthreads();
+      NN_STAMP(kt, 3);
       gload(min(kt + 1, nkt - 1));  // in flight under the MFMAs; past the last tile: a redundant reload, never stored
+      NN_STAMP(kt, 4);
       bf16x8 af[SRT][3];
 #pragma unroll
       for (int i = 0; i < SRT; ++i)
@@ -171,6 +191,7 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           acc[i][j] = c;
         }
       }
+      NN_STAMP(kt, 5);
     }
 
     // epilogue: transpose 16 rows at a time through the wave's LDS slab, then whole-row 16-byte stores (as k_gemm_nn)
