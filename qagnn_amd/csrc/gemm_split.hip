@@ -25,6 +25,12 @@ namespace qagnn {
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+// 16-byte load through a buffer descriptor: per-lane byte offset + wave-uniform byte offset; out of range reads return zeros
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff = 0) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
 
 constexpr int SBK = 32, SBM = 128, SWAVES = 4, SRT = 2, STHR = SWAVES * 64;
 
@@ -72,7 +78,11 @@ __device__ unsigned long long g_nn_trace[4][40][7];
 #define NN_STAMP(kt, ph)
 #endif
 
-template <int NT, bool AFFINE>
+// FLAT: operands addressed with 64-bit pointers (row gather through a_rowidx, or an operand of 2 GB and more); otherwise every
+// load goes through a buffer descriptor: per-thread 32-bit row offsets fixed per output tile, the k position as the instruction's
+// scalar offset, rows past M / columns past No / k past K answered with zeros by the bounds check -- the 64-bit address arithmetic
+// and the zeroing selects were 100 of the 468 VALU instructions per wave and k-tile (profiles/r2_run57_nn_trace.txt).
+template <int NT, bool AFFINE, bool FLAT>
 __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn_split(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
                                                                                            int ldn1, const float* __restrict__ B2n,
                                                                                            int ldn2, int ntiles) {
@@ -107,9 +117,29 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       arow[p] = row < a.M ? (a.a_rowidx ? a.a_rowidx[row] : (int64_t)row) : -1;
     }
     float4 ra[A_IT], rb[B_IT];
-    // unconditional loads from clamped addresses (branches around loads make hipcc fall back to vmcnt(0)); what lies past the
+    constexpr uint32_t OOB = 0x80000000u;
+    auto gload_buf = [&](int kt) {
+      const bool first = kt < nk1;
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? a.A1 : a.A2), 0, a.M * (first ? a.lda1 : a.lda2) * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? B1n : B2n), 0, a.No * (first ? ldn1 : ldn2) * 4, 0x00020000);
+      const uint32_t lda4 = (uint32_t)(first ? a.lda1 : a.lda2) * 4u, ldn4 = (uint32_t)(first ? ldn1 : ldn2) * 4u;
+      const int K = first ? a.K1 : a.K2, kb = (first ? kt : kt - nk1) * SBK;
+      const uint32_t kofs = (kb + kq * 4 < K) ? (uint32_t)kq * 16u : OOB;  // k past K: the whole float4 is outside (K % 4 == 0)
+      const uint32_t soff = (uint32_t)kb * 4u;
+#pragma unroll
+      for (int p = 0; p < A_IT; ++p) {
+        const int row = m0 + lr + p * 32;
+        ra[p] = bload4(rA, (row < a.M ? (uint32_t)row * lda4 : OOB) + kofs, soff);
+      }
+#pragma unroll
+      for (int q = 0; q < B_IT; ++q) {
+        const int col = n0 + lr + q * 32;
+        rb[q] = bload4(rB, (col < a.No ? (uint32_t)col * ldn4 : OOB) + kofs, soff);
+      }
+    };
+    // FLAT: unconditional loads from clamped addresses (branches around loads make hipcc fall back to vmcnt(0)); what lies past the
     // operand -- rows >= M, columns >= No, k >= K -- is zeroed with selects when the tile goes to LDS
-    auto gload = [&](int kt) {
+    auto gload_flat = [&](int kt) {
       const bool first = kt < nk1;
       const float* A = first ? a.A1 : a.A2;
       const float* Bn = first ? B1n : B2n;
@@ -122,6 +152,10 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       }
 #pragma unroll
       for (int q = 0; q < B_IT; ++q) rb[q] = ld4(Bn + (int64_t)min(n0 + lr + q * 32, a.No - 1) * ldn + kc);
+    };
+    auto gload = [&](int kt) {
+      if constexpr (FLAT) gload_flat(kt);
+      else gload_buf(kt);
     };
     auto lstore = [&](int kt) {
       const bool first = kt < nk1;
@@ -139,15 +173,17 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
           v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
         }
-        const bool ok = kin && (!first || arow[p] >= 0) && (first || m0 + lr + p * 32 < a.M);
-        v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FLAT) {
+          const bool ok = kin && (!first || arow[p] >= 0) && (first || m0 + lr + p * 32 < a.M);
+          v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }  // (buffer loads: zeros already; under AFFINE an out-of-range k leaves relu(shift) here, multiplied by B's zeros)
         store_split(As, A_EL, swz(lr + p * 32, kl), v);
       }
 #pragma unroll
       for (int q = 0; q < B_IT; ++q) {
         const int col = lr + q * 32;
         if (col < BN) {
-          const float4 v = (kin && n0 + col < a.No) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 v = (!FLAT || (kin && n0 + col < a.No)) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
           store_split(Bs, B_EL, swz(col, kl), v);
         }
       }
@@ -240,8 +276,17 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
   const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, SBM);
   const int cap = (split_num_cus() * 2) & ~7;
   const int grid = ntiles < cap ? ntiles : cap;
-  if (a.a_scale) k_gemm_nn_split<NT, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
-  else k_gemm_nn_split<NT, false><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  const int64_t lim = (int64_t)0x7FFFFFFF;
+  static const int force_flat = getenv("QAGNN_NN_FLAT") ? atoi(getenv("QAGNN_NN_FLAT")) : 0;  // 1 = the 64-bit-pointer loads everywhere (A/B switch)
+  const bool flat = force_flat || a.a_rowidx || (int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.M * a.lda2 * 4 >= lim ||
+                    (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim;
+  if (flat) {
+    if (a.a_scale) k_gemm_nn_split<NT, true, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+    else k_gemm_nn_split<NT, false, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  } else {
+    if (a.a_scale) k_gemm_nn_split<NT, true, false><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+    else k_gemm_nn_split<NT, false, false><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  }
   QAGNN_LAUNCH_CHECK("k_gemm_nn_split");
   return QAGNN_OK;
 }
@@ -267,11 +312,6 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
 // registers across the column loop); the tiles of the KT%4 leftover strips are dealt out one by one (tile q -> wave q % 4).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TKR = 32, TCP = 40, TTHR = 256;
-typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff) {
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
-}
 
 // 8 rows of one column -> three 16-byte chunks
 __device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_elems, const float (&x)[8]) {
