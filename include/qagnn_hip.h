@@ -324,9 +324,12 @@ int qagnn_stack_bwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t st
  *                                                                   divide by the mean |.| over the adj_len real nodes + 1e-5)
  *   modeling_qagnn.py:173-177  pooling mask                      -> mask [B][n] (uint8: PAD or context node; slot 0 cleared when
  *                                                                   every slot would be masked)
- * raw_scores [B][n] fp32, adj_len [B], node_type [B][n], concept_ids [B][n] int64 as the reference holds them. */
+ * raw_scores [B][n] fp32, adj_len [B], node_type [B][n], concept_ids [B][n] int64 as the reference holds them.
+ * table_rows > 0: ids outside [1, table_rows] in the slots 1.. (the reference's nn.Embedding raises on them) become the zero row (-1)
+ * and set err[0] = 1 (err may be NULL; the caller zeroes it). */
 int qagnn_node_prep_f32(const float* raw_scores, const int64_t* adj_len, const int64_t* node_type, const int64_t* concept_ids,
-                        int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, qagnn_stream_t stream);
+                        int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, int64_t table_rows, int32_t* err,
+                        qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused multi-tensor RAdam step.  Replaces the per-parameter Python loop of

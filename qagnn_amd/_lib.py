@@ -25,7 +25,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 9  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32)
+ABI_VERSION = 10  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -73,7 +73,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_prep.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
-    lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]
+    lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
     lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp] + [C.c_double] * 6 + [_i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_nn_split_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp]
@@ -139,30 +139,34 @@ class _ErrWatch:
     def __init__(self):
         self.pending = []
 
-    def watch(self, flags, what):
+    def watch(self, flags, what, reset=None):
+        """`reset`: a persistent flag tensor to clear once its error has been reported (per-call flag arrays need none)."""
         if torch.cuda.is_current_stream_capturing():
             return
         host = torch.empty(4, dtype=torch.int32, pin_memory=True)
         host.copy_(flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((ev, host, what))
+        self.pending.append((ev, host, what, reset))
         if VALIDATE:
             self.poll(block=True)
 
     def poll(self, block=False):
         keep, bad = [], None
-        for ev, host, what in self.pending:
+        for ev, host, what, reset in self.pending:
             if block:
                 ev.synchronize()
             if not ev.query():
-                keep.append((ev, host, what))
-            elif int(host[0]) != 0 and bad is None:
-                bad = what
+                keep.append((ev, host, what, reset))
+            elif int(host[0]) != 0:
+                if reset is not None:
+                    reset.zero_()
+                if bad is None:
+                    bad = what
         self.pending = keep
         if bad is not None:
-            raise RuntimeError(f'qagnn_graph_prep: out-of-range edge endpoint / relation id / node type in {bad} '
-                               '(the device clamped it; the results of that batch are not the reference\'s)')
+            raise RuntimeError(f'out-of-range input in {bad}: the device replaced it by a safe value; the results of that batch '
+                               'are not the reference\'s (which raises in its one-hot / index ops)')
 
 
 ERR_WATCH = _ErrWatch()
@@ -253,6 +257,7 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
+        self._np_flags = {}  # per device: the persistent validation flag of node_prep
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -283,7 +288,7 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(rc, 'qagnn_graph_prep_blocked')
         G = HipGraph(storage, g, N, E, n_etype, n_ntype, int(block_n))
         ERR_WATCH.poll()  # flags of earlier batches that have landed since
-        ERR_WATCH.watch(G.array('err', 4), f'the batch with N={N} node rows, E={E} edges')
+        ERR_WATCH.watch(G.array('err', 4), f'the graph of the batch with N={N} node rows, E={E} edges (edge endpoint / relation id / node type)')
         return G
 
     def graph_from_blobs(self, packed, node_type):
@@ -303,11 +308,13 @@ class HipKernels(metaclass=_GuardedMeta):
         G.keep = packed.buf  # the blobs are read by the kernel just enqueued
         G.max_sub_ep = packed.max_sub_ep  # host-side bound on E_g + n per subgraph: sizes the LDS of the edge kernels
         ERR_WATCH.poll()
-        ERR_WATCH.watch(G.array('err', 4), f'the blob batch with B={B} samples, E={E} edges')
+        ERR_WATCH.watch(G.array('err', 4), f'the graph of the blob batch with B={B} samples, E={E} edges (edge endpoint / relation id / node type)')
         return G
 
-    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids):
-        """-> (normalised scores [B, n] fp32, pooling mask [B, n] bool, entity-table row ids [B*n] int64); qagnn_node_prep_f32."""
+    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids, table_rows=0):
+        """-> (normalised scores [B, n] fp32, pooling mask [B, n] bool, entity-table row ids [B*n] int64); qagnn_node_prep_f32.
+        table_rows > 0: concept ids outside the entity table become the zero row and are reported through ERR_WATCH (the
+        reference's nn.Embedding raises on them)."""
         B, n = node_type_ids.shape
         raw = node_scores.reshape(B, n).float().contiguous()  # the reference computes the normalisation in fp32 (qagnn.py: fp32 inputs)
         assert raw.dtype == torch.float32 and raw.is_contiguous() and adj_lengths.dtype == torch.long and adj_lengths.is_contiguous()
@@ -316,9 +323,16 @@ class HipKernels(metaclass=_GuardedMeta):
         score = torch.empty((B, n), dtype=torch.float32, device=dev)
         mask = torch.empty((B, n), dtype=torch.bool, device=dev)
         ridx = torch.empty(B * n, dtype=torch.long, device=dev)
+        flags = None
+        if table_rows > 0:
+            flags = self._np_flags.get(dev)
+            if flags is None:
+                flags = self._np_flags[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
         rc = self.lib.qagnn_node_prep_f32(raw.data_ptr(), adj_lengths.data_ptr(), node_type_ids.data_ptr(), concept_ids.data_ptr(), B, n,
-                                          score.data_ptr(), mask.data_ptr(), ridx.data_ptr(), self._stream())
+                                          score.data_ptr(), mask.data_ptr(), ridx.data_ptr(), int(table_rows), _ptr(flags), self._stream())
         self._check(rc, 'qagnn_node_prep_f32')
+        if flags is not None:
+            ERR_WATCH.watch(flags, 'concept_ids (an id outside the entity table)', reset=flags)
         return score, mask, ridx
 
     def radam_step(self, params, grads, exp_avgs, exp_avg_sqs, beta1, beta2, eps, lr, weight_decay, step_size, mode):

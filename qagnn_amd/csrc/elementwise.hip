@@ -391,7 +391,8 @@ extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, fl
 namespace qagnn {
 __global__ __launch_bounds__(256) void k_node_prep(const float* __restrict__ raw, const int64_t* __restrict__ adj_len,
                                                    const int64_t* __restrict__ node_type, const int64_t* __restrict__ concept_ids, int n,
-                                                   float* __restrict__ score, uint8_t* __restrict__ mask, int64_t* __restrict__ ridx) {
+                                                   float* __restrict__ score, uint8_t* __restrict__ mask, int64_t* __restrict__ ridx,
+                                                   int64_t table_rows, int32_t* __restrict__ err) {
   __shared__ double wsum[4];
   __shared__ int wall[4];
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -417,15 +418,21 @@ __global__ __launch_bounds__(256) void k_node_prep(const float* __restrict__ raw
     score[i] = d / denom;
     const bool m = v >= len || node_type[i] == 3;
     mask[i] = (v == 0 && all_masked) ? 0 : (m ? 1 : 0);
-    ridx[i] = v == 0 ? -1 : concept_ids[i] - 1;
+    int64_t r = v == 0 ? -1 : concept_ids[i] - 1;
+    if (table_rows > 0 && v != 0 && (r < 0 || r >= table_rows)) {  // nn.Embedding raises on such an id (utils/layers.py:604); here: zero row + flag
+      r = -1;
+      if (err) err[0] = 1;
+    }
+    ridx[i] = r;
   }
 }
 }  // namespace qagnn
 
 extern "C" int qagnn_node_prep_f32(const float* raw_scores, const int64_t* adj_len, const int64_t* node_type, const int64_t* concept_ids,
-                                   int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, qagnn_stream_t stream_) {
+                                   int32_t B, int32_t n, float* score, uint8_t* mask, int64_t* ridx, int64_t table_rows, int32_t* err,
+                                   qagnn_stream_t stream_) {
   QAGNN_REQUIRE(raw_scores && adj_len && node_type && concept_ids && score && mask && ridx && B > 0 && n > 0, QAGNN_EINVAL, "node_prep: bad arguments");
-  qagnn::k_node_prep<<<B, 256, 0, (hipStream_t)stream_>>>(raw_scores, adj_len, node_type, concept_ids, n, score, mask, ridx);
+  qagnn::k_node_prep<<<B, 256, 0, (hipStream_t)stream_>>>(raw_scores, adj_len, node_type, concept_ids, n, score, mask, ridx, table_rows, err);
   QAGNN_LAUNCH_CHECK("k_node_prep");
   return QAGNN_OK;
 }

@@ -496,7 +496,7 @@ class QAGNN(nn.Module):
         # built without boolean-mask indexing: `mask[mask.all(1), 0] = 0` makes the host wait for the whole GNN forward (nonzero()
         # synchronises) and lets the GPU idle while the backward is launched.
         node_scores, mask, ridx = ops.kernels().node_prep(node_scores.contiguous(), adj_lengths.contiguous(), node_type_ids,
-                                                          concept_ids.contiguous())
+                                                          concept_ids.contiguous(), table_rows=ce.emb.weight.size(0) if fused_input else 0)
         node_scores = node_scores.unsqueeze(2)
         if fused_input:
             # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout; context-node rows

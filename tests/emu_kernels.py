@@ -116,8 +116,11 @@ class EmuKernels:
             grads[l] = r[2:]
         return dy, dS, grads
 
-    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids):
+    def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids, table_rows=0):
         B, n = node_type_ids.shape
+        if table_rows > 0:
+            bad = (concept_ids[:, 1:] < 1) | (concept_ids[:, 1:] > table_rows)
+            assert not bool(bad.any()), 'concept id outside the entity table (the reference raises in nn.Embedding)'
         ar = torch.arange(n, device=node_type_ids.device)
         real = (ar < adj_lengths.unsqueeze(1)).to(node_scores.dtype)
         s = -node_scores.reshape(B, n)

@@ -629,3 +629,23 @@ def test_node_prep_matches_the_reference_ops(case):
     score, mask, ridx = hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), cids.cuda())
     assert torch.equal(mask.cpu(), mask_e) and torch.equal(ridx.cpu(), ridx_e) and not bool(mask_e[0, 0]) and bool(mask_e[0, 1:].all())
     assert torch.equal(score.cpu(), score_e), (score.cpu() - score_e).abs().max()
+    # concept ids outside the entity table: nn.Embedding raises in the reference; here they become the zero row (no out-of-bounds
+    # gather) and the error surfaces through ERR_WATCH like the graph-preparation flag
+    from qagnn_amd import _lib
+    _lib.ERR_WATCH.poll(block=True)
+    rows = int(cids.max())                     # a table that just holds every id of the batch
+    _, _, ridx_ok = hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), cids.cuda(), table_rows=rows)
+    _lib.ERR_WATCH.poll(block=True)            # nothing to report
+    assert torch.equal(ridx_ok.cpu(), ridx_e)
+    bad = cids.clone()
+    bad[1, 3] = rows + 1
+    bad[2, 5] = 0
+    _, _, ridx_bad = hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), bad.cuda(), table_rows=rows)
+    want = ridx_e.clone().view(B, n)
+    want[1, 3] = -1
+    want[2, 5] = -1
+    assert torch.equal(ridx_bad.cpu().view(B, n), want)
+    with pytest.raises(RuntimeError, match='out-of-range input in concept_ids'):
+        _lib.ERR_WATCH.poll(block=True)
+    hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), cids.cuda(), table_rows=rows)
+    _lib.ERR_WATCH.poll(block=True)            # the persistent flag was cleared when its error was reported
