@@ -4,14 +4,15 @@
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
 with torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1], synthetic stand-in of SURVEY.md 8(d)): CommonsenseQA-shaped batch of 64 questions
+Headline workload (BASELINE.json configs[1], synthetic stand-in of SURVEY.md 8(d)): CommonsenseQA-shaped batch of 64 questions
 x 5 choices = 320 subgraphs per GPU, n = 200 node slots, 40..199 concepts and 400..2000 directed edges per subgraph,
 38 relation types, 5 GAT layers, d = 200, 4 heads, sent_dim = concept_in_dim = 1024, frozen 100 000 x 1024 entity
 table, dropout 0.2 everywhere (the reference's run-script values), train-mode BatchNorm, fp32.  The LM encoder is
 outside the metric (north_star): `sent_vecs` is a random [B, 1024] tensor.  All inputs are resident in HBM before
-the timed region.  One step = zero_grad + QAGNN.forward + cross-entropy over the 5 choices + backward; with N > 1
+the timed region.  One step = zero_grad + QAGNN.forward + cross-entropy over the choices + backward; with N > 1
 every rank runs its own 64 questions (weak scaling) and the step additionally all-reduces the decoder gradients and
-all-gathers the logits over RCCL.
+all-gathers the logits over RCCL.  `value` is the MEDIAN of `repeats` (default 3) back-to-back timed regions of exactly K steps
+each (each bracketed by barrier + synchronize, max over ranks); all regions are listed in `repeat_ms_per_step`.
 
 Extra objects on the JSON line:
   roofline     the edge stage of GATConvE forward (qagnn_edge_attn_fwd_f32: scores + segment softmax + aggregate), one launch
@@ -25,9 +26,20 @@ Extra objects on the JSON line:
                profiles/pmc_edge_fwd.json is then quoted and labelled as such).  The ALGORITHMIC figure of SURVEY.md 8(d)
                (E'*2410 + N*800: every per-edge row gather priced as memory traffic) is reported next to it as
                `algorithmic_bytes_per_launch` / `achieved_algorithmic`; L1/L2 serve the re-reads, so it is not an HBM fraction.
-  cpu_baseline the CPU oracle (reference formulation, torch CPU) on a bounded sample of the same workload (B = 10 subgraphs =
+  roofline_mfma  all GEMM launches of a step against BOTH ceilings: the fp32-input MFMA peak (157.3 TFLOP/s) and the
+               fp32-equivalent ceiling of the exact 3 x bf16 split the kernels actually run (2500 / 6 = 417 TFLOP/s).
+  configs      the other single-GPU configurations of BASELINE.json on the same line: configs[0] (B = 5, n = 100, e = 800),
+               configs[2] (OpenBookQA 128 x 4 = 512 subgraphs), the per-GPU MedQA-USMLE shard of configs[4] (16 questions x 4 =
+               64 subgraphs, 34 relations, ~3 k-edge graphs, no node scores, 768-d SapBERT table): value, ms_per_step, the
+               edge-forward and GEMM time per step, whether the step is bound by the host, and the CPU oracle on two questions of
+               the same shape beside the GPU on those same two questions.
+  cpu_baseline the CPU oracle (reference formulation, torch CPU) on a bounded sample of the headline workload (B = 10 subgraphs =
                the reference's own mini-batch of 2 questions), fwd+bwd; `small_batch` is the GPU on that SAME batch size, so
                `speedup_vs_cpu_baseline_same_batch` compares like with like (the headline `value` is at B = 320).
+  N > 1:       `comm_ms_per_step` (gradient all-reduce + logits all-gather, HIP events on the compute stream around the
+               collectives), `rank_ms_per_step` (min / max over ranks of each rank's own time for the median region).
+               `--global-batch Q` switches to STRONG scaling: one global batch of Q questions with skewed subgraph sizes, dealt out to
+               the ranks by parallel.balance_questions (sum of E'_g per rank), variable-size logits gather, question order restored.
 """
 import argparse
 import json
@@ -43,30 +55,53 @@ sys.path.insert(0, ROOT)
 from qagnn_amd import data_utils, ops, parallel, synthetic  # noqa: E402
 from qagnn_amd import modeling_qagnn as MQ  # noqa: E402
 
-D, K_LAYERS, N_ETYPE, N_NTYPE, SENT_DIM, CONCEPT_IN, N_NODE, NC = 200, 5, 38, 4, 1024, 1024, 200, 5
+D, K_LAYERS, N_NTYPE = 200, 5, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz (v_mfma_f32_16x16x4_f32: 32 cyc/SIMD)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak; an exact fp32 product costs six bf16 MFMAs -> 417 TFLOP/s fp32-equivalent
+
+# BASELINE.json configurations that fit one GPU.  `questions` x `nc` = subgraphs per GPU.
+WORKLOADS = {
+    'configs[1]': dict(shape='csqa', nc=5, n=200, n_rel=17, n_etype=38, sent_dim=1024, concept_in=1024, questions=64,
+                       what='CSQA-shaped batch 64 questions x 5 choices = 320 subgraphs per GPU, n=200 node slots, 400..2000 edges/subgraph, '
+                            '38 relations (run_qagnn__csqa.sh)'),
+    'configs[0]': dict(shape='config1', nc=5, n=100, n_rel=17, n_etype=38, sent_dim=1024, concept_in=1024, questions=1,
+                       what='synthetic CSQA-shaped subgraphs: 1 question x 5 choices, 100 nodes, 800 edges each, 38 relations (SURVEY 8d config 1)'),
+    'configs[2]': dict(shape='csqa', nc=4, n=200, n_rel=17, n_etype=38, sent_dim=1024, concept_in=1024, questions=128,
+                       what='OpenBookQA-shaped batch 128 questions x 4 choices = 512 subgraphs, n=200, 400..2000 edges/subgraph (run_qagnn__obqa.sh:16)'),
+    'configs[4]/gpu': dict(shape='medqa', nc=4, n=200, n_rel=15, n_etype=34, sent_dim=768, concept_in=768, questions=16,
+                           what='MedQA-USMLE per-GPU shard of 128 x 4 over 8 GPUs: 16 questions x 4 = 64 subgraphs, 34 relations, ~3 k-edge '
+                                'graphs, no node scores, 768-d SapBERT table and sentence vectors (run_qagnn__medqa_usmle.sh:16-21)'),
+}
+HEADLINE = 'configs[1]'
 
 
-def make_batch(n_questions, seed, n_concept):
-    recs = synthetic.make_records(n_questions * NC, seed=seed, shape='csqa', n_concept_vocab=n_concept)
-    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, N_NODE, NC)
-    bei, bet = data_utils.batch_graph(ei, et, N_NODE)
+def make_batch(wl, questions, seed, n_concept, zipf=False):
+    nc, n = wl['nc'], wl['n']
+    recs = synthetic.make_records(questions * nc, seed=seed, shape=wl['shape'], n_rel=wl['n_rel'], n_concept_vocab=n_concept, zipf=zipf)
+    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, nc)
+    return batch_from_lists(wl, cids, nt, ns, al, ei, et, seed)
+
+
+def batch_from_lists(wl, cids, nt, ns, al, ei, et, seed):
+    nc, n = wl['nc'], wl['n']
+    questions = cids.size(0) // nc
+    bei, bet = data_utils.batch_graph(ei, et, n)
     g = torch.Generator().manual_seed(seed + 1)
-    sent = torch.randn(n_questions * NC, SENT_DIM, generator=g)
-    labels = torch.randint(0, NC, (n_questions,), generator=g)
+    sent = torch.randn(questions * nc, wl['sent_dim'], generator=g)
+    labels = torch.randint(0, nc, (questions,), generator=g)
     # the same graph as load-time blobs (qagnn_amd.data_utils.GraphBlobStore): what the batch generator ships to the device
-    store = data_utils.GraphBlobStore.build(ei, et, nt, N_ETYPE, N_NTYPE)
+    store = data_utils.GraphBlobStore.build(ei, et, nt, wl['n_etype'], N_NTYPE)
     ids = list(range(len(store)))
     buf, B, E = store.pack(ids)
     return dict(sent=sent, cids=cids, nt=nt, ns=ns, al=al, ei=bei, et=bet, labels=labels, blobs=buf, blob_meta=(B, E, store, ids))
 
 
-def build_model(cls_module, n_concept, p=0.2, seed=0):
+def build_model(cls_module, wl, n_concept, p=0.2, seed=0):
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(1234)
-    table = torch.randn(n_concept, CONCEPT_IN, generator=g) * 0.1
-    model = cls_module.QAGNN(None, K_LAYERS, N_NTYPE, N_ETYPE, SENT_DIM, n_concept, D, CONCEPT_IN, 2, 200, 0, p, p, p,
+    table = torch.randn(n_concept, wl['concept_in'], generator=g) * 0.1
+    model = cls_module.QAGNN(None, K_LAYERS, N_NTYPE, wl['n_etype'], wl['sent_dim'], n_concept, D, wl['concept_in'], 2, 200, 0, p, p, p,
                              pretrained_concept_emb=table, freeze_ent_emb=True, init_range=0.02)
     # init_range=0.02 re-initialises the embedding too (reference _init_weights quirk); restore the "pretrained" table
     model.concept_emb.emb.weight.data.copy_(table)
@@ -79,11 +114,14 @@ class TimedKernels:
     def __init__(self, inner, names, work=None):
         self._inner, self._names = inner, set(names)
         self.name = inner.name
-        self.events = {n: [] for n in names}
-        self.work = {n: 0.0 for n in names}   # e.g. FLOPs, accumulated per timed call by work[name](*args, **kwargs)
         self._work_fn = work or {}
         self.enabled = False
         self.active = set(names)  # subset of names currently bracketed (keeps the timed region's instrumentation minimal)
+        self.reset()
+
+    def reset(self):
+        self.events = {n: [] for n in self._names}
+        self.work = {n: 0.0 for n in self._names}   # e.g. FLOPs, accumulated per timed call by work[name](*args, **kwargs)
 
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
@@ -120,23 +158,52 @@ def _tn_flops(A, B, **kw):
     return 2.0 * B.size(0) * A.size(1) * B.size(1)
 
 
-def step(model, b, world, flat_grad_params, bucket=None):
+TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn']
+
+
+class Comm:
+    """What a step does across ranks: the flat-bucket gradient all-reduce and the logits gather, bracketed by HIP events."""
+
+    def __init__(self, params, world, assignment=None, n_global=None):
+        self.world, self.assignment = world, assignment
+        self.bucket = parallel.GradBucket(params) if world > 1 else None
+        self.n_global = n_global
+        self.events = []
+
+    def __call__(self, logits):
+        if self.world == 1:
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.bucket.allreduce()  # RCCL all-reduce(sum) of ~2.85 M fp32 through one persistent flat bucket (parallel.GradBucket)
+        if self.assignment is None:
+            parallel.allgather_logits(logits, equal_shards=True)  # per-batch logits of all ranks, for accuracy / reporting
+        else:  # balanced shards differ in size: variable-size gather, then back to question order
+            parallel.scatter_logits_by_assignment(parallel.allgather_logits(logits), self.assignment)
+        e1.record()
+        self.events.append((e0, e1))
+
+    def mean_ms(self, last):
+        ev = self.events[-last:] if last else []
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+
+
+def step(model, b, nc, loss_weight, flat_grad_params, comm=None):
     for p in flat_grad_params:
         p.grad = None
     logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'])
-    logits = logits.view(-1, NC)
+    logits = logits.view(-1, nc)
     # the reference's mini-batch loss weight (b - a) / bs with bs = all questions of the global batch (qagnn.py:261)
-    loss = torch.nn.functional.cross_entropy(logits, b['labels']) * parallel.shard_loss_weight(1, world)
+    loss = torch.nn.functional.cross_entropy(logits, b['labels']) * loss_weight
     loss.backward()
-    if world > 1:
-        bucket.allreduce()  # RCCL all-reduce(sum) of ~2.85 M fp32 through one persistent flat bucket (parallel.GradBucket)
-        parallel.allgather_logits(logits, equal_shards=True)  # per-batch logits of all ranks, for accuracy / reporting
+    if comm is not None:
+        comm(logits)
     return logits
 
 
 # kernels one qagnn_edge_attn_fwd_f32 call launches (substring of the demangled name): their FETCH_SIZE / WRITE_SIZE add up to
 # the forward edge stage's traffic per launch
-EDGE_FWD_KERNELS = ('qagnn::k_edge_scores(', 'qagnn::k_edge_aggregate(', 'qagnn::k_edge_fwd_')
+EDGE_FWD_KERNELS = ('qagnn::k_edge_scores', 'qagnn::k_edge_aggregate', 'qagnn::k_edge_fwd_', 'qagnn::k_edge_iso')
 PMC_CAL_KERNEL = 'k_gelu_dropout<false>'  # reads and writes exactly N*DP*4 bytes: checks the counter units in the same run
 
 
@@ -156,7 +223,7 @@ def measure_edge_traffic(args, N, DP):
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         td = tempfile.mkdtemp(prefix=f'qagnn_pmc_{ctr}_', dir='/tmp')
         cmd = [rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', td, '-o', 'p', '--', sys.executable,
-               os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-pmc', '--pmc-child',
+               os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-pmc', '--pmc-child',
                '--questions', str(args.questions), '--n-concept', str(args.n_concept), '--dropout', str(args.dropout)] + \
               (['--edge-lists'] if args.edge_lists else [])
         try:
@@ -189,45 +256,61 @@ def measure_edge_traffic(args, N, DP):
                                                '128-B reads at 64 B)' + cal)
 
 
-def to_device(batch, dev, use_blobs):
+def to_device(batch, dev, use_blobs, nc):
     """Inputs resident in HBM: either the reference's (edge_index, edge_type) int64 pair or the packed blob buffer."""
     b = {k: v.to(dev) for k, v in batch.items() if torch.is_tensor(v)}
     if use_blobs:
         B, E, store, ids = batch['blob_meta']
-        b['adj'] = data_utils.PackedGraphBatch(b['blobs'], B, E, store, ids, NC)
+        b['adj'] = data_utils.PackedGraphBatch(b['blobs'], B, E, store, ids, nc)
     else:
         b['adj'] = (b['ei'], b['et'])
     return b
 
 
-def small_batch_line(args, dev, questions=2, steps=30, warmup=5):
-    """The same step at the reference's own mini-batch (2 questions x 5 choices = 10 subgraphs, run_qagnn__csqa.sh:17)."""
-    b = to_device(make_batch(questions, seed=123, n_concept=args.n_concept), dev, not args.edge_lists)
-    model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
-    model.train()
-    params = [p for p in model.parameters() if p.requires_grad]
-    for _ in range(warmup):
-        step(model, b, 1, params)
-    torch.cuda.synchronize()
+def timed_steps(run_step, steps, sync):
+    """-> (seconds for `steps` steps incl. the final synchronisation, seconds the HOST needed to enqueue them)."""
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(model, b, 1, params)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return dict(subgraphs=questions * NC, value=round(questions * NC / dt, 1), unit='QA-subgraphs/s', ms_per_step=round(dt * 1e3, 3),
-                steps=steps, note='same step, same model, at the batch size the cpu_baseline runs (the reference\'s mbs = 2 questions)')
+        run_step()
+    t1 = time.perf_counter()
+    sync()
+    return time.perf_counter() - t0, t1 - t0
 
 
-def cpu_baseline(budget_s=10.0):
-    """CPU oracle (reference formulation) on the host cores, B = 10 subgraphs of the same distribution."""
+def instrumented_pass(run_step, timed, sync, n_steps):
+    """Extra steps with HIP events around every GEMM launch and the edge stages, weight-gradient overlap and native hop sequencing
+    off (both hide kernels from the events: see main()).  Returns per-step numbers."""
+    timed.reset()
+    timed.enabled = True
+    timed.active = {'gemm_nn', 'gemm_tn', 'edge_attn_bwd', 'edge_attn_fwd'}
+    overlap, fused, ops.WGRAD_OVERLAP, ops.FUSED_HOP = ops.WGRAD_OVERLAP, ops.FUSED_HOP, False, False
+    try:
+        for _ in range(n_steps):
+            run_step()
+        sync()
+    finally:
+        ops.WGRAD_OVERLAP, ops.FUSED_HOP = overlap, fused
+        timed.enabled = False
+    gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn')
+    flops = timed.work['gemm_nn'] + timed.work['gemm_tn']
+    return dict(gemm_ms=gemm_ms / n_steps, gemm_flops=flops / n_steps,
+                gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn'])) // n_steps,
+                edge_fwd_ms=timed.mean_ms('edge_attn_fwd')[0], edge_bwd_ms=timed.mean_ms('edge_attn_bwd')[0],
+                n_edge_fwd=timed.mean_ms('edge_attn_fwd')[1], n_edge_bwd=timed.mean_ms('edge_attn_bwd')[1])
+
+
+def cpu_oracle(wl, budget_s=6.0, questions=2):
+    """CPU oracle (reference formulation) on the host cores, `questions` questions of the workload's distribution."""
     from oracle import qagnn_oracle as O
     # torch's intra-op pool degrades badly when a small-op workload is spread over hundreds of hardware threads
     # (measured on the 256-thread GPU host: 131 s per iteration with 256 threads); `cores` reports what was used.
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    n_concept = 5000  # table size does not matter on CPU (pure gather of 1990 rows); keeps RAM small
-    b = make_batch(2, seed=123, n_concept=n_concept)
-    model = build_model(O, n_concept)
+    n_concept = 5000  # table size does not matter on CPU (pure gather of ~2000 rows); keeps RAM small
+    nc = wl['nc']
+    b = make_batch(wl, questions, seed=123, n_concept=n_concept)
+    model = build_model(O, wl, n_concept)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
 
@@ -235,7 +318,7 @@ def cpu_baseline(budget_s=10.0):
         for p in params:
             p.grad = None
         logits, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], (b['ei'], b['et']))
-        torch.nn.functional.cross_entropy(logits.view(-1, NC), b['labels']).backward()
+        torch.nn.functional.cross_entropy(logits.view(-1, nc), b['labels']).backward()
     one()
     t0 = time.perf_counter()
     reps = 0
@@ -245,9 +328,58 @@ def cpu_baseline(budget_s=10.0):
         if time.perf_counter() - t0 > budget_s or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=round(10 / dt, 2), unit='QA-subgraphs/s', cores=cores, kind='port',
-                sample=f'oracle (reference formulation, torch CPU fp32) fwd+bwd, B=10 subgraphs (2 questions x 5), n=200, '
+    B = questions * nc
+    return dict(value=round(B / dt, 2), unit='QA-subgraphs/s', cores=cores, kind='port',
+                sample=f'oracle (reference formulation, torch CPU fp32) fwd+bwd, B={B} subgraphs ({questions} questions x {nc}), n={wl["n"]}, '
                        f'{reps} reps, {dt * 1e3:.0f} ms each, E={b["ei"].size(1)} edges')
+
+
+def gpu_small_batch(wl, args, dev, questions=2, steps=30, warmup=5):
+    """The same step at the reference's own mini-batch (2 questions, run_qagnn__csqa.sh:17): what the cpu baseline runs."""
+    nc = wl['nc']
+    b = to_device(make_batch(wl, questions, seed=123, n_concept=args.n_concept), dev, not args.edge_lists, nc)
+    model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    run = lambda: step(model, b, nc, 1.0, params)  # noqa: E731
+    for _ in range(warmup):
+        run()
+    dt, enq = timed_steps(run, steps, torch.cuda.synchronize)
+    return dict(subgraphs=questions * nc, value=round(questions * nc * steps / dt, 1), unit='QA-subgraphs/s', ms_per_step=round(dt / steps * 1e3, 3),
+                host_enqueue_ms_per_step=round(enq / steps * 1e3, 3), steps=steps,
+                note='same step, same model, at the batch size the cpu baseline runs (the reference\'s mbs = 2 questions)')
+
+
+def secondary_config(name, wl, args, dev, timed):
+    """One of the other single-GPU configurations: throughput, where the time goes, host-bound or not, CPU oracle beside it."""
+    nc, n = wl['nc'], wl['n']
+    b = to_device(make_batch(wl, wl['questions'], seed=2000, n_concept=args.n_concept), dev, not args.edge_lists, nc)
+    model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    run = lambda: step(model, b, nc, 1.0, params)  # noqa: E731
+    for _ in range(4):
+        run()
+    steps = 10
+    regions = [timed_steps(run, steps, torch.cuda.synchronize) for _ in range(3)]
+    dt, enq = sorted(regions)[1]
+    ins = instrumented_pass(run, timed, torch.cuda.synchronize, 2)
+    B = wl['questions'] * nc
+    E = b['ei'].size(1)
+    out = dict(workload=wl['what'], subgraphs=B, nodes=B * n, edges=E, value=round(B * steps / dt, 1), unit='QA-subgraphs/s',
+               ms_per_step=round(dt / steps * 1e3, 3), host_enqueue_ms_per_step=round(enq / steps * 1e3, 3),
+               host_bound=bool(enq > 0.9 * dt), edge_fwd_ms_per_step=round(ins['edge_fwd_ms'] * K_LAYERS, 3),
+               edge_bwd_ms_per_step=round(ins['edge_bwd_ms'] * K_LAYERS, 3), gemm_ms_per_step=round(ins['gemm_ms'], 3),
+               gemm_tflops=round(ins['gemm_flops'] / (ins['gemm_ms'] * 1e-3) / 1e12, 1) if ins['gemm_ms'] > 0 else 0.0)
+    del model, b
+    torch.cuda.empty_cache()
+    if not args.no_cpu_baseline:
+        small = gpu_small_batch(wl, args, dev, steps=20, warmup=4)
+        cpu = cpu_oracle(wl, budget_s=4.0)
+        out['small_batch'] = small
+        out['cpu_baseline'] = cpu
+        out['speedup_vs_cpu_baseline_same_batch'] = round(small['value'] / cpu['value'], 1)
+    return out
 
 
 def main():
@@ -255,9 +387,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=3, help='timed regions of --steps steps each; the median is the headline')
     ap.add_argument('--questions', type=int, default=64, help='questions per GPU (x5 choices = subgraphs per GPU)')
+    ap.add_argument('--global-batch', type=int, default=0, help='N > 1: strong scaling -- ONE global batch of this many questions (skewed '
+                    'subgraph sizes), dealt out to the ranks by parallel.balance_questions')
     ap.add_argument('--n-concept', type=int, default=100000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the other single-GPU configurations (configs object)')
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--edge-lists', action='store_true', help='feed the graph as int64 (edge_index, edge_type) (the reference protocol; the '
                     'graph orderings are then re-derived per batch) instead of the load-time blobs of qagnn_amd.data_utils')
@@ -301,14 +437,38 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    b = to_device(make_batch(args.questions, seed=1000 + rank, n_concept=args.n_concept), dev, not args.edge_lists)
-    model = build_model(MQ, args.n_concept, p=args.dropout).to(dev)
+    wl = WORKLOADS[HEADLINE]
+    nc, n = wl['nc'], wl['n']
+    assignment, loss_weight, scaling = None, 1.0 / world, 'weak'
+    if args.global_batch and world > 1:
+        # strong scaling: every rank derives the SAME global batch and the same assignment (no communication), keeps its questions
+        scaling = 'strong'
+        recs = synthetic.make_records(args.global_batch * nc, seed=1000, shape=wl['shape'], n_rel=wl['n_rel'], n_concept_vocab=args.n_concept,
+                                      zipf=True)
+        _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, nc)
+        cost = parallel.question_costs([e.size(1) for e in ei], n, nc)
+        assignment = parallel.balance_questions(cost, world)
+        mine = [q * nc + j for q in assignment[rank] for j in range(nc)]
+        idx = torch.tensor(mine, dtype=torch.long)
+        host_batch = batch_from_lists(wl, cids[idx], nt[idx], ns[idx], al[idx], [ei[i] for i in mine], [et[i] for i in mine], seed=1000 + rank)
+        loss_weight = parallel.shard_loss_weight(len(assignment[rank]), args.global_batch)
+        loads = [sum(cost[q] for q in part) for part in assignment]
+        balance = dict(questions_per_rank=[len(p) for p in assignment], max_over_mean_load=round(max(loads) / (sum(loads) / world), 4),
+                       contiguous_max_over_mean=round(max(sum(cost[slice(*parallel.shard_questions(args.global_batch, r, world))]) for r in range(world))
+                                                      / (sum(cost) / world), 4))
+        my_questions = len(assignment[rank])
+    else:
+        host_batch = make_batch(wl, args.questions, seed=1000 + rank, n_concept=args.n_concept)
+        balance = None
+        my_questions = args.questions
+    b = to_device(host_batch, dev, not args.edge_lists, nc)
+    model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    bucket = parallel.GradBucket(params) if world > 1 else None
-    timed = TimedKernels(ops.kernels(), ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn'],
-                         work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
+    comm = Comm(params, world, assignment=assignment)
+    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
     ops.set_kernels(timed)
+    run = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
 
     def sync():
         torch.cuda.synchronize()
@@ -318,46 +478,52 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(model, b, world, params, bucket)
+        run()
     sync()
     timed.enabled = True
-    timed.active = {'edge_attn_fwd', 'graph_prep', 'graph_from_blobs'}  # 6 event pairs per step inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(model, b, world, params, bucket)
-    sync()
-    dt = time.perf_counter() - t0
-    # the 72 GEMM launches per step are bracketed in a separate short pass: 144 more event records per step would cost the
-    # headline number ~2 %.  The backward edge stage is timed here too, with the weight-gradient overlap switched off: in the
-    # timed region above those GEMMs run on a side stream UNDER the edge backward (ops.WGRAD_OVERLAP), so an event pair around
-    # either would measure the co-running kernels, not the kernel.
-    GEMM_STEPS = 3
-    # Host-bound batches take the natively sequenced hop (ops.use_fused_hop), whose kernels are not visible from Python: this
-    # pass composes the hops from the per-kernel entry points (same launches) so that they can be bracketed.
-    timed.active = {'gemm_nn', 'gemm_tn', 'edge_attn_bwd'} | ({'edge_attn_fwd'} if not timed.events['edge_attn_fwd'] else set())
-    overlap, fused, ops.WGRAD_OVERLAP, ops.FUSED_HOP = ops.WGRAD_OVERLAP, ops.FUSED_HOP, False, False
-    for _ in range(GEMM_STEPS):
-        step(model, b, world, params, bucket)
-    sync()
-    ops.WGRAD_OVERLAP, ops.FUSED_HOP = overlap, fused
+    timed.active = {'edge_attn_fwd', 'graph_prep', 'graph_from_blobs'}  # 6 event pairs per step inside the timed regions
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        dt_r, enq_r = timed_steps(run, args.steps, sync)
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+            tmin = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            regions.append((t.item(), enq_r, tmin.item()))
+        else:
+            regions.append((dt_r, enq_r, dt_r))
     timed.enabled = False
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    dt, enq, dt_min = regions[order[len(order) // 2]]
+    fwd_ms, n_fwd = timed.mean_ms('edge_attn_fwd')
+    prep_ms, _ = timed.mean_ms('graph_prep' if args.edge_lists else 'graph_from_blobs')
+    comm_ms = comm.mean_ms(args.steps * len(regions))
+    # the ~72 GEMM launches per step are bracketed in a separate short pass: 144 more event records per step would cost the
+    # headline number ~2 %.  The backward edge stage is timed there too, with the weight-gradient overlap switched off: in the
+    # timed regions above those GEMMs run on a side stream UNDER the edge backward (ops.WGRAD_OVERLAP), so an event pair around
+    # either would measure the co-running kernels, not the kernel.  Host-bound batches take the natively sequenced hop
+    # (ops.use_fused_hop), whose kernels are not visible from Python: the pass composes the hops from the per-kernel entry points.
+    GEMM_STEPS = 3
+    ins = instrumented_pass(run, timed, sync, GEMM_STEPS)
+    if n_fwd == 0:
+        fwd_ms, n_fwd = ins['edge_fwd_ms'], ins['n_edge_fwd']
+    bwd_ms, n_bwd = ins['edge_bwd_ms'], ins['n_edge_bwd']
+    total_subgraphs = my_questions * nc
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        t = torch.tensor([float(total_subgraphs)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        total_subgraphs = int(t.item())
 
     if rank == 0:
-        B = args.questions * NC
-        N = B * N_NODE
+        B = my_questions * nc
+        N = B * n
         E = b['ei'].size(1)
         h2d = b['blobs'].numel() * 4 if not args.edge_lists else (b['ei'].numel() + b['et'].numel()) * 8
         Ep = E + N
-        fwd_ms, n_fwd = timed.mean_ms('edge_attn_fwd')
-        bwd_ms, n_bwd = timed.mean_ms('edge_attn_bwd')
-        prep_ms, _ = timed.mean_ms('graph_prep' if args.edge_lists else 'graph_from_blobs')
-        gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn')
-        gemm_flops = timed.work['gemm_nn'] + timed.work['gemm_tn']
+        gemm_ms, gemm_flops = ins['gemm_ms'], ins['gemm_flops']
         alg_fwd = Ep * 2410 + N * 800
         alg_bwd = Ep * 5610 + N * 800
         DP = 4 * ((D // 4 + 3) // 4 * 4)  # head-padded row width (208 floats at d = 200)
@@ -377,19 +543,23 @@ def main():
         hbm_bytes = max(compulsory, traffic or 0)
         achieved = hbm_bytes / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
         achieved_alg = alg_fwd / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        bwd_comp = N * 4 * DP * 4 + Ep * 14 + N * 3 * DP * 4 + 4 * Ep * 16
         out = {
-            'metric': 'QA-subgraphs/sec (batch x num_choice) fwd+bwd', 'value': round(B * world * args.steps / dt, 1),
+            'metric': 'QA-subgraphs/sec (batch x num_choice) fwd+bwd', 'value': round(total_subgraphs * args.steps / dt, 1),
             'unit': 'QA-subgraphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',  # fp32 storage and fp32-accurate arithmetic everywhere (see roofline_mfma.note)
-            'config': {'workload': 'configs[1]: CSQA-shaped batch 64 questions x 5 choices = 320 subgraphs per GPU, n=200 node slots, '
-                                   '400..2000 edges/subgraph, 5-layer GAT d=200 H=4, 38 relations, QAGNN decoder fwd+bwd '
-                                   '(LM encoder excluded: random sent_vecs), dropout 0.2, train-mode BN',
+            'repeats': len(regions), 'repeat_ms_per_step': [round(r[0] / args.steps * 1e3, 3) for r in regions],
+            'value_is': f'median of {len(regions)} timed regions of {args.steps} steps each (max over ranks per region)',
+            'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'host_bound': bool(enq > 0.9 * dt),
+            'config': {'workload': f'{HEADLINE}: ' + wl['what'] + ', 5-layer GAT d=200 H=4, QAGNN decoder fwd+bwd (LM encoder excluded: random '
+                                   f'sent_vecs), dropout {args.dropout}, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
                        'graph_input': ('int64 (edge_index, edge_type), orderings derived per batch' if args.edge_lists else
                                        'load-time int32 blobs (qagnn_graph_from_blobs)') + f', {h2d / max(E, 1):.1f} B/edge on the wire',
                        'parallelism': f'dp{world}' if world > 1 else 'single'},
-            'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (k_edge_scores [scores + segment softmax] + k_edge_aggregate), per GAT layer',
+            'roofline': {'bound': 'hbm', 'kernel': 'qagnn_edge_attn_fwd_f32 (scores + segment softmax, aggregate), per GAT layer',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(min(achieved / HBM_PEAK_GBS, 1.0), 4),
                          'traffic': traffic, 'traffic_source': traffic_source,
                          'hbm_bytes_per_launch': hbm_bytes, 'hbm_bytes_are': 'measured traffic' if (traffic or 0) >= compulsory else 'compulsory bytes',
@@ -400,30 +570,43 @@ def main():
                          'algorithmic_bytes_per_launch': alg_fwd, 'achieved_algorithmic': round(achieved_alg, 1),
                          'avg_launch_ms': round(fwd_ms, 4), 'launches_timed': n_fwd,
                          'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
-                                      'compulsory_bytes_per_launch': N * 4 * DP * 4 + Ep * 14 + N * 3 * DP * 4 + 4 * Ep * 16,
-                                      'achieved': round((N * 4 * DP * 4 + Ep * 14 + N * 3 * DP * 4 + 4 * Ep * 16) / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
+                                      'compulsory_bytes_per_launch': bwd_comp,
+                                      'achieved': round(bwd_comp / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
                                       'achieved_algorithmic': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
-                                      'timed_in': 'extra steps after the timed region, weight-gradient overlap off (see source)'}},
-            # the dense side of the step: every fp32-MFMA GEMM launch (k_gemm_nn, k_gemm_tn_strip / k_gemm_tn + chunk sum),
-            # algorithmic FLOPs of the products over their HIP-event time, against the dense fp32 matrix peak
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'qagnn_gemm_nn_f32 + qagnn_gemm_tn_f32 (all launches of the step)',
-                              'achieved': round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
-                              'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if gemm_ms > 0 else 0.0,
-                              'gflop_per_step': round(gemm_flops / GEMM_STEPS / 1e9, 1), 'ms_per_step': round(gemm_ms / GEMM_STEPS, 3),
-                              'launches_per_step': (len(timed.events['gemm_nn']) + len(timed.events['gemm_tn'])) // GEMM_STEPS,
-                              'timed_in': f'{GEMM_STEPS} extra steps after the timed region (HIP events around every launch)',
-                              'note': 'fp32-equivalent FLOPs of all GEMM launches against the fp32-input MFMA peak.  The NN products run as six '
-                                      'bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per product = one fp32 rounding; fp32-equivalent '
-                                      'ceiling 2500 / 6 = 417 TFLOP/s) unless QAGNN_GEMM_SPLIT=0, the weight-gradient (TN) products the same way with the tiles transposed into LDS unless QAGNN_TN_SPLIT=0'},
+                                      'timed_in': 'extra steps after the timed regions, weight-gradient overlap off (see source)'}},
+            # the dense side of the step: every GEMM launch, algorithmic FLOPs of the products over their HIP-event time
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'all GEMM launches of the step (qagnn_gemm_nn_split_f32 / qagnn_gemm_nn_f32 / qagnn_gemm_tn_f32)',
+                              'achieved': round(gemm_tf, 1), 'unit': 'TFLOP/s',
+                              'peak': round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), 'frac': round(gemm_tf / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
+                              'peak_is': 'fp32-equivalent ceiling of the kernels that run: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per exact 3 x bf16 product',
+                              'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'frac_of_fp32_mfma_peak': round(gemm_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                              'gflop_per_step': round(gemm_flops / 1e9, 1), 'ms_per_step': round(gemm_ms, 3),
+                              'launches_per_step': ins['gemm_launches'],
+                              'timed_in': f'{GEMM_STEPS} extra steps after the timed regions (HIP events around every launch)',
+                              'note': 'fp32-equivalent FLOPs.  The NN products run as six bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per '
+                                      'product = one fp32 rounding) unless QAGNN_GEMM_SPLIT=0, the weight-gradient (TN) products the same way with the '
+                                      'tiles transposed into LDS unless QAGNN_TN_SPLIT=0'},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
-                                      'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms / GEMM_STEPS, 3)},
+                                      'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms, 3)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out['small_batch'] = small_batch_line(args, dev)
-            out['cpu_baseline'] = cpu_baseline()
-            # like for like: both at B = 10 subgraphs.  (value / cpu_baseline.value would compare B = 320 with B = 10.)
-            out['speedup_vs_cpu_baseline_same_batch'] = round(out['small_batch']['value'] / out['cpu_baseline']['value'], 1)
+        if world > 1:
+            out['comm_ms_per_step'] = round(comm_ms, 4)
+            out['comm_is'] = 'RCCL all-reduce(sum) of the flat 11.4 MB gradient bucket + logits all-gather, HIP events on the compute stream (rank 0)'
+            out['rank_ms_per_step'] = {'min': round(dt_min / args.steps * 1e3, 3), 'max': round(dt / args.steps * 1e3, 3)}
+            if balance is not None:
+                out['balance'] = balance
+        if world == 1 and not args.pmc_child:
+            if not args.no_cpu_baseline:
+                out['small_batch'] = gpu_small_batch(wl, args, dev)
+                out['cpu_baseline'] = cpu_oracle(wl, budget_s=10.0)
+                # like for like: both at B = 10 subgraphs.  (value / cpu_baseline.value would compare B = 320 with B = 10.)
+                out['speedup_vs_cpu_baseline_same_batch'] = round(out['small_batch']['value'] / out['cpu_baseline']['value'], 1)
+            else:
+                out['cpu_baseline'] = None
+            if not args.no_configs:
+                del model, b
+                torch.cuda.empty_cache()
+                out['configs'] = {name: secondary_config(name, w, args, dev, timed) for name, w in WORKLOADS.items() if name != HEADLINE}
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

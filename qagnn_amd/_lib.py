@@ -257,7 +257,6 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
-        self._np_flags = {}  # per device: the persistent validation flag of node_prep
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -323,16 +322,14 @@ class HipKernels(metaclass=_GuardedMeta):
         score = torch.empty((B, n), dtype=torch.float32, device=dev)
         mask = torch.empty((B, n), dtype=torch.bool, device=dev)
         ridx = torch.empty(B * n, dtype=torch.long, device=dev)
-        flags = None
-        if table_rows > 0:
-            flags = self._np_flags.get(dev)
-            if flags is None:
-                flags = self._np_flags[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+        # a fresh flag per call, like graph_prep's err words: a persistent one would still read 1 in the batch AFTER a bad id
+        flags = torch.zeros(4, dtype=torch.int32, device=dev) if table_rows > 0 else None
         rc = self.lib.qagnn_node_prep_f32(raw.data_ptr(), adj_lengths.data_ptr(), node_type_ids.data_ptr(), concept_ids.data_ptr(), B, n,
                                           score.data_ptr(), mask.data_ptr(), ridx.data_ptr(), int(table_rows), _ptr(flags), self._stream())
         self._check(rc, 'qagnn_node_prep_f32')
         if flags is not None:
-            ERR_WATCH.watch(flags, 'concept_ids (an id outside the entity table)', reset=flags)
+            ERR_WATCH.poll()
+            ERR_WATCH.watch(flags, 'concept_ids (an id outside the entity table)')
         return score, mask, ridx
 
     def radam_step(self, params, grads, exp_avgs, exp_avg_sqs, beta1, beta2, eps, lr, weight_decay, step_size, mode):

@@ -710,19 +710,23 @@ extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KM
   const int ccap = lds_class_cap(n, HP, ecap, g->C);
   const int64_t bytes = qagnn_edge_attn_fwd_lds_bytes(n, HP, max_sub_ep, g->C);
   QAGNN_REQUIRE(ccap > 0 && bytes <= 160 * 1024, QAGNN_EUNSUPPORTED, "edge_attn_fwd_lds: n=%d, %d edges per subgraph do not fit the LDS", n, max_sub_ep);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // per DEVICE, not per process: the reference's own layout puts the encoder on cuda:0 and the decoder on cuda:1 (qagnn.py:133-134)
+  static bool attr_set[64] = {};
+  static int n_cu_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("edge_attn_fwd_lds: cannot query the current device"); return QAGNN_EHIP; }
+  const int di = dev & 63;
+  if (!attr_set[di]) {
     hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("edge_attn_fwd_lds: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
-    attr_set = true;
+    attr_set[di] = true;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("edge_attn_fwd_lds: cannot query the device"); return QAGNN_EHIP; }
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (n_cu_dev[di] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu_dev[di] = v;
   }
+  const int n_cu = n_cu_dev[di];
   const int ntiles = (g->N / n) * 4;
   const int grid = ntiles < n_cu ? ntiles : n_cu;  // persistent: one 16-wave workgroup per CU (the LDS allows no second one)
   k_edge_fwd_lds<<<grid, LDS_THREADS, (size_t)bytes, stream>>>(g->rowptr_s, g->rowptr_t, g->pk_s, g->pk_t, g->pos_t, g->sub_ncls, g->sub_cls, KMQ,

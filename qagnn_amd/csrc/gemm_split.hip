@@ -124,17 +124,19 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first ? B1n : B2n), 0, a.No * (first ? ldn1 : ldn2) * 4, 0x00020000);
       const uint32_t lda4 = (uint32_t)(first ? a.lda1 : a.lda2) * 4u, ldn4 = (uint32_t)(first ? ldn1 : ldn2) * 4u;
       const int K = first ? a.K1 : a.K2, kb = (first ? kt : kt - nk1) * SBK;
-      const uint32_t kofs = (kb + kq * 4 < K) ? (uint32_t)kq * 16u : OOB;  // k past K: the whole float4 is outside (K % 4 == 0)
+      const bool kin = kb + kq * 4 < K;  // k past K: the whole float4 is outside (K % 4 == 0)
       const uint32_t soff = (uint32_t)kb * 4u;
+      // ONE select per load: a slot outside in the row (column) direction, in k, or in both gets the out-of-range offset (two
+      // separate OOB terms would add up to 0x80000000 + 0x80000000 = 0 and read row 0 instead of zeros)
 #pragma unroll
       for (int p = 0; p < A_IT; ++p) {
         const int row = m0 + lr + p * 32;
-        ra[p] = bload4(rA, (row < a.M ? (uint32_t)row * lda4 : OOB) + kofs, soff);
+        ra[p] = bload4(rA, (kin && row < a.M) ? (uint32_t)row * lda4 + (uint32_t)kq * 16u : OOB, soff);
       }
 #pragma unroll
       for (int q = 0; q < B_IT; ++q) {
         const int col = n0 + lr + q * 32;
-        rb[q] = bload4(rB, (col < a.No ? (uint32_t)col * ldn4 : OOB) + kofs, soff);
+        rb[q] = bload4(rB, (kin && col < a.No) ? (uint32_t)col * ldn4 + (uint32_t)kq * 16u : OOB, soff);
       }
     };
     // FLAT: unconditional loads from clamped addresses (branches around loads make hipcc fall back to vmcnt(0)); what lies past the

@@ -10,7 +10,8 @@ tests of the training driver) are updated with the same formulas in torch.
 import math
 
 import torch
-from torch.optim import SGD, Adam, AdamW
+from torch.optim import SGD, Adam
+from torch.optim import AdamW as _TorchAdamW
 from torch.optim.optimizer import Optimizer
 
 
@@ -27,6 +28,17 @@ def radam_step_size(step, beta1, beta2, degenerated_to_sgd=True):
     else:
         step_size = -1
     return n_sma, step_size
+
+
+class AdamW(_TorchAdamW):
+    """`transformers.AdamW` as the reference imports it (utils/optimization_utils.py:3; removed from current transformers): the
+    decoupled-weight-decay update of torch.optim.AdamW with THAT class's defaults -- eps = 1e-6 and weight_decay = 0.0, not
+    torch's 1e-8 / 0.01.  The reference's driver sets weight_decay per parameter group and never passes eps (qagnn.py:196-206),
+    so `--optim adamw` trains with eps = 1e-6 there and must do so here."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, **kwargs):
+        kwargs.pop('correct_bias', None)  # transformers' switch; True (its default) is what torch implements
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
 
 
 class RAdam(Optimizer):
@@ -96,6 +108,6 @@ class RAdam(Optimizer):
 OPTIMIZER_CLASSES = {
     'sgd': SGD,
     'adam': Adam,
-    'adamw': AdamW,   # the reference takes transformers.AdamW (removed upstream); torch.optim.AdamW is its documented successor
+    'adamw': AdamW,   # transformers.AdamW's defaults (eps 1e-6, weight_decay 0) over torch.optim.AdamW's update
     'radam': RAdam,
 }

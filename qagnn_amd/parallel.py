@@ -82,7 +82,9 @@ class GradBucket:
 
     def allreduce(self, group=None):
         """Sum the gradients across ranks in place; returns the number of elements reduced.  A parameter without a gradient on
-        this rank contributes zeros (and receives the other ranks' sum only if it has a gradient tensor to receive it)."""
+        this rank contributes zeros and RECEIVES the sum like every other rank (its p.grad becomes a fresh tensor holding it):
+        a parameter that only some ranks' shards touch must not leave the replicas with different gradients -- what DDP
+        guarantees, and what the reference's single-process gradient accumulation does by construction."""
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         if len(have) != len(self.params):
             self.flat.zero_()
@@ -91,6 +93,9 @@ class GradBucket:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if have:
             torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                p.grad = v.clone()
         return self.flat.numel()
 
 

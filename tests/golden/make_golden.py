@@ -6,7 +6,8 @@ are all that travels to the GPU box.  Usage:  python tests/golden/make_golden.py
 
 What is executed from the reference, unmodified, straight from /root/reference:
   * utils/data_utils.py   load_sparse_adj_data_with_contextnode   (on pickles of our synthetic records)
-  * modeling/modeling_qagnn.py   QAGNN, QAGNN_Message_Passing, GATConvE, make_one_hot, LM_QAGNN.batch_graph
+  * modeling/modeling_qagnn.py   QAGNN, QAGNN_Message_Passing, GATConvE, make_one_hot, LM_QAGNN.batch_graph, and LM_QAGNN itself
+                                 (constructor + forward, with helpers.StubTextEncoder as the LM: lm_<case>.npz, `--lm-only`)
   * utils/layers.py       GELU, MLP, MultiheadAttPoolLayer, CustomizedEmbedding
 
 modeling_qagnn.py cannot be imported as-is here: it imports torch_geometric==1.7.0 / torch_scatter==2.0.7
@@ -93,7 +94,8 @@ def install_standins():
     ts.scatter = _scatter
     ts.scatter_add = lambda src, index, dim=0, out=None, dim_size=None: _scatter(src, index, dim, out, dim_size, 'sum')
     enc = types.ModuleType('modeling.modeling_encoder')
-    enc.TextEncoder = object
+    import helpers
+    enc.TextEncoder = helpers.StubTextEncoder  # LM_QAGNN.__init__ builds its encoder from this name (modeling_qagnn.py:197)
     enc.MODEL_NAME_TO_CLASS = {}
     tg.nn, tg.utils = tg_nn, tg_utils
     sys.modules.update({'torch_geometric': tg, 'torch_geometric.nn': tg_nn, 'torch_geometric.utils': tg_utils,
@@ -214,10 +216,68 @@ def run_reference_model(ref_mq, name, c, cfg, inp, cids, ntypes, nscores, alens,
     return fix
 
 
+def run_reference_lm(ref_mq, name):
+    """The reference's OWN LM_QAGNN (modeling_qagnn.py:191-251: constructor, forward with the (bs, nc) flatten, the nested-list
+    `sum(x, [])`, batch_graph, the detail=True return) with helpers.StubTextEncoder standing in for the LM -> lm_<name>.npz.
+    Graph inputs are those of the case's main fixture (the reference loader's output).  Like the main fixtures, a second run with
+    every graph's edge list permuted records the reference's own fp32 re-ordering noise per tensor (`noise::<key>`)."""
+    import helpers
+    c = helpers.GOLDEN_CASES[name]
+    cfg = c['cfg']
+    nq, nc, n = c['nq'], c['nc'], c['n']
+    B = nq * nc
+    fix0 = helpers.load_golden(name)
+    _, cids, nt, ns, al, _, _ = helpers.golden_inputs(name, fix0)
+    nested_ei, nested_et = helpers.nested_graph_lists(name, fix0)
+    lm_in = helpers.lm_inputs(name)
+
+    def run(nei, net):
+        torch.manual_seed(0)
+        model = ref_mq.LM_QAGNN(None, 'stub', cfg['k'], cfg['n_ntype'], cfg['n_etype'], cfg['n_concept'], cfg['concept_dim'],
+                                cfg['concept_in_dim'], cfg['n_attention_head'], cfg['fc_dim'], cfg['n_fc_layer'], cfg['p_emb'], cfg['p_gnn'],
+                                cfg['p_fc'], pretrained_concept_emb=None, freeze_ent_emb=True, init_range=cfg['init_range'],
+                                encoder_config=dict(sent_dim=cfg['sent_dim'], in_dim=helpers.LM_CASES[name]['in_dim']))
+        helpers.det_fill_(model, c['seed'], c['std'])
+        model.decoder.pooler.dropout.p = 0.0
+        model.decoder.pooler.attention.dropout.p = 0.0
+        model.train(c['train'])
+        out = model(lm_in, cids.view(nq, nc, n), nt.view(nq, nc, n), ns.view(nq, nc, n, 1), al.view(nq, nc), nei, net, detail=True)
+        logits, attn, cids_o, nt_o, ei_o, et_o = out
+        assert logits.shape == (nq, nc) and cids_o.shape == (nq, nc, n) and ei_o is nei and et_o is net
+        fix = {'lm_in': lm_in.numpy(), 'logits': logits.detach().numpy(), 'pool_attn': attn.detach().numpy(),
+               'detail_concept_ids': cids_o.numpy(), 'detail_node_type_ids': nt_o.numpy()}
+        (logits * torch.linspace(0.5, 1.5, B).view(nq, nc)).sum().backward()
+        for pname, p in model.named_parameters():
+            if p.grad is not None:
+                helpers.store(fix, 'grad::' + pname, p.grad, name.startswith('small'))
+        for bname, b in model.named_buffers():
+            fix['buf::' + bname] = b.detach().clone().numpy()
+        return fix
+
+    fix = run(nested_ei, nested_et)
+    g = torch.Generator().manual_seed(c['seed'] + 6)
+    perms = [[torch.randperm(e.size(1), generator=g) for e in row] for row in nested_ei]
+    alt = run([[e[:, p] for e, p in zip(row, prow)] for row, prow in zip(nested_ei, perms)],
+              [[t[p] for t, p in zip(row, prow)] for row, prow in zip(nested_et, perms)])
+    for key in list(fix.keys()):
+        if key.endswith('::sum') or key not in alt or fix[key].dtype != np.float32 or key == 'lm_in':
+            continue
+        base = key[:-len('::head')] if key.endswith('::head') else (key[:-len('::rows')] if key.endswith('::rows') else key)
+        dn = float(np.abs(fix[key].astype(np.float64) - alt[key].astype(np.float64)).max()) if fix[key].size else 0.0
+        fix['noise::' + base] = np.array(max(dn, float(fix.get('noise::' + base, 0.0))))
+    path = os.path.join(HERE, 'lm_' + name + '.npz')
+    np.savez_compressed(path, **fix)
+    print(f'lm_{name}: logits={fix["logits"].reshape(-1)[:3].tolist()} -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     import helpers
     ref_du, ref_mq = import_reference()
     torch.set_num_threads(8)
+    if '--lm-only' in sys.argv:  # the main fixtures stay byte-identical; only the LM_QAGNN fixtures are (re)written
+        for name in helpers.LM_CASES:
+            run_reference_lm(ref_mq, name)
+        return
     for name, c in helpers.GOLDEN_CASES.items():
         cfg = c['cfg']
         inp = helpers.make_case_inputs(name)
@@ -258,6 +318,8 @@ def main():
         np.savez_compressed(path, **fix)
         print(f'{name}: B={B} n={n} E={edge_index.size(1)} logits={fix["logits"].reshape(-1)[:3].tolist()} '
               f'-> {os.path.getsize(path) / 1024:.0f} KiB')
+    for name in helpers.LM_CASES:
+        run_reference_lm(ref_mq, name)
 
 
 if __name__ == '__main__':

@@ -111,6 +111,44 @@ def make_case_inputs(case):
                 edge_index_list=edge_index, edge_type_list=edge_type)
 
 
+class StubTextEncoder(torch.nn.Module):
+    """Stand-in for the reference's `modeling_encoder.TextEncoder` (the LM is outside the hot path): same constructor shape
+    (`model_name, **encoder_config`), `.sent_dim`, and `forward(*lm_inputs, layer_id=-1) -> (sent_vecs, all_hidden_states)`.
+    tests/golden/make_golden.py installs this very class as the reference's TextEncoder when it runs the reference's own
+    LM_QAGNN.forward (modeling_qagnn.py:207-239); the tests hand it to qagnn_amd's LM_QAGNN as `encoder=`."""
+
+    def __init__(self, model_name='stub', sent_dim=24, in_dim=12, **kwargs):
+        super().__init__()
+        self.sent_dim = sent_dim
+        self.lin = torch.nn.Linear(in_dim, sent_dim)
+
+    def forward(self, x, layer_id=-1):
+        return torch.tanh(self.lin(x)), None
+
+
+LM_CASES = {'small_train': dict(in_dim=12), 'csqa_b10': dict(in_dim=20)}  # GOLDEN_CASES entries that also have an LM_QAGNN fixture
+
+
+def lm_inputs(case):
+    """Seeded LM-side input [bs, nc, in_dim] of the LM_QAGNN fixtures."""
+    c = GOLDEN_CASES[case]
+    g = torch.Generator().manual_seed(c['seed'] + 555)
+    return torch.randn(c['nq'], c['nc'], LM_CASES[case]['in_dim'], generator=g)
+
+
+def nested_graph_lists(case, fix):
+    """The loader's nested [bs][nc] lists of per-graph (edge_index [2, E_g] local ids, edge_type [E_g]) from a fixture."""
+    c = GOLDEN_CASES[case]
+    nq, nc = c['nq'], c['nc']
+    counts = fix['edge_counts']
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    ei_local = torch.from_numpy(fix['edge_index_cat'].astype(np.int64))
+    et_cat = torch.from_numpy(fix['edge_type_cat'].astype(np.int64))
+    nested_ei = [[ei_local[:, offs[q * nc + j]:offs[q * nc + j + 1]] for j in range(nc)] for q in range(nq)]
+    nested_et = [[et_cat[offs[q * nc + j]:offs[q * nc + j + 1]] for j in range(nc)] for q in range(nq)]
+    return nested_ei, nested_et
+
+
 def grad_summary(t):
     """Compact, order-sensitive description of a tensor: norm, signed projection, first elements."""
     f = t.detach().double().flatten()

@@ -648,4 +648,36 @@ def test_node_prep_matches_the_reference_ops(case):
     with pytest.raises(RuntimeError, match='out-of-range input in concept_ids'):
         _lib.ERR_WATCH.poll(block=True)
     hip().node_prep(ns.cuda(), al.cuda(), nt.cuda(), cids.cuda(), table_rows=rows)
-    _lib.ERR_WATCH.poll(block=True)            # the persistent flag was cleared when its error was reported
+    _lib.ERR_WATCH.poll(block=True)            # every call has its own flag words: a clean batch after a bad one reports nothing
+
+
+@pytest.mark.gpu
+def test_node_prep_on_unquantised_scores():
+    """The synthetic LM scores of the parity suite are multiples of 1/64 (order-exact row sums, see qagnn_amd/synthetic.py).  Real
+    LM scores are not: here the raw scores are arbitrary fp32 numbers.  qagnn_node_prep_f32 takes the row sum of |score| in float64
+    and rounds once, i.e. it returns the CORRECTLY ROUNDED fp32 sum; any fp32 summation order of <= n terms is within a few ulp of
+    that, so the normalised scores must (1) equal, bit for bit, the same formula evaluated with a float64 row sum, and (2) sit within
+    4 ulp of the reference's own fp32 op sequence (modeling_qagnn.py:160-167) -- the 1-ulp-class difference the reference itself shows
+    between its CPU and GPU reductions (and that sin(1.1^j * score) then amplifies identically for everybody)."""
+    g = torch.Generator().manual_seed(5)
+    B, n = 12, 200
+    raw = -(20.0 + 40.0 * torch.rand(B, n, 1, generator=g)) * (1.0 + 1e-3 * torch.randn(B, n, 1, generator=g))
+    raw[:, 0] = raw.max(dim=1).values + 1.0
+    al = torch.randint(2, n + 1, (B,), generator=g)
+    al[0], al[1] = n, 1
+    nt = torch.randint(0, 3, (B, n), generator=g)
+    nt[:, 0] = 3
+    cids = torch.randint(1, 500, (B, n), generator=g)
+    score, mask, _ = hip().node_prep(raw.cuda(), al.cuda(), nt.cuda(), cids.cuda())
+    # (1) the kernel's formula with the row sum in float64, rounded once
+    ar = torch.arange(n)
+    real = (ar < al.unsqueeze(1)).float()
+    d = (-raw.view(B, n) - (-raw.view(B, n)[:, 0:1])) * real
+    total = d.abs().double().sum(1).float()
+    want = d / (total / al.float() + 1e-05).unsqueeze(1)
+    assert torch.equal(score.cpu(), want)
+    # (2) the reference's fp32 op sequence (torch CPU reduction order)
+    ref = d / (d.abs().sum(1) / al.float() + 1e-05).unsqueeze(1)
+    ulp = torch.finfo(torch.float32).eps * ref.abs().clamp_min(1e-30)
+    assert bool(((score.cpu() - ref).abs() <= 4 * ulp).all()), ((score.cpu() - ref).abs() / ulp).max()
+    assert mask.dtype == torch.bool and bool(mask[1, 1:].all()) and not bool(mask[1, 0])

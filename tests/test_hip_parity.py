@@ -341,3 +341,117 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
     assert all(torch.equal(g0[k], g1[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g1[k])][:5]
     assert all(torch.equal(g0[k], g2[k]) for k in g0), [k for k in g0 if not torch.equal(g0[k], g2[k])][:5]
     assert all(torch.equal(b0[k], b1[k]) and torch.equal(b0[k], b2[k]) for k in b0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The step bench.py times, at the size it times it: B = 320 subgraphs (configs[1]: 64 questions x 5), n = 200, d = 200, 5 layers,
+# 1024-d sentence vectors and entity table, TRAIN mode, forward + cross-entropy + backward.  At N = 64 000 node rows the stack takes
+# the composed per-kernel path with the weight-gradient GEMMs queued onto a side stream under the edge backward
+# (ops.WGRAD_OVERLAP) -- a different code path from the natively sequenced stack the smaller train-mode cases take.  Dropout is off
+# (it cannot be replayed on the oracle); everything else is the bench's step.  Bars: the fixed ones of test_reference_gradients.py.
+# ---------------------------------------------------------------------------------------------------------------------------------
+_BENCH_SIZE = {}
+
+
+def _bench_size_case():
+    """Inputs + the fp32 CPU oracle's logits and gradients (computed once per session: ~30 GB of autograd state, tens of seconds)."""
+    if _BENCH_SIZE:
+        return _BENCH_SIZE
+    from oracle import qagnn_oracle as O
+    nq, nc, n = 64, 5, 200
+    B = nq * nc
+    cfg = helpers.model_cfg(d=200, k=5, sent_dim=1024, n_concept=20000, concept_in_dim=1024)
+    recs = synthetic.make_records(B, seed=91, shape='csqa', n_rel=17, n_concept_vocab=20000)
+    _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, nc)
+    bei, bet = data_utils.batch_graph(ei, et, n)
+    g = torch.Generator().manual_seed(92)
+    sv = torch.randn(B, 1024, generator=g)
+    labels = torch.randint(0, nc, (nq,), generator=g)
+    torch.manual_seed(0)
+    omodel = O.build_qagnn(cfg)
+    helpers.det_fill_(omodel, 7, 0.6)
+    omodel.pooler.dropout.p = omodel.pooler.attention.dropout.p = 0.0
+    omodel.train()
+    ologits, _ = omodel(sv, cids, nt, ns, al, (bei, bet))
+    torch.nn.functional.cross_entropy(ologits.view(nq, nc), labels).backward()
+    _BENCH_SIZE.update(cfg=cfg, inputs=(sv, cids, nt, ns, al, bei, bet), labels=labels, ei=ei, et=et, nt=nt,
+                       logits=ologits.detach(), grads={k: p.grad for k, p in omodel.named_parameters() if p.grad is not None},
+                       bufs={k: b.detach().clone() for k, b in omodel.named_buffers()})
+    return _BENCH_SIZE
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('variant', ['default', 'poison', 'blobs'])
+def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
+    """default: int64 edge lists; poison: deferred weight gradients start as NaN (a reader that runs before the side-stream join
+    would carry the NaN into a gradient); blobs: the graph arrives as load-time blobs, as in bench.py's default mode."""
+    import re
+    from qagnn_amd import modeling_qagnn as MQ
+    from test_reference_gradients import FIXED_GRAD_BAR, KINK_BAR
+    ref = _bench_size_case()
+    cfg, nq, nc, n = ref['cfg'], 64, 5, 200
+    if variant == 'poison':
+        monkeypatch.setattr(ops, 'WGRAD_POISON', True)
+    assert ops.WGRAD_OVERLAP and not ops.use_fused_hop(nq * nc * n), 'this test is about the composed path + weight-gradient overlap'
+    torch.manual_seed(0)
+    model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
+    helpers.det_fill_(model, 7, 0.6)
+    model.pooler.dropout.p = model.pooler.attention.dropout.p = 0.0
+    model = model.cuda().train()
+    sv, cids, nt, ns, al, bei, bet = cu(*ref['inputs'])
+    if variant == 'blobs':
+        store = data_utils.GraphBlobStore.build(ref['ei'], ref['et'], ref['nt'], 38, 4)
+        buf, Bb, E = store.pack(list(range(nq * nc)))
+        adj = data_utils.PackedGraphBatch(buf.cuda(), Bb, E, store, list(range(nq * nc)), nc)
+    else:
+        adj = (bei, bet)
+    deferred0 = ops._WgradQueue.n_deferred
+    logits, _ = model(sv, cids, nt, ns, al, adj)
+    torch.nn.functional.cross_entropy(logits.view(nq, nc), ref['labels'].cuda()).backward()
+    torch.cuda.synchronize()
+    assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the path bench.py times'
+    helpers._close(logits.detach().cpu(), ref['logits'], what='B=320 train-mode logits', **FWD)
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(ref['grads'])
+    worst, n_checked, fails = (0.0, None), 0, []
+    for k, gref in ref['grads'].items():
+        assert torch.isfinite(grads[k]).all(), f'{k}: non-finite gradient ({variant})'
+        if helpers.has_null_gradient(k, True):
+            continue
+        scale = gref.abs().max().item()
+        err = (grads[k].cpu() - gref).abs().max().item()
+        bar = KINK_BAR if re.search(r'(mlp|edge_encoder)\.1\.(weight|bias)$', k) else FIXED_GRAD_BAR
+        n_checked += 1
+        if err / (scale + 1e-30) > worst[0]:
+            worst = (err / (scale + 1e-30), k)
+        if err > bar * scale + 1e-9:
+            fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.0e})')
+    if helpers.REPORT:
+        with open(helpers.REPORT, 'a') as f:
+            f.write(f'bench-size B=320 train [{variant}] vs fp32 oracle: {n_checked} tensors, worst {worst[0]:.3e} of scale ({worst[1]})\n')
+    assert n_checked >= 60 and not fails, fails[:10]
+    for bname, b in model.named_buffers():
+        helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=1e-4, atol=1e-6, what='buffer ' + bname)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The non-default GEMM families through the module-level parity tests (they are selected by environment variables that the library
+# reads once per process, so each variant runs in its own interpreter): QAGNN_GEMM_SPLIT=0 / QAGNN_TN_SPLIT=0 pin the fp32-MFMA
+# kernels, QAGNN_WGRAD_POISON=1 starts deferred weight gradients as NaN.
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('env', ['QAGNN_GEMM_SPLIT=0', 'QAGNN_TN_SPLIT=0', 'QAGNN_GEMM_SPLIT=0 QAGNN_TN_SPLIT=0', 'QAGNN_WGRAD_POISON=1'])
+def test_module_parity_under_the_non_default_kernel_families(env):
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('QAGNN_VARIANT_CHILD'):
+        pytest.skip('already inside a variant run')
+    child_env = dict(os.environ, QAGNN_VARIANT_CHILD='1', **dict(kv.split('=') for kv in env.split()))
+    sel = ('test_qagnn_matches_reference and (csqa_b10 or sapbert_b4 or small_train) or test_oracle_parity_odd_shapes or '
+           'test_message_passing_stack_matches_reference and (medqa_b8 or roberta_b5)')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q', '-x', '-p', 'no:cacheprovider', '-k', sel],
+                       env=child_env, cwd=helpers.ROOT, capture_output=True, text=True, timeout=800)
+    tail = (r.stdout or '')[-1500:] + (r.stderr or '')[-500:]
+    assert r.returncode == 0, f'{env}:\n{tail}'
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, tail

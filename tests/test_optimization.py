@@ -129,3 +129,18 @@ def test_fused_radam_decoder_tensor_list_vs_float64(step, wd):
         np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), rm, rtol=2e-6, atol=3e-8)   # two O(0.1) terms may cancel
         np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), rv, rtol=2e-6, atol=1e-10)
         np.testing.assert_allclose(p.detach().cpu().numpy(), rp, rtol=2e-6, atol=1e-7)
+
+
+def test_adamw_keeps_the_defaults_of_the_class_the_reference_imports():
+    """The reference's OPTIMIZER_CLASSES['adamw'] is transformers.AdamW (utils/optimization_utils.py:3, 103): eps 1e-6, weight_decay 0.
+    Its driver never passes eps (qagnn.py:196-206), so the mirror must default to the same values, not to torch's 1e-8 / 0.01."""
+    import torch
+    p = torch.nn.Parameter(torch.ones(3))
+    opt = OU.OPTIMIZER_CLASSES['adamw']([{'params': [p], 'weight_decay': 0.01, 'lr': 1e-3}])
+    g = opt.param_groups[0]
+    assert g['eps'] == 1e-6 and g['weight_decay'] == 0.01 and g['betas'] == (0.9, 0.999)
+    assert OU.OPTIMIZER_CLASSES['adamw']([p], lr=1e-3).param_groups[0]['weight_decay'] == 0.0
+    p.grad = torch.full((3,), 0.5)
+    opt.step()  # first step of Adam with bias correction: p -= lr * (wd * p + g / (|g| + eps))
+    want = 1.0 - 1e-3 * 0.01 * 1.0 - 1e-3 * 0.5 / (0.5 + 1e-6)
+    assert torch.allclose(p.detach(), torch.full((3,), want), rtol=0, atol=1e-7)

@@ -25,17 +25,28 @@ def _build():
 
 def _run_questions(model, inp, a, b, n_global):
     """fwd+bwd on questions [a, b) with the reference's mini-batch loss weight; returns logits [b-a, nc]."""
+    return _run_question_list(model, inp, list(range(a, b)), n_global)
+
+
+def _run_question_list(model, inp, qs, n_global):
+    """The same for an arbitrary (ascending) list of questions: what a rank runs under parallel.balance_questions."""
     from qagnn_amd import data_utils, parallel
     nc, n = CASE['nc'], CASE['n']
-    sl = slice(a * nc, b * nc)
-    ei, et = data_utils.batch_graph(inp['edge_index_list'][sl], inp['edge_type_list'][sl], n)
-    logits, _ = model(inp['sent_vecs'][sl], inp['concept_ids'][sl], inp['node_type_ids'][sl], inp['node_scores'][sl],
-                      inp['adj_lengths'][sl], (ei, et))
-    logits = logits.view(b - a, nc)
-    labels = (torch.arange(a, b) % nc)
-    loss = torch.nn.functional.cross_entropy(logits, labels) * parallel.shard_loss_weight(b - a, n_global)
+    sub = [q * nc + j for q in qs for j in range(nc)]
+    idx = torch.tensor(sub, dtype=torch.long)
+    ei, et = data_utils.batch_graph([inp['edge_index_list'][i] for i in sub], [inp['edge_type_list'][i] for i in sub], n)
+    logits, _ = model(inp['sent_vecs'][idx], inp['concept_ids'][idx], inp['node_type_ids'][idx], inp['node_scores'][idx],
+                      inp['adj_lengths'][idx], (ei, et))
+    logits = logits.view(len(qs), nc)
+    labels = torch.tensor(qs, dtype=torch.long) % nc
+    loss = torch.nn.functional.cross_entropy(logits, labels, reduction='sum') / len(qs) * parallel.shard_loss_weight(len(qs), n_global)
     loss.backward()
     return logits.detach()
+
+
+def _question_costs(inp):
+    from qagnn_amd import parallel
+    return parallel.question_costs([e.size(1) for e in inp['edge_index_list']], CASE['n'], CASE['nc'])
 
 
 def _worker(rank, world, port, q):
@@ -63,8 +74,24 @@ def _worker(rank, world, port, q):
     allz = parallel.allgather_logits(logits)
     same = parallel.allgather_logits(logits[:2], equal_shards=True)  # the no-sync path (every rank contributes 2 rows)
     assert same.shape == (2 * world, logits.size(1)) and torch.equal(same[2 * rank:2 * rank + 2], logits[:2])
+    res = (n, allz.numpy(), {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    # ---- a parameter whose gradient exists on one rank only: every rank must end up with the sum (DDP semantics) ----
+    ps = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(3))]
+    ps[0].grad = torch.full((4,), float(rank + 1))
     if rank == 0:
-        q.put((n, allz.numpy(), {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}))
+        ps[1].grad = torch.full((3,), 5.0)
+    parallel.GradBucket(ps).allreduce()
+    assert ps[1].grad is not None and torch.equal(ps[1].grad, torch.full((3,), 5.0)) and torch.equal(ps[0].grad, torch.full((4,), 3.0))
+    # ---- strong scaling: the questions of ONE global batch dealt out by sum E'_g (parallel.balance_questions): shards of unequal
+    #      size, the variable-size logits gather, question order restored by scatter_logits_by_assignment ----
+    model2 = _build()
+    parts = parallel.balance_questions(_question_costs(inp), world)
+    logits2 = _run_question_list(model2, inp, parts[rank], CASE['nq'])
+    params2 = [p for p in model2.parameters() if p.requires_grad]
+    parallel.GradBucket(params2).allreduce()
+    z2 = parallel.scatter_logits_by_assignment(parallel.allgather_logits(logits2), parts)
+    if rank == 0:
+        q.put(res + (parts, z2.numpy(), {k: p.grad.numpy().copy() for k, p in model2.named_parameters() if p.grad is not None}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,7 +116,7 @@ def test_two_rank_gloo_matches_gradient_accumulation():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    n, allz, grads = q.get(timeout=240)
+    n, allz, grads, parts, z2, grads2 = q.get(timeout=240)
     allz, grads = torch.from_numpy(allz), {k: torch.from_numpy(v) for k, v in grads.items()}
     for p in procs:
         p.join(60)
@@ -113,6 +140,23 @@ def test_two_rank_gloo_matches_gradient_accumulation():
         if helpers.has_null_gradient(k, True):
             continue
         assert torch.allclose(grads[k], ref[k], rtol=1e-4, atol=1e-6 + 1e-4 * ref[k].abs().max().item()), k
+    # the balanced assignment: the same thing with the shards the two ranks derived (identically) from the edge counts
+    old = ops.set_kernels(EmuKernels())
+    try:
+        assert parts == parallel.balance_questions(_question_costs(inp), 2) and sorted(parts[0] + parts[1]) == list(range(CASE['nq']))
+        model = _build()
+        zs = [_run_question_list(model, inp, part, CASE['nq']) for part in parts]
+    finally:
+        ops.set_kernels(old)
+    want = torch.empty(CASE['nq'], CASE['nc'])
+    for part, z in zip(parts, zs):
+        want[torch.tensor(part)] = z
+    assert torch.allclose(torch.from_numpy(z2), want, rtol=1e-5, atol=1e-6)
+    ref = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(ref) == set(grads2)
+    for k in ref:
+        if not helpers.has_null_gradient(k, True):
+            assert torch.allclose(torch.from_numpy(grads2[k]), ref[k], rtol=1e-4, atol=1e-6 + 1e-4 * ref[k].abs().max().item()), k
 
 
 def test_balance_questions_by_edge_count():
