@@ -52,7 +52,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from qagnn_amd import data_utils, ops, parallel, synthetic  # noqa: E402
+from qagnn_amd import data_utils, graphed, ops, parallel, synthetic  # noqa: E402
 from qagnn_amd import modeling_qagnn as MQ  # noqa: E402
 
 D, K_LAYERS, N_NTYPE = 200, 5, 4
@@ -201,6 +201,22 @@ def step(model, b, nc, loss_weight, flat_grad_params, comm=None):
     return logits
 
 
+def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
+    """-> (run, run_eager, graph_step or None).  use_graph: the step is captured once per edge-capacity bucket and replayed as ONE hipGraph
+    launch (qagnn_amd.graphed.GraphedStep: static input buffers refilled before every replay, true edge counts read on the device,
+    dropout masks advanced per replay); the collectives stay outside the graph."""
+    run_eager = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
+    if not (use_graph and isinstance(b['adj'], data_utils.PackedGraphBatch)):
+        return run_eager, run_eager, None
+    gs = graphed.GraphedStep(model, nc)
+
+    def run():
+        logits, _ = gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], loss_weight)
+        if comm is not None:
+            comm(logits.view(-1, nc))
+    return run, run_eager, gs
+
+
 # kernels one qagnn_edge_attn_fwd_f32 call launches (substring of the demangled name): their FETCH_SIZE / WRITE_SIZE add up to
 # the forward edge stage's traffic per launch
 EDGE_FWD_KERNELS = ('qagnn::k_edge_scores', 'qagnn::k_edge_aggregate', 'qagnn::k_edge_fwd_', 'qagnn::k_edge_iso')
@@ -223,7 +239,7 @@ def measure_edge_traffic(args, N, DP):
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         td = tempfile.mkdtemp(prefix=f'qagnn_pmc_{ctr}_', dir='/tmp')
         cmd = [rocprof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', td, '-o', 'p', '--', sys.executable,
-               os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-pmc', '--pmc-child',
+               os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--repeats', '1', '--graphs', '0', '--no-cpu-baseline', '--no-pmc', '--pmc-child',
                '--questions', str(args.questions), '--n-concept', str(args.n_concept), '--dropout', str(args.dropout)] + \
               (['--edge-lists'] if args.edge_lists else [])
         try:
@@ -341,12 +357,12 @@ def gpu_small_batch(wl, args, dev, questions=2, steps=30, warmup=5):
     model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    run = lambda: step(model, b, nc, 1.0, params)  # noqa: E731
+    run, _, gs = make_runner(model, b, nc, 1.0, params, None, args.graphs)
     for _ in range(warmup):
         run()
     dt, enq = timed_steps(run, steps, torch.cuda.synchronize)
     return dict(subgraphs=questions * nc, value=round(questions * nc * steps / dt, 1), unit='QA-subgraphs/s', ms_per_step=round(dt / steps * 1e3, 3),
-                host_enqueue_ms_per_step=round(enq / steps * 1e3, 3), steps=steps,
+                host_enqueue_ms_per_step=round(enq / steps * 1e3, 3), steps=steps, hip_graph=gs is not None,
                 note='same step, same model, at the batch size the cpu baseline runs (the reference\'s mbs = 2 questions)')
 
 
@@ -357,21 +373,21 @@ def secondary_config(name, wl, args, dev, timed):
     model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    run = lambda: step(model, b, nc, 1.0, params)  # noqa: E731
+    run, run_eager, gs = make_runner(model, b, nc, 1.0, params, None, args.graphs)
     for _ in range(4):
         run()
     steps = 10
     regions = [timed_steps(run, steps, torch.cuda.synchronize) for _ in range(3)]
     dt, enq = sorted(regions)[1]
-    ins = instrumented_pass(run, timed, torch.cuda.synchronize, 2)
+    ins = instrumented_pass(run_eager, timed, torch.cuda.synchronize, 2)
     B = wl['questions'] * nc
     E = b['ei'].size(1)
     out = dict(workload=wl['what'], subgraphs=B, nodes=B * n, edges=E, value=round(B * steps / dt, 1), unit='QA-subgraphs/s',
                ms_per_step=round(dt / steps * 1e3, 3), host_enqueue_ms_per_step=round(enq / steps * 1e3, 3),
-               host_bound=bool(enq > 0.9 * dt), edge_fwd_ms_per_step=round(ins['edge_fwd_ms'] * K_LAYERS, 3),
+               host_bound=bool(enq > 0.9 * dt), hip_graph=gs is not None, edge_fwd_ms_per_step=round(ins['edge_fwd_ms'] * K_LAYERS, 3),
                edge_bwd_ms_per_step=round(ins['edge_bwd_ms'] * K_LAYERS, 3), gemm_ms_per_step=round(ins['gemm_ms'], 3),
                gemm_tflops=round(ins['gemm_flops'] / (ins['gemm_ms'] * 1e-3) / 1e12, 1) if ins['gemm_ms'] > 0 else 0.0)
-    del model, b
+    del model, b, run, run_eager, gs
     torch.cuda.empty_cache()
     if not args.no_cpu_baseline:
         small = gpu_small_batch(wl, args, dev, steps=20, warmup=4)
@@ -397,6 +413,8 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--edge-lists', action='store_true', help='feed the graph as int64 (edge_index, edge_type) (the reference protocol; the '
                     'graph orderings are then re-derived per batch) instead of the load-time blobs of qagnn_amd.data_utils')
+    ap.add_argument('--graphs', type=int, default=int(os.environ.get('QAGNN_BENCH_GRAPHS', '1')), help='1: every step is ONE hipGraph replay '
+                    '(qagnn_amd.graphed.GraphedStep; needs the blob input form); 0: eager launches')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -468,7 +486,7 @@ def main():
     comm = Comm(params, world, assignment=assignment)
     timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
     ops.set_kernels(timed)
-    run = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
+    run, run_eager, gs = make_runner(model, b, nc, loss_weight, params, comm, args.graphs)
 
     def sync():
         torch.cuda.synchronize()
@@ -480,8 +498,10 @@ def main():
     for _ in range(args.warmup):
         run()
     sync()
-    timed.enabled = True
-    timed.active = {'edge_attn_fwd', 'graph_prep', 'graph_from_blobs'}  # 6 event pairs per step inside the timed regions
+    # eager: 6 event pairs per step inside the timed regions (the forward edge stage and the graph preparation); under hipGraph replay
+    # there are no per-launch events -- those durations then come from the instrumented eager pass below
+    timed.enabled = gs is None
+    timed.active = {'edge_attn_fwd', 'graph_prep', 'graph_from_blobs'}
     regions = []
     for _ in range(max(1, args.repeats)):
         dt_r, enq_r = timed_steps(run, args.steps, sync)
@@ -506,7 +526,7 @@ def main():
     # either would measure the co-running kernels, not the kernel.  Host-bound batches take the natively sequenced hop
     # (ops.use_fused_hop), whose kernels are not visible from Python: the pass composes the hops from the per-kernel entry points.
     GEMM_STEPS = 3
-    ins = instrumented_pass(run, timed, sync, GEMM_STEPS)
+    ins = instrumented_pass(run_eager, timed, sync, GEMM_STEPS)
     if n_fwd == 0:
         fwd_ms, n_fwd = ins['edge_fwd_ms'], ins['n_edge_fwd']
     bwd_ms, n_bwd = ins['edge_bwd_ms'], ins['n_edge_bwd']
@@ -553,6 +573,7 @@ def main():
             'repeats': len(regions), 'repeat_ms_per_step': [round(r[0] / args.steps * 1e3, 3) for r in regions],
             'value_is': f'median of {len(regions)} timed regions of {args.steps} steps each (max over ranks per region)',
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'host_bound': bool(enq > 0.9 * dt),
+            'hip_graph': (f'one hipGraph replay per step ({gs.n_graphs} capture(s): qagnn_amd.graphed.GraphedStep)' if gs is not None else 'eager launches'),
             'config': {'workload': f'{HEADLINE}: ' + wl['what'] + ', 5-layer GAT d=200 H=4, QAGNN decoder fwd+bwd (LM encoder excluded: random '
                                    f'sent_vecs), dropout {args.dropout}, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
@@ -604,7 +625,7 @@ def main():
             else:
                 out['cpu_baseline'] = None
             if not args.no_configs:
-                del model, b
+                del model, b, run, run_eager, gs
                 torch.cuda.empty_cache()
                 out['configs'] = {name: secondary_config(name, w, args, dev, timed) for name, w in WORKLOADS.items() if name != HEADLINE}
         else:

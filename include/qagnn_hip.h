@@ -118,7 +118,11 @@ int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const int64_t* ed
  *   w2[i]                       position in the local source order of TARGET-order edge i (sorted by (tgt, local edge id))
  * i.e. 12 bytes per edge + 8 per node slot; self loops are not stored (inserted here, one per node row, last in their segments).
  * node_type is the batch's [B*n] int64 tensor (the self loops' classes).  Produces arrays bit-identical to
- * qagnn_graph_prep_blocked(edge_index = batch_graph(...), block_n = n); err[0] is set if a blob field is out of range. */
+ * qagnn_graph_prep_blocked(edge_index = batch_graph(...), block_n = n); err[0] is set if a blob field is out of range.
+ * `E` is the edge CAPACITY the arrays (and every launch shape that follows: g->E, g->Ep, g->max_chunks) are laid out for; the batch's
+ * true edge count is read on the device from edge_off[B] and must not exceed it (the caller packed the batch: it knows).  With
+ * E == edge_off[B] this is the plain call; with a bucketed E one hipGraph capture of the whole step serves every batch of the bucket
+ * (qagnn_amd/graphed.py).  The true E' = edge_off[B] + B*n stays available on the device as g->rowptr_s[N]. */
 int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const int32_t* blobs, const int32_t* blob_off /* [B+1] */,
                            const int32_t* edge_off /* [B+1] */, const int64_t* node_type /* [B*n] */, int32_t B, int32_t n, int32_t E,
                            int32_t R, int32_t T, qagnn_stream_t stream);
@@ -224,6 +228,14 @@ int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, in
                                  const float* sum_dy_hhat, float inv_rows, const float* roww, float* colsum /* [Cc] */, float* workspace,
                                  qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);
+
+/* Dropout under hipGraph replay.  Every dropout launch of this library (qagnn_gelu_dropout_*, qagnn_pool_attn_*, the hops) takes
+ * its seed by value; a captured graph would replay it verbatim and draw the SAME keep masks in every training step
+ * (torch's nn.Dropout solves the same problem with a device-side philox offset).  The kernels therefore add one device-resident
+ * word per device, the seed EPOCH (0 until advanced), into the seed.  A captured training step ends with
+ * qagnn_seed_epoch_advance(1): replay k uses epoch k, forward and backward of one replay agree, eager callers never notice. */
+int qagnn_seed_epoch_advance(uint64_t delta, qagnn_stream_t stream);
+int qagnn_seed_epoch_set(uint64_t value, qagnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The edge kernels: relation-aware multi-head graph attention over the batched subgraphs.  Replace

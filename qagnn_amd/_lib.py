@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')  # QAGNN_LIB: an alternate build (kernel A/B runs)
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
-           'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32',
+           'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
            'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
@@ -25,7 +25,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 10  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids)
+ABI_VERSION = 11  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -74,6 +74,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_graph_prep_blocked.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_graph_from_blobs.argtypes = [C.POINTER(qagnn_graph), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]
     lib.qagnn_node_prep_f32.argtypes = [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
+    lib.qagnn_seed_epoch_advance.argtypes = [_u64, _vp]
+    lib.qagnn_seed_epoch_set.argtypes = [_u64, _vp]
     lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp] + [C.c_double] * 6 + [_i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_nn_split_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp]
@@ -152,6 +154,8 @@ class _ErrWatch:
             self.poll(block=True)
 
     def poll(self, block=False):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return  # event queries are not legal while a hipGraph is being captured; the flags are looked at by the next eager call
         keep, bad = [], None
         for ev, host, what, reset in self.pending:
             if block:
@@ -179,6 +183,7 @@ class HipGraph:
         self.storage, self.c = storage, cstruct
         self.N, self.E, self.Ep, self.R, self.T = N, E, E + N, R, T
         self.block_n = block_n
+        self.dynamic = False
         self.C = R * T * T + T
         self.max_chunks = cstruct.max_chunks
 
@@ -291,9 +296,15 @@ class HipKernels(metaclass=_GuardedMeta):
         return G
 
     def graph_from_blobs(self, packed, node_type):
-        """packed: data_utils.PackedGraphBatch on the device (the batch's load-time blobs); node_type [B*n] int64."""
+        """packed: data_utils.PackedGraphBatch on the device (the batch's load-time blobs); node_type [B*n] int64.
+        packed.e_cap (optional, >= packed.E): lay the arrays out for that many edges -- every launch shape of the step then depends
+        on (B, n, e_cap) only and the true count is read on the device, which is what lets one captured hipGraph serve all batches
+        of a capacity bucket (qagnn_amd.graphed)."""
         assert packed.buf.is_cuda and packed.buf.dtype == torch.int32 and node_type.dtype == torch.long and node_type.is_contiguous()
-        B, n, E, R, T = packed.B, packed.n, packed.E, packed.n_etype, packed.n_ntype
+        B, n, R, T = packed.B, packed.n, packed.n_etype, packed.n_ntype
+        e_cap = getattr(packed, 'e_cap', None)
+        E = packed.E if e_cap is None else int(e_cap)
+        assert E >= packed.E, f'edge capacity {E} below the batch\'s {packed.E} edges'
         N = B * n
         assert node_type.numel() == N
         elems = self.lib.qagnn_graph_storage_elems(N, E, R, T)
@@ -304,11 +315,19 @@ class HipKernels(metaclass=_GuardedMeta):
                                              node_type.data_ptr(), B, n, E, R, T, self._stream())
         self._check(rc, 'qagnn_graph_from_blobs')
         G = HipGraph(storage, g, N, E, R, T, n)
+        G.dynamic = e_cap is not None  # E / Ep are capacities: the true E' lives on the device (rowptr_s[N] = sum of cls_count)
         G.keep = packed.buf  # the blobs are read by the kernel just enqueued
         G.max_sub_ep = packed.max_sub_ep  # host-side bound on E_g + n per subgraph: sizes the LDS of the edge kernels
         ERR_WATCH.poll()
-        ERR_WATCH.watch(G.array('err', 4), f'the graph of the blob batch with B={B} samples, E={E} edges (edge endpoint / relation id / node type)')
+        ERR_WATCH.watch(G.array('err', 4), f'the graph of the blob batch with B={B} samples, E={packed.E} edges (edge endpoint / relation id / node type)')
         return G
+
+    def seed_epoch_advance(self, delta=1):
+        """Advance this device's dropout seed epoch (see qagnn_seed_epoch_advance): the last launch of a captured training step."""
+        self._check(self.lib.qagnn_seed_epoch_advance(int(delta), self._stream()), 'qagnn_seed_epoch_advance')
+
+    def seed_epoch_set(self, value=0):
+        self._check(self.lib.qagnn_seed_epoch_set(int(value), self._stream()), 'qagnn_seed_epoch_set')
 
     def node_prep(self, node_scores, adj_lengths, node_type_ids, concept_ids, table_rows=0):
         """-> (normalised scores [B, n] fp32, pooling mask [B, n] bool, entity-table row ids [B*n] int64); qagnn_node_prep_f32.

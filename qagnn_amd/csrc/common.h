@@ -46,6 +46,15 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return base + slot;
 }
 
+// Dropout seeds under hipGraph replay.  Every dropout launch takes its seed BY VALUE, which a captured graph would replay verbatim:
+// the same keep masks in every training step.  The kernels therefore mix one device-resident word -- the seed EPOCH, one per device,
+// 0 unless a caller advances it -- into the seed; a captured step ends with qagnn_seed_epoch_advance(), so each replay draws new
+// masks while forward and backward of one replay still agree.  With the epoch at 0 (eager use) the seeds are used as passed.
+const unsigned long long* seed_epoch_ptr();  // device address of the current device's epoch word (elementwise.hip)
+__device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const unsigned long long* __restrict__ epoch) {
+  return seed + (uint64_t)epoch[0] * 0xD1B54A32D192ED03ull;
+}
+
 // counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index); same value in fwd and bwd
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;

@@ -87,23 +87,14 @@ __device__ __forceinline__ float4 wave_sum4(float4 v) {
   return make_float4(wave_sum(v.x), wave_sum(v.y), wave_sum(v.z), wave_sum(v.w));
 }
 
-__global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
-                                                     const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
-                                                     const float* __restrict__ EkEm, int lde, int HP, float qscale,
-                                                     float* __restrict__ score, float* __restrict__ a, float* __restrict__ alpha,
-                                                     int N, int C) {
-  __shared__ float4 slab[4][SLAB_ROWS];
-  const int s = wave_node();
-  if (s >= N) return;
-  const Lane L = lane_info(HP);
-  const int DP = 4 * HP;
-  const uint32_t pk = (uint32_t)ldk * 4u, pe = (uint32_t)lde * 4u;
-  const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe);
-  const float4 q = buf_ld4(rK, L.voff + 2u * DP * 4u, (uint32_t)s * pk);
-  const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+// hub segment (> 64 out-edges): raw scores chunk by chunk through the LDS slab into `score`, then max / sum / normalise in three
+// sweeps over what this wave stored
+__device__ __forceinline__ void scores_hub(float4 (&slab)[SLAB_ROWS], const Lane& L, const int* __restrict__ tgt_s,
+                                           const int* __restrict__ cls_s, rsrc_t rK, rsrc_t rE, uint32_t pk, uint32_t pe, float4 q,
+                                           float qscale, int beg, int end, float* __restrict__ score, float* __restrict__ a,
+                                           float* __restrict__ alpha) {
   const float deg = (float)(end - beg);
-  const bool in_wave = end - beg <= 64;
-  float* const sl = reinterpret_cast<float*>(slab[L.w]) + L.g;
+  float* const sl = reinterpret_cast<float*>(slab) + L.g;
   for (int e0 = beg; e0 < end; e0 += 64) {
     const int cnt = min(64, end - e0), lc = e0 + min(L.lane, cnt - 1);
     const uint32_t tv = (uint32_t)tgt_s[lc] * pk, cv = (uint32_t)cls_s[lc] * pe;
@@ -121,24 +112,10 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
         if (L.j == 0) sl[(i + u) * 4] = p;  // rows past cnt take the clamped duplicates: never used
       }
     }
-    const float4 sc = slab[L.w][L.lane];  // lane i: the 4 head scores of edge e0 + i
-    if (in_wave) {
-      const bool live = L.lane < cnt;
-      const float ninf = -INFINITY;
-      const float4 m = wave_max4(live ? sc : make_float4(ninf, ninf, ninf, ninf));
-      const float4 ex = live ? make_float4(expf(sc.x - m.x), expf(sc.y - m.y), expf(sc.z - m.z), expf(sc.w - m.w)) : zero4();
-      const float4 sum = wave_sum4(ex);
-      if (live) {
-        const float4 av = make_float4(ex.x / (sum.x + 1e-16f), ex.y / (sum.y + 1e-16f), ex.z / (sum.z + 1e-16f), ex.w / (sum.w + 1e-16f));
-        st4(a + (int64_t)(e0 + L.lane) * 4, av);
-        st4(alpha + (int64_t)(e0 + L.lane) * 4, make_float4(av.x * deg, av.y * deg, av.z * deg, av.w * deg));
-      }
-    } else if (L.lane < cnt) {
-      st4(score + (int64_t)(e0 + L.lane) * 4, sc);
-    }
+    const float4 sc = slab[L.lane];  // lane i: the 4 head scores of edge e0 + i
+    if (L.lane < cnt) st4(score + (int64_t)(e0 + L.lane) * 4, sc);
   }
-  if (in_wave) return;
-  // hub segment: make the raw scores this wave stored visible to all of its lanes, then max / sum / normalise in three sweeps
+  // make the raw scores this wave stored visible to all of its lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   float m = -INFINITY;
@@ -151,6 +128,95 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
     const float av = expf(score[(int64_t)e * 4 + L.g] - m) / (sum + 1e-16f);
     a[(int64_t)e * 4 + L.g] = av;
     alpha[(int64_t)e * 4 + L.g] = av * deg;
+  }
+}
+
+// One wave per SOURCE node.  Three shapes of segment (rocprof of the first form: 64 000 waves x ~300 instructions of per-node work
+// -- a 4-component wave-wide softmax with bpermute round trips -- against ~20 per edge; 40 % of the node rows of a CSQA batch are
+// PAD rows whose only edge is their self loop):
+//   deg == 1   the self loop alone (every PAD row, every isolated node): softmax of one score is exp(0) / (exp(0) + 1e-16) = 1 in
+//              fp32 whatever the score, alpha = deg * a = 1 -- two 16-byte stores, no row is read;
+//   deg <= 64  scores stay in REGISTERS in (head, edge) layout: the row-of-16 reduction leaves head g's score of edge i in all 16
+//              lanes of DPP row g, lane (g, i & 15) keeps it (one v_cndmask); the softmax is then ONE component per lane: an in-row
+//              max and an in-row sum (4 DPP steps each, no LDS, no bpermute), one exp and one divide per (edge, head);
+//   deg > 64   hubs: scores_hub above.
+__global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ rowptr_s, const int* __restrict__ tgt_s,
+                                                     const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
+                                                     const float* __restrict__ EkEm, int lde, int HP, float qscale,
+                                                     float* __restrict__ score, float* __restrict__ a, float* __restrict__ alpha,
+                                                     int N, int C) {
+  __shared__ float4 slab[4][SLAB_ROWS];
+  const int s = wave_node();
+  if (s >= N) return;
+  const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+  const int cnt = end - beg;
+  const int lane = threadIdx.x & 63;
+  if (cnt == 1) {
+    if (lane < 2) st4((lane == 0 ? a : alpha) + (int64_t)beg * 4, make_float4(1.f, 1.f, 1.f, 1.f));
+    return;
+  }
+  const Lane L = lane_info(HP);
+  const int DP = 4 * HP;
+  const uint32_t pk = (uint32_t)ldk * 4u, pe = (uint32_t)lde * 4u;
+  const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe);
+  const float4 q = buf_ld4(rK, L.voff + 2u * DP * 4u, (uint32_t)s * pk);
+  if (cnt > 64) {
+    scores_hub(slab[L.w], L, tgt_s, cls_s, rK, rE, pk, pe, q, qscale, beg, end, score, a, alpha);
+    return;
+  }
+  const float deg = (float)cnt;
+  const int lc = beg + min(L.lane, cnt - 1);
+  const uint32_t tv = (uint32_t)tgt_s[lc] * pk, cv = (uint32_t)cls_s[lc] * pe;
+  float sc[4];
+#pragma unroll
+  for (int grp = 0; grp < 4; ++grp) {
+    sc[grp] = -INFINITY;
+    if (grp * 16 < cnt) {  // wave-uniform
+      const int gcnt = min(16, cnt - grp * 16);
+      for (int i = 0; i < gcnt; i += EDGE_UNROLL) {
+        float4 k[EDGE_UNROLL], ek[EDGE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < EDGE_UNROLL; ++u) {
+          const int idx = min(grp * 16 + i + u, cnt - 1);
+          k[u] = buf_ld4(rK, L.voff, rl(tv, idx));
+          ek[u] = buf_ld4(rE, L.voff, rl(cv, idx));
+        }
+#pragma unroll
+        for (int u = 0; u < EDGE_UNROLL; ++u) {
+          const float p = row16_sum(dot4(q, add4(k[u], ek[u]))) * qscale;
+          sc[grp] = (L.j == i + u) ? p : sc[grp];  // slots past the segment take clamped duplicates: masked below
+        }
+      }
+    }
+  }
+  // PyG softmax over the segment (max, exp, sum, / (sum + 1e-16)), then * out-degree; lane (g, j) owns edges j, j + 16, ... of head g.
+  // Groups past the segment are skipped by wave-uniform branches (most segments fit one or two groups).
+  float m = sc[0];  // group 0 is never empty; its slots past the segment hold -inf
+  m = (L.j < cnt) ? m : -INFINITY;
+#pragma unroll
+  for (int grp = 1; grp < 4; ++grp)
+    if (grp * 16 < cnt) m = (grp * 16 + L.j < cnt) ? fmaxf(m, sc[grp]) : m;
+  m = row16_max(m);
+  float ex[4], sum = 0.f;
+#pragma unroll
+  for (int grp = 0; grp < 4; ++grp) {
+    ex[grp] = 0.f;
+    if (grp * 16 < cnt) {
+      ex[grp] = (grp * 16 + L.j < cnt) ? expf(sc[grp] - m) : 0.f;
+      sum += ex[grp];
+    }
+  }
+  sum = row16_sum(sum) + 1e-16f;
+#pragma unroll
+  for (int grp = 0; grp < 4; ++grp) {
+    if (grp * 16 < cnt) {
+      if (grp * 16 + L.j < cnt) {
+        const float av = ex[grp] / sum;
+        const int64_t o = (int64_t)(beg + grp * 16 + L.j) * 4 + L.g;
+        a[o] = av;
+        alpha[o] = av * deg;
+      }
+    }
   }
 }
 
@@ -168,6 +234,15 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
   const uint32_t pk = (uint32_t)ldk * 4u, pe = (uint32_t)lde * 4u, vm = L.voff + (uint32_t)DP * 4u;  // M | Em halves
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe);
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_t[t]), end = __builtin_amdgcn_readfirstlane(rowptr_t[t + 1]);
+  if (end - beg == 1) {
+    // one in-edge: the node's own self loop (every PAD row, 40 % of a CSQA batch): no chunk staging, no LDS
+    const int sv = __builtin_amdgcn_readfirstlane(src_t[beg]), cv = __builtin_amdgcn_readfirstlane(cls_t[beg]);
+    const int pv = __builtin_amdgcn_readfirstlane(pos_t[beg]);
+    const float4 m1 = buf_ld4(rK, vm, (uint32_t)sv * pk), em1 = buf_ld4(rE, vm, (uint32_t)cv * pe);
+    const float al = alpha[(int64_t)pv * 4 + L.g];
+    if (L.act) st4(aggr + (int64_t)t * lda + L.off, fma4(al, add4(m1, em1), zero4()));
+    return;
+  }
   slab_init(slab[L.w], L.lane);
   const float* const sl = reinterpret_cast<const float*>(slab[L.w]) + L.g;
   float4 acc = zero4();
@@ -211,8 +286,19 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
   const int DP = 4 * HP;
   const uint32_t pk = (uint32_t)ldk * 4u, pe = (uint32_t)lde * 4u, pg = (uint32_t)ldg * 4u, vm = L.voff + (uint32_t)DP * 4u;
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe), rG = make_rsrc(G, (uint32_t)N * pg);
-  const float4 mrow = buf_ld4(rK, vm, (uint32_t)s * pk);
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+  if (end - beg == 1) {
+    // the self loop alone: a = alpha = 1, so dM[s] = G[s]; its softmax gradient gs = qscale * a * (ga - a * ga) is exactly 0, which
+    // src pass 2 reproduces from ga = 0, rs = 0 without reading a row (and then leaves dQ[s] = 0, gs = 0 behind)
+    const float4 g1 = buf_ld4(rG, L.voff, (uint32_t)s * pg);
+    if (L.act) st4(dKMQ + (int64_t)s * ldk + DP + L.off, g1);
+    if (L.lane == 0) {
+      st4(ga + (int64_t)beg * 4, zero4());
+      st4(rs + (int64_t)s * 4, zero4());
+    }
+    return;
+  }
+  const float4 mrow = buf_ld4(rK, vm, (uint32_t)s * pk);
   const float deg = (float)(end - beg);
   slab_init(slab[0][L.w], L.lane);
   slab_init(slab[1][L.w], L.lane);
@@ -262,6 +348,10 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
   const uint32_t pk = (uint32_t)ldk * 4u, pe = (uint32_t)lde * 4u;
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk), rE = make_rsrc(EkEm, (uint32_t)C * pe);
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
+  if (end - beg == 1) {  // the self loop alone: gs = 0 (src pass 1 left ga = 0 there), so dQ[s] = 0
+    if (L.act) st4(dKMQ + (int64_t)s * ldk + 2 * DP + L.off, zero4());
+    return;
+  }
   const float4 r4 = ld4(rs + (int64_t)s * 4);  // the node's 4 head values, same address in every lane
   slab_init(slab[L.w], L.lane);
   const float* const sl = reinterpret_cast<const float*>(slab[L.w]) + L.g;
@@ -304,6 +394,13 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
   const uint32_t pk = (uint32_t)ldk * 4u, vq = L.voff + 2u * DP * 4u;
   const rsrc_t rK = make_rsrc(KMQ, (uint32_t)N * pk);
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_t[t]), end = __builtin_amdgcn_readfirstlane(rowptr_t[t + 1]);
+  if (end - beg == 1) {  // one in-edge (the self loop): dK[t] = gs * Q[src], no staging
+    const int sv = __builtin_amdgcn_readfirstlane(src_t[beg]), pv = __builtin_amdgcn_readfirstlane(pos_t[beg]);
+    const float4 q1 = buf_ld4(rK, vq, (uint32_t)sv * pk);
+    const float gs1 = gsb[(int64_t)pv * 4 + L.g];
+    if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, fma4(gs1, q1, zero4()));
+    return;
+  }
   slab_init(slab[L.w], L.lane);
   const float* const sl = reinterpret_cast<const float*>(slab[L.w]) + L.g;
   float4 dK = zero4();

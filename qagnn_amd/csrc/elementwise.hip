@@ -180,9 +180,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 template <bool BWD>
 __global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
-                               float p, uint64_t seed) {
+                               float p, uint64_t seed, const unsigned long long* __restrict__ epoch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
+  if (p > 0.f) seed = epoch_seed(seed, epoch);
   const float4 x = ld4(X + i * 4);
   float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
   if (BWD) g = ld4(dY + i * 4);
@@ -256,6 +257,23 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
   const int c = threadIdx.x;
   if (blockIdx.x * 256 + c < Cc)
     part[(int64_t)blockIdx.y * Cc + blockIdx.x * 256 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ---- the dropout seed epoch (see common.h) --------------------------------------------------------------------
+__device__ unsigned long long g_seed_epoch = 0;  // one instance per device (module globals are per device)
+__global__ void k_seed_epoch(unsigned long long* w, unsigned long long v, int add) { *w = add ? *w + v : v; }
+
+const unsigned long long* seed_epoch_ptr() {
+  static const unsigned long long* cache[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long*& p = cache[dev & 63];
+  if (!p) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_seed_epoch)) != hipSuccess) return nullptr;
+    p = static_cast<const unsigned long long*>(a);
+  }
+  return p;
 }
 
 __global__ void k_sin_basis(const float* __restrict__ score, const float* __restrict__ js, float* __restrict__ out, int ldo, int R,
@@ -335,7 +353,7 @@ extern "C" int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, f
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(X && Y && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(Y), QAGNN_EINVAL, "gelu_dropout_fwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_fwd: p=%f", p);
-  k_gelu_dropout<false><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, nullptr, Y, n / 4, p, seed);
+  k_gelu_dropout<false><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, nullptr, Y, n / 4, p, seed, seed_epoch_ptr());
   QAGNN_LAUNCH_CHECK("k_gelu_dropout_fwd");
   return QAGNN_OK;
 }
@@ -346,8 +364,24 @@ extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float
   QAGNN_REQUIRE(X && dY && dX && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX), QAGNN_EINVAL,
                 "gelu_dropout_bwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd: p=%f", p);
-  k_gelu_dropout<true><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, dY, dX, n / 4, p, seed);
+  k_gelu_dropout<true><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, dY, dX, n / 4, p, seed, seed_epoch_ptr());
   QAGNN_LAUNCH_CHECK("k_gelu_dropout_bwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_seed_epoch_advance(uint64_t delta, qagnn_stream_t stream_) {
+  unsigned long long* w = const_cast<unsigned long long*>(seed_epoch_ptr());
+  QAGNN_REQUIRE(w, QAGNN_EHIP, "seed_epoch: cannot resolve the epoch word on this device");
+  k_seed_epoch<<<1, 1, 0, (hipStream_t)stream_>>>(w, delta, 1);
+  QAGNN_LAUNCH_CHECK("k_seed_epoch");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_seed_epoch_set(uint64_t value, qagnn_stream_t stream_) {
+  unsigned long long* w = const_cast<unsigned long long*>(seed_epoch_ptr());
+  QAGNN_REQUIRE(w, QAGNN_EHIP, "seed_epoch: cannot resolve the epoch word on this device");
+  k_seed_epoch<<<1, 1, 0, (hipStream_t)stream_>>>(w, value, 0);
+  QAGNN_LAUNCH_CHECK("k_seed_epoch");
   return QAGNN_OK;
 }
 

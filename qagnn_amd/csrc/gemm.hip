@@ -574,35 +574,40 @@ __global__ void k_sum_chunks(const float* __restrict__ P, float* __restrict__ C,
   *d = accumulate ? *d + s : s;
 }
 
-// Same reduction, bandwidth-shaped: a thread owns one float4 column, the block's 8 waves split the chunks (wave g takes
-// chunks g, g+8, ...: 8x the loads in flight of the scalar kernel, which was latency-bound at ~3 TB/s), and the 8 partial
-// sums meet in LDS and are added in wave order.  The summation order is fixed by (nchunks), never by timing.
-constexpr int SC_G = 8;
+// Same reduction, latency-shaped: a thread owns one float4 column, the block's 16 waves split the chunks (wave g takes chunks g,
+// g+16, ...) and every wave issues FOUR of its loads back to back before it adds anything, so the ~84 partials of a 64 000-row
+// weight gradient are fetched in two round trips per thread instead of five (the partials were written by the kernel in front and
+// sit in L2 / Infinity Cache: the kernel is bound by load latency, not by bytes -- it ran at 1.5 TB/s with 2 loads in flight
+// over 8 waves: profiles/r2_run60_by_shape.txt).  The 16 partial sums meet in LDS and are added in wave order.  The summation
+// order is fixed by (nchunks), never by timing.
+constexpr int SC_G = 16;
 __global__ __launch_bounds__(SC_G * 64) void k_sum_chunks4(const float* __restrict__ P, float* __restrict__ C, int ldc, int Ka, int No,
                                                            int nchunks, int accumulate) {
   __shared__ float4 part[SC_G][64];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t n4 = (int64_t)Ka * No / 4, i4 = (int64_t)blockIdx.x * 64 + lane;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i4 < n4) {
     const float4* src = reinterpret_cast<const float4*>(P) + i4;
-    int c = g;
-    for (; c + SC_G < nchunks; c += 2 * SC_G) {  // two independent chains keep 2 x 16 B per lane in flight
-      s0 = add4(s0, src[(int64_t)c * n4]);
-      s1 = add4(s1, src[(int64_t)(c + SC_G) * n4]);
+    for (int c0 = g; c0 < nchunks; c0 += 4 * SC_G) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)min(c0 + u * SC_G, nchunks - 1) * n4];  // clamped: unconditional, in flight together
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u * SC_G < nchunks) s = add4(s, v[u]);
     }
-    if (c < nchunks) s0 = add4(s0, src[(int64_t)c * n4]);
   }
-  part[g][lane] = add4(s0, s1);
+  part[g][lane] = s;
   __syncthreads();
   if (g == 0 && i4 < n4) {
-    float4 s = part[0][lane];
+    float4 t = part[0][lane];
 #pragma unroll
-    for (int k = 1; k < SC_G; ++k) s = add4(s, part[k][lane]);
+    for (int k = 1; k < SC_G; ++k) t = add4(t, part[k][lane]);
     const int64_t e = i4 * 4;
     float* d = C + (e / No) * ldc + (e % No);
-    if (accumulate) s = add4(s, ld4(d));
-    st4(d, s);
+    if (accumulate) t = add4(t, ld4(d));
+    st4(d, t);
   }
 }
 

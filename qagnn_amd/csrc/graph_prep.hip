@@ -192,7 +192,7 @@ __device__ __forceinline__ int seg_owner(const int* __restrict__ rp, int n, int 
 
 __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict__ blobs, const int32_t* __restrict__ blob_off,
                                                        const int32_t* __restrict__ edge_off, const int64_t* __restrict__ node_type,
-                                                       int n, int B, int E, int R, int T, int* __restrict__ rowptr_s,
+                                                       int n, int B, int R, int T, int* __restrict__ rowptr_s,
                                                        int* __restrict__ tgt_s, int* __restrict__ src_s, int* __restrict__ cls_s,
                                                        int* __restrict__ eid_s, int* __restrict__ rowptr_t, int* __restrict__ src_t,
                                                        int* __restrict__ tgt_t, int* __restrict__ cls_t, int* __restrict__ pos_t,
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
   int* const rank = rp_t + n + 1;
   const int C = R * T * T + T;
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int E = edge_off[B];  // the batch's edge count, read on the device: the host only fixes the CAPACITY of the arrays (hipGraph replay)
   const int32_t* blob = blobs + blob_off[g];
   const int Eoff = edge_off[g], Eg = edge_off[g + 1] - Eoff, node0 = g * n, Epoff = Eoff + node0;
   const int32_t *cnt_s = blob, *cnt_t = blob + n;
@@ -299,9 +300,12 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
 
 // ---- stable counting sort of the source-ordered positions by class -------------------------------------------
 #define CLS_BLK 1024
+// (Ep is read from the device -- rowptr_s[N], written by the kernels in front: the launch shapes below are sized by the arrays'
+// CAPACITY, so that one captured launch sequence serves every batch of a capacity bucket)
 __global__ __launch_bounds__(256) void k_cls_hist(const int* __restrict__ cls_s, int* __restrict__ hist,
-                                                  int* __restrict__ cls_count, int Ep, int C) {
+                                                  int* __restrict__ cls_count, const int* __restrict__ Ep_dev, int C) {
   extern __shared__ int lh[];
+  const int Ep = *Ep_dev;
   for (int c = threadIdx.x; c < C; c += 256) lh[c] = 0;
   __syncthreads();
   const int base = blockIdx.x * CLS_BLK;
@@ -349,8 +353,9 @@ __global__ __launch_bounds__(256) void k_grp_base(int* __restrict__ hist, const 
 __global__ __launch_bounds__(64) void k_cls_scatter(const int* __restrict__ cls_s, const int* __restrict__ src_s,
                                                     const int* __restrict__ tgt_s, const int* __restrict__ hist,
                                                     int* __restrict__ src_c, int* __restrict__ tgt_c, int* __restrict__ pos_c,
-                                                    int Ep, int C) {
+                                                    const int* __restrict__ Ep_dev, int C) {
   extern __shared__ int cnt[];  // [C] next class-order slot of class c for this block
+  const int Ep = *Ep_dev;
   const int lane = threadIdx.x, base = blockIdx.x * CLS_BLK;
   for (int c = lane; c < C; c += 64) cnt[c] = hist[(int64_t)blockIdx.x * C + c];
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));  // lanes below this one
@@ -459,7 +464,8 @@ static carved carve(qagnn_graph* g, int32_t* storage, int N, int E, int R, int T
 
 static int class_pass(qagnn_graph* g, int32_t* hist, int32_t* gc_cnt, int32_t* gcptr, int32_t* nch, int nblk, int gb, int NG, int pairs,
                       hipStream_t stream) {
-  const int TB = 256, Ep = g->Ep, C = g->C;
+  const int TB = 256, C = g->C;
+  const int* Ep = g->rowptr_s + g->N;  // device: the true E' (g->Ep is the capacity the arrays and the grids are sized for)
   k_cls_hist<<<nblk, 256, C * sizeof(int), stream>>>(g->cls_s, hist, g->cls_count, Ep, C);
   QAGNN_LAUNCH_CHECK("k_cls_hist");
   k_grp_count<<<cdiv(pairs, TB), TB, 0, stream>>>(hist, gc_cnt, nblk, C, gb, NG);
@@ -478,7 +484,7 @@ static int class_pass(qagnn_graph* g, int32_t* hist, int32_t* gc_cnt, int32_t* g
 }
 
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 10; }
+extern "C" int qagnn_abi_version(void) { return 11; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;
@@ -560,7 +566,7 @@ extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const in
   carved cv = carve(g, storage, (int)N64, E, R, T, n);
   hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)cv.es - (char*)g->cls_count), stream);
   if (he != hipSuccess) { set_error("graph_from_blobs: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
-  k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1) + C64) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, E, R, T, g->rowptr_s,
+  k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1) + C64) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, R, T, g->rowptr_s,
                                                                                   g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t,
                                                                                   g->tgt_t, g->cls_t, g->pos_t, g->pk_s, g->pk_t, g->sub_ncls,
                                                                                   g->sub_cls, g->err);

@@ -19,8 +19,9 @@ constexpr int POOL_W = 8;  // waves per workgroup; a wave takes 4 consecutive ro
 // grid = B, block = 512 (8 waves)
 __global__ __launch_bounds__(64 * POOL_W) void k_pool_fwd(const float* __restrict__ u, const float* __restrict__ cvec, const float* __restrict__ K,
                                                   int ldk, const uint8_t* __restrict__ mask, int n, int NH, int Cc, float inv_temp,
-                                                  float p, uint64_t seed, float* __restrict__ attn, float* __restrict__ attn_d,
-                                                  float* __restrict__ z) {
+                                                  float p, uint64_t seed, const unsigned long long* __restrict__ epoch, float* __restrict__ attn,
+                                                  float* __restrict__ attn_d, float* __restrict__ z) {
+  if (p > 0.f) seed = epoch_seed(seed, epoch);
   __shared__ float sc[POOL_MAXH * POOL_MAXN];
   __shared__ __attribute__((aligned(16))) float red[POOL_W][POOL_MAXH][256];
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -110,10 +111,11 @@ __global__ __launch_bounds__(64 * POOL_W) void k_pool_fwd(const float* __restric
 
 // backward: given dz [B, NH, Cc] and (optionally) d attn_d [B, NH, n] -> dK rows (written, not accumulated), du, dc
 __global__ __launch_bounds__(64 * POOL_W) void k_pool_bwd(const float* __restrict__ u, const float* __restrict__ K, int ldk, int n, int NH, int Cc,
-                                                  float inv_temp, float p, uint64_t seed, const float* __restrict__ attn,
-                                                  const float* __restrict__ attn_d, const float* __restrict__ dz,
-                                                  const float* __restrict__ dattn_d,
+                                                  float inv_temp, float p, uint64_t seed, const unsigned long long* __restrict__ epoch,
+                                                  const float* __restrict__ attn, const float* __restrict__ attn_d,
+                                                  const float* __restrict__ dz, const float* __restrict__ dattn_d,
                                                   float* __restrict__ dK, int lddk, float* __restrict__ du, float* __restrict__ dc) {
+  if (p > 0.f) seed = epoch_seed(seed, epoch);
   __shared__ float ga[POOL_MAXH * POOL_MAXN];  // sweep 1: d attn_d from the z path; then ds (already x 1/temperature)
   __shared__ __attribute__((aligned(16))) float red[POOL_W][POOL_MAXH][256];
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -225,7 +227,7 @@ extern "C" int qagnn_pool_attn_fwd_f32(const float* u, const float* cvec, const 
   QAGNN_REQUIRE(u && cvec && K && mask && attn && attn_d && z, QAGNN_EINVAL, "pool_attn_fwd: null pointer");
   QAGNN_REQUIRE(aligned16(u) && aligned16(K) && aligned16(z), QAGNN_EINVAL, "pool_attn_fwd: u / K / z must be 16-byte aligned");
   if (int rc = pool_check("pool_attn_fwd", B, n, NH, Cc, ldk, p)) return rc;
-  k_pool_fwd<<<B, 64 * POOL_W, 0, stream>>>(u, cvec, K, ldk, mask, n, NH, Cc, inv_temp, p, seed, attn, attn_d, z);
+  k_pool_fwd<<<B, 64 * POOL_W, 0, stream>>>(u, cvec, K, ldk, mask, n, NH, Cc, inv_temp, p, seed, seed_epoch_ptr(), attn, attn_d, z);
   QAGNN_LAUNCH_CHECK("k_pool_fwd");
   return QAGNN_OK;
 }
@@ -238,7 +240,7 @@ extern "C" int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t l
   QAGNN_REQUIRE(aligned16(u) && aligned16(K) && aligned16(dz) && aligned16(dK) && aligned16(du) && lddk % 4 == 0 && lddk >= Cc, QAGNN_EINVAL,
                 "pool_attn_bwd: operands must be 16-byte aligned, lddk=%d", lddk);
   if (int rc = pool_check("pool_attn_bwd", B, n, NH, Cc, ldk, p)) return rc;
-  k_pool_bwd<<<B, 64 * POOL_W, 0, stream>>>(u, K, ldk, n, NH, Cc, inv_temp, p, seed, attn, attn_d, dz, dattn_d, dK, lddk, du, dc);
+  k_pool_bwd<<<B, 64 * POOL_W, 0, stream>>>(u, K, ldk, n, NH, Cc, inv_temp, p, seed, seed_epoch_ptr(), attn, attn_d, dz, dattn_d, dK, lddk, du, dc);
   QAGNN_LAUNCH_CHECK("k_pool_bwd");
   return QAGNN_OK;
 }

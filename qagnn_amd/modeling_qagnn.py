@@ -113,6 +113,22 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
     if key not in _CLASS_FEATS:
         _CLASS_FEATS[key] = F.pad(edge_class_features(graph.R, graph.T, W1t.device, W1t.dtype), (0, FP - (graph.R + 1 + 2 * graph.T)))
     use_batch_stats = training or not bn.track_running_stats
+    rm_p, rv_p = L.pad(bn.running_mean), L.pad(bn.running_var)
+    if getattr(graph, 'dynamic', False):
+        # graph.Ep is only the CAPACITY its arrays are laid out for (one captured hipGraph per capacity bucket, qagnn_amd.graphed): the
+        # true E' is the sum of the class counts, on the device -- the weights and the unbiased-variance factor become tensors, and the
+        # running statistics are updated here instead of inside the BN bookkeeping kernel (which takes that factor as a host float)
+        cnt = graph.cls_count.to(W1t.dtype)
+        Ep_t = cnt.sum()
+        tab_p, mean_p, var_p = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p, use_batch_stats, bn.eps, 0.0,
+                                           apply_act=False, running=None, row_weight=cnt / Ep_t if use_batch_stats else None)
+        if training and bn.track_running_stats:
+            with torch.no_grad():
+                wgt = 1.0 - (1.0 - bn_momentum(bn)) ** n_updates
+                bn.running_mean.lerp_(L.unpad(mean_p), wgt)
+                bn.running_var.lerp_(L.unpad(var_p) * (Ep_t / torch.clamp(Ep_t - 1.0, min=1.0)), wgt)
+                bn.num_batches_tracked += n_updates
+        return tab_p
     Ep = float(graph.Ep)
     running = None
     if training and bn.track_running_stats:
@@ -120,7 +136,7 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
         # n identical momentum updates in closed form; the batch counter is bumped by n below (the kernel would add 1)
         running = (bn.running_mean, bn.running_var, None, L.dense_pos, 1.0 - (1.0 - m) ** n_updates, Ep / max(Ep - 1.0, 1.0))
         bn.num_batches_tracked += n_updates
-    tab_p, _, _ = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, L.pad(bn.running_mean), L.pad(bn.running_var),
+    tab_p, _, _ = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p,
                               use_batch_stats, bn.eps, 0.0, apply_act=False, running=running,
                               row_weight=graph.cls_count.to(W1t.dtype) / Ep if use_batch_stats else None)
     return tab_p

@@ -1,0 +1,84 @@
+#!/bin/bash
+# One GPU-box visit of round 3: legs are named on the command line.  Small logs land in gpurun_out/ (< 64 MiB).
+#   tests      the driver's `pytest tests -m gpu` (no -x: everything is reported), with the parity report file
+#   smoke      __graft_entry__.smoke()
+#   bench      the driver's `python bench.py` (defaults) -> gpurun_out/bench.json
+#   benchq     bench.py without configs / cpu baseline / pmc (quick headline + breakdown)
+#   prof       rocprofv3 --kernel-trace --stats of a short bench run -> gpurun_out/prof/
+#   ab:VAR     interleaved A/B of an environment switch (0 1 0 1), quick bench
+#   b10        quick bench at 2 questions (the reference's mini-batch)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+REPO="$PWD"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+T0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - T0 )) s] $*" >> gpurun_out/summary.txt; }
+: > gpurun_out/summary.txt
+( rocm-smi --showproductname 2>/dev/null | head -4; nproc; free -g | head -2 ) > gpurun_out/gpu.txt
+( time python __graft_entry__.py ) > gpurun_out/build.log 2>&1
+stamp "build check done: $(tail -n 4 gpurun_out/build.log | head -n 1)"
+for arg in "$@"; do
+  case "$arg" in
+    tests)
+      rm -f gpurun_out/parity_report.txt
+      QAGNN_PARITY_REPORT=$REPO/gpurun_out/parity_report.txt timeout 2400 python -m pytest tests -m gpu -q --tb=short -rf --timeout 1500 -p no:cacheprovider --durations=12 > /tmp/test_all.log 2>&1
+      echo "tests exit $?" >> gpurun_out/summary.txt
+      ( head -c 30000 /tmp/test_all.log; echo; echo "......"; tail -c 12000 /tmp/test_all.log ) > gpurun_out/test_all.log
+      stamp tests ;;
+    tests:*)
+      sel="${arg#tests:}"
+      QAGNN_PARITY_REPORT=$REPO/gpurun_out/parity_report.txt timeout 1800 python -m pytest tests -m gpu -q --tb=short -rf --timeout 1500 -p no:cacheprovider -k "$sel" > /tmp/test_sel.log 2>&1
+      echo "tests[$sel] exit $?" >> gpurun_out/summary.txt
+      ( head -c 20000 /tmp/test_sel.log; echo; echo "......"; tail -c 8000 /tmp/test_sel.log ) > "gpurun_out/test_sel.log"
+      stamp "tests:$sel" ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke 2>&1 | tail -n 20 > gpurun_out/smoke.log
+      echo "smoke exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt; stamp smoke ;;
+    bench)
+      timeout 1200 python bench.py > /tmp/bench.out 2> gpurun_out/bench.err
+      echo "bench exit $?" >> gpurun_out/summary.txt
+      tail -n 1 /tmp/bench.out > gpurun_out/bench.json; tail -n 5 gpurun_out/bench.err > gpurun_out/bench.log; stamp bench ;;
+    benchq)
+      timeout 600 python bench.py --no-cpu-baseline --no-pmc --no-configs 2> gpurun_out/benchq.err | tail -n 1 > gpurun_out/benchq.json
+      echo "benchq exit ${PIPESTATUS[0]}" >> gpurun_out/summary.txt; stamp benchq ;;
+    b10)
+      timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | tail -n 1 > gpurun_out/bench_b10.json; stamp b10 ;;
+    prof)
+      rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/prof
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r3 -- python "$REPO/bench.py" --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof.log
+      echo "prof exit $?" >> gpurun_out/summary.txt
+      find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} gpurun_out/prof/kernel_stats.csv \;
+      python scripts/trace_by_shape.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape.txt 2>&1
+      stamp prof ;;
+    prof10)
+      rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log
+      python scripts/trace_by_shape.py "$(find /tmp/prof10 -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape_b10.txt 2>&1
+      stamp prof10 ;;
+    ab:*)
+      var="${arg#ab:}"
+      for v in 0 1 0 1; do
+        echo "$var=$v" >> gpurun_out/ab_$var.txt
+        env $var=$v timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 > /tmp/ab_line.txt
+        python - <<PY >> gpurun_out/ab_$var.txt
+import json
+d = json.load(open('/tmp/ab_line.txt'))
+print(d['value'], d['ms_per_step'], d['repeat_ms_per_step'], d['breakdown_ms_per_step'])
+PY
+      done; stamp "ab:$var" ;;
+    ab10:*)
+      var="${arg#ab10:}"
+      for v in 0 1 0 1; do
+        echo "$var=$v (2 questions)" >> gpurun_out/ab10_$var.txt
+        env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/ab10_$var.txt
+      done; stamp "ab10:$var" ;;
+    hostprof)
+      timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt; stamp hostprof ;;
+    cmd:*)
+      c="${arg#cmd:}"
+      bash -c "$c" > gpurun_out/cmd.log 2>&1; echo "cmd exit $?" >> gpurun_out/summary.txt; stamp "cmd" ;;
+  esac
+done
+for f in gpurun_out/*.log; do echo "== $f"; tail -n 5 "$f"; done
+cat gpurun_out/summary.txt
+du -sh gpurun_out

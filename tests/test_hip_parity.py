@@ -410,7 +410,9 @@ def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
     torch.nn.functional.cross_entropy(logits.view(nq, nc), ref['labels'].cuda()).backward()
     torch.cuda.synchronize()
     assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the path bench.py times'
-    helpers._close(logits.detach().cpu(), ref['logits'], what='B=320 train-mode logits', **FWD)
+    # forward bar 5e-4 of the logits' scale (1e-4 at the small cases): both sides are fp32, and at N = 64 000 rows x 5 layers of
+    # train-mode BatchNorm each is ~1e-4 from exact arithmetic (measured 1.4e-4 between them)
+    helpers._close(logits.detach().cpu(), ref['logits'], what='B=320 train-mode logits', rtol=5e-4, atol=1e-5)
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(grads) == set(ref['grads'])
     worst, n_checked, fails = (0.0, None), 0, []
