@@ -206,7 +206,12 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
     launch (qagnn_amd.graphed.GraphedStep: static input buffers refilled before every replay, true edge counts read on the device,
     dropout masks advanced per replay); the collectives stay outside the graph."""
     run_eager = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
-    if not (use_graph and isinstance(b['adj'], data_utils.PackedGraphBatch)):
+    if use_graph == 'auto':
+        # measured (profiles/r3_run2_graph_ab.txt): replay beats eager launches wherever the step is bound by the host (10 subgraphs:
+        # 3.92 vs 5.7-6.4 ms) and loses 2.7 % where it is bound by the GPU (320 subgraphs: 9.25 vs 9.00 ms) -- the same
+        # boundary as the natively sequenced stack (ops.use_fused_hop)
+        use_graph = ops.use_fused_hop(b['nt'].numel())
+    if not (int(use_graph) and isinstance(b['adj'], data_utils.PackedGraphBatch)):
         return run_eager, run_eager, None
     gs = graphed.GraphedStep(model, nc)
 
@@ -413,8 +418,9 @@ def main():
     ap.add_argument('--dropout', type=float, default=0.2)
     ap.add_argument('--edge-lists', action='store_true', help='feed the graph as int64 (edge_index, edge_type) (the reference protocol; the '
                     'graph orderings are then re-derived per batch) instead of the load-time blobs of qagnn_amd.data_utils')
-    ap.add_argument('--graphs', type=int, default=int(os.environ.get('QAGNN_BENCH_GRAPHS', '1')), help='1: every step is ONE hipGraph replay '
-                    '(qagnn_amd.graphed.GraphedStep; needs the blob input form); 0: eager launches')
+    ap.add_argument('--graphs', default=os.environ.get('QAGNN_BENCH_GRAPHS', 'auto'), choices=['auto', '0', '1'],
+                    help='1: every step is ONE hipGraph replay (qagnn_amd.graphed.GraphedStep; needs the blob input form); 0: eager launches; '
+                         'auto (default): replay where the step is host-bound (fewer than ops.FUSED_HOP_MAX_ROWS node rows)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()

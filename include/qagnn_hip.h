@@ -148,6 +148,10 @@ typedef struct qagnn_gemm_nn_args {
   const int64_t* a_rowidx;           /* [M] or NULL: row m of A1 is A1[a_rowidx[m]] (embedding-table gather fused into the
                                         operand load, utils/layers.py:604-605); a negative index reads a zero row */
   int32_t xcd_remap;                 /* set by the library (XCD-contiguous tile order); callers leave it 0 */
+  float* colstat_part;               /* NULL, or [ceil(M/128)][3][No] (qagnn_gemm_nn_split_f32 only, No <= 208, bias-only epilogue):
+                                        per 128-row tile t and output column c, over the tile's rows of C:  x0 = C[first row][c],
+                                        S1 = sum (C - x0),  S2 = sum (C - x0)^2 -- BatchNorm batch statistics as a by-product of the
+                                        GEMM that produces the BatchNorm input (qagnn_bn_stats_finalize_f32 combines the tiles) */
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 /* The same product on the bf16 matrix cores by EXACT operand splitting (csrc/gemm_split.hip): every fp32 operand is the exact sum
@@ -228,6 +232,14 @@ int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, in
                                  const float* sum_dy_hhat, float inv_rows, const float* roww, float* colsum /* [Cc] */, float* workspace,
                                  qagnn_stream_t stream);
 int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t ldo, int32_t R, int32_t J, qagnn_stream_t stream);
+/* BatchNorm1d batch statistics from the per-tile partials a GEMM left in qagnn_gemm_nn_args.colstat_part, and the bookkeeping of
+ * qagnn_bn_finalize_f32, in ONE launch (modeling_qagnn.py:408: BatchNorm1d over all N rows of GATConvE.mlp's first Linear).
+ * Tiles are combined with the pairwise update of Chan et al.: mean = sum_t (n_t x0_t + S1_t) / R, M2 = sum_t [S2_t - S1_t^2 / n_t +
+ * n_t (mean_t - mean)^2] -- as accurate as the two-pass form (each tile is shifted by one of its own values), in a fixed order.
+ * stats: [5][Cc] = mean | biased var | invstd | scale | shift.  Running statistics / batch counter as in qagnn_bn_finalize_f32. */
+int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, int32_t R, int32_t Cc, const float* gamma, const float* beta, float eps,
+                                float* stats, float* run_mean, float* run_var, int64_t* num_batches_tracked, const int64_t* dense_pos,
+                                int32_t d, float momentum, float unbias, qagnn_stream_t stream);
 
 /* Dropout under hipGraph replay.  Every dropout launch of this library (qagnn_gelu_dropout_*, qagnn_pool_attn_*, the hops) takes
  * its seed by value; a captured graph would replay it verbatim and draw the SAME keep masks in every training step

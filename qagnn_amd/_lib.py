@@ -16,7 +16,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
            'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
-           'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_relu_bwd_f32',
+           'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
@@ -44,7 +44,7 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('A2', _vp), ('lda2', _i32), ('K2', _i32), ('B2', _vp), ('ldb2', _i32),
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
-                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32)]
+                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32), ('colstat_part', _vp)]
 
 
 class qagnn_hop_args(C.Structure):
@@ -88,6 +88,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]
     lib.qagnn_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
+    lib.qagnn_bn_stats_finalize_f32.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
     lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
@@ -364,10 +365,18 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(rc, 'qagnn_radam_step_f32')
 
     # -- GEMMs ---------------------------------------------------------------------------------------------------
+    STAT_TILE = 128  # rows per tile of the column statistics a GEMM can leave behind (gemm_split.hip: SBM)
+
+    def colstats_supported(self, M, K1, No):
+        """Can gemm_nn(..., colstats=True) deliver per-tile column statistics for this shape?  (the bf16-split kernel, 193..208 columns)"""
+        return self.gemm_split and 192 < No <= 208 and K1 % 4 == 0 and M * max(K1, No) * 4 < 2 ** 31 - 1
+
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None):
+                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None, colstats=False):
         """B1n / B2n: the same weights as B1 / B2 in their [No, K] layout (optional); with them the product runs on the bf16 matrix
-        cores by exact operand splitting (see gemm_split.hip), else on the fp32-input MFMAs."""
+        cores by exact operand splitting (see gemm_split.hip), else on the fp32-input MFMAs.
+        colstats=True (only where colstats_supported()): returns (C, part) with part [ceil(M/128), 3, No] = per 128-row tile x0 | S1 | S2
+        of C's columns, for bn_stats_finalize."""
         _chk2d(A1, 'A1'), _chk2d(B1, 'B1')
         K1 = A1.size(1)
         M = A1.size(0) if a_rowidx is None else a_rowidx.numel()
@@ -400,6 +409,12 @@ class HipKernels(metaclass=_GuardedMeta):
         if a_rowidx is not None:
             assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
             a.a_rowidx = a_rowidx.data_ptr()
+        part = None
+        if colstats:
+            assert self.colstats_supported(M, K1, No) and B1n is not None and A2 is None and rowtab is None and a_scale is None and a_rowidx is None \
+                and not accumulate, 'gemm_nn(colstats=True): bias-only epilogue on the split kernel'
+            part = torch.empty((-(-M // self.STAT_TILE), 3, No), dtype=torch.float32, device=A1.device)
+            a.colstat_part = part.data_ptr()
         if self.gemm_split and B1n is not None and (A2 is None or B2n is not None) and K1 % 4 == 0 and (A2 is None or A2.size(1) % 4 == 0):
             _chk2d(B1n, 'B1n')
             assert B1n.shape == (No, K1)
@@ -409,7 +424,7 @@ class HipKernels(metaclass=_GuardedMeta):
                 assert B2n.shape == (No, A2.size(1))
                 n2, ld2 = B2n.data_ptr(), B2n.size(1)
             self._check(self.lib.qagnn_gemm_nn_split_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, self._stream()), 'qagnn_gemm_nn_split_f32')
-            return out
+            return (out, part) if colstats else out
         assert K1 % 16 == 0 and (A2 is None or A2.size(1) % 16 == 0), 'the fp32-MFMA kernel needs K to be a multiple of 16'
         self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')
         return out
@@ -471,6 +486,23 @@ class HipKernels(metaclass=_GuardedMeta):
                                             _ptr(pos), d, float(mom), float(unb), self._stream())
         self._check(rc, 'qagnn_bn_finalize_f32')
         return out[0], out[1], out[2]
+
+    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None):
+        """part: what gemm_nn(colstats=True) returned for the [rows, Cc] BatchNorm input -> stats [5, Cc] = mean | biased var | invstd |
+        scale | shift, plus (running given) the train-mode running-statistics update: qagnn_bn_stats_finalize_f32, one launch."""
+        nt, _, Cc = part.shape
+        assert part.is_contiguous() and nt == -(-rows // self.STAT_TILE)
+        stats = torch.empty((5, Cc), dtype=torch.float32, device=part.device)
+        rm = rv = nbt = pos = None
+        d, mom, unb = 0, 0.0, 1.0
+        if running is not None:
+            rm, rv, nbt, pos, mom, unb = running
+            d = rm.numel()
+            assert rm.is_contiguous() and rv.is_contiguous() and (nbt is None or nbt.dtype == torch.long)
+        rc = self.lib.qagnn_bn_stats_finalize_f32(part.data_ptr(), nt, int(rows), Cc, gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(),
+                                                  _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(pos), d, float(mom), float(unb), self._stream())
+        self._check(rc, 'qagnn_bn_stats_finalize_f32')
+        return stats
 
     def bn_bwd_reduce(self, dR, H, mean, invstd, scale, shift):
         _chk2d(H, 'H')

@@ -167,6 +167,71 @@ __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __res
   if (nbt && i == 0) *nbt += 1;
 }
 
+// BatchNorm batch statistics from the per-tile partials of the GEMM that wrote the BatchNorm input (qagnn_gemm_nn_args.colstat_part:
+// per 128-row tile t and column c: x0 = the tile's first value, S1 = sum (x - x0), S2 = sum (x - x0)^2), combined by the pairwise
+// update of Chan, Golub & LeVeque -- every tile is shifted by one of its own values, so nothing cancels -- plus the whole
+// bookkeeping of k_bn_finalize, in one launch.  64 columns x CF_Q partitions per block, partitions added in a fixed order.
+constexpr int ST_TILE = 128;  // = SBM of gemm_split.hip
+__global__ __launch_bounds__(64 * CF_Q) void k_bn_stats_finalize(const float* __restrict__ part, int nt, int R, int Cc,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ stats, float* __restrict__ run_mean,
+                                                                 float* __restrict__ run_var, int64_t* __restrict__ nbt, int d,
+                                                                 float momentum, float unbias) {
+  __shared__ float red[CF_Q][64];
+  __shared__ float mean_s[64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool act = c < Cc;
+  float s = 0.f;
+  if (act)
+    for (int t = q; t < nt; t += CF_Q) {
+      const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
+      s += fmaf(n_t, part[((int64_t)t * 3 + 0) * Cc + c], part[((int64_t)t * 3 + 1) * Cc + c]);
+    }
+  red[q][lane] = s;
+  __syncthreads();
+  if (q == 0) {
+    float tot = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < CF_Q; ++k) tot += red[k][lane];
+    mean_s[lane] = tot / (float)R;
+  }
+  __syncthreads();
+  const float mean = mean_s[lane];
+  float m2 = 0.f;
+  if (act)
+    for (int t = q; t < nt; t += CF_Q) {
+      const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
+      const float x0 = part[((int64_t)t * 3 + 0) * Cc + c], S1 = part[((int64_t)t * 3 + 1) * Cc + c], S2 = part[((int64_t)t * 3 + 2) * Cc + c];
+      const float dm = (x0 + S1 / n_t) - mean;
+      m2 += (S2 - S1 * S1 / n_t) + n_t * dm * dm;
+    }
+  __syncthreads();  // pass 1's partition sums have been consumed
+  red[q][lane] = m2;
+  __syncthreads();
+  if (q == 0 && act) {
+    float tot = red[0][lane];
+#pragma unroll
+    for (int k = 1; k < CF_Q; ++k) tot += red[k][lane];
+    const float var = fmaxf(tot / (float)R, 0.f);  // biased, as BatchNorm normalises with
+    const float is = rsqrtf(var + eps), sc = gamma[c] * is;
+    stats[c] = mean;
+    stats[Cc + c] = var;
+    stats[2 * Cc + c] = is;
+    stats[3 * Cc + c] = sc;
+    stats[4 * Cc + c] = beta[c] - mean * sc;
+    if (run_mean) {  // head-padded column c = h * HP + j is dense feature h * dh + j when j < dh (4 heads: ops.HeadLayout)
+      const int HP = Cc >> 2, dh = d >> 2, h = c / HP, j = c - h * HP;
+      if (j < dh) {
+        const int i = h * dh + j;
+        run_mean[i] += momentum * (mean - run_mean[i]);
+        run_var[i] += momentum * (var * unbias - run_var[i]);
+      }
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
 // ---- GELU (tanh form) + dropout -----------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_f(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -346,6 +411,20 @@ extern "C" int qagnn_bn_finalize_f32(const float* mean, const float* var, const 
   k_bn_finalize<<<cdiv(Cc, 256), 256, 0, stream>>>(mean, var, gamma, beta, eps, invstd, scale, shift, Cc, run_mean, run_var,
                                                    num_batches_tracked, dense_pos, d, momentum, unbias);
   QAGNN_LAUNCH_CHECK("k_bn_finalize");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, int32_t R, int32_t Cc, const float* gamma, const float* beta,
+                                           float eps, float* stats, float* run_mean, float* run_var, int64_t* num_batches_tracked,
+                                           const int64_t* dense_pos, int32_t d, float momentum, float unbias, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(part && gamma && beta && stats && R > 0 && Cc > 0 && n_tiles == cdiv(R, ST_TILE), QAGNN_EINVAL,
+                "bn_stats_finalize: bad arguments (R=%d needs %d tiles of %d rows, got %d)", R, cdiv(R, ST_TILE), ST_TILE, n_tiles);
+  QAGNN_REQUIRE(!run_mean || (run_var && d > 0 && d % 4 == 0 && Cc % 4 == 0 && d <= Cc), QAGNN_EINVAL, "bn_stats_finalize: running-stat arguments");
+  (void)dense_pos;  // the head-padded layout is implied by (Cc, d); kept in the signature for symmetry with qagnn_bn_finalize_f32
+  k_bn_stats_finalize<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var,
+                                                              num_batches_tracked, d, momentum, unbias);
+  QAGNN_LAUNCH_CHECK("k_bn_stats_finalize");
   return QAGNN_OK;
 }
 

@@ -82,7 +82,10 @@ __device__ unsigned long long g_nn_trace[4][40][7];
 // load goes through a buffer descriptor: per-thread 32-bit row offsets fixed per output tile, the k position as the instruction's
 // scalar offset, rows past M / columns past No / k past K answered with zeros by the bounds check -- the 64-bit address arithmetic
 // and the zeroing selects were 100 of the 468 VALU instructions per wave and k-tile (profiles/r2_run57_nn_trace.txt).
-template <int NT, bool AFFINE, bool FLAT>
+// STATS: the epilogue additionally leaves, per 128-row tile and output column, x0 = the tile's first value, S1 = sum (x - x0) and
+// S2 = sum (x - x0)^2 over the tile's rows of C in a.colstat_part (BatchNorm batch statistics as a by-product of the GEMM that
+// produces the BatchNorm input; the two stand-alone passes over h1 they replace cost 35 us + 4 launches per layer).
+template <int NT, bool AFFINE, bool FLAT, bool STATS = false>
 __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn_split(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
                                                                                            int ldn1, const float* __restrict__ B2n,
                                                                                            int ldn2, int ntiles) {
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[KLOOP_B > STAGE_B ? KLOOP_B : STAGE_B];
   uint16_t* const As = reinterpret_cast<uint16_t*>(smem_raw);
   uint16_t* const Bs = As + 3 * A_EL;
+  __shared__ float cstat[STATS ? SWAVES : 1][2][STATS ? BN : 1];  // per-wave column sums of a tile, combined in wave order
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ncb = (a.No + BN - 1) / BN;
@@ -235,6 +239,10 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     // epilogue: transpose 16 rows at a time through the wave's LDS slab, then whole-row 16-byte stores (as k_gemm_nn)
     float* const St = reinterpret_cast<float*>(smem_raw) + w * SLAB_ROWS * PS;
     constexpr int ROW_F4 = BN / 4, TILE_F4 = SLAB_ROWS * ROW_F4, ST_IT = (TILE_F4 + 63) / 64;
+    constexpr int SC = (BN + 63) / 64;  // STATS: columns lane, lane + 64, ... of the tile per lane
+    float x0r[SC], s1[SC], s2[SC];
+#pragma unroll
+    for (int cc = 0; cc < SC; ++cc) x0r[cc] = s1[cc] = s2[cc] = 0.f;
 #pragma unroll
     for (int i = 0; i < SRT; ++i) {
       __syncthreads();  // k-loop reads (first pass) / the previous pass's slab reads are done before the slab is overwritten
@@ -244,6 +252,24 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
         for (int r = 0; r < 4; ++r) St[(lr0 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
       __syncthreads();
+      if constexpr (STATS) {
+        // every wave's slab is complete: row 0 of wave 0's first slab is the tile's first row (the shift of this tile's sums)
+        const float* const S0 = reinterpret_cast<const float*>(smem_raw);
+#pragma unroll
+        for (int cc = 0; cc < SC; ++cc) {
+          const int c = lane + cc * 64;
+          if (c < BN && n0 + c < a.No) {
+            const float bc = a.bias ? a.bias[n0 + c] : 0.f;
+            if (i == 0) x0r[cc] = S0[c] + bc;
+            const int rows = min(SLAB_ROWS, a.M - (m0 + (w * SRT + i) * 16));  // <= 0 past M
+            for (int r = 0; r < rows; ++r) {
+              const float dlt = (St[r * PS + c] + bc) - x0r[cc];  // the value the store loop below writes, minus the shift
+              s1[cc] += dlt;
+              s2[cc] = fmaf(dlt, dlt, s2[cc]);
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int it = 0; it < ST_IT; ++it) {
         const int idx = lane + it * 64;
@@ -258,6 +284,24 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (a.accumulate) v = add4(v, ld4(dst));
         st4(dst, v);
       }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int cc = 0; cc < SC; ++cc) {
+        const int c = lane + cc * 64;
+        if (c < BN) { cstat[w][0][c] = s1[cc]; cstat[w][1][c] = s2[cc]; }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < a.No) {  // thread (w, lane) = column w * 64 + lane: its own x0r[w] is that column's shift
+        float x0c = x0r[0];
+#pragma unroll
+        for (int cc = 1; cc < SC; ++cc) x0c = (w == cc) ? x0r[cc] : x0c;
+        float* const pt = a.colstat_part + (int64_t)(tile / ncb) * 3 * a.No + n0 + tid;
+        pt[0] = x0c;
+        pt[a.No] = (cstat[0][0][tid] + cstat[1][0][tid]) + (cstat[2][0][tid] + cstat[3][0][tid]);
+        pt[2 * a.No] = (cstat[0][1][tid] + cstat[1][1][tid]) + (cstat[2][1][tid] + cstat[3][1][tid]);
+      }
+      // (cstat is rewritten only after the next tile's k-loop and slab barriers)
     }
   }
 }
@@ -282,6 +326,13 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
   static const int force_flat = getenv("QAGNN_NN_FLAT") ? atoi(getenv("QAGNN_NN_FLAT")) : 0;  // 1 = the 64-bit-pointer loads everywhere (A/B switch)
   const bool flat = force_flat || a.a_rowidx || (int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.M * a.lda2 * 4 >= lim ||
                     (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim;
+  if constexpr (NT == 13) {
+    if (a.colstat_part) {  // (validated by the entry point: bias-only epilogue, no gather, 32-bit offsets)
+      k_gemm_nn_split<13, false, false, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+      QAGNN_LAUNCH_CHECK("k_gemm_nn_split<stats>");
+      return QAGNN_OK;
+    }
+  }
   if (flat) {
     if (a.a_scale) k_gemm_nn_split<NT, true, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
     else k_gemm_nn_split<NT, false, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
@@ -596,6 +647,13 @@ extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float*
   QAGNN_REQUIRE(!a->a_scale || (a->a_shift && aligned16(a->a_scale) && aligned16(a->a_shift)), QAGNN_EINVAL,
                 "gemm_nn_split: a_scale/a_shift must both be given and 16-byte aligned");
   const int nt16 = cdiv(a->No, 16);
+  if (a->colstat_part) {
+    const int64_t lim = (int64_t)0x7FFFFFFF;
+    QAGNN_REQUIRE(nt16 == 13 && !a->a_scale && !a->a_rowidx && !a->rowtab && !a->accumulate && a->K2 == 0, QAGNN_EUNSUPPORTED,
+                  "gemm_nn_split: column statistics need 193..208 output columns and a bias-only epilogue (No=%d)", a->No);
+    QAGNN_REQUIRE((int64_t)a->M * a->lda1 * 4 < lim && (int64_t)a->No * ldn1 * 4 < lim, QAGNN_EUNSUPPORTED,
+                  "gemm_nn_split: column statistics with operands of 2 GB and more");
+  }
   if (nt16 >= 13) return launch_split<13>(*a, B1n, ldn1, B2n, ldn2, stream);
   if (nt16 >= 8) return launch_split<8>(*a, B1n, ldn1, B2n, ldn2, stream);
   if (nt16 >= 7) return launch_split<7>(*a, B1n, ldn1, B2n, ldn2, stream);

@@ -56,7 +56,7 @@ using namespace qagnn;
   } while (0)
 
 extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP) {
-  return up4((int64_t)Ep * 4) + up4(qagnn_colreduce_workspace_elems(N, DP, 1));
+  return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
 }
 
 // NN product through the kernel family the caller asked for (qagnn_hop_args.gemm_split): the bf16-split kernel takes B in its
@@ -72,7 +72,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
   Carver w{h->ws, h->ws + h->ws_elems};
   float* score = w.take((int64_t)Ep * 4);
-  float* crws = w.take(qagnn_colreduce_workspace_elems(N, DP, 1));
+  float* crws = w.take(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_fwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   float* mean = h->stats, *var = h->stats + DP, *invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
 
@@ -88,22 +88,31 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   // mlp: Linear -> BatchNorm1d -> ReLU -> Linear (:443, 408); BN + ReLU are folded into the second GEMM's operand load
   qagnn_gemm_nn_args g1 = {};
   g1.A1 = h->aggr; g1.lda1 = DP; g1.K1 = DP; g1.B1 = h->W1t; g1.ldb1 = DP; g1.C = h->h1; g1.ldc = DP; g1.M = N; g1.No = DP; g1.bias = h->b1;
+  // batch statistics as a by-product of this GEMM's epilogue where the split kernel can provide them (same rule as ops.GatMlpFn)
+  const bool fused_stats = h->batch_stats && h->gemm_split && DP > 192 && DP <= 208;
+  if (fused_stats) g1.colstat_part = crws;
   HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, stream));
-  const float* mean_u = mean;
-  const float* var_u = var;
-  if (h->batch_stats) {
-    const float inv_rows = (float)(1.0 / (double)N);  // rounded like the composed path's Python double -> float
-    HOP_TRY(qagnn_colreduce_f32(0, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, inv_rows, mean, crws,
-                                stream));
-    HOP_TRY(qagnn_colreduce_f32(1, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, mean, nullptr, nullptr, nullptr, nullptr, inv_rows, var, crws,
-                                stream));
-  } else {
-    mean_u = h->run_mean_p;
-    var_u = h->run_var_p;
-  }
   const double Rd = (double)N;
-  HOP_TRY(qagnn_bn_finalize_f32(mean_u, var_u, h->gamma, h->beta, h->eps, invstd, scale, shift, DP, h->run_mean, h->run_var,
-                                h->num_batches_tracked, h->dense_pos, h->d, h->momentum, (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0)), stream));
+  const float unbias = (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0));
+  if (fused_stats) {
+    HOP_TRY(qagnn_bn_stats_finalize_f32(crws, cdiv(N, 128), N, DP, h->gamma, h->beta, h->eps, h->stats, h->run_mean, h->run_var,
+                                        h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, stream));
+  } else {
+    const float* mean_u = mean;
+    const float* var_u = var;
+    if (h->batch_stats) {
+      const float inv_rows = (float)(1.0 / (double)N);  // rounded like the composed path's Python double -> float
+      HOP_TRY(qagnn_colreduce_f32(0, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, inv_rows, mean, crws,
+                                  stream));
+      HOP_TRY(qagnn_colreduce_f32(1, h->h1, DP, nullptr, DP, N, DP, nullptr, 1, mean, nullptr, nullptr, nullptr, nullptr, inv_rows, var, crws,
+                                  stream));
+    } else {
+      mean_u = h->run_mean_p;
+      var_u = h->run_var_p;
+    }
+    HOP_TRY(qagnn_bn_finalize_f32(mean_u, var_u, h->gamma, h->beta, h->eps, invstd, scale, shift, DP, h->run_mean, h->run_var,
+                                  h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, stream));
+  }
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
   g2.a_scale = scale; g2.a_shift = shift;

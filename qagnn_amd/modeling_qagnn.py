@@ -98,6 +98,14 @@ def _edge_class_features(n_etype, n_ntype, device):
     return feat
 
 
+def _class_weights(graph, dtype):
+    """n_c / E' per edge class: the weights under which the C distinct encoder rows reproduce BatchNorm statistics over the E' edge
+    rows.  A quotient of two DEVICE tensors in every layout (a division by the host-side E' compiles to a multiplication by its
+    reciprocal: one ulp away, and a capacity-laid-out graph has no host-side E' at all)."""
+    cnt = graph.cls_count.to(dtype)
+    return cnt / cnt.sum()
+
+
 def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
     """edge_class_table() in the kernels' head-padded layout, for the stack: tab_p [C, DP] (pads exactly 0).
 
@@ -118,10 +126,10 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
         # graph.Ep is only the CAPACITY its arrays are laid out for (one captured hipGraph per capacity bucket, qagnn_amd.graphed): the
         # true E' is the sum of the class counts, on the device -- the weights and the unbiased-variance factor become tensors, and the
         # running statistics are updated here instead of inside the BN bookkeeping kernel (which takes that factor as a host float)
-        cnt = graph.cls_count.to(W1t.dtype)
-        Ep_t = cnt.sum()
+        Ep_t = graph.cls_count.to(W1t.dtype).sum()
         tab_p, mean_p, var_p = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p, use_batch_stats, bn.eps, 0.0,
-                                           apply_act=False, running=None, row_weight=cnt / Ep_t if use_batch_stats else None)
+                                           apply_act=False, running=None,
+                                           row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None)
         if training and bn.track_running_stats:
             with torch.no_grad():
                 wgt = 1.0 - (1.0 - bn_momentum(bn)) ** n_updates
@@ -138,7 +146,7 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
         bn.num_batches_tracked += n_updates
     tab_p, _, _ = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p,
                               use_batch_stats, bn.eps, 0.0, apply_act=False, running=running,
-                              row_weight=graph.cls_count.to(W1t.dtype) / Ep if use_batch_stats else None)
+                              row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None)
     return tab_p
 
 

@@ -570,15 +570,21 @@ class GatMlpFn(torch.autograd.Function):
                 row_weight):
         K = kernels()
         R = aggr.size(0)
-        h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
-        if training:
-            sc = 1.0 / R if row_weight is None else 1.0  # row_weight [R] (sums to 1): weighted statistics
-            mean = K.colsum(h1, scale=sc, roww=row_weight)[0]
-            var = K.colvar_sum(h1, mean, scale=sc, roww=row_weight)  # biased
+        if training and row_weight is None and _colstats_ok(K, R, aggr.size(1), W1t.size(1)):
+            # batch statistics as a by-product of the first Linear's GEMM epilogue (per-tile partials) + ONE launch that combines
+            # them and does the BatchNorm bookkeeping, instead of two more passes over h1 and five launches
+            h1, part = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1, colstats=True)
+            mean, var, invstd, scale, shift = K.bn_stats_finalize(part, R, gamma, beta, eps, running).unbind(0)
         else:
-            mean, var = run_mean, run_var
-        # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
-        invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
+            h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
+            if training:
+                sc = 1.0 / R if row_weight is None else 1.0  # row_weight [R] (sums to 1): weighted statistics
+                mean = K.colsum(h1, scale=sc, roww=row_weight)[0]
+                var = K.colvar_sum(h1, mean, scale=sc, roww=row_weight)  # biased
+            else:
+                mean, var = run_mean, run_var
+            # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
+            invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
         out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift, B1n=W2)
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
         ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t)
@@ -618,6 +624,11 @@ class GatMlpFn(torch.autograd.Function):
         return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
 
 
+def _colstats_ok(K, rows, k1, no):
+    fn = getattr(K, 'colstats_supported', None)
+    return fn is not None and fn(rows, k1, no)
+
+
 def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True, running=None,
             row_weight=None):
     """`batch_stats`: BatchNorm uses batch statistics (train mode); `p`: dropout rate (0 disables); `apply_act`: GELU+dropout
@@ -655,17 +666,22 @@ def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
     KMQ = K.gemm_nn(X, Wx_t, S, Ws_t, rowtab=TT, rowidx=ntype, B1n=Wx, B2n=Ws)
     aggr, a, alpha = K.edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
-    h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
-    if batch_stats:
-        sc = 1.0 / aggr.size(0)
-        mean = K.colsum(h1, scale=sc)[0]
-        var = K.colvar_sum(h1, mean, scale=sc)
+    if batch_stats and _colstats_ok(K, aggr.size(0), aggr.size(1), W1t.size(1)):
+        h1, part = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1, colstats=True)
+        stats = K.bn_stats_finalize(part, aggr.size(0), gamma, beta, eps, running)
     else:
-        mean, var = run_mean_p, run_var_p
-    invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
-    out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift, B1n=W2)
+        h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
+        if batch_stats:
+            sc = 1.0 / aggr.size(0)
+            mean = K.colsum(h1, scale=sc)[0]
+            var = K.colvar_sum(h1, mean, scale=sc)
+        else:
+            mean, var = run_mean_p, run_var_p
+        invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
+        stats = torch.stack([mean, var, invstd, scale, shift])
+    out = K.gemm_nn(h1, W2t, bias=b2, a_scale=stats[3], a_shift=stats[4], B1n=W2)
     y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
-    return y, (KMQ, torch.stack([a, alpha]), aggr, h1, out, torch.stack([mean, var, invstd, scale, shift]))
+    return y, (KMQ, torch.stack([a, alpha]), aggr, h1, out, stats)
 
 
 def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,

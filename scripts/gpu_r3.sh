@@ -45,14 +45,14 @@ for arg in "$@"; do
       timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | tail -n 1 > gpurun_out/bench_b10.json; stamp b10 ;;
     prof)
       rm -rf /tmp/prof; mkdir -p /tmp/prof gpurun_out/prof
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r3 -- python "$REPO/bench.py" --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof.log
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r3 -- python "$REPO/bench.py" --steps 5 --warmup 2 --repeats 1 --graphs 0 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof.log
       echo "prof exit $?" >> gpurun_out/summary.txt
       find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} gpurun_out/prof/kernel_stats.csv \;
       python scripts/trace_by_shape.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape.txt 2>&1
       stamp prof ;;
     prof10)
       rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
-      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 0 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log
       python scripts/trace_by_shape.py "$(find /tmp/prof10 -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape_b10.txt 2>&1
       stamp prof10 ;;
     ab:*)

@@ -25,3 +25,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_dropout_epoch():
+    """The dropout seed epoch of libqagnn_hip (advanced by every hipGraph replay of qagnn_amd.graphed) is process-wide device state:
+    tests that predict keep masks from their seeds need it at 0."""
+    import torch
+    if torch.cuda.is_available():
+        from qagnn_amd import ops
+        k = ops._K
+        if k is not None and hasattr(k, 'seed_epoch_set'):
+            k.seed_epoch_set(0)
+    yield

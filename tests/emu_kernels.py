@@ -142,8 +142,34 @@ class EmuKernels:
             return A
         return A[idx.clamp(min=0)] * (idx >= 0).to(A.dtype).unsqueeze(1)
 
+    STAT_TILE = 128
+
+    def colstats_supported(self, M, K1, No):
+        return 192 < No <= 208 and K1 % 4 == 0
+
+    @classmethod
+    def col_partials(cls, Cm):
+        """[ceil(M/128), 3, No]: per 128-row tile x0 (first row) | S1 = sum (x - x0) | S2 = sum (x - x0)^2 -- the interface of
+        qagnn_gemm_nn_args.colstat_part."""
+        parts = []
+        for t0 in range(0, Cm.size(0), cls.STAT_TILE):
+            blk = Cm[t0:t0 + cls.STAT_TILE]
+            d = blk - blk[0:1]
+            parts.append(torch.stack([blk[0], d.sum(0), (d * d).sum(0)]))
+        return torch.stack(parts)
+
+    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None):
+        nt = part.size(0)
+        n_t = torch.tensor([min(self.STAT_TILE, rows - t * self.STAT_TILE) for t in range(nt)], dtype=part.dtype).unsqueeze(1)
+        x0, S1, S2 = part[:, 0], part[:, 1], part[:, 2]
+        mean = (n_t * x0 + S1).sum(0) / rows
+        dm = x0 + S1 / n_t - mean
+        var = ((S2 - S1 * S1 / n_t) + n_t * dm * dm).sum(0) / rows
+        invstd, scale, shift = self.bn_finalize(mean, var, gamma, beta, eps, running)
+        return torch.stack([mean, var, invstd, scale, shift])
+
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None):
+                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None, colstats=False):
         _chk(A1, B1, A2, B2, out, rowtab, B1n, B2n)
         assert B1n is None or (B1n.shape == (B1.size(1), B1.size(0)) and torch.equal(B1n, B1.t())), 'B1n must be B1 transposed'
         assert B2n is None or (B2n.shape == (B2.size(1), B2.size(0)) and torch.equal(B2n, B2.t())), 'B2n must be B2 transposed'
@@ -163,6 +189,9 @@ class EmuKernels:
             else:
                 out.copy_(C)
             return out
+        if colstats:
+            assert A2 is None and rowtab is None and a_scale is None and a_rowidx is None
+            return C, self.col_partials(C)
         return C
 
     def gemm_tn(self, A, B, a_scale=None, a_shift=None, out=None, accumulate=False, a_rowidx=None, colsum_groups=0,

@@ -681,3 +681,47 @@ def test_node_prep_on_unquantised_scores():
     ulp = torch.finfo(torch.float32).eps * ref.abs().clamp_min(1e-30)
     assert bool(((score.cpu() - ref).abs() <= 4 * ulp).all()), ((score.cpu() - ref).abs() / ulp).max()
     assert mask.dtype == torch.bool and bool(mask[1, 1:].all()) and not bool(mask[1, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [64000, 2000, 129, 77])
+def test_gemm_column_statistics_and_bn_stats_finalize(M):
+    """BatchNorm batch statistics as a by-product of the GEMM that writes the BatchNorm input (qagnn_gemm_nn_args.colstat_part:
+    per 128-row tile x0 | S1 | S2) + qagnn_bn_stats_finalize_f32 (pairwise combination of the tiles, invstd / scale / shift, running
+    statistics, batch counter) against float64 statistics of the GEMM's own output and torch.nn.BatchNorm1d's bookkeeping."""
+    from qagnn_amd import ops
+    g = torch.Generator().manual_seed(M)
+    Kd, No, d = 208, 208, 200
+    L = ops.HeadLayout(d, 'cpu')
+    A = torch.randn(M, Kd, generator=g)
+    Bt = torch.randn(Kd, No, generator=g) * 0.1
+    bias = torch.randn(No, generator=g) * 3.0 + 5.0   # a mean far from 0 relative to the spread: what a naive E[x^2] - E[x]^2 loses digits on
+    gamma, beta = torch.rand(No, generator=g) + 0.5, torch.randn(No, generator=g)
+    K = hip()
+    assert K.colstats_supported(M, Kd, No)
+    out, part = K.gemm_nn(A.cuda(), Bt.cuda(), bias=bias.cuda(), B1n=Bt.t().contiguous().cuda(), colstats=True)
+    plain = K.gemm_nn(A.cuda(), Bt.cuda(), bias=bias.cuda(), B1n=Bt.t().contiguous().cuda())
+    assert torch.equal(out, plain), 'the statistics epilogue changed the product'
+    nt = -(-M // 128)
+    assert part.shape == (nt, 3, No)
+    o64 = out.cpu().double()
+    first = torch.stack([o64[t * 128] for t in range(nt)])
+    assert torch.equal(part[:, 0].cpu().double(), first)          # x0 = the tile's first row, as stored
+    want = EMU.col_partials(o64)
+    assert (part.cpu().double() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    rm0, rv0 = torch.randn(d, generator=g) * 0.1, torch.rand(d, generator=g) + 0.5
+    rm, rv, nbt = rm0.clone().cuda(), rv0.clone().cuda(), torch.tensor(7, dtype=torch.long, device='cuda')
+    unb = M / max(M - 1.0, 1.0)
+    stats = K.bn_stats_finalize(part, M, gamma.cuda(), beta.cuda(), 1e-5, running=(rm, rv, nbt, L.dense_pos.cuda(), 0.1, unb)).cpu().double()
+    mean64, var64 = o64.mean(0), o64.var(0, unbiased=False)
+    assert (stats[0] - mean64).abs().max().item() <= 2e-6 * mean64.abs().max().item()
+    assert ((stats[1] - var64).abs() / var64).max().item() <= 1e-5   # relative, per column: no cancellation against the large mean
+    invstd = 1.0 / torch.sqrt(var64 + 1e-5)
+    assert ((stats[2] - invstd).abs() / invstd).max().item() <= 1e-5
+    assert (stats[3] - gamma.double() * invstd).abs().max().item() <= 1e-5 * (gamma.double() * invstd).abs().max().item()
+    shift64 = beta.double() - mean64 * gamma.double() * invstd
+    assert (stats[4] - shift64).abs().max().item() <= 2e-5 * shift64.abs().max().item()
+    pos = L.dense_pos
+    assert torch.allclose(rm.cpu().double(), rm0.double() + 0.1 * (mean64[pos] - rm0.double()), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu().double(), rv0.double() + 0.1 * (var64[pos] * unb - rv0.double()), rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 8
