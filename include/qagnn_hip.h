@@ -78,13 +78,6 @@ typedef struct qagnn_graph {
                                   [1] = 1: some edge leaves its block of block_n consecutive node rows */
   int32_t block_n;             /* 0, or the node-block size the graph was checked against (subgraph = n consecutive rows) */
   int32_t n_groups;            /* position groups of the class order */
-  /* Per-SUBGRAPH views for the LDS-resident edge kernels; only filled by qagnn_graph_from_blobs (NULL otherwise).  A subgraph
-   * uses ~120 of the C edge classes: sub_cls lists them, and the packed words address nodes and classes LOCALLY, so a workgroup
-   * can hold "its" class-table rows in LDS next to its node rows. */
-  int32_t* pk_s;               /* [Ep] source order:  (tgt - g*n) | local class << 16 */
-  int32_t* pk_t;               /* [Ep] target order:  (src - g*n) | local class << 16 */
-  int32_t* sub_ncls;           /* [N / block_n] distinct classes of subgraph g (self-loop classes included) */
-  int32_t* sub_cls;            /* [N / block_n][C] ascending class ids of subgraph g, first sub_ncls[g] entries valid */
 } qagnn_graph;
 
 #define QAGNN_CLS_CHUNK 64
@@ -266,18 +259,6 @@ int qagnn_seed_epoch_set(uint64_t value, qagnn_stream_t stream);
 int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                             qagnn_stream_t stream);
-/* Forward for block-structured batches (g->block_n = n > 0, e.g. from qagnn_graph_from_blobs), LDS-resident: one workgroup per
- * (subgraph, head) stages that head's slice of the subgraph's K rows (then M rows) in LDS -- n * HP floats, 41.6 KB at n = 200,
- * d = 200 -- together with the same slice of the class-table rows the subgraph uses (g->sub_cls; Ek, then Em), the subgraph's
- * packed edge words (g->pk_s / pk_t) and its scores / alpha values, and computes scores, segment softmax and aggregation out of
- * LDS; HBM sees each K | M | Q slice once.  The second phase's slabs are fetched into registers under the first phase.  `max_sub_ep` must bound E_g + n over the batch's subgraphs (the
- * host knows it from the blob store); qagnn_edge_attn_fwd_lds_bytes() is the dynamic LDS per workgroup, QAGNN_EUNSUPPORTED above
- * 160 KB (callers then use qagnn_edge_attn_fwd_f32).  Same outputs as qagnn_edge_attn_fwd_f32 up to the summation order of the
- * softmax denominator (a, alpha agree to 1 ulp; aggr to the usual fp32 bound); deterministic. */
-int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep, int32_t C);
-int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
-                                float qscale, float* a, float* alpha, float* aggr, int32_t lda, int32_t max_sub_ep,
-                                qagnn_stream_t stream);
 int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
                             float qscale, const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ,
                             float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream);

@@ -14,7 +14,6 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
-           'qagnn_edge_attn_fwd_lds_bytes', 'qagnn_edge_attn_fwd_lds_f32',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
@@ -25,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 11  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch)
+ABI_VERSION = 11  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -35,8 +34,7 @@ class qagnn_graph(C.Structure):
                 [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'tgt_t', 'cls_t', 'pos_t',
                                     'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
-                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)] +
-                [(n, _vp) for n in ('pk_s', 'pk_t', 'sub_ncls', 'sub_cls')])
+                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
 
 
 class qagnn_gemm_nn_args(C.Structure):
@@ -97,9 +95,6 @@ def load_library(path=LIB_PATH):
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
-    lib.qagnn_edge_attn_fwd_lds_bytes.restype = _i64
-    lib.qagnn_edge_attn_fwd_lds_bytes.argtypes = [_i32, _i32, _i32, _i32]
-    lib.qagnn_edge_attn_fwd_lds_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
     lib.qagnn_hop_fwd_workspace_elems.restype = _i64
@@ -256,10 +251,6 @@ class HipKernels(metaclass=_GuardedMeta):
         self.lib = load_library()
         if self.lib.qagnn_abi_version() != ABI_VERSION:
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
-        # LDS-resident edge forward (qagnn_edge_attn_fwd_lds_f32) for block-structured batches whose largest subgraph is known on
-        # the host (graphs built from load-time blobs).  Measured 0.177 ms per layer against 0.126 ms for the generic L2-gather kernels at the
-        # CSQA batch (profiles/r2_run8_edge_lds_variants.txt: bound by VALU issue, 120 wave-instructions per edge): off by default, QAGNN_EDGE_LDS=1.
-        self.edge_lds = os.environ.get('QAGNN_EDGE_LDS', '0') == '1'
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
@@ -318,7 +309,6 @@ class HipKernels(metaclass=_GuardedMeta):
         G = HipGraph(storage, g, N, E, R, T, n)
         G.dynamic = e_cap is not None  # E / Ep are capacities: the true E' lives on the device (rowptr_s[N] = sum of cls_count)
         G.keep = packed.buf  # the blobs are read by the kernel just enqueued
-        G.max_sub_ep = packed.max_sub_ep  # host-side bound on E_g + n per subgraph: sizes the LDS of the edge kernels
         ERR_WATCH.poll()
         ERR_WATCH.watch(G.array('err', 4), f'the graph of the blob batch with B={B} samples, E={packed.E} edges (edge endpoint / relation id / node type)')
         return G
@@ -594,14 +584,6 @@ class HipKernels(metaclass=_GuardedMeta):
         a = torch.empty((graph.Ep, 4), dtype=torch.float32, device=dev)
         alpha = torch.empty_like(a)
         aggr = torch.empty((graph.N, DP), dtype=torch.float32, device=dev)
-        max_sub_ep = getattr(graph, 'max_sub_ep', 0)
-        if (self.edge_lds and graph.block_n > 0 and max_sub_ep > 0 and graph.block_n < 65536 and graph.C < 65536 and
-                self.lib.qagnn_edge_attn_fwd_lds_bytes(graph.block_n, HP, max_sub_ep, graph.C) <= 160 * 1024):
-            # block-structured batch, largest subgraph known: one LDS-resident workgroup (16 waves) per CU
-            rc = self.lib.qagnn_edge_attn_fwd_lds_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale),
-                                                      a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, int(max_sub_ep), self._stream())
-            self._check(rc, 'qagnn_edge_attn_fwd_lds_f32')
-            return aggr, a, alpha
         score = torch.empty_like(a)  # scratch of the generic kernels (raw scores of hub segments)
         rc = self.lib.qagnn_edge_attn_fwd_f32(C.byref(graph.c), KMQ.data_ptr(), 3 * DP, EkEm.data_ptr(), 2 * DP, HP, float(qscale), score.data_ptr(),
                                               a.data_ptr(), alpha.data_ptr(), aggr.data_ptr(), DP, self._stream())

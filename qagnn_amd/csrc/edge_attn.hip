@@ -519,226 +519,6 @@ __global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ s
   st4(dEkEm + (int64_t)c * lde + col4 * 4, s);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward, LDS-resident (the shape north_star names: destination rows staged in LDS, segmented reductions over the CSR-sorted
-// edge list).  One workgroup per (subgraph, head): a QA subgraph is n consecutive node rows and its edges never leave it
-// (LM_QAGNN.batch_graph), so ONE head's slice of the subgraph's K rows -- n x HP floats, 41.6 KB at n = 200, d = 200 -- fits
-// the LDS with room for two workgroups per CU.  The two phases need different matrices and share the buffer:
-//   phase 1  rows <- K slice;  a 16-lane group (13 lanes carry the head's 52 floats as float4 = one DPP row) owns a SOURCE node:
-//            Q slice in registers, per out-edge K[tgt] from LDS + Ek[cls] through L1, 16-lane DPP dot product, raw score into
-//            the LDS score array; then the group normalises its own segment (max, sum, divide: three strided sweeps over LDS)
-//            and leaves alpha = deg * a in place of the score
-//   phase 2  rows <- M slice;  a group owns a TARGET node: sum of alpha[pos] * (M[src] + Em[cls]) over its in-edges.
-// Per-edge indices are packed into LDS words once per phase (tgt | cls << 16; src | cls << 16, pos), so the inner loops issue
-// no dependent global index loads.  HBM sees every K | M | Q slice exactly once (the compulsory bytes); what still goes through
-// L1/L2 per edge is the class-table row (612 rows in all; ~120 distinct ones per subgraph).
-// Node order = node index, round-robin over the 32 groups: real nodes (index < adj_len) come first, PAD rows (one self loop
-// each) last, which balances the groups without a sort.  Every reduction has a fixed order: deterministic.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef LDS_UNROLL_N
-#define LDS_UNROLL_N 2
-#endif
-#ifndef LDS_PF_N
-#define LDS_PF_N 6
-#endif
-#ifndef LDS_THREADS_N
-#define LDS_THREADS_N 1024
-#endif
-constexpr int LDS_UNROLL = LDS_UNROLL_N;
-constexpr int LDS_THREADS = LDS_THREADS_N;      // 16 waves = 64 groups of 16 lanes
-constexpr int LDS_GROUPS = LDS_THREADS / 16;
-constexpr int LDS_PF = LDS_PF_N;                  // float4 registers per thread that carry the next phase's slabs under the current one
-
-constexpr int LDS_IW = 4;  // per-thread registers for a phase's per-edge words (covers subgraphs of <= 4096 edges without a reload loop)
-
-// One tile = (subgraph, head).  The kernel is PERSISTENT -- one 16-wave workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... --
-// and software-pipelined: everything a phase reads from LDS (a node-row slab, the class-row slab, the per-edge words, the segment
-// starts) is fetched from global memory into REGISTERS one phase ahead and only copied into LDS at the phase boundary:
-//     phase 1 of tile i   runs while   phase 2's slabs of tile i     are in flight
-//     phase 2 of tile i   runs while   phase 1's slabs of tile i + 1 are in flight
-// so a workgroup never waits on HBM except for its very first tile (with one workgroup per CU there is nobody else to hide it).
-struct lds_tile {
-  int node0, h, ebase, Eg, nc;
-};
-
-__global__ __launch_bounds__(LDS_THREADS) void k_edge_fwd_lds(const int* __restrict__ rowptr_s, const int* __restrict__ rowptr_t,
-                                                              const int* __restrict__ pk_s, const int* __restrict__ pk_t,
-                                                              const int* __restrict__ pos_t, const int* __restrict__ sub_ncls,
-                                                              const int* __restrict__ sub_cls, const float* __restrict__ KMQ, int ldk,
-                                                              const float* __restrict__ EkEm, int lde, int HP, float qscale, int n,
-                                                              int ecap, int ccap, float* __restrict__ a, float* __restrict__ alpha,
-                                                              float* __restrict__ aggr, int lda, int N, int C, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float sm_lds[];
-  const int tid = threadIdx.x, grp = tid >> 4, j = tid & 15;
-  const int DP = 4 * HP, f4 = HP >> 2;
-  const bool act = j < f4;
-  float* const rows = sm_lds;                                     // [n][HP]     K slice, then M slice
-  float* const crow = rows + n * HP;                              // [ccap][HP]  Ek rows of the subgraph's classes, then Em rows
-  float* const sc = crow + ccap * HP;                             // [ecap]      raw score -> alpha, local source-order position
-  uint32_t* const idx = reinterpret_cast<uint32_t*>(sc + ecap);   // [2*ecap]    packed per-edge words of the current phase
-  int* const rp = reinterpret_cast<int*>(idx + 2 * ecap);         // [n+1]       local segment starts of the current phase
-  const uint32_t pe = (uint32_t)lde * 4u;
-  const rsrc_t rE = make_rsrc(EkEm, (uint32_t)C * pe);
-
-  auto tile_of = [&](int t) {
-    lds_tile T;
-    const int gph = t >> 2;
-    T.h = t & 3;
-    T.node0 = gph * n;
-    T.ebase = rowptr_s[T.node0];
-    T.Eg = rowptr_s[T.node0 + n] - T.ebase;  // same range in the target order (block structure)
-    T.nc = min(sub_ncls[gph], ccap);         // classes with local id >= ccap (none at these sizes) are read through L1 instead
-    return T;
-  };
-  // Slab rows: LDS row r < n is node row node0 + r (matrix `part_off` of K|M|Q), LDS row n + k is the subgraph's k-th class row
-  // (half `half_off` of Ek|Em); a 16-lane group moves one row per round (lane j < f4 carries float4 j of the head's slice), so the
-  // row of round k is grp + k * LDS_GROUPS and both the LDS offset and the global address are one multiply-add away.
-  auto slab_ptr = [&](const lds_tile& T, int r, int part_off, int half_off) -> const float* {
-    if (r < n) return KMQ + (int64_t)(T.node0 + r) * ldk + part_off + T.h * HP + j * 4;
-    return EkEm + (int64_t)sub_cls[(int64_t)(T.node0 / n) * C + (r - n)] * lde + half_off + T.h * HP + j * 4;
-  };
-  auto fetch_slab = [&](const lds_tile& T, int part_off, int half_off, float4 (&pf)[LDS_PF]) {
-#pragma unroll
-    for (int k = 0; k < LDS_PF; ++k) {
-      const int r = grp + k * LDS_GROUPS;
-      pf[k] = (act && r < n + T.nc) ? ld4(slab_ptr(T, r, part_off, half_off)) : zero4();
-    }
-  };
-  auto store_slab = [&](const lds_tile& T, int part_off, int half_off, const float4 (&pf)[LDS_PF]) {
-#pragma unroll
-    for (int k = 0; k < LDS_PF; ++k) {
-      const int r = grp + k * LDS_GROUPS;
-      if (act && r < n + T.nc) st4(rows + r * HP + j * 4, pf[k]);
-    }
-    for (int r = grp + LDS_PF * LDS_GROUPS; r < n + T.nc; r += LDS_GROUPS)  // more rows than the registers cover: plain reload
-      if (act) st4(rows + r * HP + j * 4, ld4(slab_ptr(T, r, part_off, half_off)));
-  };
-
-  if ((int)blockIdx.x >= ntiles) return;
-  lds_tile T = tile_of(blockIdx.x);
-  float4 pf[LDS_PF];
-  uint32_t iw[LDS_IW], iw2[LDS_IW];
-  int rpr;
-  // prologue: phase-1 data of the first tile
-  fetch_slab(T, 0, 0, pf);
-#pragma unroll
-  for (int r = 0; r < LDS_IW; ++r) iw[r] = (uint32_t)pk_s[T.ebase + min(tid + r * LDS_THREADS, max(T.Eg - 1, 0))];
-  rpr = tid <= n ? rowptr_s[T.node0 + tid] - T.ebase : 0;
-
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const int node0 = T.node0, h = T.h, ebase = T.ebase, Eg = T.Eg;
-    // ---- phase-1 registers -> LDS ----
-    store_slab(T, 0, 0, pf);
-#pragma unroll
-    for (int r = 0; r < LDS_IW; ++r)
-      if (tid + r * LDS_THREADS < Eg) idx[tid + r * LDS_THREADS] = iw[r];
-    for (int e = tid + LDS_IW * LDS_THREADS; e < Eg; e += LDS_THREADS) idx[e] = (uint32_t)pk_s[ebase + e];
-    if (tid <= n) rp[tid] = rpr;
-    for (int v = tid + LDS_THREADS; v <= n; v += LDS_THREADS) rp[v] = rowptr_s[node0 + v] - ebase;
-    // ---- phase-2 data of this tile starts flying ----
-    fetch_slab(T, DP, DP, pf);
-#pragma unroll
-    for (int r = 0; r < LDS_IW; ++r) {
-      const int e = ebase + min(tid + r * LDS_THREADS, max(Eg - 1, 0));
-      iw[r] = (uint32_t)pk_t[e];
-      iw2[r] = (uint32_t)(pos_t[e] - ebase);
-    }
-    rpr = tid <= n ? rowptr_t[node0 + tid] - ebase : 0;
-    __syncthreads();
-
-    // ---- phase 1: scores + segment softmax, one 16-lane group per source node ----
-    {
-      const float* qp = KMQ + 2 * DP + h * HP + j * 4;
-      float4 qn = (grp < n && act) ? ld4(qp + (int64_t)(node0 + grp) * ldk) : zero4();
-      for (int v = grp; v < n; v += LDS_GROUPS) {
-        const float4 q = qn;
-        if (v + LDS_GROUPS < n && act) qn = ld4(qp + (int64_t)(node0 + v + LDS_GROUPS) * ldk);  // next node's Q slice flies under this segment
-        const int beg = rp[v], end = rp[v + 1];
-        for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-          float4 k4[LDS_UNROLL], ek[LDS_UNROLL];
-#pragma unroll
-          for (int u = 0; u < LDS_UNROLL; ++u) {
-            const uint32_t w = idx[min(e0 + u, end - 1)];
-            const uint32_t lc = w >> 16;
-            k4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
-            if (lc < (uint32_t)ccap) ek[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
-            else ek[u] = buf_ld4(rE, act ? (uint32_t)(h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)sub_cls[(int64_t)(node0 / n) * C + lc] * pe);
-          }
-#pragma unroll
-          for (int u = 0; u < LDS_UNROLL; ++u) {
-            const float p = row16_sum(dot4(q, add4(k4[u], ek[u]))) * qscale;
-            if (j == 0 && e0 + u < end) sc[e0 + u] = p;
-          }
-        }
-        // the group's own segment: its scores were written by its lane 0 (LDS operations of one wave retire in order)
-        float m = -INFINITY;
-        for (int e = beg + j; e < end; e += 16) m = fmaxf(m, sc[e]);
-        m = row16_max(m);
-        float sum = 0.f;
-        for (int e = beg + j; e < end; e += 16) sum += expf(sc[e] - m);
-        sum = row16_sum(sum);
-        const float deg = (float)(end - beg), inv = 1.0f / (sum + 1e-16f);
-        for (int e = beg + j; e < end; e += 16) {
-          const float av = expf(sc[e] - m) * inv, al = av * deg;
-          a[(int64_t)(ebase + e) * 4 + h] = av;
-          alpha[(int64_t)(ebase + e) * 4 + h] = al;
-          sc[e] = al;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- phase-2 registers -> LDS ----
-    store_slab(T, DP, DP, pf);
-#pragma unroll
-    for (int r = 0; r < LDS_IW; ++r)
-      if (tid + r * LDS_THREADS < Eg) {
-        idx[2 * (tid + r * LDS_THREADS)] = iw[r];
-        idx[2 * (tid + r * LDS_THREADS) + 1] = iw2[r];
-      }
-    for (int e = tid + LDS_IW * LDS_THREADS; e < Eg; e += LDS_THREADS) {
-      idx[2 * e] = (uint32_t)pk_t[ebase + e];
-      idx[2 * e + 1] = (uint32_t)(pos_t[ebase + e] - ebase);
-    }
-    if (tid <= n) rp[tid] = rpr;
-    for (int v = tid + LDS_THREADS; v <= n; v += LDS_THREADS) rp[v] = rowptr_t[node0 + v] - ebase;
-    // ---- phase-1 data of the NEXT tile starts flying ----
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) {
-      T = tile_of(tn);
-      fetch_slab(T, 0, 0, pf);
-#pragma unroll
-      for (int r = 0; r < LDS_IW; ++r) iw[r] = (uint32_t)pk_s[T.ebase + min(tid + r * LDS_THREADS, max(T.Eg - 1, 0))];
-      rpr = tid <= n ? rowptr_s[T.node0 + tid] - T.ebase : 0;
-    }
-    __syncthreads();
-
-    // ---- phase 2: weighted sum of messages, one group per target node ----
-    for (int v = grp; v < n; v += LDS_GROUPS) {
-      const int beg = rp[v], end = rp[v + 1];
-      float4 acc = zero4();
-      for (int e0 = beg; e0 < end; e0 += LDS_UNROLL) {
-        float4 m4[LDS_UNROLL], em[LDS_UNROLL];
-        float al[LDS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < LDS_UNROLL; ++u) {
-          const int e = min(e0 + u, end - 1);
-          const uint32_t w = idx[2 * e];
-          const uint32_t lc = w >> 16;
-          m4[u] = act ? ld4(rows + (w & 0xFFFFu) * HP + j * 4) : zero4();
-          if (lc < (uint32_t)ccap) em[u] = act ? ld4(crow + lc * HP + j * 4) : zero4();
-          else em[u] = buf_ld4(rE, act ? (uint32_t)(DP + h * HP + j * 4) * 4u : OOB_OFF, (uint32_t)sub_cls[(int64_t)(node0 / n) * C + lc] * pe);
-          al[u] = e0 + u < end ? sc[idx[2 * e + 1]] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < LDS_UNROLL; ++u) acc = fma4(al[u], add4(m4[u], em[u]), acc);
-      }
-      if (act) st4(aggr + (int64_t)(node0 + v) * lda + h * HP + j * 4, acc);
-    }
-    __syncthreads();  // every read of this tile's LDS is done before the next tile's phase-1 registers are stored
-  }
-}
-
 static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const float* EkEm, int lde, int HP, const char* who) {
   QAGNN_REQUIRE(g && KMQ && EkEm, QAGNN_EINVAL, "%s: null pointer", who);
   QAGNN_REQUIRE(HP > 0 && HP % 4 == 0 && HP <= 64, QAGNN_EUNSUPPORTED, "%s: head pitch HP=%d must be a multiple of 4, <= 64", who, HP);
@@ -774,62 +554,6 @@ extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, i
                                        int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                                        qagnn_stream_t stream_) {
   return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, (hipStream_t)stream_);
-}
-
-// class rows a workgroup keeps in LDS: everything the 160 KB allow next to the node rows and the per-edge arrays, at most C
-static int lds_class_cap(int n, int HP, int ecap, int C) {
-  const int64_t fixed = ((int64_t)n * HP + 3 * (int64_t)ecap + (n + 1 + 3)) * 4;
-  const int64_t room = 156 * 1024 - fixed;
-  if (room < (int64_t)HP * 4 * 16) return 0;
-  const int64_t cap = room / (HP * 4);
-  return (int)(cap < C ? cap : C);
-}
-
-extern "C" int64_t qagnn_edge_attn_fwd_lds_bytes(int32_t n, int32_t HP, int32_t max_sub_ep, int32_t C) {
-  const int ecap = (max_sub_ep + 3) & ~3;
-  const int ccap = lds_class_cap(n, HP, ecap, C);
-  if (ccap <= 0) return (int64_t)1 << 40;
-  return ((int64_t)n * HP + (int64_t)ccap * HP + 3 * (int64_t)ecap + (n + 1 + 3)) * (int64_t)sizeof(float);
-}
-
-extern "C" int qagnn_edge_attn_fwd_lds_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
-                                           int32_t HP, float qscale, float* a, float* alpha, float* aggr, int32_t lda,
-                                           int32_t max_sub_ep, qagnn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd_lds");
-  if (rc != QAGNN_OK) return rc;
-  QAGNN_REQUIRE(a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL, "edge_attn_fwd_lds: bad output arguments");
-  QAGNN_REQUIRE(g->block_n > 0 && g->N % g->block_n == 0 && g->pk_s && g->pk_t && g->sub_ncls && g->sub_cls, QAGNN_EINVAL,
-                "edge_attn_fwd_lds: the graph has no per-subgraph views (build it with qagnn_graph_from_blobs)");
-  const int n = g->block_n;
-  QAGNN_REQUIRE(max_sub_ep >= n && n < 65536 && g->C < 65536, QAGNN_EINVAL, "edge_attn_fwd_lds: max_sub_ep=%d must bound every subgraph's E_g + n", max_sub_ep);
-  const int ecap = (max_sub_ep + 3) & ~3;
-  const int ccap = lds_class_cap(n, HP, ecap, g->C);
-  const int64_t bytes = qagnn_edge_attn_fwd_lds_bytes(n, HP, max_sub_ep, g->C);
-  QAGNN_REQUIRE(ccap > 0 && bytes <= 160 * 1024, QAGNN_EUNSUPPORTED, "edge_attn_fwd_lds: n=%d, %d edges per subgraph do not fit the LDS", n, max_sub_ep);
-  // per DEVICE, not per process: the reference's own layout puts the encoder on cuda:0 and the decoder on cuda:1 (qagnn.py:133-134)
-  static bool attr_set[64] = {};
-  static int n_cu_dev[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("edge_attn_fwd_lds: cannot query the current device"); return QAGNN_EHIP; }
-  const int di = dev & 63;
-  if (!attr_set[di]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_edge_fwd_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("edge_attn_fwd_lds: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
-    attr_set[di] = true;
-  }
-  if (n_cu_dev[di] == 0) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu_dev[di] = v;
-  }
-  const int n_cu = n_cu_dev[di];
-  const int ntiles = (g->N / n) * 4;
-  const int grid = ntiles < n_cu ? ntiles : n_cu;  // persistent: one 16-wave workgroup per CU (the LDS allows no second one)
-  k_edge_fwd_lds<<<grid, LDS_THREADS, (size_t)bytes, stream>>>(g->rowptr_s, g->rowptr_t, g->pk_s, g->pk_t, g->pos_t, g->sub_ncls, g->sub_cls, KMQ,
-                                                              ldk, EkEm, lde, HP, qscale, n, ecap, ccap, a, alpha, aggr, lda, g->N, g->C, ntiles);
-  QAGNN_LAUNCH_CHECK("k_edge_fwd_lds");
-  return QAGNN_OK;
 }
 
 extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,

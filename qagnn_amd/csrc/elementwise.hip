@@ -170,50 +170,39 @@ __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __res
 // BatchNorm batch statistics from the per-tile partials of the GEMM that wrote the BatchNorm input (qagnn_gemm_nn_args.colstat_part:
 // per 128-row tile t and column c: x0 = the tile's first value, S1 = sum (x - x0), S2 = sum (x - x0)^2), combined by the pairwise
 // update of Chan, Golub & LeVeque -- every tile is shifted by one of its own values, so nothing cancels -- plus the whole
-// bookkeeping of k_bn_finalize, in one launch.  64 columns x CF_Q partitions per block, partitions added in a fixed order.
+// bookkeeping of k_bn_finalize, in one launch and ONE pass over the partials.  A block owns 16 columns; its 1024 threads are
+// 16 columns x 64 partitions (partition q merges tiles q, q + 64, ... in order), the 64 partition results are merged in partition
+// order by the column's first thread: a fixed order, whatever the timing.
 constexpr int ST_TILE = 128;  // = SBM of gemm_split.hip
-__global__ __launch_bounds__(64 * CF_Q) void k_bn_stats_finalize(const float* __restrict__ part, int nt, int R, int Cc,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                                 float* __restrict__ stats, float* __restrict__ run_mean,
-                                                                 float* __restrict__ run_var, int64_t* __restrict__ nbt, int d,
-                                                                 float momentum, float unbias) {
-  __shared__ float red[CF_Q][64];
-  __shared__ float mean_s[64];
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const bool act = c < Cc;
-  float s = 0.f;
-  if (act)
-    for (int t = q; t < nt; t += CF_Q) {
-      const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
-      s += fmaf(n_t, part[((int64_t)t * 3 + 0) * Cc + c], part[((int64_t)t * 3 + 1) * Cc + c]);
-    }
-  red[q][lane] = s;
-  __syncthreads();
-  if (q == 0) {
-    float tot = red[0][lane];
-#pragma unroll
-    for (int k = 1; k < CF_Q; ++k) tot += red[k][lane];
-    mean_s[lane] = tot / (float)R;
-  }
-  __syncthreads();
-  const float mean = mean_s[lane];
-  float m2 = 0.f;
-  if (act)
-    for (int t = q; t < nt; t += CF_Q) {
+constexpr int BF_COLS = 16, BF_PARTS = 64;
+struct Moments { float n, mean, m2; };
+__device__ __forceinline__ void merge(Moments& a, float nb, float mb, float m2b) {
+  if (nb <= 0.f) return;
+  const float n = a.n + nb, d = mb - a.mean;
+  a.mean += d * (nb / n);
+  a.m2 += m2b + d * d * (a.n * nb / n);
+  a.n = n;
+}
+__global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const float* __restrict__ part, int nt, int R, int Cc,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        float eps, float* __restrict__ stats, float* __restrict__ run_mean,
+                                                                        float* __restrict__ run_var, int64_t* __restrict__ nbt, int d,
+                                                                        float momentum, float unbias) {
+  __shared__ float sn[BF_PARTS][BF_COLS], sm[BF_PARTS][BF_COLS], s2[BF_PARTS][BF_COLS];
+  const int cl = threadIdx.x & (BF_COLS - 1), q = threadIdx.x / BF_COLS;
+  const int c = blockIdx.x * BF_COLS + cl;
+  Moments a = {0.f, 0.f, 0.f};
+  if (c < Cc)
+    for (int t = q; t < nt; t += BF_PARTS) {
       const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
       const float x0 = part[((int64_t)t * 3 + 0) * Cc + c], S1 = part[((int64_t)t * 3 + 1) * Cc + c], S2 = part[((int64_t)t * 3 + 2) * Cc + c];
-      const float dm = (x0 + S1 / n_t) - mean;
-      m2 += (S2 - S1 * S1 / n_t) + n_t * dm * dm;
+      merge(a, n_t, x0 + S1 / n_t, S2 - S1 * S1 / n_t);
     }
-  __syncthreads();  // pass 1's partition sums have been consumed
-  red[q][lane] = m2;
+  sn[q][cl] = a.n; sm[q][cl] = a.mean; s2[q][cl] = a.m2;
   __syncthreads();
-  if (q == 0 && act) {
-    float tot = red[0][lane];
-#pragma unroll
-    for (int k = 1; k < CF_Q; ++k) tot += red[k][lane];
-    const float var = fmaxf(tot / (float)R, 0.f);  // biased, as BatchNorm normalises with
+  if (q == 0 && c < Cc) {
+    for (int k = 1; k < BF_PARTS; ++k) merge(a, sn[k][cl], sm[k][cl], s2[k][cl]);
+    const float mean = a.mean, var = fmaxf(a.m2 / (float)R, 0.f);  // biased, as BatchNorm normalises with
     const float is = rsqrtf(var + eps), sc = gamma[c] * is;
     stats[c] = mean;
     stats[Cc + c] = var;
@@ -422,7 +411,7 @@ extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, i
                 "bn_stats_finalize: bad arguments (R=%d needs %d tiles of %d rows, got %d)", R, cdiv(R, ST_TILE), ST_TILE, n_tiles);
   QAGNN_REQUIRE(!run_mean || (run_var && d > 0 && d % 4 == 0 && Cc % 4 == 0 && d <= Cc), QAGNN_EINVAL, "bn_stats_finalize: running-stat arguments");
   (void)dense_pos;  // the head-padded layout is implied by (Cc, d); kept in the signature for symmetry with qagnn_bn_finalize_f32
-  k_bn_stats_finalize<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var,
+  k_bn_stats_finalize<<<cdiv(Cc, BF_COLS), BF_COLS * BF_PARTS, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var,
                                                               num_batches_tracked, d, momentum, unbias);
   QAGNN_LAUNCH_CHECK("k_bn_stats_finalize");
   return QAGNN_OK;

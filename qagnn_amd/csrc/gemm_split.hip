@@ -261,9 +261,13 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           if (c < BN && n0 + c < a.No) {
             const float bc = a.bias ? a.bias[n0 + c] : 0.f;
             if (i == 0) x0r[cc] = S0[c] + bc;
-            const int rows = min(SLAB_ROWS, a.M - (m0 + (w * SRT + i) * 16));  // <= 0 past M
-            for (int r = 0; r < rows; ++r) {
-              const float dlt = (St[r * PS + c] + bc) - x0r[cc];  // the value the store loop below writes, minus the shift
+            const int rows = a.M - (m0 + (w * SRT + i) * 16);  // rows of this slab inside the matrix (<= 0 past M)
+            float v[SLAB_ROWS];
+#pragma unroll
+            for (int r = 0; r < SLAB_ROWS; ++r) v[r] = St[r * PS + c];  // 16 LDS reads in flight, then the arithmetic
+#pragma unroll
+            for (int r = 0; r < SLAB_ROWS; ++r) {
+              const float dlt = r < rows ? (v[r] + bc) - x0r[cc] : 0.f;  // the value the store loop below writes, minus the shift
               s1[cc] += dlt;
               s2[cc] = fmaf(dlt, dlt, s2[cc]);
             }
@@ -654,9 +658,16 @@ extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float*
     QAGNN_REQUIRE((int64_t)a->M * a->lda1 * 4 < lim && (int64_t)a->No * ldn1 * 4 < lim, QAGNN_EUNSUPPORTED,
                   "gemm_nn_split: column statistics with operands of 2 GB and more");
   }
-  if (nt16 >= 13) return launch_split<13>(*a, B1n, ldn1, B2n, ldn2, stream);
-  if (nt16 >= 8) return launch_split<8>(*a, B1n, ldn1, B2n, ldn2, stream);
-  if (nt16 >= 7) return launch_split<7>(*a, B1n, ldn1, B2n, ldn2, stream);
-  if (nt16 >= 4) return launch_split<4>(*a, B1n, ldn1, B2n, ldn2, stream);
-  return launch_split<2>(*a, B1n, ldn1, B2n, ldn2, stream);
+  int nt = nt16 >= 13 ? 13 : nt16 >= 8 ? 8 : nt16 >= 7 ? 7 : nt16 >= 4 ? 4 : 2;
+  // few row tiles (host-bound batches: 2 000 node rows are 16 tiles on 256 CUs): QAGNN_NN_SMALL_NT=<2|4|7> takes narrower column
+  // tiles there, i.e. more, lighter blocks (measurement switch; per-element arithmetic does not depend on the tile shape)
+  static const int small_nt = getenv("QAGNN_NN_SMALL_NT") ? atoi(getenv("QAGNN_NN_SMALL_NT")) : 0;
+  if (small_nt > 0 && small_nt < nt && !a->colstat_part && cdiv(a->M, SBM) * cdiv(a->No, nt * 16) * 2 <= split_num_cus()) nt = small_nt;
+  switch (nt) {
+    case 13: return launch_split<13>(*a, B1n, ldn1, B2n, ldn2, stream);
+    case 8: return launch_split<8>(*a, B1n, ldn1, B2n, ldn2, stream);
+    case 7: return launch_split<7>(*a, B1n, ldn1, B2n, ldn2, stream);
+    case 4: return launch_split<4>(*a, B1n, ldn1, B2n, ldn2, stream);
+    default: return launch_split<2>(*a, B1n, ldn1, B2n, ldn2, stream);
+  }
 }

@@ -196,15 +196,11 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
                                                        int* __restrict__ tgt_s, int* __restrict__ src_s, int* __restrict__ cls_s,
                                                        int* __restrict__ eid_s, int* __restrict__ rowptr_t, int* __restrict__ src_t,
                                                        int* __restrict__ tgt_t, int* __restrict__ cls_t, int* __restrict__ pos_t,
-                                                       int* __restrict__ pk_s, int* __restrict__ pk_t, int* __restrict__ sub_ncls,
-                                                       int* __restrict__ sub_cls, int* __restrict__ err) {
-  extern __shared__ int rp[];  // rp_s[n+1] | rp_t[n+1]: local exclusive scans of the degrees | rank[C]: local id of each class
+                                                       int* __restrict__ err) {
+  extern __shared__ int rp[];  // rp_s[n+1] | rp_t[n+1]: local exclusive scans of the degrees
   __shared__ int wsum[2][4];
-  __shared__ int csum[4];
   int* const rp_s = rp;
   int* const rp_t = rp + n + 1;
-  int* const rank = rp_t + n + 1;
-  const int C = R * T * T + T;
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int E = edge_off[B];  // the batch's edge count, read on the device: the host only fixes the CAPACITY of the arrays (hipGraph replay)
   const int32_t* blob = blobs + blob_off[g];
@@ -236,37 +232,6 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
   if (tid == 255) { rp_s[n] = run_s; rp_t[n] = run_t; }
   __syncthreads();
   bool bad = rp_s[n] != Eg || rp_t[n] != Eg;
-  // the subgraph's distinct classes -> local ids (ascending class order): presence flags, then an exclusive scan over the C classes
-  if (pk_s) {
-    for (int c = tid; c < C; c += 256) rank[c] = 0;
-    __syncthreads();
-    for (int i = tid; i < Eg; i += 256) rank[min((int)(w0[i] >> 16), R * T * T - 1)] = 1;
-    for (int v = tid; v < n; v += 256) rank[R * T * T + (int)min(max(node_type[node0 + v], (int64_t)0), (int64_t)T - 1)] = 1;
-    __syncthreads();
-    const int cper = (C + 255) >> 8, c0 = tid * cper;
-    int cs = 0;
-    for (int k = 0; k < cper; ++k)
-      if (c0 + k < C) cs += rank[c0 + k];
-    int cinc = cs;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(cinc, o, 64);
-      if (lane >= o) cinc += u;
-    }
-    if (lane == 63) csum[wid] = cinc;
-    __syncthreads();
-    int crun = cinc - cs;
-    for (int w = 0; w < wid; ++w) crun += csum[w];
-    for (int k = 0; k < cper; ++k)
-      if (c0 + k < C) {
-        const int present = rank[c0 + k];
-        rank[c0 + k] = crun;                                        // local id (valid where present)
-        if (present) sub_cls[(int64_t)g * C + crun] = c0 + k;
-        crun += present;
-      }
-    if (tid == 255) sub_ncls[g] = crun;
-    __syncthreads();
-  }
   // node rows: segment starts and the self loops
   for (int v = tid; v < n; v += 256) {
     rowptr_s[node0 + v] = Epoff + rp_s[v] + v;
@@ -277,7 +242,6 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
     const int ps = Epoff + rp_s[v + 1] + v, pt = Epoff + rp_t[v + 1] + v;
     tgt_s[ps] = node0 + v; src_s[ps] = node0 + v; cls_s[ps] = c; eid_s[ps] = E + node0 + v;
     src_t[pt] = node0 + v; tgt_t[pt] = node0 + v; cls_t[pt] = c; pos_t[pt] = ps;
-    if (pk_s) { pk_s[ps] = v | (rank[c] << 16); pk_t[pt] = v | (rank[c] << 16); }
   }
   if (g == B - 1 && tid == 0) { rowptr_s[(int64_t)B * n] = E + B * n; rowptr_t[(int64_t)B * n] = E + B * n; }
   const int C_real = R * T * T;
@@ -293,7 +257,6 @@ __global__ __launch_bounds__(256) void k_blob_assemble(const int32_t* __restrict
     src_t[q] = node0 + slc; tgt_t[q] = node0 + t; pos_t[q] = Epoff + posc + slc;
     const int ct = min((int)(w0[posc] >> 16), C_real - 1);
     cls_t[q] = ct;
-    if (pk_s) { pk_s[p] = min(tl, n - 1) | (rank[min(cl, C_real - 1)] << 16); pk_t[q] = slc | (rank[ct] << 16); }
   }
   if (bad) *err = 1;
 }
@@ -454,11 +417,6 @@ static carved carve(qagnn_graph* g, int32_t* storage, int N, int E, int R, int T
   cv.es = take(Ep); cv.et = take(Ep); cv.ec = take(Ep);
   cv.tmp_s = take(Ep); cv.tmp_t = take(Ep); cv.srcpos = take(Ep);
   cv.hist = take((int64_t)cv.nblk * C);
-  g->pk_s = g->pk_t = g->sub_ncls = g->sub_cls = nullptr;
-  if (block_n >= 8) {
-    g->pk_s = take(Ep); g->pk_t = take(Ep);
-    g->sub_ncls = take(N / 8 + 1); g->sub_cls = take((int64_t)(N / 8 + 1) * C);
-  }
   return cv;
 }
 
@@ -503,9 +461,6 @@ extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, in
   tot += 2 * up4(N);          // cnt_s, cnt_t
   tot += 6 * up4(Ep);         // es et ec tmp_s tmp_t srcpos
   tot += up4(nblk * C);       // per-block class histograms
-  // per-subgraph views (qagnn_graph_from_blobs): pk_s, pk_t, and per subgraph a count + a class list; the number of subgraphs is
-  // not known here, N / 8 bounds it for node blocks of >= 8 rows (smaller blocks get no LDS views)
-  tot += 2 * up4(Ep) + up4(N / 8 + 1) + up4((int64_t)(N / 8 + 1) * C);
   return tot;
 }
 
@@ -528,7 +483,6 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_prep: %lld edge classes > 8192", (long long)C64);
   const int Ep = (int)Ep64;
   carved cv = carve(g, storage, N, E, R, T, block_n);
-  g->pk_s = g->pk_t = g->sub_ncls = g->sub_cls = nullptr;  // only qagnn_graph_from_blobs builds the per-subgraph views
   int32_t *cnt_s = cv.cnt_s, *cnt_t = cv.cnt_t, *es = cv.es, *et = cv.et, *ec = cv.ec, *tmp_s = cv.tmp_s, *tmp_t = cv.tmp_t;
   int32_t *srcpos = cv.srcpos, *eid_t = cv.eid_t, *hist = cv.hist, *gc_cnt = cv.gc_cnt, *gcptr = cv.gcptr, *nch = cv.nch;
   const int nblk = cv.nblk, gb = cv.gb, NG = cv.NG, pairs = cv.pairs;
@@ -558,7 +512,7 @@ extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const in
   QAGNN_REQUIRE(g && storage && blobs && blob_off && edge_off && node_type, QAGNN_EINVAL, "graph_from_blobs: null pointer");
   QAGNN_REQUIRE(B > 0 && n > 0 && E >= 0 && R > 0 && T > 0, QAGNN_EINVAL, "graph_from_blobs: bad sizes B=%d n=%d E=%d R=%d T=%d", B, n, E, R, T);
   QAGNN_REQUIRE(n < 65536 && (int64_t)R * T * T < 65536, QAGNN_EUNSUPPORTED, "graph_from_blobs: n=%d or R*T*T=%d does not fit the 16-bit blob fields", n, R * T * T);
-  QAGNN_REQUIRE((size_t)(2 * (n + 1) + (int64_t)R * T * T + T) * sizeof(int) <= 64 * 1024, QAGNN_EUNSUPPORTED, "graph_from_blobs: n=%d node slots per sample exceed the LDS scan", n);
+  QAGNN_REQUIRE((size_t)(2 * (n + 1)) * sizeof(int) <= 64 * 1024, QAGNN_EUNSUPPORTED, "graph_from_blobs: n=%d node slots per sample exceed the LDS scan", n);
   QAGNN_REQUIRE(aligned16(storage), QAGNN_EINVAL, "graph_from_blobs: storage must be 16-byte aligned");
   const int64_t N64 = (int64_t)B * n, Ep64 = (int64_t)E + N64, C64 = (int64_t)R * T * T + T;
   QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_from_blobs: E+N=%lld too large", (long long)Ep64);
@@ -566,10 +520,9 @@ extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const in
   carved cv = carve(g, storage, (int)N64, E, R, T, n);
   hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)cv.es - (char*)g->cls_count), stream);
   if (he != hipSuccess) { set_error("graph_from_blobs: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
-  k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1) + C64) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, R, T, g->rowptr_s,
-                                                                                  g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t,
-                                                                                  g->tgt_t, g->cls_t, g->pos_t, g->pk_s, g->pk_t, g->sub_ncls,
-                                                                                  g->sub_cls, g->err);
+  k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1)) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, R, T, g->rowptr_s,
+                                                                           g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t, g->tgt_t,
+                                                                           g->cls_t, g->pos_t, g->err);
   QAGNN_LAUNCH_CHECK("k_blob_assemble");
   return class_pass(g, cv.hist, cv.gc_cnt, cv.gcptr, cv.nch, cv.nblk, cv.gb, cv.NG, cv.pairs, stream);
 }

@@ -312,8 +312,6 @@ class PackedGraphBatch:
         self.sample_ids, self.num_choice = list(sample_ids), num_choice
         self.n, self.n_etype, self.n_ntype = store.n, store.n_etype, store.n_ntype
         self.head = (2 * (B + 1) + 3) // 4 * 4
-        # largest subgraph of the batch incl. its n self loops (host-side knowledge the LDS-resident edge kernels are sized by)
-        self.max_sub_ep = int(store.edge_count[self.sample_ids].max()) + store.n if B else store.n
 
     @property
     def device(self):

@@ -81,7 +81,6 @@ class GraphedStep:
         c.blob = torch.zeros(packed.head + 2 * n * B + 3 * e_cap, dtype=torch.int32, device=dev)
         c.packed = PackedGraphBatch(c.blob, B, packed.E, packed.store, packed.sample_ids, packed.num_choice)
         c.packed.e_cap = e_cap
-        c.packed.max_sub_ep = 0  # per-batch host knowledge (sizes the optional LDS-resident edge kernel): not valid across replays
         c.replays = 0
         self._load(c, args)
         # warm-up outside the capture (lazy initialisation: operand-packing plans, LDS attribute raises, allocator pools), on a side

@@ -50,6 +50,19 @@ for arg in "$@"; do
       find /tmp/prof -name "*kernel_stats*.csv" -exec cp {} gpurun_out/prof/kernel_stats.csv \;
       python scripts/trace_by_shape.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape.txt 2>&1
       stamp prof ;;
+    profno)   # the same with every side stream off: pure per-kernel times (nothing co-runs)
+      rm -rf /tmp/profno; mkdir -p /tmp/profno gpurun_out/prof
+      ( cd /tmp && QAGNN_WGRAD_OVERLAP=0 QAGNN_PREP_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profno -o r3 -- python "$REPO/bench.py" --steps 5 --warmup 2 --repeats 1 --graphs 0 --no-cpu-baseline --no-pmc --no-configs ) > gpurun_out/profno.log 2>&1
+      python scripts/trace_by_shape.py "$(find /tmp/profno -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape_no_overlap.txt 2>&1
+      tail -n 4 gpurun_out/profno.log > /tmp/x && mv /tmp/x gpurun_out/profno.log
+      stamp profno ;;
+    nnmicro)   # small-M NN GEMMs under rocprofv3 (kernel durations; the Python launch loop itself is host-bound), per column-tile width
+      for nt in 0 7 4 2; do
+        rm -rf /tmp/nnm; mkdir -p /tmp/nnm
+        ( cd /tmp && QAGNN_NN_SMALL_NT=$nt timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nnm -o m -- python "$REPO/tools/nn_micro.py" --small ) > /tmp/nnm.log 2>&1
+        echo "== QAGNN_NN_SMALL_NT=$nt" >> gpurun_out/nn_micro.txt
+        python scripts/nn_micro_trace.py "$(find /tmp/nnm -name '*kernel_trace.csv' | head -n 1)" >> gpurun_out/nn_micro.txt 2>&1
+      done; stamp nnmicro ;;
     prof10)
       rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 0 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log

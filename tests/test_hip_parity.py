@@ -424,7 +424,9 @@ def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
     worst, n_checked, fails = (0.0, None), 0, []
     for k, gref in ref['grads'].items():
         assert torch.isfinite(grads[k]).all(), f'{k}: non-finite gradient ({variant})'
-        if helpers.has_null_gradient(k, True):
+        # besides the usual null gradients: cross-entropy over a question's choices is invariant to a constant added to all of its
+        # logits, which is all the head's two output biases do -- their exact gradient is 0 and both sides hold rounding noise
+        if helpers.has_null_gradient(k, True) or k in ('fc.layers.0-Linear.bias', 'pooler.w_vs.bias'):
             continue
         scale = gref.abs().max().item()
         err = (grads[k].cpu() - gref).abs().max().item()
