@@ -330,9 +330,9 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
   static const int force_flat = getenv("QAGNN_NN_FLAT") ? atoi(getenv("QAGNN_NN_FLAT")) : 0;  // 1 = the 64-bit-pointer loads everywhere (A/B switch)
   const bool flat = force_flat || a.a_rowidx || (int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.M * a.lda2 * 4 >= lim ||
                     (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim;
-  if constexpr (NT == 13) {
+  if constexpr (NT == 13 || NT == 7 || NT == 4 || NT == 2) {
     if (a.colstat_part) {  // (validated by the entry point: bias-only epilogue, no gather, 32-bit offsets)
-      k_gemm_nn_split<13, false, false, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+      k_gemm_nn_split<NT, false, false, true><<<grid, STHR, 0, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
       QAGNN_LAUNCH_CHECK("k_gemm_nn_split<stats>");
       return QAGNN_OK;
     }
@@ -659,10 +659,20 @@ extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float*
                   "gemm_nn_split: column statistics with operands of 2 GB and more");
   }
   int nt = nt16 >= 13 ? 13 : nt16 >= 8 ? 8 : nt16 >= 7 ? 7 : nt16 >= 4 ? 4 : 2;
-  // few row tiles (host-bound batches: 2 000 node rows are 16 tiles on 256 CUs): QAGNN_NN_SMALL_NT=<2|4|7> takes narrower column
-  // tiles there, i.e. more, lighter blocks (measurement switch; per-element arithmetic does not depend on the tile shape)
+  // Few row tiles (the host-bound configurations: 10 subgraphs are 16 row tiles, a 64-subgraph MedQA shard 100, on 256 CUs): a
+  // block's time is its own serial k-loop, which scales with the column tiles it carries, and the other CUs idle -- so the column
+  // tile narrows until there are about 1.5 blocks per CU (or it is 32 columns wide).  Measured, rocprofv3 kernel durations
+  // (profiles/r3_run5_nn_small_m.txt): 2 000 x 208 x 208 25.3 -> 9.4 us at 32 columns; 12 800 rows 27.3 -> 16.3 us at 64 columns
+  // (18.6 at 32); 624 -> 208 at 12 800 rows 63 -> 37 us.  The arithmetic per output element does not depend on the tile shape:
+  // results are bit-identical.  QAGNN_NN_SMALL_NT=13 pins the wide tile (A/B switch).
   static const int small_nt = getenv("QAGNN_NN_SMALL_NT") ? atoi(getenv("QAGNN_NN_SMALL_NT")) : 0;
-  if (small_nt > 0 && small_nt < nt && !a->colstat_part && cdiv(a->M, SBM) * cdiv(a->No, nt * 16) * 2 <= split_num_cus()) nt = small_nt;
+  if (small_nt != 13) {
+    const int row_tiles = cdiv(a->M, SBM), want = split_num_cus() * 3 / 2;
+    const int cands[3] = {7, 4, 2};
+    for (int ci = 0; ci < 3 && row_tiles * cdiv(a->No, nt * 16) < want; ++ci)
+      if (cands[ci] < nt) nt = cands[ci];
+    if (small_nt > 0 && small_nt < nt) nt = small_nt;
+  }
   switch (nt) {
     case 13: return launch_split<13>(*a, B1n, ldn1, B2n, ldn2, stream);
     case 8: return launch_split<8>(*a, B1n, ldn1, B2n, ldn2, stream);

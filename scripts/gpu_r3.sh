@@ -85,6 +85,16 @@ PY
         echo "$var=$v (2 questions)" >> gpurun_out/ab10_$var.txt
         env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/ab10_$var.txt
       done; stamp "ab10:$var" ;;
+    abx10:*)   # abx10:VAR=a,b  -- interleaved A/B of two values of a switch at 2 questions (hipGraph replay as bench.py chooses)
+      spec="${arg#abx10:}"; var="${spec%%=*}"; vals="${spec#*=}"; va="${vals%%,*}"; vb="${vals#*,}"
+      for v in $va $vb $va $vb; do
+        echo "$var=$v (2 questions)" >> gpurun_out/abx10_$var.txt
+        env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/abx10_$var.txt
+      done; stamp "abx10:$var" ;;
+    dp2)   # two ranks time-slicing the one GPU over gloo: exercises the N > 1 code paths of bench.py (comm events, strong scaling)
+      QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 2>&1 | tail -n 3 > gpurun_out/bench_dp2_weak.log
+      QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --global-batch 32 2>&1 | tail -n 3 > gpurun_out/bench_dp2_strong.log
+      stamp dp2 ;;
     hostprof)
       timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt; stamp hostprof ;;
     cmd:*)

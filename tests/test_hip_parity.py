@@ -441,7 +441,7 @@ def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
             f.write(f'bench-size B=320 train [{variant}] vs fp32 oracle: {n_checked} tensors, worst {worst[0]:.3e} of scale ({worst[1]})\n')
     assert n_checked >= 60 and not fails, fails[:10]
     for bname, b in model.named_buffers():
-        helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=1e-4, atol=1e-6, what='buffer ' + bname)
+        helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=5e-4, atol=1e-6, what='buffer ' + bname)  # the forward bar: statistics of activations that agree to ~1e-4
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
