@@ -206,6 +206,8 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
     launch (qagnn_amd.graphed.GraphedStep: static input buffers refilled before every replay, true edge counts read on the device,
     dropout masks advanced per replay); the collectives stay outside the graph."""
     run_eager = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
+    if use_graph == 'auto' and comm is not None and comm.world > 1:
+        use_graph = '0'  # multi-rank runs stay on eager launches unless --graphs 1 asks otherwise (replay + RCCL has not been measured)
     if use_graph == 'auto':
         # measured (profiles/r3_run2_graph_ab.txt): replay beats eager launches wherever the step is bound by the host (10 subgraphs:
         # 3.92 vs 5.7-6.4 ms) and loses 2.7 % where it is bound by the GPU (320 subgraphs: 9.25 vs 9.00 ms) -- the same
