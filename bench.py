@@ -18,9 +18,10 @@ Extra objects on the JSON line:
   roofline     the edge stage of GATConvE forward (qagnn_edge_attn_fwd_f32: scores + segment softmax + aggregate), one launch
                per GAT layer, average duration from HIP events on the launch stream around every call inside the timed steps.
                `achieved` / `frac` are PHYSICAL: bytes that cross the HBM interface per launch = max(compulsory bytes,
-               measured fabric traffic) / duration, against the 8 TB/s peak -- never above 1.  The compulsory bytes are every
-               K|M|Q row read once + indices + the output row written once + the a / alpha arrays written and read once:
-               N*3*DP*4 + E'*10 + N*DP*4 + 2*E'*16.  `traffic` is measured by THIS run: two rocprofv3 --pmc passes
+               measured fabric traffic) / duration, against the 8 TB/s peak -- never above 1.  The compulsory bytes are what the kernels
+               MUST move: the K|M|Q row of every node with edges read once (3 rows), only the M row of a node whose single edge is its
+               self loop (every PAD row: its score is never needed, softmax of one element is 1), indices, the output row written once,
+               the a / alpha arrays written and read once: N_edged*3*DP*4 + N_lone*DP*4 + E'*10 + N*DP*4 + 2*E'*16.  `traffic` is measured by THIS run: two rocprofv3 --pmc passes
                (FETCH_SIZE, WRITE_SIZE; separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md, checked on a
                kernel of known bytes) over a 2-step child run of this script (--no-pmc skips them; the committed
                profiles/pmc_edge_fwd.json is then quoted and labelled as such).  The ALGORITHMIC figure of SURVEY.md 8(d)
@@ -555,7 +556,10 @@ def main():
         alg_fwd = Ep * 2410 + N * 800
         alg_bwd = Ep * 5610 + N * 800
         DP = 4 * ((D // 4 + 3) // 4 * 4)  # head-padded row width (208 floats at d = 200)
-        compulsory = N * 3 * DP * 4 + Ep * 10 + N * DP * 4 + 2 * Ep * 16
+        # node rows whose only edge is their self loop (PAD rows, isolated nodes): the edge kernels read their M row only
+        deg = torch.bincount(b['ei'][0], minlength=N) + torch.bincount(b['ei'][1], minlength=N)
+        n_lone = int((deg == 0).sum().item())
+        compulsory = (N - n_lone) * 3 * DP * 4 + n_lone * DP * 4 + Ep * 10 + N * DP * 4 + 2 * Ep * 16
         traffic, traffic_source = None, None
         if world == 1 and not args.no_pmc and not args.pmc_child:
             traffic, traffic_source = measure_edge_traffic(args, N, DP)
@@ -592,7 +596,7 @@ def main():
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(min(achieved / HBM_PEAK_GBS, 1.0), 4),
                          'traffic': traffic, 'traffic_source': traffic_source,
                          'hbm_bytes_per_launch': hbm_bytes, 'hbm_bytes_are': 'measured traffic' if (traffic or 0) >= compulsory else 'compulsory bytes',
-                         'compulsory_bytes_per_launch': compulsory,
+                         'compulsory_bytes_per_launch': compulsory, 'self_loop_only_rows': n_lone,
                          'note': 'achieved = max(compulsory bytes, measured fabric traffic) / average launch duration: bytes that physically cross '
                                  'the HBM interface.  The per-edge row gathers of the SURVEY 8d byte model are re-reads served by L1/L2; they are '
                                  'reported as achieved_algorithmic and are not an HBM fraction',

@@ -56,6 +56,14 @@ __device__ __forceinline__ void store_split(uint16_t* __restrict__ img, int img_
   *reinterpret_cast<uint2*>(img + img_elems + off) = make_uint2(pack_hi(a2, b2), pack_hi(c2, d2));
   *reinterpret_cast<uint2*>(img + 2 * img_elems + off) = make_uint2(pack_hi(a3, b3), pack_hi(c3, d3));
 }
+// timing ablations only (QAGNN_ABL_NO?SPLIT): the three stores without the split arithmetic
+__device__ __forceinline__ void store_nosplit(uint16_t* __restrict__ img, int img_elems, int off, float4 v) {
+  const uint2 h = make_uint2(pack_hi(__builtin_bit_cast(uint32_t, v.x), __builtin_bit_cast(uint32_t, v.y)),
+                             pack_hi(__builtin_bit_cast(uint32_t, v.z), __builtin_bit_cast(uint32_t, v.w)));
+  *reinterpret_cast<uint2*>(img + off) = h;
+  *reinterpret_cast<uint2*>(img + img_elems + off) = h;
+  *reinterpret_cast<uint2*>(img + 2 * img_elems + off) = h;
+}
 // element offset of (row, k) in a swizzled [rows][32] bf16 image
 // The XOR pattern follows ds_read_b128's lane groups (MI355X_MICROARCH.md, LDS): a fragment read (lane -> row lane & 15, chunk lane >> 4)
 // is serviced in four NON-contiguous 16-lane groups, e.g. {0-3, 12-15, 20-27} = rows 0-3, 12-15 of chunk c with rows 4-11 of chunk
@@ -183,14 +191,22 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           const bool ok = kin && (!first || arow[p] >= 0) && (first || m0 + lr + p * 32 < a.M);
           v = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }  // (buffer loads: zeros already; under AFFINE an out-of-range k leaves relu(shift) here, multiplied by B's zeros)
+#ifdef QAGNN_ABL_NOASPLIT  // timing ablation (tools/): no split arithmetic for A -- the high halves go to all three images
+        store_nosplit(As, A_EL, swz(lr + p * 32, kl), v);
+#else
         store_split(As, A_EL, swz(lr + p * 32, kl), v);
+#endif
       }
 #pragma unroll
       for (int q = 0; q < B_IT; ++q) {
         const int col = lr + q * 32;
         if (col < BN) {
           const float4 v = (!FLAT || (kin && n0 + col < a.No)) ? rb[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef QAGNN_ABL_NOBSPLIT  // timing ablation (tools/): what a weight operand that arrives pre-split would save
+          store_nosplit(Bs, B_EL, swz(col, kl), v);
+#else
           store_split(Bs, B_EL, swz(col, kl), v);
+#endif
         }
       }
     };

@@ -63,6 +63,13 @@ for arg in "$@"; do
         echo "== QAGNN_NN_SMALL_NT=$nt" >> gpurun_out/nn_micro.txt
         python scripts/nn_micro_trace.py "$(find /tmp/nnm -name '*kernel_trace.csv' | head -n 1)" >> gpurun_out/nn_micro.txt 2>&1
       done; stamp nnmicro ;;
+    nnabl)   # NN split GEMM at M = 64 000 with the operand-split arithmetic ablated (B only / A and B): what pre-split operands could buy
+      for lib in "" tools/bin/libqagnn_hip_nobsplit.so tools/bin/libqagnn_hip_nosplit.so; do
+        rm -rf /tmp/nna; mkdir -p /tmp/nna
+        ( cd /tmp && QAGNN_LIB=${lib:+$REPO/$lib} timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nna -o m -- python "$REPO/tools/nn_micro.py" ) > /tmp/nna.log 2>&1
+        echo "== library: ${lib:-qagnn_amd/libqagnn_hip.so (shipped)}" >> gpurun_out/nn_ablate.txt
+        python scripts/nn_micro_trace.py "$(find /tmp/nna -name '*kernel_trace.csv' | head -n 1)" --big >> gpurun_out/nn_ablate.txt 2>&1
+      done; stamp nnabl ;;
     prof10)
       rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 0 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log

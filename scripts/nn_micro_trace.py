@@ -5,8 +5,12 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'k_gemm_nn_split' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-shapes = ['mlp 208->208', 'proj 320->624', 'dX 624->208', 'dS 624->112']
-Ms = [500, 2000, 12800]
+if '--big' in sys.argv:   # tools/nn_micro.py without --small: M = 64 000, all eight shapes
+    shapes = ['mlp 208->208', 'proj 320->624', 'dX 624->208', '640->208', '1024->208', '416->208', 'dS 624->112', '[dX|dS] 624->320']
+    Ms = [64000]
+else:
+    shapes = ['mlp 208->208', 'proj 320->624', 'dX 624->208', 'dS 624->112']
+    Ms = [500, 2000, 12800]
 i = 0
 for M in Ms:
     for sh in shapes:
