@@ -56,7 +56,7 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64), ('gemm_split', _i32)])
+                [('ws_elems', _i64), ('gemm_split', _i32), ('tab_col', _i32)])
 
 
 def load_library(path=LIB_PATH):
@@ -607,7 +607,7 @@ class HipKernels(metaclass=_GuardedMeta):
         return dKMQ, dEkEm
 
     # -- one GATConvE hop per call (csrc/hop.hip) ---------------------------------------------------------------------------
-    def _hop_struct(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act):
+    def _hop_struct(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col=-1):
         Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
         DP = 4 * HP
         _chk2d(X, 'X'), _chk2d(Wx_t, 'Wx_t'), _chk2d(Wx, 'Wx'), _chk2d(TT, 'TT'), _chk2d(EkEm, 'EkEm')
@@ -633,6 +633,7 @@ class HipKernels(metaclass=_GuardedMeta):
         h.run_mean_p, h.run_var_p = run_mean_p.data_ptr(), run_var_p.data_ptr()
         h.apply_act, h.p_drop, h.seed = (1 if apply_act else 0), float(p), int(seed)
         h.gemm_split = 1 if self.gemm_split else 0
+        h.tab_col = int(tab_col) if S is not None else -1
         return h
 
     def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
@@ -658,9 +659,9 @@ class HipKernels(metaclass=_GuardedMeta):
         return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats)
 
     def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
-                dX_acc=None, dS_acc=None):
+                dX_acc=None, dS_acc=None, tab_col=-1):
         """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)"""
-        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
+        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col)
         KMQ, aa, aggr, h1, out, stats = saved
         N, DP, dev, SP, T = graph.N, 4 * HP, X.device, h.SP, h.T
         _chk2d(dy, 'dy')
@@ -723,7 +724,7 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(self.lib.qagnn_stack_fwd_f32(hops, k, self._stream()), 'qagnn_stack_fwd_f32')
         return rows[k - 1, 3], (KMQ, aa, rows, stats)
 
-    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None):
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1):
         """-> (dX, dS, [per layer: (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)]); dX_acc: an existing running total of
         the stack input's gradient (the output GEMM's share), added to in place."""
         k = len(prms)
@@ -751,7 +752,7 @@ class HipKernels(metaclass=_GuardedMeta):
             offs.append(offs[-1] + n)
         for l in range(k):
             x = X if l == 0 else rows[l - 1, 3]
-            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
+            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, tab_col)
             h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out = (p_rows + (4 * l + i) * row_b for i in range(3))

@@ -178,8 +178,16 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
   if (SP > 0)
     HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
-  HOP_TRY(qagnn_colreduce_f32(0, dKMQ, 3 * DP, nullptr, 3 * DP, N, 3 * DP, h->ntype, h->T, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->dTT,
-                              crws, stream));
+  if (SP > 0 && h->tab_col >= 0) {
+    // the type indicators ride in S's padding columns: their rows of dWs_t ARE the type-table gradient
+    QAGNN_REQUIRE(h->tab_col + h->T <= SP, QAGNN_EINVAL, "hop_bwd: tab_col=%d + T=%d exceeds SP=%d", h->tab_col, h->T, SP);
+    hipError_t he = hipMemcpyAsync(h->dTT, h->dWs_t + (int64_t)h->tab_col * 3 * DP, (size_t)h->T * 3 * DP * sizeof(float), hipMemcpyDeviceToDevice,
+                                   (hipStream_t)stream);
+    if (he != hipSuccess) { set_error("hop_bwd: dTT copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  } else {
+    HOP_TRY(qagnn_colreduce_f32(0, dKMQ, 3 * DP, nullptr, 3 * DP, N, 3 * DP, h->ntype, h->T, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->dTT,
+                                crws, stream));
+  }
   if (h->dX) {
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;

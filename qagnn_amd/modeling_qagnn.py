@@ -265,7 +265,7 @@ class GATConvE(nn.Module):
 
     N_PACKED = 18
 
-    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None, acc=None):
+    def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None, acc=None, tab_col=-1):
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
@@ -299,8 +299,8 @@ class GATConvE(nn.Module):
                 return ops.gat_hop(Xp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head),
                                    (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
                                    self.training or not bn.track_running_stats, bn.eps, p_drop if self.training else 0.0, apply_act,
-                                   running, acc=acc)
-            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc)
+                                   running, acc=acc, tab_col=tab_col)
+            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc, tabcol=tab_col)
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]
@@ -355,6 +355,7 @@ class QAGNN_Message_Passing(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.dropout_rate = dropout
         self._js = {}
+        self._tab_col = -1
         self._plan = ops.GatherPlan()
 
     def _js_table(self, device):
@@ -407,7 +408,13 @@ class QAGNN_Message_Passing(nn.Module):
         temb = gelu(self.emb_node_type.weight.t() + self.emb_node_type.bias)
         sinB = ops.sin_basis(node_score_flat.contiguous(), self._js_table(dev), Wes_t.size(0))
         pre = ops.linear_nn(sinB, Wes_t, Wes, bias=bes)
-        return temb, ops.gelu_dropout(pre, 0.0, False)
+        S = ops.gelu_dropout(pre, 0.0, False)
+        # room in S's zero padding for the node-type indicators: the type-table gradients then fall out of the S^T dKMQ products
+        h = self.hidden_size // 2
+        self._tab_col = h if S.size(1) - h >= self.n_ntype else -1
+        if self._tab_col >= 0:
+            S = ops.type_indicators(S, node_type_flat, h, self.n_ntype)
+        return temb, S
 
     @_fp32_region
     def forward(self, H, A, node_type, node_score, cache_output=False, graph=None, padded_input=False, padded_output=False):
@@ -457,11 +464,12 @@ class QAGNN_Message_Passing(nn.Module):
                 bn0 = self.gnn_layers[0].mlp[1]
                 Xp = ops.gat_stack(Hp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.gnn_layers[0].dim_per_head), prms,
                                    self.training or not bn0.track_running_stats, bn0.eps, self.dropout_rate if self.training else 0.0,
-                                   runnings, accX=accX)
+                                   runnings, accX=accX, tab_col=self._tab_col)
                 per_layer = []
             for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
                 Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),
-                                  packed=pk, tables=(TT[l], ekem[l]), acc=(accX if l == 0 else None, True, accS, l == 0))
+                                  packed=pk, tables=(TT[l], ekem[l]), acc=(accX if l == 0 else None, True, accS, l == 0),
+                                  tab_col=self._tab_col)
             Y = ops.linear_nn(Hp, Vh_t, Vh, Xp, Vx_t, Vx, bias=bVh + bVx, acc=(accX, False, None, False))
         out = ops.gelu_dropout(Y, self.dropout_rate, self.training)  # :92-93
         if padded_output:

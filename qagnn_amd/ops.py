@@ -356,11 +356,14 @@ class LinearNNFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc):
+    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol=-1):
         K = kernels()
         C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx, B1n=B1, B2n=B2)
         ctx.save_for_backward(A1, B1, A2, B2, rowidx, B1t, B2t)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
+        # tabcol >= 0: columns [tabcol, tabcol + G) of A2 hold the indicators of rowidx (see type_indicators): the row-table gradient
+        # is then rows [tabcol, tabcol + G) of A2^T dC, a by-product of the weight-gradient GEMM
+        ctx.tabcol = tabcol if (A2 is not None and rowtab is not None) else -1
         ctx.defer = _DEFER[0]
         ctx.acc = acc if acc is not None else (None, False, None, False)
         return C
@@ -383,7 +386,9 @@ class LinearNNFn(torch.autograd.Function):
             if A2 is not None and need[4]:
                 dB2t = _wg_empty(dC, (A2.size(1), dC.size(1)))
                 jobs.append(lambda: K.gemm_tn(A2, dC, out=dB2t))
-            if want_tab:  # consumed inside the graph (table GEMM backward): stays on the main stream
+            if want_tab and ctx.tabcol >= 0 and dB2t is not None and not want_bias:
+                drowtab = dB2t[ctx.tabcol:ctx.tabcol + G]  # (deferred with dB2t: its consumer, SplitColsFn.backward, joins the side stream)
+            elif want_tab:  # consumed inside the graph (table GEMM backward): stays on the main stream
                 drowtab = K.colsum(dC, rowidx, G)
                 if want_bias:
                     dbias = drowtab.sum(0)
@@ -401,16 +406,19 @@ class LinearNNFn(torch.autograd.Function):
                     dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t))
             if A2 is not None and need[3]:
                 dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
-            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
+            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
         cs = None
         if FUSED_COLSUM and need[1] and (want_tab or want_bias):
             # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
             dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
         else:
             dB1t = K.gemm_tn(A1, dC) if need[1] else None
-            if want_tab or want_bias:
+            tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
+            if (want_tab or want_bias) and not tab_from_wgrad:
                 cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
         dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
+        if want_tab and ctx.tabcol >= 0 and dB2t is not None and cs is None:
+            cs = dB2t[ctx.tabcol:ctx.tabcol + G]
         if want_tab:
             drowtab = cs
             if want_bias:
@@ -427,11 +435,22 @@ class LinearNNFn(torch.autograd.Function):
         dA2 = None
         if A2 is not None and need[3]:
             dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
-        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None
+        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
 
 
-def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None, acc=None):
-    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc)
+def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None, acc=None, tabcol=-1):
+    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol)
+
+
+def type_indicators(S, ntype, col0, T):
+    """S [N, SP] with exactly-zero padding columns from col0 on -> a copy whose columns [col0, col0 + T) hold the one-hot of ntype.
+    The matching rows of every weight that multiplies S are zero padding, so no product changes; but rows [col0, col0 + T) of
+    S^T dC -- computed anyway, as part of the weight gradient -- are then the per-type column sums of dC, i.e. the gradient of the
+    node-type table TT that the projection adds by node type.  That retires a grouped column reduction over dKMQ [N, 3 DP] per layer
+    (41 us + a 19-27 us final stage at 64 000 rows).  The gradient that flows back into S is zeroed at the indicator positions by
+    scatter's own backward."""
+    assert col0 + T <= S.size(1)
+    return S.scatter(1, (ntype.view(-1, 1) + col0), 1.0)
 
 
 class SplitColsFn(torch.autograd.Function):
@@ -448,6 +467,7 @@ class SplitColsFn(torch.autograd.Function):
     def backward(ctx, *grads):
         R, k, W = ctx.shape
         ref = next(g for g in grads if g is not None)
+        join_wgrads(ref)  # the type-table gradients are rows of deferred weight-gradient products (LinearNNFn.tabcol)
         gs = [g if g is not None else torch.zeros_like(ref) for g in grads]
         return torch.stack(gs, 1).reshape(R, k * W), None
 
@@ -685,7 +705,7 @@ def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
 
 
 def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
-                     dX_acc=None, dS_acc=None):
+                     dX_acc=None, dS_acc=None, tab_col=-1):
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
     KMQ, aa, aggr, h1, out, stats = saved
     mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
@@ -701,7 +721,10 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
     dWx_t = K.gemm_tn(X, dKMQ)
     dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
-    dTT = K.colsum(dKMQ, ntype, TT.size(0))
+    if dWs_t is not None and tab_col >= 0:
+        dTT = dWs_t[tab_col:tab_col + TT.size(0)].clone()  # rows of the type indicators in S (qagnn_hop_args.tab_col)
+    else:
+        dTT = K.colsum(dKMQ, ntype, TT.size(0))
     dX = K.gemm_nn(dKMQ, Wx, out=dX_acc, accumulate=dX_acc is not None, B1n=Wx_t) if need_dX else None
     dS = K.gemm_nn(dKMQ, Ws, out=dS_acc, accumulate=dS_acc is not None, B1n=Ws_t) if (S is not None and need_dS) else None
     return dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, red[1], red[0], dW2t, db2
@@ -712,13 +735,14 @@ class HopFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seed, apply_act, running, acc, *prm):
+    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seed, apply_act, running, acc, tab_col, *prm):
         K = kernels()
         fwd = getattr(K, 'hop_fwd', None)
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
         y, saved = fwd(*args, running) if fwd is not None else hop_fwd_composed(K, *args, running)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seed, apply_act, len(prm))
+        ctx.tab_col = tab_col
         ctx.acc = acc if acc is not None else (None, False, None, False)  # GradAcc of X / S and whether this hop returns the totals
         a = saved[1][0]
         ctx.mark_non_differentiable(a)
@@ -736,22 +760,22 @@ class HopFn(torch.autograd.Function):
         accX, lastX, accS, lastS = ctx.acc
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy.contiguous(),
                 ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None,
-                accS.buf if accS is not None else None)
+                accS.buf if accS is not None else None, ctx.tab_col)
         dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2 = bwd(*args) if bwd is not None else hop_bwd_composed(K, *args)
         if accX is not None and dX is not None:  # dX / dS are the running totals now (accumulated in place when a buffer existed)
             accX.buf, dX = (None, dX) if lastX else (dX, None)
         if accS is not None and dS is not None:
             accS.buf, dS = (None, dS) if lastS else (dS, None)
         #        X   S   ntype graph HP    qscale bstats eps  p     seed  act   running acc  | Wx_t  Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1
-        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None,
+        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, None, dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None,
                 db1, dgamma, dbeta, dW2t, None, db2, None, None)
 
 
-def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act, running, acc=None):
+def gat_hop(X, S, ntype, graph, HP, qscale, prm, batch_stats, eps, p, apply_act, running, acc=None, tab_col=-1):
     """prm: the 16 packed operands named in HOP_PARAMS.  `p`: dropout rate after the GELU (0 disables).
     acc = (accX, lastX, accS, lastS): GradAcc of X / S, see GradAcc."""
     p = float(p) if apply_act else 0.0
-    return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, acc, *prm)
+    return HopFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, p, next_seed() if p > 0 else 0, apply_act, running, acc, tab_col, *prm)
 
 
 class StackFn(torch.autograd.Function):
@@ -761,14 +785,14 @@ class StackFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seeds, runnings, accX, k, *prm):
+    def forward(ctx, X, S, ntype, graph, HP, qscale, batch_stats, eps, p, seeds, runnings, accX, tab_col, k, *prm):
         K = kernels()
         npk = len(prm) // k
         prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
         y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seeds, k, npk)
-        ctx.accX = accX
+        ctx.accX, ctx.tab_col = accX, tab_col
         return y
 
     @staticmethod
@@ -782,22 +806,22 @@ class StackFn(torch.autograd.Function):
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under the hops
         accX = ctx.accX
         dX, dS, grads = K.stack_bwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy.contiguous(),
-                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None)
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None, ctx.tab_col)
         if accX is not None:
             accX.buf = None  # handed over: this node is the last reader of the stack input (it was created first)
         out = []
         for (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2) in grads:
             #       Wx_t   Wx    Ws_t   Ws    TT   EkEm   W1t   W1   b1   gamma   beta   W2t   W2   b2  run_mean run_var
             out += [dWx_t, None, dWs_t, None, dTT, dEkEm, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None]
-        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, *out)
+        return (dX, dS, None, None, None, None, None, None, None, None, None, None, None, None, *out)
 
 
-def gat_stack(X, S, ntype, graph, HP, qscale, prms, batch_stats, eps, p, runnings, accX=None):
+def gat_stack(X, S, ntype, graph, HP, qscale, prms, batch_stats, eps, p, runnings, accX=None, tab_col=-1):
     """prms: per-layer lists of the 16 packed operands named in HOP_PARAMS."""
     k = len(prms)
     seeds = [next_seed() if p > 0 else 0 for _ in range(k)]
     flat = [t for prm in prms for t in prm]
-    return StackFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, float(p), seeds, runnings, accX, k, *flat)
+    return StackFn.apply(X, S, ntype, graph, HP, qscale, batch_stats, eps, float(p), seeds, runnings, accX, tab_col, k, *flat)
 
 
 class PoolAttnFn(torch.autograd.Function):

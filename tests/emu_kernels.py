@@ -103,14 +103,14 @@ class EmuKernels:
             x = y
         return x, tuple(t for _, sv in saved for t in sv) + tuple(xi for xi, _ in saved)
 
-    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None):
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1):
         from qagnn_amd import ops
         k = len(prms)
         svs, xs = [saved[6 * l:6 * l + 6] for l in range(k)], saved[6 * k:]
         dS, grads = None, [None] * k
         for l in range(k - 1, -1, -1):
             r = ops.hop_bwd_composed(self, graph, HP, qscale, xs[l], S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, svs[l], dy,
-                                     True if l else need_dX, need_dS, dX_acc if l == 0 else None, dS)
+                                     True if l else need_dX, need_dS, dX_acc if l == 0 else None, dS, tab_col)
             dy = r[0]
             dS = r[1] if r[1] is not None else dS
             grads[l] = r[2:]
