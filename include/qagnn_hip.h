@@ -198,7 +198,10 @@ int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* 
  * and num_batches_tracked += 1.  dense_pos[k] = padded column of dense feature k. */
 int qagnn_bn_finalize_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* invstd,
                           float* scale, float* shift, int32_t Cc, float* run_mean, float* run_var, int64_t* num_batches_tracked,
-                          const int64_t* dense_pos, int32_t d, float momentum, float unbias, qagnn_stream_t stream);
+                          const int64_t* dense_pos, int32_t d, float momentum, float unbias,
+                          int32_t ones_col /* -1, or a zero-padding column c: scale[c] = 0, shift[c] = 1, i.e. relu(bn(h))[:, c] = 1 -- the
+                                              weight gradient relu(bn(h))^T dout then carries the bias gradient colsum(dout) in row c */,
+                          qagnn_stream_t stream);
 int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
                           const float* invstd, const float* scale, const float* shift, const float* gamma, const float* sum_dy,
                           const float* sum_dy_hhat, float inv_rows /* 1/R with batch statistics, 0 with running statistics */,
@@ -232,7 +235,7 @@ int qagnn_sin_basis_f32(const float* score, const float* js, float* out, int32_t
  * stats: [5][Cc] = mean | biased var | invstd | scale | shift.  Running statistics / batch counter as in qagnn_bn_finalize_f32. */
 int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, int32_t R, int32_t Cc, const float* gamma, const float* beta, float eps,
                                 float* stats, float* run_mean, float* run_var, int64_t* num_batches_tracked, const int64_t* dense_pos,
-                                int32_t d, float momentum, float unbias, qagnn_stream_t stream);
+                                int32_t d, float momentum, float unbias, int32_t ones_col, qagnn_stream_t stream);
 
 /* Dropout under hipGraph replay.  Every dropout launch of this library (qagnn_gelu_dropout_*, qagnn_pool_attn_*, the hops) takes
  * its seed by value; a captured graph would replay it verbatim and draw the SAME keep masks in every training step
@@ -311,6 +314,7 @@ typedef struct qagnn_hop_args {
   float* dW2t; float* db2;         /* [DP, DP], [DP] */
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
   int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split) */
+  int32_t ones_col;                /* see qagnn_bn_finalize_f32: >= 0 makes db2 = row ones_col of dW2t (no column reduction of d out) */
   int32_t tab_col;                 /* >= 0: columns [tab_col, tab_col + T) of S hold the node-type indicators (1 at tab_col + ntype[r], S's
                                       zero padding otherwise; the matching rows of Ws_t are zero), so dTT = rows [tab_col, tab_col + T) of
                                       dWs_t = S^T dKMQ: the type-table gradient falls out of the weight-gradient GEMM instead of costing a

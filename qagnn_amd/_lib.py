@@ -56,7 +56,7 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64), ('gemm_split', _i32), ('tab_col', _i32)])
+                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32)])
 
 
 def load_library(path=LIB_PATH):
@@ -85,8 +85,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_colreduce_workspace_elems.restype = _i64
     lib.qagnn_colreduce_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_colreduce_f32.argtypes = [_i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp]
-    lib.qagnn_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
-    lib.qagnn_bn_stats_finalize_f32.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp]
+    lib.qagnn_bn_finalize_f32.argtypes = [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp]
+    lib.qagnn_bn_stats_finalize_f32.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _i32, _vp]
     lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
@@ -460,9 +460,10 @@ class HipKernels(metaclass=_GuardedMeta):
     def colvar_sum(self, X, mean, scale=1.0, roww=None):
         return self._colreduce(1, X, None, None, 1, mean, None, None, None, 1, scale, roww)[0]
 
-    def bn_finalize(self, mean, var, gamma, beta, eps, running=None):
+    def bn_finalize(self, mean, var, gamma, beta, eps, running=None, ones_col=-1):
         """-> invstd, scale, shift [Cc]; running = (run_mean [d], run_var [d], num_batches_tracked, dense_pos [d], momentum, unbias)
-        additionally applies the train-mode running-statistics update in the same launch."""
+        additionally applies the train-mode running-statistics update in the same launch.  ones_col >= 0: that (padding) column gets
+        scale 0 / shift 1, i.e. relu(bn(h)) carries a column of ones there (see qagnn_bn_finalize_f32)."""
         Cc = mean.numel()
         out = torch.empty((3, Cc), dtype=torch.float32, device=mean.device)
         rm = rv = nbt = pos = None
@@ -473,11 +474,11 @@ class HipKernels(metaclass=_GuardedMeta):
             assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
         rc = self.lib.qagnn_bn_finalize_f32(mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), Cc, _ptr(rm), _ptr(rv), _ptr(nbt),
-                                            _ptr(pos), d, float(mom), float(unb), self._stream())
+                                            _ptr(pos), d, float(mom), float(unb), int(ones_col), self._stream())
         self._check(rc, 'qagnn_bn_finalize_f32')
         return out[0], out[1], out[2]
 
-    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None):
+    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None, ones_col=-1):
         """part: what gemm_nn(colstats=True) returned for the [rows, Cc] BatchNorm input -> stats [5, Cc] = mean | biased var | invstd |
         scale | shift, plus (running given) the train-mode running-statistics update: qagnn_bn_stats_finalize_f32, one launch."""
         nt, _, Cc = part.shape
@@ -490,7 +491,7 @@ class HipKernels(metaclass=_GuardedMeta):
             d = rm.numel()
             assert rm.is_contiguous() and rv.is_contiguous() and (nbt is None or nbt.dtype == torch.long)
         rc = self.lib.qagnn_bn_stats_finalize_f32(part.data_ptr(), nt, int(rows), Cc, gamma.data_ptr(), beta.data_ptr(), float(eps), stats.data_ptr(),
-                                                  _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(pos), d, float(mom), float(unb), self._stream())
+                                                  _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(pos), d, float(mom), float(unb), int(ones_col), self._stream())
         self._check(rc, 'qagnn_bn_stats_finalize_f32')
         return stats
 
@@ -633,12 +634,14 @@ class HipKernels(metaclass=_GuardedMeta):
         h.run_mean_p, h.run_var_p = run_mean_p.data_ptr(), run_var_p.data_ptr()
         h.apply_act, h.p_drop, h.seed = (1 if apply_act else 0), float(p), int(seed)
         h.gemm_split = 1 if self.gemm_split else 0
-        h.tab_col = int(tab_col) if S is not None else -1
+        tc, oc = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)  # (type-indicator column of S, ones column of relu(bn(h1)))
+        h.tab_col = int(tc) if S is not None else -1
+        h.ones_col = int(oc)
         return h
 
-    def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
+    def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running, cols=-1):
         """-> (y, saved) with saved = (KMQ, aa [2, Ep, 4] = a | alpha, aggr, h1, out, stats [5, DP]); y is `out` when not apply_act."""
-        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
+        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, cols)
         N, DP, dev = graph.N, 4 * HP, X.device
         KMQ = torch.empty((N, 3 * DP), dtype=torch.float32, device=dev)
         aa = torch.empty((2, graph.Ep, 4), dtype=torch.float32, device=dev)
@@ -695,7 +698,7 @@ class HipKernels(metaclass=_GuardedMeta):
                 dW1t.view(DP, DP), db1, dbn[DP:], dbn[:DP], dW2t.view(DP, DP), db2)
 
     # -- the whole k-hop stack per call (csrc/hop.hip: qagnn_stack_{fwd,bwd}_f32) -------------------------------------------------------
-    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings):
+    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, cols=-1):
         """k hops with GELU + dropout after each; prms / seeds / runnings: per-layer lists.  -> (y [N, DP], saved)."""
         k = len(prms)
         N, DP, dev = graph.N, 4 * HP, X.device
@@ -709,7 +712,7 @@ class HipKernels(metaclass=_GuardedMeta):
         # addresses by arithmetic: a view tensor per pointer costs the host-bound batches ~0.3 ms per step
         p_kmq, p_aa, p_rows, p_stats, row_b = KMQ.data_ptr(), aa.data_ptr(), rows.data_ptr(), stats.data_ptr(), N * DP * 4
         for l in range(k):
-            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True)
+            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, cols)
             h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out, h.y = (p_rows + (4 * l + i) * row_b for i in range(4))

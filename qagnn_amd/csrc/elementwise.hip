@@ -151,13 +151,17 @@ __global__ void k_bn_relu_bwd(const float* __restrict__ dR, const float* __restr
 __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
                               const float* __restrict__ beta, float eps, float* __restrict__ invstd, float* __restrict__ scale,
                               float* __restrict__ shift, int Cc, float* __restrict__ run_mean, float* __restrict__ run_var,
-                              int64_t* __restrict__ nbt, const int64_t* __restrict__ dense_pos, int d, float momentum, float unbias) {
+                              int64_t* __restrict__ nbt, const int64_t* __restrict__ dense_pos, int d, float momentum, float unbias,
+                              int ones_col) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < Cc) {
     const float is = rsqrtf(var[i] + eps), sc = gamma[i] * is;
     invstd[i] = is;
-    scale[i] = sc;
-    shift[i] = beta[i] - mean[i] * sc;
+    // ones_col (a zero-padding column of the head-padded layout, or -1): relu(h * 0 + 1) = 1 there, so the operand relu(bn(h1))
+    // carries a column of ones -- its row of the weight gradient relu(bn(h1))^T dout is then the bias gradient colsum(dout) for free,
+    // while the forward product is unchanged (the matching weight row is zero padding)
+    scale[i] = i == ones_col ? 0.f : sc;
+    shift[i] = i == ones_col ? 1.f : beta[i] - mean[i] * sc;
   }
   if (run_mean && i < d) {
     const int64_t p = dense_pos[i];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const 
                                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                         float eps, float* __restrict__ stats, float* __restrict__ run_mean,
                                                                         float* __restrict__ run_var, int64_t* __restrict__ nbt, int d,
-                                                                        float momentum, float unbias) {
+                                                                        float momentum, float unbias, int ones_col) {
   __shared__ float sn[BF_PARTS][BF_COLS], sm[BF_PARTS][BF_COLS], s2[BF_PARTS][BF_COLS];
   const int cl = threadIdx.x & (BF_COLS - 1), q = threadIdx.x / BF_COLS;
   const int c = blockIdx.x * BF_COLS + cl;
@@ -207,8 +211,8 @@ __global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const 
     stats[c] = mean;
     stats[Cc + c] = var;
     stats[2 * Cc + c] = is;
-    stats[3 * Cc + c] = sc;
-    stats[4 * Cc + c] = beta[c] - mean * sc;
+    stats[3 * Cc + c] = c == ones_col ? 0.f : sc;                     // (see k_bn_finalize: the column of ones)
+    stats[4 * Cc + c] = c == ones_col ? 1.f : beta[c] - mean * sc;
     if (run_mean) {  // head-padded column c = h * HP + j is dense feature h * dh + j when j < dh (4 heads: ops.HeadLayout)
       const int HP = Cc >> 2, dh = d >> 2, h = c / HP, j = c - h * HP;
       if (j < dh) {
@@ -393,26 +397,28 @@ extern "C" int qagnn_bn_relu_bwd_f32(const float* dR, const float* Hh, float* dH
 
 extern "C" int qagnn_bn_finalize_f32(const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* invstd,
                                      float* scale, float* shift, int32_t Cc, float* run_mean, float* run_var, int64_t* num_batches_tracked,
-                                     const int64_t* dense_pos, int32_t d, float momentum, float unbias, qagnn_stream_t stream_) {
+                                     const int64_t* dense_pos, int32_t d, float momentum, float unbias, int32_t ones_col,
+                                     qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(mean && var && gamma && beta && invstd && scale && shift && Cc > 0, QAGNN_EINVAL, "bn_finalize: null pointer");
   QAGNN_REQUIRE(!run_mean || (run_var && dense_pos && d > 0 && d <= Cc), QAGNN_EINVAL, "bn_finalize: running-stat arguments");
   k_bn_finalize<<<cdiv(Cc, 256), 256, 0, stream>>>(mean, var, gamma, beta, eps, invstd, scale, shift, Cc, run_mean, run_var,
-                                                   num_batches_tracked, dense_pos, d, momentum, unbias);
+                                                   num_batches_tracked, dense_pos, d, momentum, unbias, ones_col);
   QAGNN_LAUNCH_CHECK("k_bn_finalize");
   return QAGNN_OK;
 }
 
 extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, int32_t R, int32_t Cc, const float* gamma, const float* beta,
                                            float eps, float* stats, float* run_mean, float* run_var, int64_t* num_batches_tracked,
-                                           const int64_t* dense_pos, int32_t d, float momentum, float unbias, qagnn_stream_t stream_) {
+                                           const int64_t* dense_pos, int32_t d, float momentum, float unbias, int32_t ones_col,
+                                           qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(part && gamma && beta && stats && R > 0 && Cc > 0 && n_tiles == cdiv(R, ST_TILE), QAGNN_EINVAL,
                 "bn_stats_finalize: bad arguments (R=%d needs %d tiles of %d rows, got %d)", R, cdiv(R, ST_TILE), ST_TILE, n_tiles);
   QAGNN_REQUIRE(!run_mean || (run_var && d > 0 && d % 4 == 0 && Cc % 4 == 0 && d <= Cc), QAGNN_EINVAL, "bn_stats_finalize: running-stat arguments");
   (void)dense_pos;  // the head-padded layout is implied by (Cc, d); kept in the signature for symmetry with qagnn_bn_finalize_f32
   k_bn_stats_finalize<<<cdiv(Cc, BF_COLS), BF_COLS * BF_PARTS, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var,
-                                                              num_batches_tracked, d, momentum, unbias);
+                                                              num_batches_tracked, d, momentum, unbias, ones_col);
   QAGNN_LAUNCH_CHECK("k_bn_stats_finalize");
   return QAGNN_OK;
 }

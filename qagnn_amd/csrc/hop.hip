@@ -96,7 +96,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   const float unbias = (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0));
   if (fused_stats) {
     HOP_TRY(qagnn_bn_stats_finalize_f32(crws, cdiv(N, 128), N, DP, h->gamma, h->beta, h->eps, h->stats, h->run_mean, h->run_var,
-                                        h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, stream));
+                                        h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, h->ones_col, stream));
   } else {
     const float* mean_u = mean;
     const float* var_u = var;
@@ -111,7 +111,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
       var_u = h->run_var_p;
     }
     HOP_TRY(qagnn_bn_finalize_f32(mean_u, var_u, h->gamma, h->beta, h->eps, invstd, scale, shift, DP, h->run_mean, h->run_var,
-                                  h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, stream));
+                                  h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, h->ones_col, stream));
   }
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
@@ -156,9 +156,14 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
     HOP_TRY(qagnn_gelu_dropout_bwd_f32(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, stream));
     dout = bufA;
   }
-  HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
+  if (h->ones_col < 0)
+    HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
+  if (h->ones_col >= 0) {  // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient
+    hipError_t he = hipMemcpyAsync(h->db2, h->dW2t + (int64_t)h->ones_col * DP, (size_t)DP * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (he != hipSuccess) { set_error("hop_bwd: db2 copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  }
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
   HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, stream));

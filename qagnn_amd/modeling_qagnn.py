@@ -129,7 +129,7 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
         Ep_t = graph.cls_count.to(W1t.dtype).sum()
         tab_p, mean_p, var_p = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p, use_batch_stats, bn.eps, 0.0,
                                            apply_act=False, running=None,
-                                           row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None)
+                                           row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None, ones_col=L.ones_col)
         if training and bn.track_running_stats:
             with torch.no_grad():
                 wgt = 1.0 - (1.0 - bn_momentum(bn)) ** n_updates
@@ -146,7 +146,7 @@ def edge_class_table_padded(edge_encoder, graph, training, n_updates, L, enc):
         bn.num_batches_tracked += n_updates
     tab_p, _, _ = ops.gat_mlp(_CLASS_FEATS[key], W1t, W1, b1, gamma, beta, W2t, W2, b2, rm_p, rv_p,
                               use_batch_stats, bn.eps, 0.0, apply_act=False, running=running,
-                              row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None)
+                              row_weight=_class_weights(graph, W1t.dtype) if use_batch_stats else None, ones_col=L.ones_col)
     return tab_p
 
 
@@ -266,6 +266,7 @@ class GATConvE(nn.Module):
     N_PACKED = 18
 
     def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None, acc=None, tab_col=-1):
+        cols = (tab_col, L.ones_col)  # (type-indicator column of S, ones column of relu(bn(h1))): by-product gradients, see ops
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
@@ -299,7 +300,7 @@ class GATConvE(nn.Module):
                 return ops.gat_hop(Xp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head),
                                    (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
                                    self.training or not bn.track_running_stats, bn.eps, p_drop if self.training else 0.0, apply_act,
-                                   running, acc=acc, tab_col=tab_col)
+                                   running, acc=acc, tab_col=cols)
             KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc, tabcol=tab_col)
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
@@ -311,7 +312,7 @@ class GATConvE(nn.Module):
             running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, L.dense_pos,
                        bn_momentum(bn), R / max(R - 1.0, 1.0))
         y, mean_p, var_p = ops.gat_mlp(aggr, *mlp_ops, use_batch_stats, bn.eps, p_drop if self.training else 0.0,
-                                       apply_act, running)
+                                       apply_act, running, ones_col=L.ones_col)
         return y, a
 
     @_fp32_region
@@ -411,7 +412,7 @@ class QAGNN_Message_Passing(nn.Module):
         S = ops.gelu_dropout(pre, 0.0, False)
         # room in S's zero padding for the node-type indicators: the type-table gradients then fall out of the S^T dKMQ products
         h = self.hidden_size // 2
-        self._tab_col = h if S.size(1) - h >= self.n_ntype else -1
+        self._tab_col = h if (S.size(1) - h >= self.n_ntype and ops.BYPRODUCT_GRADS) else -1
         if self._tab_col >= 0:
             S = ops.type_indicators(S, node_type_flat, h, self.n_ntype)
         return temb, S
@@ -464,7 +465,7 @@ class QAGNN_Message_Passing(nn.Module):
                 bn0 = self.gnn_layers[0].mlp[1]
                 Xp = ops.gat_stack(Hp, S, ntype, graph, L.HP, 1.0 / math.sqrt(self.gnn_layers[0].dim_per_head), prms,
                                    self.training or not bn0.track_running_stats, bn0.eps, self.dropout_rate if self.training else 0.0,
-                                   runnings, accX=accX, tab_col=self._tab_col)
+                                   runnings, accX=accX, tab_col=(self._tab_col, L.ones_col))
                 per_layer = []
             for l, (layer, pk) in enumerate(zip(self.gnn_layers, per_layer)):  # mp_helper (:45-50): GATConvE -> GELU -> dropout, fused
                 Xp, _ = layer.hop(Xp, None, graph, None, L, apply_act=True, p_drop=self.dropout_rate, typed=(temb, ntype, S),

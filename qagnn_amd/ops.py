@@ -37,6 +37,11 @@ def set_kernels(k):
 
 H_HEADS = 4  # GATConvE hard-codes head_count=4 (reference modeling_qagnn.py:387)
 
+import os as _os0
+# bias / type-table gradients as rows of weight-gradient products that are computed anyway (type indicators in S's padding, a column
+# of ones in relu(bn(h1))): QAGNN_BYPRODUCT_GRADS=0 goes back to the stand-alone column reductions (A/B switch)
+BYPRODUCT_GRADS = _os0.environ.get('QAGNN_BYPRODUCT_GRADS', '1') == '1'
+
 
 def roundup(x, m):
     return (x + m - 1) // m * m
@@ -55,6 +60,9 @@ class HeadLayout:
         j = torch.arange(self.DP)
         h, i = j // self.HP, j % self.HP
         self.dense_pos = torch.nonzero(i < self.dh).flatten().to(device)  # [d] padded position of dense index k (ascending)
+        # a padding column (exactly 0 in every activation, zero row / column in every packed weight), or -1 when dh needs no padding:
+        # where relu(bn(h1)) is made to carry a column of ones (see GatMlpFn)
+        self.ones_col = self.dh if (self.HP > self.dh and BYPRODUCT_GRADS) else -1
 
     def pad(self, x):
         """[*, d] -> [*, DP] (zeros in the pads): one constant-pad of the [*, H, dh] view (its backward is a slice, no scatter)."""
@@ -587,14 +595,14 @@ class GatMlpFn(torch.autograd.Function):
     @staticmethod
     @_fwd
     def forward(ctx, aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, training, eps, p, seed, apply_act, running,
-                row_weight):
+                row_weight, ones_col=-1):
         K = kernels()
         R = aggr.size(0)
         if training and row_weight is None and _colstats_ok(K, R, aggr.size(1), W1t.size(1)):
             # batch statistics as a by-product of the first Linear's GEMM epilogue (per-tile partials) + ONE launch that combines
             # them and does the BatchNorm bookkeeping, instead of two more passes over h1 and five launches
             h1, part = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1, colstats=True)
-            mean, var, invstd, scale, shift = K.bn_stats_finalize(part, R, gamma, beta, eps, running).unbind(0)
+            mean, var, invstd, scale, shift = K.bn_stats_finalize(part, R, gamma, beta, eps, running, ones_col).unbind(0)
         else:
             h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
             if training:
@@ -604,9 +612,10 @@ class GatMlpFn(torch.autograd.Function):
             else:
                 mean, var = run_mean, run_var
             # invstd / scale / shift and (train mode) the module's running-statistics update: one launch
-            invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
+            invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running, ones_col)
         out = K.gemm_nn(h1, W2t, bias=b2, a_scale=scale, a_shift=shift, B1n=W2)
         y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
+        ctx.ones_col = ones_col
         ctx.save_for_backward(aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t)
         ctx.cfg = (training, p, seed, R, apply_act)
         ctx.defer = _DEFER[0]
@@ -620,10 +629,13 @@ class GatMlpFn(torch.autograd.Function):
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
         dout = K.gelu_dropout_bwd(out, dy.contiguous(), p, seed) if apply_act else dy.contiguous()
-        db2 = K.colsum(dout)[0]
+        oc = ctx.ones_col  # >= 0: relu(bn(h1)) carries a column of ones there, so row oc of dW2t = relu(bn(h1))^T dout IS colsum(dout)
+        db2 = K.colsum(dout)[0] if oc < 0 else None
         if ctx.defer:  # weight gradients of both Linears queued for the next edge backward (see defer_wgrads)
             Cc = dout.size(1)
             dW2t = _wg_empty(dout, (h1.size(1), Cc))
+            if oc >= 0:
+                db2 = dW2t[oc]  # deferred with dW2t; its only reader is GatherPlan's backward, which joins the side stream
             dr = K.gemm_nn(dout, W2, B1n=W2t)
             red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
             dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if training else 0.0,
@@ -632,8 +644,10 @@ class GatMlpFn(torch.autograd.Function):
             defer_wgrads([lambda: K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift, out=dW2t), lambda: K.gemm_tn(aggr, dh1, out=dW1t)],
                          (h1, dout, scale, shift, aggr, dh1))
             daggr = K.gemm_nn(dh1, W1, B1n=W1t) if ctx.needs_input_grad[0] else None
-            return (daggr, dW1t, None, db1, red[1], red[0], dW2t, None, db2, None, None, None, None, None, None, None, None, None)
+            return (daggr, dW1t, None, db1, red[1], red[0], dW2t, None, db2, None, None, None, None, None, None, None, None, None, None)
         dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
+        if oc >= 0:
+            db2 = dW2t[oc]
         dr = K.gemm_nn(dout, W2, B1n=W2t)
         red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)  # [sum dy, sum dy*hhat]
         dbeta, dgamma = red[0], red[1]
@@ -641,7 +655,7 @@ class GatMlpFn(torch.autograd.Function):
                                         roww=row_weight if training else None)
         dW1t = K.gemm_tn(aggr, dh1)
         daggr = K.gemm_nn(dh1, W1, B1n=W1t) if ctx.needs_input_grad[0] else None
-        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None
+        return daggr, dW1t, None, db1, dgamma, dbeta, dW2t, None, db2, None, None, None, None, None, None, None, None, None, None
 
 
 def _colstats_ok(K, rows, k1, no):
@@ -650,13 +664,13 @@ def _colstats_ok(K, rows, k1, no):
 
 
 def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p, apply_act=True, running=None,
-            row_weight=None):
+            row_weight=None, ones_col=-1):
     """`batch_stats`: BatchNorm uses batch statistics (train mode); `p`: dropout rate (0 disables); `apply_act`: GELU+dropout
     fused after the second Linear (False returns the raw GATConvE output); `row_weight` [R] (sums to 1): rows enter the batch
     statistics with these weights instead of 1/R (the edge encoder on distinct edge classes, weighted by class counts)."""
     p = float(p) if apply_act else 0.0
     return GatMlpFn.apply(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batch_stats, eps, p,
-                          next_seed() if p > 0 else 0, apply_act, running, row_weight)
+                          next_seed() if p > 0 else 0, apply_act, running, row_weight, ones_col)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -682,13 +696,14 @@ def use_fused_hop(n_rows):
 HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta', 'W2t', 'W2', 'b2', 'run_mean_p', 'run_var_p')
 
 
-def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running):
+def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running, cols=-1):
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
+    ones_col = cols[1] if isinstance(cols, tuple) else -1
     KMQ = K.gemm_nn(X, Wx_t, S, Ws_t, rowtab=TT, rowidx=ntype, B1n=Wx, B2n=Ws)
     aggr, a, alpha = K.edge_attn_fwd(graph, KMQ, EkEm, HP, qscale)
     if batch_stats and _colstats_ok(K, aggr.size(0), aggr.size(1), W1t.size(1)):
         h1, part = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1, colstats=True)
-        stats = K.bn_stats_finalize(part, aggr.size(0), gamma, beta, eps, running)
+        stats = K.bn_stats_finalize(part, aggr.size(0), gamma, beta, eps, running, ones_col)
     else:
         h1 = K.gemm_nn(aggr, W1t, bias=b1, B1n=W1)
         if batch_stats:
@@ -697,7 +712,7 @@ def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
             var = K.colvar_sum(h1, mean, scale=sc)
         else:
             mean, var = run_mean_p, run_var_p
-        invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running)
+        invstd, scale, shift = K.bn_finalize(mean, var, gamma, beta, eps, running, ones_col)
         stats = torch.stack([mean, var, invstd, scale, shift])
     out = K.gemm_nn(h1, W2t, bias=b2, a_scale=stats[3], a_shift=stats[4], B1n=W2)
     y = K.gelu_dropout_fwd(out, p, seed) if apply_act else out
@@ -710,9 +725,10 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     KMQ, aa, aggr, h1, out, stats = saved
     mean, invstd, scale, shift = (stats[0] if batch_stats else run_mean_p), stats[2], stats[3], stats[4]
     R = aggr.size(0)
+    tab_col, ones_col = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)
     dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
-    db2 = K.colsum(dout)[0]
     dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
+    db2 = K.colsum(dout)[0] if ones_col < 0 else dW2t[ones_col].clone()
     dr = K.gemm_nn(dout, W2, B1n=W2t)
     red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
     dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
@@ -739,7 +755,7 @@ class HopFn(torch.autograd.Function):
         K = kernels()
         fwd = getattr(K, 'hop_fwd', None)
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act)
-        y, saved = fwd(*args, running) if fwd is not None else hop_fwd_composed(K, *args, running)
+        y, saved = fwd(*args, running, tab_col) if fwd is not None else hop_fwd_composed(K, *args, running, tab_col)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seed, apply_act, len(prm))
         ctx.tab_col = tab_col
@@ -789,7 +805,7 @@ class StackFn(torch.autograd.Function):
         K = kernels()
         npk = len(prm) // k
         prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
-        y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings)
+        y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, tab_col)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seeds, k, npk)
         ctx.accX, ctx.tab_col = accX, tab_col

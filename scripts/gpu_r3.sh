@@ -102,6 +102,16 @@ PY
       QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 2>&1 | tail -n 3 > gpurun_out/bench_dp2_weak.log
       QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --global-batch 32 2>&1 | tail -n 3 > gpurun_out/bench_dp2_strong.log
       stamp dp2 ;;
+    pmc)   # fabric traffic of the edge kernels (FETCH_SIZE / WRITE_SIZE in separate passes) -> gpurun_out/pmc_edge_fwd.json
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pmc_$ctr; mkdir -p /tmp/pmc_$ctr
+        ( cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --repeats 1 --graphs 0 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 3 > gpurun_out/pmc_$ctr.log
+        python scripts/pmc_by_kernel.py "$(find /tmp/pmc_$ctr -name '*counter_collection.csv' | head -n 1)" > gpurun_out/pmc_$ctr.txt 2>&1
+      done
+      python scripts/pmc_edge_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -n 1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -n 1)" 64000 208 > gpurun_out/pmc_edge_fwd.json 2> gpurun_out/pmc_edge_traffic.err
+      stamp pmc ;;
+    census)   # kernel launches of one step by forward region (backward attributed through autograd sequence numbers)
+      timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 260 > gpurun_out/op_census.txt; stamp census ;;
     hostprof)
       timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt; stamp hostprof ;;
     cmd:*)

@@ -94,11 +94,11 @@ class EmuKernels:
         return EmuGraph(edge_index, edge_type, node_type, n_etype, n_ntype, block_n)
 
     # whole-stack sequencing, defined by the composed per-kernel path (what qagnn_stack_{fwd,bwd}_f32 must equal launch for launch)
-    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings):
+    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, cols=-1):
         from qagnn_amd import ops
         x, saved = X, []
         for l, prm in enumerate(prms):
-            y, sv = ops.hop_fwd_composed(self, graph, HP, qscale, x, S, ntype, prm, batch_stats, eps, p, seeds[l], True, runnings[l])
+            y, sv = ops.hop_fwd_composed(self, graph, HP, qscale, x, S, ntype, prm, batch_stats, eps, p, seeds[l], True, runnings[l], cols)
             saved.append((x, sv))
             x = y
         return x, tuple(t for _, sv in saved for t in sv) + tuple(xi for xi, _ in saved)
@@ -158,14 +158,14 @@ class EmuKernels:
             parts.append(torch.stack([blk[0], d.sum(0), (d * d).sum(0)]))
         return torch.stack(parts)
 
-    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None):
+    def bn_stats_finalize(self, part, rows, gamma, beta, eps, running=None, ones_col=-1):
         nt = part.size(0)
         n_t = torch.tensor([min(self.STAT_TILE, rows - t * self.STAT_TILE) for t in range(nt)], dtype=part.dtype).unsqueeze(1)
         x0, S1, S2 = part[:, 0], part[:, 1], part[:, 2]
         mean = (n_t * x0 + S1).sum(0) / rows
         dm = x0 + S1 / n_t - mean
         var = ((S2 - S1 * S1 / n_t) + n_t * dm * dm).sum(0) / rows
-        invstd, scale, shift = self.bn_finalize(mean, var, gamma, beta, eps, running)
+        invstd, scale, shift = self.bn_finalize(mean, var, gamma, beta, eps, running, ones_col)
         return torch.stack([mean, var, invstd, scale, shift])
 
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
@@ -226,10 +226,13 @@ class EmuKernels:
             d2 = d2 * roww.unsqueeze(1)
         return d2.sum(0) * scale
 
-    def bn_finalize(self, mean, var, gamma, beta, eps, running=None):
+    def bn_finalize(self, mean, var, gamma, beta, eps, running=None, ones_col=-1):
         invstd = torch.rsqrt(var + eps)
         scale = gamma * invstd
         shift = beta - mean * scale
+        if ones_col >= 0:  # the column of ones of relu(bn(h)) (see qagnn_bn_finalize_f32)
+            scale, shift = scale.clone(), shift.clone()
+            scale[ones_col], shift[ones_col] = 0.0, 1.0
         if running is not None:
             rm, rv, nbt, pos, mom, unb = running
             rm += mom * (mean[pos] - rm)

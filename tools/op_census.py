@@ -30,15 +30,17 @@ label(MQ.QAGNN_Message_Passing, 'forward', 'mp_other')
 label(MQ.QAGNN, 'forward', 'qagnn_other')
 
 dev = torch.device('cuda', 0)
-b = bench.to_device(bench.make_batch(64, seed=1000, n_concept=100000), dev, True)
-model = bench.build_model(MQ, 100000, p=0.2).to(dev).train()
+wl = bench.WORKLOADS[bench.HEADLINE]
+nq = int(os.environ.get('CENSUS_QUESTIONS', wl['questions']))
+b = bench.to_device(bench.make_batch(wl, nq, seed=1000, n_concept=100000), dev, True, wl['nc'])
+model = bench.build_model(MQ, wl, 100000, p=0.2).to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
 for _ in range(3):
-    bench.step(model, b, 1, params)
+    bench.step(model, b, wl['nc'], 1.0, params)
 torch.cuda.synchronize()
 with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA], record_shapes=True) as prof:
     with record_function('REGION:step_other'):
-        bench.step(model, b, 1, params)
+        bench.step(model, b, wl['nc'], 1.0, params)
     torch.cuda.synchronize()
 
 evs = [e for e in prof.events()]
