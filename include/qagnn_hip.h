@@ -319,10 +319,19 @@ typedef struct qagnn_hop_args {
                                       zero padding otherwise; the matching rows of Ws_t are zero), so dTT = rows [tab_col, tab_col + T) of
                                       dWs_t = S^T dKMQ: the type-table gradient falls out of the weight-gradient GEMM instead of costing a
                                       grouped column reduction over dKMQ (60 us per layer at 64 000 rows).  -1: reduce dKMQ by node type */
+  qagnn_stream_t side_stream;      /* backward only; NULL or a second stream of the same device: the four weight-gradient products of
+                                      each hop (and the gradients copied out of their rows) are launched there, forked from `stream`
+                                      by events as soon as their operands exist and joined before the call returns -- they feed
+                                      nothing downstream and would otherwise sit in the serial data-gradient chain.  Results are
+                                      bit-identical either way (same launches).  Capture-safe: the fork makes the side stream part
+                                      of a capture in progress on `stream`, the join closes the branch.  In a stack call the field of
+                                      the LAST hop is the one that is read */
 } qagnn_hop_args;
 int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);
 int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP,
                                       int32_t cls_part_rows /* g->max_chunks + QAGNN_CLS_SLICES * g->C */);
+/* (the backward workspace holds TWO sets of the buffers the weight-gradient stream reads -- d out, d h1, d K|M|Q -- so that stream may
+ * lag the data-gradient chain by a whole hop; the hops of a stack call share one workspace) */
 int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream);
 /* The whole k-hop stack per call (QAGNN_Message_Passing.mp_helper, modeling_qagnn.py:45-50, and its backward): hops[l] is a complete

@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 11  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed)
+ABI_VERSION = 12  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -56,7 +56,7 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32)])
+                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32), ('side_stream', _vp)])
 
 
 def load_library(path=LIB_PATH):
@@ -254,12 +254,23 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
+        # weight-gradient products of the natively sequenced hops on a second stream (qagnn_hop_args.side_stream); ops.py keeps this in
+        # step with its own QAGNN_WGRAD_OVERLAP switch
+        self.wgrad_overlap = os.environ.get('QAGNN_WGRAD_OVERLAP', '1') == '1'
+        self._side_streams = {}
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
         # raw handle of the current device's current stream (torch.cuda.current_stream() builds a Stream object: ~10 us per call,
         # 25 calls per step); the entry points run under _on_operand_device, so "current device" is the operands' device
         return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+    def _side_stream(self):
+        dev = torch.cuda.current_device()
+        st = self._side_streams.get(dev)
+        if st is None:
+            st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        return st.cuda_stream
 
     def _check(self, rc, what):
         if rc != 0:
@@ -637,6 +648,7 @@ class HipKernels(metaclass=_GuardedMeta):
         tc, oc = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)  # (type-indicator column of S, ones column of relu(bn(h1)))
         h.tab_col = int(tc) if S is not None else -1
         h.ones_col = int(oc)
+        h.side_stream = self._side_stream() if self.wgrad_overlap else None
         return h
 
     def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running, cols=-1):

@@ -11,6 +11,8 @@
 // qagnn_hop_{fwd,bwd}_workspace_elems().
 #include "common.h"
 
+#include <mutex>
+
 namespace qagnn {
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
@@ -125,30 +127,89 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
 extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t cls_part_rows) {
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
-  return 2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
+  // two sets of the buffers the weight-gradient stream reads (d out, d h1, d K|M|Q) + what the main stream keeps to itself
+  return 2 * (2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP)) + up4((int64_t)N * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
          up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
 }
 
-extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+namespace qagnn {
+
+// Events that order the main stream and the weight-gradient stream (qagnn_hop_args.side_stream): created once per device, reused
+// round-robin (a wait refers to the record that preceded it, so an event may be recorded again once its wait is enqueued).
+constexpr int HOP_MAX_DEV = 16, HOP_EV_POOL = 64;
+static hipEvent_t g_hop_ev[HOP_MAX_DEV][HOP_EV_POOL];
+static bool g_hop_ev_made[HOP_MAX_DEV];
+static std::mutex g_hop_ev_mu;
+
+struct SideSync {
+  hipStream_t main, side;  // side == nullptr: everything on `main`, no events
+  hipEvent_t* ev;
+  int next;
+  hipEvent_t take() { return ev[next++ % HOP_EV_POOL]; }
+};
+
+static int side_sync_init(SideSync* s, hipStream_t main, hipStream_t side) {
+  s->main = main;
+  s->side = (side && side != main) ? side : nullptr;
+  s->ev = nullptr;
+  s->next = 0;
+  if (!s->side) return QAGNN_OK;
+  int dev = 0;
+  hipError_t he = hipGetDevice(&dev);
+  QAGNN_REQUIRE(he == hipSuccess && dev >= 0 && dev < HOP_MAX_DEV, QAGNN_EHIP, "hop_bwd: device %d outside the event table", dev);
+  std::lock_guard<std::mutex> lk(g_hop_ev_mu);
+  if (!g_hop_ev_made[dev]) {
+    for (int i = 0; i < HOP_EV_POOL; ++i) {
+      he = hipEventCreateWithFlags(&g_hop_ev[dev][i], hipEventDisableTiming);
+      QAGNN_REQUIRE(he == hipSuccess, QAGNN_EHIP, "hop_bwd: hipEventCreate failed: %s", hipGetErrorString(he));
+    }
+    g_hop_ev_made[dev] = true;
+  }
+  s->ev = g_hop_ev[dev];
+  return QAGNN_OK;
+}
+// `to` continues after everything enqueued on `from` so far
+static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
+  hipError_t he = hipEventRecord(ev, from);
+  if (he == hipSuccess) he = hipStreamWaitEvent(to, ev, 0);
+  QAGNN_REQUIRE(he == hipSuccess, QAGNN_EHIP, "hop_bwd: stream fork / join failed: %s", hipGetErrorString(he));
+  return QAGNN_OK;
+}
+
+// One hop's backward.  The four weight-gradient products (and the gradients read off their rows) feed nothing downstream, they are
+// latency-bound split-K launches with tiny outputs, and the data-gradient chain next to them is a serial chain of launches: with a
+// side stream they leave the chain (fork after each of their operands is complete, join at the end of the stack).  What they read
+// from the workspace (d out, d h1, d K|M|Q) lives in buffer set `set`; the caller alternates sets from hop to hop and makes the
+// main stream wait for `*done` before it reuses one, so the side stream may lag the main stream by a whole hop.
+static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_t* done) {
   HOP_TRY(check_hop(h, "hop_bwd"));
   QAGNN_REQUIRE(h->dy && h->dWx_t && h->dTT && h->dEkEm && h->dW1t && h->db1 && h->dbn && h->dW2t && h->db2, QAGNN_EINVAL,
                 "hop_bwd: null gradient pointer");
   QAGNN_REQUIRE(h->SP == 0 || h->dWs_t, QAGNN_EINVAL, "hop_bwd: dWs_t missing");
   const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
   Carver w{h->ws, h->ws + h->ws_elems};
-  float* bufA = w.take((int64_t)N * DP);  // d out, then d h1
-  float* bufB = w.take((int64_t)N * DP);  // d relu(bn(h1)), then d aggr
-  float* dKMQ = w.take((int64_t)N * 3 * DP);
+  float *bufA2[2], *bufC2[2], *dKMQ2[2];
+  for (int i = 0; i < 2; ++i) {
+    bufA2[i] = w.take((int64_t)N * DP);
+    bufC2[i] = w.take((int64_t)N * DP);
+    dKMQ2[i] = w.take((int64_t)N * 3 * DP);
+  }
+  float* bufA = bufA2[set];  // d out
+  float* bufC = bufC2[set];  // d h1
+  float* dKMQ = dKMQ2[set];
+  float* bufB = w.take((int64_t)N * DP);  // d relu(bn(h1)), then d aggr (main stream only)
   float* gab = w.take((int64_t)Ep * 4);
   float* rs = w.take((int64_t)N * 4);
   float* cls_part = w.take(((int64_t)h->g->max_chunks + (int64_t)QAGNN_CLS_SLICES * h->g->C) * 2 * DP);
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
-  float* tnws = w.take(tn);
-  float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
+  float* tnws = w.take(tn);  // split-K partials: used by the weight-gradient products only, which are in order on one stream
+  float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));  // column-reduction partials: main stream only
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
   const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
+  const qagnn_stream_t stream = (qagnn_stream_t)ss->main;
+  const qagnn_stream_t wstream = (qagnn_stream_t)(ss->side ? ss->side : ss->main);  // where the weight gradients go
 
   // GELU + dropout backward
   const float* dout = h->dy;
@@ -159,39 +220,47 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   if (h->ones_col < 0)
     HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
-  HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, stream));
+  if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
+  HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, wstream));
   if (h->ones_col >= 0) {  // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient
-    hipError_t he = hipMemcpyAsync(h->db2, h->dW2t + (int64_t)h->ones_col * DP, (size_t)DP * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    hipError_t he = hipMemcpyAsync(h->db2, h->dW2t + (int64_t)h->ones_col * DP, (size_t)DP * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)wstream);
     if (he != hipSuccess) { set_error("hop_bwd: db2 copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   }
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
   HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, stream));
-  // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1 (overwrites d out: it is dead by now)
+  // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
-  HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufA, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
+  HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufC, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
                                        h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, h->db1, crws, stream));
   // first Linear (db1 = colsum(d h1) came out of the pass above)
-  HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufA, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+  if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
+  HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufC, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   qagnn_gemm_nn_args gg = {};
-  gg.A1 = bufA; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
+  gg.A1 = bufC; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
   HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, stream));
   // attention backward
   HOP_TRY(qagnn_edge_attn_bwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs,
                                   cls_part, stream));
   // projection: weight gradients, node-type-table gradient, data gradients
-  HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+  if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
+  HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   if (SP > 0)
-    HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, stream));
+    HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   if (SP > 0 && h->tab_col >= 0) {
     // the type indicators ride in S's padding columns: their rows of dWs_t ARE the type-table gradient
     QAGNN_REQUIRE(h->tab_col + h->T <= SP, QAGNN_EINVAL, "hop_bwd: tab_col=%d + T=%d exceeds SP=%d", h->tab_col, h->T, SP);
     hipError_t he = hipMemcpyAsync(h->dTT, h->dWs_t + (int64_t)h->tab_col * 3 * DP, (size_t)h->T * 3 * DP * sizeof(float), hipMemcpyDeviceToDevice,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)wstream);
     if (he != hipSuccess) { set_error("hop_bwd: dTT copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   } else {
     HOP_TRY(qagnn_colreduce_f32(0, dKMQ, 3 * DP, nullptr, 3 * DP, N, 3 * DP, h->ntype, h->T, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->dTT,
                                 crws, stream));
+  }
+  if (ss->side) {  // the side stream is done with this buffer set (and with everything queued on it before) once this event fires
+    *done = ss->take();
+    hipError_t he = hipEventRecord(*done, ss->side);
+    QAGNN_REQUIRE(he == hipSuccess, QAGNN_EHIP, "hop_bwd: hipEventRecord failed: %s", hipGetErrorString(he));
   }
   if (h->dX) {
     qagnn_gemm_nn_args gx = {};
@@ -208,6 +277,37 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   return QAGNN_OK;
 }
 
+// k hops, last first; the buffer sets alternate and the main stream joins the weight-gradient stream before it returns
+static int stack_bwd_impl(const qagnn_hop_args* hops, int k, hipStream_t main) {
+  SideSync ss;
+  HOP_TRY(side_sync_init(&ss, main, (hipStream_t)hops[k - 1].side_stream));
+  hipEvent_t done[2] = {nullptr, nullptr};
+  int rc = QAGNN_OK;
+  for (int it = 0, l = k - 1; l >= 0 && rc == QAGNN_OK; --l, ++it) {
+    const int set = it & 1;
+    if (ss.side && done[set]) {  // the hop before last read this set on the side stream
+      hipError_t he = hipStreamWaitEvent(ss.main, done[set], 0);
+      if (he != hipSuccess) { set_error("stack_bwd: hipStreamWaitEvent failed: %s", hipGetErrorString(he)); rc = QAGNN_EHIP; break; }
+    }
+    rc = hop_bwd_one(&hops[l], &ss, set, &done[set]);
+  }
+  // join even after an error: whatever was forked must not outlive the call (a capture would be left with an unjoined branch)
+  if (ss.side) {
+    hipEvent_t ev = ss.take();
+    hipError_t he = hipEventRecord(ev, ss.side);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ss.main, ev, 0);
+    if (he != hipSuccess && rc == QAGNN_OK) { set_error("stack_bwd: joining the weight-gradient stream failed: %s", hipGetErrorString(he)); rc = QAGNN_EHIP; }
+  }
+  return rc;
+}
+
+}  // namespace qagnn
+
+extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+  QAGNN_REQUIRE(h, QAGNN_EINVAL, "hop_bwd: null argument block");
+  return stack_bwd_impl(h, 1, (hipStream_t)stream);
+}
+
 // ---- the whole k-hop stack per call (qagnn_mp_forward / qagnn_mp_backward) -------------------------------------
 // hops[l] is a complete qagnn_hop_args; the caller chains them (hops[l+1].X = hops[l].y, hops[l].dy = hops[l+1].dX, shared dS
 // with accumulate_dS = 1 on all but the hop whose backward runs first).  Pure sequencing: the same launches, in the same order,
@@ -220,6 +320,5 @@ extern "C" int qagnn_stack_fwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_
 
 extern "C" int qagnn_stack_bwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream) {
   QAGNN_REQUIRE(hops && k > 0, QAGNN_EINVAL, "stack_bwd: no hops");
-  for (int l = k - 1; l >= 0; --l) HOP_TRY(qagnn_hop_bwd_f32(&hops[l], stream));
-  return QAGNN_OK;
+  return stack_bwd_impl(hops, k, (hipStream_t)stream);
 }

@@ -21,6 +21,7 @@ The captured work is exactly the eager step's launch sequence (same kernels, sam
 bit-identical to the eager path on the same capacity-laid-out batch (tests/test_graphed.py).
 """
 import math
+import os
 
 import torch
 
@@ -54,7 +55,12 @@ class GraphedStep:
         assert self.dev.type == 'cuda', 'GraphedStep captures a HIP graph: the model must live on the GPU'
         self._captured = {}
         self._pool = None
-        self.overlap = True  # side streams (weight gradients, graph preparation) inside the capture; switched off if a capture rejects them
+        # Side streams inside the capture.  Graph preparation under the input GEMM pays (-2 % at 65 subgraphs, more below); the
+        # weight-gradient products on a stream of their own do NOT pay in a replayed graph: every fork / join is a cross-queue
+        # dependency of the graph, and at 10 / 65 / 150 subgraphs the step is 6 % slower / equal / 2 % slower with them
+        # (profiles/r3_run13_graph_overlap_ab.txt) -- so the captured step keeps them in the chain.
+        self.overlap = os.environ.get('QAGNN_GRAPH_OVERLAP', '1') == '1'               # graph preparation; off if a capture rejects it
+        self.wgrad_overlap = os.environ.get('QAGNN_GRAPH_WGRAD_OVERLAP', '0') == '1'
 
     # -- the eager step that gets captured -------------------------------------------------------------------------------------------
     def _step(self, c):
@@ -86,26 +92,26 @@ class GraphedStep:
         # warm-up outside the capture (lazy initialisation: operand-packing plans, LDS attribute raises, allocator pools), on a side
         # stream as torch's capture recipe asks; module buffers (BatchNorm running statistics, batch counters) are put back afterwards
         saved = [(b, b.detach().clone()) for b in self.model.buffers()]
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            for _ in range(self.warmup):
-                for p in self.params:
-                    p.grad = None
-                self._step(c)
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
-        with torch.no_grad():
-            for b, v in saved:
-                b.copy_(v)
-        for p in self.params:
-            p.grad = None
-        if self._pool is None:
-            self._pool = torch.cuda.graph_pool_handle()
         old = ops.WGRAD_OVERLAP, ops.PREP_OVERLAP
-        if not self.overlap:
-            ops.WGRAD_OVERLAP = ops.PREP_OVERLAP = False
+        ops.WGRAD_OVERLAP = ops.WGRAD_OVERLAP and self.wgrad_overlap and self.overlap
+        ops.PREP_OVERLAP = ops.PREP_OVERLAP and self.overlap
         try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):
+                    for p in self.params:
+                        p.grad = None
+                    self._step(c)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                for b, v in saved:
+                    b.copy_(v)
+            for p in self.params:
+                p.grad = None
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             c.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(c.graph, pool=self._pool):
                 c.logits, c.attn, c.loss = self._step(c)

@@ -773,6 +773,7 @@ class HopFn(torch.autograd.Function):
         X, S, ntype, prm, saved = t[0], t[1], t[2], t[3:3 + nprm], t[3 + nprm:]
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under this hop
         bwd = getattr(K, 'hop_bwd', None)
+        K.wgrad_overlap = WGRAD_OVERLAP  # the native hop forks its weight-gradient products onto a side stream of its own
         accX, lastX, accS, lastS = ctx.acc
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy.contiguous(),
                 ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None,
@@ -821,6 +822,7 @@ class StackFn(torch.autograd.Function):
         prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under the hops
         accX = ctx.accX
+        K.wgrad_overlap = WGRAD_OVERLAP  # qagnn_hop_args.side_stream: weight-gradient products beside the data-gradient chain
         dX, dS, grads = K.stack_bwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy.contiguous(),
                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None, ctx.tab_col)
         if accX is not None:

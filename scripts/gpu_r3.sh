@@ -92,6 +92,12 @@ PY
         echo "$var=$v (2 questions)" >> gpurun_out/ab10_$var.txt
         env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/ab10_$var.txt
       done; stamp "ab10:$var" ;;
+    abq:*)   # abq:<questions>:<VAR>  -- interleaved A/B (0 1 0 1) of a switch at a given number of questions
+      spec="${arg#abq:}"; q="${spec%%:*}"; var="${spec#*:}"
+      for v in 0 1 0 1; do
+        echo "$var=$v ($q questions)" >> gpurun_out/abq${q}_$var.txt
+        env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions $q --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/abq${q}_$var.txt
+      done; stamp "abq:$q:$var" ;;
     abx10:*)   # abx10:VAR=a,b  -- interleaved A/B of two values of a switch at 2 questions (hipGraph replay as bench.py chooses)
       spec="${arg#abx10:}"; var="${spec%%=*}"; vals="${spec#*=}"; va="${vals%%,*}"; vb="${vals#*,}"
       for v in $va $vb $va $vb; do
