@@ -585,7 +585,9 @@ def main():
             'repeats': len(regions), 'repeat_ms_per_step': [round(r[0] / args.steps * 1e3, 3) for r in regions],
             'value_is': f'median of {len(regions)} timed regions of {args.steps} steps each (max over ranks per region)',
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'host_bound': bool(enq > 0.9 * dt),
-            'hip_graph': (f'one hipGraph replay per step ({gs.n_graphs} capture(s): qagnn_amd.graphed.GraphedStep)' if gs is not None else 'eager launches'),
+            'hip_graph': (f'one hipGraph replay per step ({gs.n_graphs} capture(s): qagnn_amd.graphed.GraphedStep; side streams in the capture: '
+                          f'graph preparation {bool(gs.overlap and ops.PREP_OVERLAP)}, weight gradients {bool(gs.overlap and gs.wgrad_overlap and ops.WGRAD_OVERLAP)})'
+                          if gs is not None else 'eager launches'),
             'config': {'workload': f'{HEADLINE}: ' + wl['what'] + ', 5-layer GAT d=200 H=4, QAGNN decoder fwd+bwd (LM encoder excluded: random '
                                    f'sent_vecs), dropout {args.dropout}, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,

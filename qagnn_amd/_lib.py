@@ -254,10 +254,7 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
-        # weight-gradient products of the natively sequenced hops on a second stream (qagnn_hop_args.side_stream); ops.py keeps this in
-        # step with its own QAGNN_WGRAD_OVERLAP switch
-        self.wgrad_overlap = os.environ.get('QAGNN_WGRAD_OVERLAP', '1') == '1'
-        self._side_streams = {}
+        self._side_streams = {}  # per device: the stream the natively sequenced hops put their weight-gradient products on
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _stream(self):
@@ -619,7 +616,7 @@ class HipKernels(metaclass=_GuardedMeta):
         return dKMQ, dEkEm
 
     # -- one GATConvE hop per call (csrc/hop.hip) ---------------------------------------------------------------------------
-    def _hop_struct(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col=-1):
+    def _hop_struct(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col=-1, side=False):
         Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
         DP = 4 * HP
         _chk2d(X, 'X'), _chk2d(Wx_t, 'Wx_t'), _chk2d(Wx, 'Wx'), _chk2d(TT, 'TT'), _chk2d(EkEm, 'EkEm')
@@ -648,7 +645,7 @@ class HipKernels(metaclass=_GuardedMeta):
         tc, oc = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)  # (type-indicator column of S, ones column of relu(bn(h1)))
         h.tab_col = int(tc) if S is not None else -1
         h.ones_col = int(oc)
-        h.side_stream = self._side_stream() if self.wgrad_overlap else None
+        h.side_stream = self._side_stream() if side else None  # backward only (qagnn_hop_args.side_stream)
         return h
 
     def hop_fwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running, cols=-1):
@@ -674,9 +671,9 @@ class HipKernels(metaclass=_GuardedMeta):
         return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats)
 
     def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
-                dX_acc=None, dS_acc=None, tab_col=-1):
-        """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)"""
-        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col)
+                dX_acc=None, dS_acc=None, tab_col=-1, overlap=True):
+        """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2); overlap: the weight-gradient products on a side stream"""
+        h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col, side=overlap)
         KMQ, aa, aggr, h1, out, stats = saved
         N, DP, dev, SP, T = graph.N, 4 * HP, X.device, h.SP, h.T
         _chk2d(dy, 'dy')
@@ -739,7 +736,8 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(self.lib.qagnn_stack_fwd_f32(hops, k, self._stream()), 'qagnn_stack_fwd_f32')
         return rows[k - 1, 3], (KMQ, aa, rows, stats)
 
-    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1):
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1,
+                  overlap=True):
         """-> (dX, dS, [per layer: (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)]); dX_acc: an existing running total of
         the stack input's gradient (the output GEMM's share), added to in place."""
         k = len(prms)
@@ -767,7 +765,7 @@ class HipKernels(metaclass=_GuardedMeta):
             offs.append(offs[-1] + n)
         for l in range(k):
             x = X if l == 0 else rows[l - 1, 3]
-            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, tab_col)
+            h = self._hop_struct(graph, HP, qscale, x, S, ntype, prms[l], batch_stats, eps, p, seeds[l], True, tab_col, side=overlap)
             h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out = (p_rows + (4 * l + i) * row_b for i in range(3))

@@ -7,12 +7,16 @@
 
 namespace qagnn {
 
-constexpr int CR_ROWS = 128;  // rows per block (4 waves x 32 rows): >= 2 blocks per CU at N = 64 000
-constexpr int CR_WR = CR_ROWS / 4;
+// rows per wave (a block = 4 waves): 32 -> >= 2 blocks per CU at N = 64 000.  Below 32 768 rows that shape leaves CUs idle while
+// every wave walks 4 dependent batches of row loads (2 000 rows: 16 blocks, 12-15 us per pass, pure latency): 8 rows per wave = ONE
+// batch in flight per wave and 4x the blocks.  The choice depends on R only, so every pass over the same matrix (and the fused
+// column-sum pass below) keeps the same partial sums.
+constexpr int CR_WR_BIG = 32, CR_WR_SMALL = 8;
+static inline int cr_wr(int R) { return R < 32768 ? CR_WR_SMALL : CR_WR_BIG; }
 
 // MODE 0: grouped column sums   MODE 1: sum (x-mean)^2   MODE 2: BN+ReLU backward reductions (2 outputs)
 // roww (modes 0, 1): optional per-row weight -> weighted sums (count-weighted BatchNorm statistics of the edge-class table)
-template <int MODE>
+template <int MODE, int CR_WR>
 __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, int ldx, const float* __restrict__ X2, int ldx2,
                                                    int R, int Cc, const int64_t* __restrict__ rowidx, int groups,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -23,6 +27,7 @@ __global__ __launch_bounds__(256) void k_colreduce(const float* __restrict__ X, 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 256 + lane * 4;
   const bool act = col < Cc;
+  constexpr int CR_ROWS = 4 * CR_WR;
   const int r0 = blockIdx.y * CR_ROWS + w * CR_WR;
   float4 acc[NOUT];
 #pragma unroll
@@ -263,6 +268,7 @@ __global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restr
 // per wave in row order, (w0 + w1) + (w2 + w3), chunk partials summed by k_colreduce_final), so the sums are bit-identical
 // to the separate pass.  (The same fusion for the GELU + dropout backward was measured and dropped: 42 us against 27 + 18 --
 // that kernel is ALU-bound and this block shape gives it only 2 blocks per CU.)
+template <int CR_WR>
 __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restrict__ dR, const float* __restrict__ Hh, float* __restrict__ dH,
                                                             int ld, int R, int Cc, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -273,6 +279,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 256 + lane * 4;
   const bool act = col < Cc;
+  constexpr int CR_ROWS = 4 * CR_WR;
   const int r0 = blockIdx.y * CR_ROWS + w * CR_WR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act) {
@@ -347,7 +354,7 @@ __global__ void k_sin_basis(const float* __restrict__ score, const float* __rest
 using namespace qagnn;
 
 extern "C" int64_t qagnn_colreduce_workspace_elems(int32_t R, int32_t Cc, int32_t groups) {
-  return (int64_t)cdiv(R, CR_ROWS) * (groups < 2 ? 2 : groups) * Cc;
+  return (int64_t)cdiv(R, 4 * cr_wr(R)) * (groups < 2 ? 2 : groups) * Cc;
 }
 
 extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, const float* X2, int32_t ldx2, int32_t R, int32_t Cc,
@@ -357,21 +364,25 @@ extern "C" int qagnn_colreduce_f32(int32_t mode, const float* X, int32_t ldx, co
   QAGNN_REQUIRE(X && out && workspace, QAGNN_EINVAL, "colreduce: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ldx % 4 == 0 && aligned16(X), QAGNN_EINVAL, "colreduce: bad sizes/alignment");
   QAGNN_REQUIRE(mode >= 0 && mode <= 2, QAGNN_EINVAL, "colreduce: bad mode %d", mode);
-  dim3 grid(cdiv(Cc, 256), cdiv(R, CR_ROWS));
+  const bool small = cr_wr(R) == CR_WR_SMALL;
+  dim3 grid(cdiv(Cc, 256), cdiv(R, 4 * cr_wr(R)));
   int nout;
   if (mode == 0) {
     QAGNN_REQUIRE(groups >= 1 && groups <= 4 && (groups == 1 || rowidx), QAGNN_EINVAL, "colreduce: groups=%d (1..4)", groups);
     nout = groups;
-    k_colreduce<0><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    if (small) k_colreduce<0, CR_WR_SMALL><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    else k_colreduce<0, CR_WR_BIG><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   } else if (mode == 1) {
     QAGNN_REQUIRE(mean && aligned16(mean), QAGNN_EINVAL, "colreduce: mode 1 needs mean");
     nout = 1;
-    k_colreduce<1><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    if (small) k_colreduce<1, CR_WR_SMALL><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    else k_colreduce<1, CR_WR_BIG><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   } else {
     QAGNN_REQUIRE(X2 && mean && invstd && scale && shift && ldx2 % 4 == 0 && aligned16(X2), QAGNN_EINVAL,
                   "colreduce: mode 2 needs X2, mean, invstd, scale, shift");
     nout = 2;
-    k_colreduce<2><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    if (small) k_colreduce<2, CR_WR_SMALL><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
+    else k_colreduce<2, CR_WR_BIG><<<grid, 256, 0, stream>>>(X, ldx, X2, ldx2, R, Cc, rowidx, groups, mean, invstd, scale, shift, roww, workspace);
   }
   QAGNN_LAUNCH_CHECK("k_colreduce");
   const int tot = nout * Cc;
@@ -478,9 +489,13 @@ extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, fl
   QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gamma && sum_dy && sum_dy_hhat && colsum && workspace, QAGNN_EINVAL,
                 "bn_relu_bwd_colsum: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd_colsum: bad sizes");
-  dim3 grid(cdiv(Cc, 256), cdiv(R, CR_ROWS));
-  k_bn_relu_bwd_colsum<<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat, inv_rows, roww,
-                                                 workspace);
+  dim3 grid(cdiv(Cc, 256), cdiv(R, 4 * cr_wr(R)));
+  if (cr_wr(R) == CR_WR_SMALL)
+    k_bn_relu_bwd_colsum<CR_WR_SMALL><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
+                                                                inv_rows, roww, workspace);
+  else
+    k_bn_relu_bwd_colsum<CR_WR_BIG><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
+                                                              inv_rows, roww, workspace);
   QAGNN_LAUNCH_CHECK("k_bn_relu_bwd_colsum");
   k_colreduce_final<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(workspace, colsum, grid.y, Cc, 1.0f);
   QAGNN_LAUNCH_CHECK("k_colreduce_final");

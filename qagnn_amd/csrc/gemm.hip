@@ -256,6 +256,15 @@ constexpr int TN_RC = 256;  // minimum rows per chunk (and the chunking the work
                             // 208 x 208 gradients at N = 64 000; launches with several tiles per chunk use longer chunks
 constexpr int TN_RC_SMALL = 64;  // ... and for reductions over <= 4096 rows (class tables, C = 612): the k-loop of a chunk is serial
 __host__ __device__ constexpr int tn_min_chunk(int R) { return R <= 4096 ? TN_RC_SMALL : TN_RC; }
+// the bf16-split weight-gradient kernel over <= 4096 rows (10 subgraphs = 2 000 node rows): one 32-row k-tile per chunk puts twice the
+// blocks on the idle chip (2 000 x 208 x 208: 126 instead of 64) and halves each block's serial work.  QAGNN_TN_SMALL_CHUNK=64 is the
+// earlier chunking (A/B switch).  The workspace query sizes for 32-row chunks there.
+constexpr int TN_RC_SPLIT_SMALL = 32;
+static int tn_split_min_chunk(int R) {
+  static const int env = getenv("QAGNN_TN_SMALL_CHUNK") ? atoi(getenv("QAGNN_TN_SMALL_CHUNK")) : 0;
+  if (R > 4096) return TN_RC;
+  return env >= TN_RC_SPLIT_SMALL ? (env + 31) / 32 * 32 : TN_RC_SPLIT_SMALL;
+}
 
 __host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w + 16; }  // rows k, k+1 land 16 banks apart
 
@@ -765,7 +774,7 @@ extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t str
 }
 
 extern "C" int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No) {
-  return (int64_t)cdiv(R, tn_min_chunk(R)) * ((int64_t)Ka * No + 4 * (int64_t)No);
+  return (int64_t)cdiv(R, R <= 4096 ? TN_RC_SPLIT_SMALL : tn_min_chunk(R)) * ((int64_t)Ka * No + 4 * (int64_t)No);
 }
 
 extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
@@ -784,7 +793,7 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
   const int nt = pick_nt(No);
   const bool split = !bsum && tn_split_ok(R, Ka, No, lda, ldb, a_rowidx != nullptr, a_scale != nullptr);
   const bool strip = nt == 13 && tn_strip_enabled() && tn_strip_ok(Ka);
-  const int crows = split ? tn_split_chunk_rows(R, Ka, No, tn_min_chunk(R)) : pick_tn_chunk_rows(R, Ka, No, nt);
+  const int crows = split ? tn_split_chunk_rows(R, Ka, No, tn_split_min_chunk(R)) : pick_tn_chunk_rows(R, Ka, No, nt);
   const int nchunks = cdiv(R, crows);
   float* Pcs = bsum ? workspace + (int64_t)nchunks * Ka * No : nullptr;
   int rc;

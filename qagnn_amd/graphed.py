@@ -145,10 +145,12 @@ class GraphedStep:
             if c is None:
                 try:
                     c = self._capture(key, args)
-                except RuntimeError:
+                except RuntimeError as e:
                     if not self.overlap:
                         raise
                     # a capture that rejects the forked side streams: same launches on one stream (no overlap inside the graph)
+                    import warnings
+                    warnings.warn(f'GraphedStep: capture with side streams failed ({str(e)[:300]}); capturing on one stream')
                     self.overlap = False
                     torch.cuda.synchronize(self.dev)
                     c = self._capture(key, args)

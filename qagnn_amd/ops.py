@@ -773,12 +773,13 @@ class HopFn(torch.autograd.Function):
         X, S, ntype, prm, saved = t[0], t[1], t[2], t[3:3 + nprm], t[3 + nprm:]
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under this hop
         bwd = getattr(K, 'hop_bwd', None)
-        K.wgrad_overlap = WGRAD_OVERLAP  # the native hop forks its weight-gradient products onto a side stream of its own
         accX, lastX, accS, lastS = ctx.acc
         args = (graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy.contiguous(),
                 ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None,
                 accS.buf if accS is not None else None, ctx.tab_col)
-        dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2 = bwd(*args) if bwd is not None else hop_bwd_composed(K, *args)
+        # (overlap: the native hop forks its weight-gradient products onto a side stream of its own, qagnn_hop_args.side_stream)
+        dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2 = (bwd(*args, overlap=WGRAD_OVERLAP) if bwd is not None
+                                                                                  else hop_bwd_composed(K, *args))
         if accX is not None and dX is not None:  # dX / dS are the running totals now (accumulated in place when a buffer existed)
             accX.buf, dX = (None, dX) if lastX else (dX, None)
         if accS is not None and dS is not None:
@@ -822,9 +823,9 @@ class StackFn(torch.autograd.Function):
         prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
         flush_wgrads(dy)  # weight gradients queued by the operators around the stack run on the side stream under the hops
         accX = ctx.accX
-        K.wgrad_overlap = WGRAD_OVERLAP  # qagnn_hop_args.side_stream: weight-gradient products beside the data-gradient chain
         dX, dS, grads = K.stack_bwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy.contiguous(),
-                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None, ctx.tab_col)
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1], accX.buf if accX is not None else None, ctx.tab_col,
+                                    overlap=WGRAD_OVERLAP)  # qagnn_hop_args.side_stream: weight gradients beside the data-gradient chain
         if accX is not None:
             accX.buf = None  # handed over: this node is the last reader of the stack input (it was created first)
         out = []

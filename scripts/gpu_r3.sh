@@ -92,6 +92,13 @@ PY
         echo "$var=$v (2 questions)" >> gpurun_out/ab10_$var.txt
         env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/ab10_$var.txt
       done; stamp "ab10:$var" ;;
+    probe10)   # which side streams the captured step really has, and what the capture said (stderr kept)
+      for e in "X=1" "QAGNN_WGRAD_OVERLAP=0" "X=1" "QAGNN_WGRAD_OVERLAP=0"; do
+        echo "== $e" >> gpurun_out/probe10.txt
+        env $e timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2> /tmp/probe10.err | tail -n 1 > /tmp/probe10.json
+        python -c "import json; d = json.load(open('/tmp/probe10.json')); print(d['ms_per_step'], d['hip_graph'])" >> gpurun_out/probe10.txt 2>&1
+        grep -i "warn\|error\|GraphedStep" /tmp/probe10.err | cut -c1-400 | head -n 6 >> gpurun_out/probe10.txt
+      done; stamp probe10 ;;
     abq:*)   # abq:<questions>:<VAR>  -- interleaved A/B (0 1 0 1) of a switch at a given number of questions
       spec="${arg#abq:}"; q="${spec%%:*}"; var="${spec#*:}"
       for v in 0 1 0 1; do

@@ -103,7 +103,8 @@ class EmuKernels:
             x = y
         return x, tuple(t for _, sv in saved for t in sv) + tuple(xi for xi, _ in saved)
 
-    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1):
+    def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1,
+                  overlap=True):
         from qagnn_amd import ops
         k = len(prms)
         svs, xs = [saved[6 * l:6 * l + 6] for l in range(k)], saved[6 * k:]
