@@ -51,7 +51,17 @@ def rand_graph(seed, N, E, R=38, T=4, hub=False):
     return torch.stack([src, tgt]), et, nt, R, T
 
 
-GRAPH_CASES = [('rand_small', lambda: rand_graph(1, 50, 300)), ('rand_hub', lambda: rand_graph(2, 700, 9000, hub=True)),
+def padded_graph(seed, B, n, real, E, R=38, T=4):
+    """B subgraphs of n node slots of which only the first `real` carry edges (the PAD tail of a CSQA batch: rows whose only edge is
+    their self loop -- the degree-1 fast paths of the edge kernels), plus a few isolated nodes among the real ones."""
+    g = torch.Generator().manual_seed(seed)
+    blk = torch.randint(0, B, (E,), generator=g) * n
+    src = blk + torch.randint(0, real - 3, (E,), generator=g)
+    tgt = blk + torch.randint(0, real - 3, (E,), generator=g)
+    return torch.stack([src, tgt]), torch.randint(0, R, (E,), generator=g), torch.randint(0, T, (B * n,), generator=g), R, T
+
+
+GRAPH_CASES = [('big_pad', lambda: padded_graph(7, 320, 200, 128, 400000)), ('rand_small', lambda: rand_graph(1, 50, 300)), ('rand_hub', lambda: rand_graph(2, 700, 9000, hub=True)),
                ('no_edges', lambda: rand_graph(3, 40, 0)), ('one_node', lambda: rand_graph(4, 1, 5)),
                ('medqa_classes', lambda: rand_graph(5, 3000, 40000, R=34)), ('big', lambda: rand_graph(6, 64000, 400000))]
 
@@ -334,7 +344,7 @@ def edge_inputs(case_or_name, HP, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,HP', [('csqa_b10', 52), ('medqa_b8', 52), ('small_train', 8), ('rand_hub', 52), ('rand_small', 28),
-                                     ('no_edges', 16), ('one_node', 52), ('big', 52)])
+                                     ('no_edges', 16), ('one_node', 52), ('big', 52), ('big_pad', 52)])
 def test_edge_attention_forward_backward(name, HP):
     (ei, et, nt, R, T), KMQ, EkEm, G, qs = edge_inputs(name, HP, 21)
     K = hip()
@@ -403,7 +413,8 @@ def test_pool_attention_forward_backward(B, n, NH, Cc, p):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,HP,mode', [('csqa_b10', 52, 'train'), ('csqa_b10', 52, 'eval'), ('small_train', 8, 'train'),
-                                          ('rand_hub', 52, 'train_noact'), ('medqa_b8', 52, 'train_noS'), ('big', 52, 'train')])
+                                          ('rand_hub', 52, 'train_noact'), ('medqa_b8', 52, 'train_noS'), ('big', 52, 'train'),
+                                          ('big_pad', 52, 'train')])
 def test_fused_hop_equals_composed_path(name, HP, mode):
     """qagnn_hop_{fwd,bwd}_f32 (csrc/hop.hip) sequences the library's own launchers: every forward buffer, every gradient and
     the BatchNorm running buffers must be BIT-identical to composing the per-kernel entry points from Python
