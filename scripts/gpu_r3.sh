@@ -123,6 +123,15 @@ PY
       done
       python scripts/pmc_edge_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -n 1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -n 1)" 64000 208 > gpurun_out/pmc_edge_fwd.json 2> gpurun_out/pmc_edge_traffic.err
       stamp pmc ;;
+    sqpmc)   # SQ counters of the NN split GEMMs at M = 64 000 (tools/nn_micro.py), two passes of <= 8 counters
+      i=0
+      for ctrs in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
+                  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC"; do
+        i=$((i+1)); rm -rf /tmp/sqp$i; mkdir -p /tmp/sqp$i
+        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/sqp$i -o p -- python "$REPO/tools/nn_micro.py" ) > gpurun_out/sqpmc$i.log 2>&1
+        tail -n 3 gpurun_out/sqpmc$i.log > /tmp/x && mv /tmp/x gpurun_out/sqpmc$i.log
+        python scripts/pmc_sq_by_kernel.py "$(find /tmp/sqp$i -name '*counter_collection.csv' | head -n 1)" 2>&1 | grep "nn_split\|Traceback\|Error" | head -n 20 >> gpurun_out/sqpmc.txt
+      done; stamp sqpmc ;;
     census)   # kernel launches of one step by forward region (backward attributed through autograd sequence numbers)
       timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 260 > gpurun_out/op_census.txt; stamp census ;;
     hostprof)
