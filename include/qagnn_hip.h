@@ -314,7 +314,8 @@ typedef struct qagnn_hop_args {
   float* dW2t; float* db2;         /* [DP, DP], [DP] */
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
   int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split) */
-  int32_t ones_col;                /* see qagnn_bn_finalize_f32: >= 0 makes db2 = row ones_col of dW2t (no column reduction of d out) */
+  int32_t ones_col;                /* see qagnn_bn_finalize_f32: >= 0 makes db2 = row ones_col of dW2t (no column reduction of d out); a caller
+                                      that passes db2 = dW2t + ones_col * DP (and, for tab_col, dTT = dWs_t + tab_col * 3 DP) gets no copy */
   int32_t tab_col;                 /* >= 0: columns [tab_col, tab_col + T) of S hold the node-type indicators (1 at tab_col + ntype[r], S's
                                       zero padding otherwise; the matching rows of Ws_t are zero), so dTT = rows [tab_col, tab_col + T) of
                                       dWs_t = S^T dKMQ: the type-table gradient falls out of the weight-gradient GEMM instead of costing a

@@ -689,6 +689,12 @@ class HipKernels(metaclass=_GuardedMeta):
         dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = parts
         h.dWx_t, h.dTT, h.dEkEm, h.dW1t, h.db1 = dWx_t.data_ptr(), dTT.data_ptr(), dEkEm.data_ptr(), dW1t.data_ptr(), db1.data_ptr()
         h.dbn, h.dW2t, h.db2 = dbn.data_ptr(), dW2t.data_ptr(), db2.data_ptr()
+        if h.ones_col >= 0:  # the bias gradient IS that row of dW2t: hand out the view, no copy
+            db2 = dW2t.view(DP, DP)[h.ones_col]
+            h.db2 = db2.data_ptr()
+        if SP and h.tab_col >= 0:  # likewise the type-table gradient: rows of dWs_t
+            dTT = dWs_t.view(SP, 3 * DP)[h.tab_col:h.tab_col + T]
+            h.dTT = dTT.data_ptr()
         dX = dS = None
         if need_dX:  # *_acc: an existing running total of this gradient, added to in place (GEMM epilogue accumulate)
             dX = dX_acc if dX_acc is not None else torch.empty((N, DP), dtype=torch.float32, device=dev)
@@ -775,6 +781,12 @@ class HipKernels(metaclass=_GuardedMeta):
             h.dWx_t, pdWs_t, h.dTT, h.dEkEm, h.dW1t, h.db1, h.dbn, h.dW2t, h.db2 = (base + o * 4 for o in offs[:9])
             fl = flat[l * per:(l + 1) * per]
             dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dbn, dW2t, db2 = fl.split(sizes)
+            if h.ones_col >= 0:  # the bias gradient IS that row of dW2t, the type-table gradient those rows of dWs_t: views, no copies
+                db2 = dW2t.view(DP, DP)[h.ones_col]
+                h.db2 = h.dW2t + h.ones_col * DP * 4
+            if SP and h.tab_col >= 0:
+                dTT = dWs_t.view(SP, 3 * DP)[h.tab_col:h.tab_col + T]
+                h.dTT = pdWs_t + h.tab_col * 3 * DP * 4
             if l > 0:
                 h.dX, h.accumulate_dX = p_dxs + (l - 1) * row_b, 0
             elif dX is not None:

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
   }
   __syncthreads();
   const int ncol4 = DP2 >> 2;
-  const int P = 1024 / ncol4;
+  const int P = (int)blockDim.x / ncol4;  // partitions: 9 at 1024 threads and DP2 = 416, 2 at 256 threads (small graphs, see the launch)
   const int col4 = threadIdx.x % ncol4, part = threadIdx.x / ncol4;
   float4 acc = zero4();
   if (part < P) {
@@ -578,10 +578,14 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
   k_edge_bwd_cls<<<cdiv(g->max_chunks, 4), 256, 0, stream>>>(g->n_chunks, g->chunk_beg, g->chunk_len, g->src_c, g->tgt_c, g->pos_c,
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part, g->N);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_cls");
-  const int P = 1024 / (DP2 / 4);
+  // 1024 threads = 9 partitions per (class, slice) where the large classes have hundreds of chunk partials; a small graph (the
+  // reference's 10-subgraph mini-batch: a handful of chunks per class) only pays for launching 2 448 x 16 waves: 256 threads there.
+  // (The choice follows g->Ep, the capacity the arrays are laid out for: a fixed function of the launch shape, like every other grid here.)
+  const int cr_threads = g->Ep < 65536 && DP2 / 4 <= 128 ? 256 : 1024;
+  const int P = cr_threads / (DP2 / 4);
   float* slices = cls_part + (int64_t)g->max_chunks * DP2;  // [C][QAGNN_CLS_SLICES][DP2] behind the chunk partials
-  k_cls_reduce<<<dim3(g->C, QAGNN_CLS_SLICES), 1024, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, slices, DP2, g->C,
-                                                                                                    g->n_groups);
+  k_cls_reduce<<<dim3(g->C, QAGNN_CLS_SLICES), cr_threads, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, slices, DP2,
+                                                                                                          g->C, g->n_groups);
   QAGNN_LAUNCH_CHECK("k_cls_reduce");
   k_cls_reduce2<<<cdiv((int64_t)g->C * (DP2 / 4), 256), 256, 0, stream>>>(slices, dEkEm, lde, DP2, g->C);
   QAGNN_LAUNCH_CHECK("k_cls_reduce2");

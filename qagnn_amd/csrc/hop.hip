@@ -222,7 +222,9 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
   HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, wstream));
-  if (h->ones_col >= 0) {  // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient
+  // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient (no copy when the caller's db2 IS
+  // that row)
+  if (h->ones_col >= 0 && h->db2 != h->dW2t + (int64_t)h->ones_col * DP) {
     hipError_t he = hipMemcpyAsync(h->db2, h->dW2t + (int64_t)h->ones_col * DP, (size_t)DP * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)wstream);
     if (he != hipSuccess) { set_error("hop_bwd: db2 copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   }
@@ -250,9 +252,11 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   if (SP > 0 && h->tab_col >= 0) {
     // the type indicators ride in S's padding columns: their rows of dWs_t ARE the type-table gradient
     QAGNN_REQUIRE(h->tab_col + h->T <= SP, QAGNN_EINVAL, "hop_bwd: tab_col=%d + T=%d exceeds SP=%d", h->tab_col, h->T, SP);
-    hipError_t he = hipMemcpyAsync(h->dTT, h->dWs_t + (int64_t)h->tab_col * 3 * DP, (size_t)h->T * 3 * DP * sizeof(float), hipMemcpyDeviceToDevice,
-                                   (hipStream_t)wstream);
-    if (he != hipSuccess) { set_error("hop_bwd: dTT copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+    if (h->dTT != h->dWs_t + (int64_t)h->tab_col * 3 * DP) {  // (no copy when the caller's dTT IS those rows)
+      hipError_t he = hipMemcpyAsync(h->dTT, h->dWs_t + (int64_t)h->tab_col * 3 * DP, (size_t)h->T * 3 * DP * sizeof(float), hipMemcpyDeviceToDevice,
+                                     (hipStream_t)wstream);
+      if (he != hipSuccess) { set_error("hop_bwd: dTT copy failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+    }
   } else {
     HOP_TRY(qagnn_colreduce_f32(0, dKMQ, 3 * DP, nullptr, 3 * DP, N, 3 * DP, h->ntype, h->T, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->dTT,
                                 crws, stream));

@@ -728,7 +728,7 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     tab_col, ones_col = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)
     dout = K.gelu_dropout_bwd(out, dy, p, seed) if apply_act else dy
     dW2t = K.gemm_tn(h1, dout, a_scale=scale, a_shift=shift)
-    db2 = K.colsum(dout)[0] if ones_col < 0 else dW2t[ones_col].clone()
+    db2 = K.colsum(dout)[0] if ones_col < 0 else dW2t[ones_col]  # (a view: the bias gradient IS that row)
     dr = K.gemm_nn(dout, W2, B1n=W2t)
     red = K.bn_bwd_reduce(dr, h1, mean, invstd, scale, shift)
     dh1, db1 = K.bn_relu_bwd_colsum(dr, h1, mean, invstd, scale, shift, gamma, red, 1.0 / R if batch_stats else 0.0)
@@ -738,7 +738,7 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     dWx_t = K.gemm_tn(X, dKMQ)
     dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
     if dWs_t is not None and tab_col >= 0:
-        dTT = dWs_t[tab_col:tab_col + TT.size(0)].clone()  # rows of the type indicators in S (qagnn_hop_args.tab_col)
+        dTT = dWs_t[tab_col:tab_col + TT.size(0)]  # (a view) rows of the type indicators in S (qagnn_hop_args.tab_col)
     else:
         dTT = K.colsum(dKMQ, ntype, TT.size(0))
     dX = K.gemm_nn(dKMQ, Wx, out=dX_acc, accumulate=dX_acc is not None, B1n=Wx_t) if need_dX else None
