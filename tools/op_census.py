@@ -93,10 +93,8 @@ for r, (n, t, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%-28s %8d %10.0f %10d' % (r, n, t, s))
 print('total kernels', sum(v[0] for v in agg.values()), 'GPU us', sum(v[1] for v in agg.values()))
 for r in sorted(detail, key=lambda r: -agg[r][1]):
-    if r.startswith('hop'):
-        continue
     print('\n==', r)
-    for name, (n, t) in sorted(detail[r].items(), key=lambda kv: -kv[1][1])[:12]:
+    for name, (n, t) in sorted(detail[r].items(), key=lambda kv: -kv[1][1])[:40]:
         print('   %4d %8.0f us  %s' % (n, t, name))
 
 print('\n== stock-torch kernels longer than 25 us: op, input shapes, enclosing ops')
