@@ -92,6 +92,7 @@ class MultiheadAttPoolLayer(nn.Module):
             nn.init.normal_(lin.weight, mean=0, std=math.sqrt(2.0 / (fan + self.d_k)))
         self.attention = MatrixVectorScaledDotProductAttention(temperature=math.sqrt(self.d_k))
         self.dropout = nn.Dropout(dropout)
+        self._plan = None  # ops.GatherPlan of the block-diagonal operands (built on first use; not part of the state dict)
 
     def forward(self, q, k, mask=None, layout=None):
         """q [b, d_q], k [b, l, d_k], mask [b, l] -> (pooled [b, n_head*d_v], attn [n_head*b, l] head-major).
@@ -107,30 +108,54 @@ class MultiheadAttPoolLayer(nn.Module):
         b, l = k.size(0), k.size(1)
         qs2 = self.w_qs(q)                                                         # [b, nh*dk]
         qs = qs2.view(b, nh, dk)
-        Wk = self.w_ks.weight.view(nh, dk, -1)
-        # per-head products as ONE plain matmul against the block-diagonal weight: the batched form runs (and
-        # differentiates) as batch-of-2 bmm calls, for which rocBLAS picks 48 us kernels at these sizes
-        u = torch.mm(qs2, torch.block_diag(*Wk.unbind(0))).view(b, nh, -1)          # query seen from node space [b, nh, d]
         c = (qs * self.w_ks.bias.view(nh, dk)).sum(2)
-        if layout is not None:
-            u = layout.pad(u)
         from . import ops
-        if layout is not None and ops.pool_attention_supported(nh, k.size(2), l):
-            # the node-sized part as one HIP kernel per direction (scores, mask, softmax, attention dropout, weighted row sum)
-            m = mask if mask is not None else torch.zeros(b, l, dtype=torch.bool, device=k.device)
-            z, attn = ops.pool_attention(u, c, k, m, 1.0 / self.attention.temperature, self.attention.dropout.p, self.training)
-        else:
-            scores = (torch.bmm(u, k.transpose(1, 2)) + c.unsqueeze(2)) / self.attention.temperature  # [b, nh, l]
-            if mask is not None:
-                scores = scores.masked_fill(mask.unsqueeze(1), -np.inf)
-            attn = self.attention.dropout(torch.softmax(scores, dim=2))
-            z = torch.bmm(attn, k)                                                  # [b, nh, d] pooled raw rows
         if layout is not None:
-            z = layout.unpad(z)
-        Wv = self.w_vs.weight.view(nh, dv, -1)
-        out = torch.mm(z.reshape(b, -1), torch.block_diag(*Wv.transpose(1, 2).unbind(0))).view(b, nh, dv) + \
-            self.w_vs.bias.view(nh, dv) * attn.sum(2, keepdim=True)
+            # The per-head products run as ONE plain matmul against a block-diagonal weight (the batched form runs, and differentiates,
+            # as batch-of-2 bmm calls for which rocBLAS picks 48 us kernels at these sizes).  Both block-diagonal operands come out of
+            # one gather (ops.GatherPlan), already in the head-padded layout of the node rows: no block_diag / pad / unpad kernels and
+            # their backward per step (8 + 6 launches, which is what a 10-subgraph step is made of).
+            BDk, BDv = self._packed_operands(layout)
+            u = torch.mm(qs2, BDk).view(b, nh, layout.DP)                          # query seen from (padded) node space
+            if ops.pool_attention_supported(nh, k.size(2), l):
+                # the node-sized part as one HIP kernel per direction (scores, mask, softmax, attention dropout, weighted row sum)
+                m = mask if mask is not None else torch.zeros(b, l, dtype=torch.bool, device=k.device)
+                z, attn = ops.pool_attention(u, c, k, m, 1.0 / self.attention.temperature, self.attention.dropout.p, self.training)
+            else:
+                z, attn = self._pool_rows(u, c, k, mask)
+            out = torch.mm(z.reshape(b, -1), BDv).view(b, nh, dv)
+        else:
+            Wk = self.w_ks.weight.view(nh, dk, -1)
+            u = torch.mm(qs2, torch.block_diag(*Wk.unbind(0))).view(b, nh, -1)      # query seen from node space [b, nh, d]
+            z, attn = self._pool_rows(u, c, k, mask)
+            Wv = self.w_vs.weight.view(nh, dv, -1)
+            out = torch.mm(z.reshape(b, -1), torch.block_diag(*Wv.transpose(1, 2).unbind(0))).view(b, nh, dv)
+        out = out + self.w_vs.bias.view(nh, dv) * attn.sum(2, keepdim=True)
         return self.dropout(out.reshape(b, nh * dv)), attn.transpose(0, 1).reshape(nh * b, l)
+
+    def _pool_rows(self, u, c, k, mask):
+        scores = (torch.bmm(u, k.transpose(1, 2)) + c.unsqueeze(2)) / self.attention.temperature  # [b, nh, l]
+        if mask is not None:
+            scores = scores.masked_fill(mask.unsqueeze(1), -np.inf)
+        attn = self.attention.dropout(torch.softmax(scores, dim=2))
+        return torch.bmm(attn, k), attn                                             # [b, nh, d] pooled raw rows
+
+    def _packed_operands(self, layout):
+        """(BDk [nh*dk, nh*DP], BDv [nh*DP, nh*dv]): blockdiag(Wk_h) with its columns, blockdiag(Wv_h^T) with its rows, at the head-padded
+        positions of the node features (zeros elsewhere)."""
+        from . import ops
+        nh, dk, dv, DP, pos = self.n_head, self.d_k, self.d_v, layout.DP, layout.dense_pos
+
+        def build(ids):
+            Wk_i, Wv_i = ids
+            BDk, BDv = Wk_i.new_zeros(nh * dk, nh * DP), Wv_i.new_zeros(nh * DP, nh * dv)
+            for h in range(nh):
+                BDk[h * dk:(h + 1) * dk, h * DP + pos] = Wk_i[h * dk:(h + 1) * dk]
+                BDv[h * DP + pos, h * dv:(h + 1) * dv] = Wv_i[h * dv:(h + 1) * dv].t()
+            return [BDk, BDv]
+        if self._plan is None:
+            self._plan = ops.GatherPlan()
+        return self._plan((self.w_ks.weight, self.w_vs.weight), build)
 
 
 class CustomizedEmbedding(nn.Module):
