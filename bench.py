@@ -209,12 +209,19 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
     run_eager = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
     if use_graph == 'auto' and comm is not None and comm.world > 1:
         use_graph = '0'  # multi-rank runs stay on eager launches unless --graphs 1 asks otherwise (replay + RCCL has not been measured)
+    can_graph = isinstance(b['adj'], data_utils.PackedGraphBatch)
+    picked = None
+    make_runner.last_choice = ''
     if use_graph == 'auto':
-        # measured (profiles/r3_run2_graph_ab.txt): replay beats eager launches wherever the step is bound by the host (10 subgraphs:
-        # 3.92 vs 5.7-6.4 ms) and loses 2.7 % where it is bound by the GPU (320 subgraphs: 9.25 vs 9.00 ms) -- the same
-        # boundary as the natively sequenced stack (ops.use_fused_hop)
+        # measured (profiles/r3_run2_graph_ab.txt, r3_run13_graph_overlap_ab.txt): replay beats eager launches wherever the step is bound
+        # by the host (10 subgraphs: 2.6 vs 5.7-6.4 ms) -- the same boundary as the natively sequenced stack (ops.use_fused_hop).
+        # Above it the step is bound by the GPU on a fast host (320 subgraphs: eager 8.50 vs replay 8.63 ms) and by the HOST on a slow one
+        # (enqueue 8.1 of 8.8 ms, visit 28): there both forms are timed for a few steps and the faster one runs.
         use_graph = ops.use_fused_hop(b['nt'].numel())
-    if not (int(use_graph) and isinstance(b['adj'], data_utils.PackedGraphBatch)):
+        picked = 'size' if use_graph else None
+        if not use_graph and can_graph:
+            picked = 'measured'
+    if not can_graph or not (int(use_graph) or picked == 'measured'):
         return run_eager, run_eager, None
     gs = graphed.GraphedStep(model, nc)
 
@@ -222,6 +229,20 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
         logits, _ = gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], loss_weight)
         if comm is not None:
             comm(logits.view(-1, nc))
+    if picked == 'measured':
+        def ms_of(fn, n=6):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        t_eager, t_replay = ms_of(run_eager), ms_of(run)
+        make_runner.last_choice = f'chosen by measurement: eager {t_eager:.3f} ms vs replay {t_replay:.3f} ms per step over 6 steps each'
+        if t_eager <= t_replay:
+            return run_eager, run_eager, None
     return run, run_eager, gs
 
 
@@ -496,6 +517,7 @@ def main():
     timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
     ops.set_kernels(timed)
     run, run_eager, gs = make_runner(model, b, nc, loss_weight, params, comm, args.graphs)
+    headline_choice = make_runner.last_choice
 
     def sync():
         torch.cuda.synchronize()
@@ -585,9 +607,9 @@ def main():
             'repeats': len(regions), 'repeat_ms_per_step': [round(r[0] / args.steps * 1e3, 3) for r in regions],
             'value_is': f'median of {len(regions)} timed regions of {args.steps} steps each (max over ranks per region)',
             'host_enqueue_ms_per_step': round(enq / args.steps * 1e3, 3), 'host_bound': bool(enq > 0.9 * dt),
-            'hip_graph': (f'one hipGraph replay per step ({gs.n_graphs} capture(s): qagnn_amd.graphed.GraphedStep; side streams in the capture: '
-                          f'graph preparation {bool(gs.overlap and ops.PREP_OVERLAP)}, weight gradients {bool(gs.overlap and gs.wgrad_overlap and ops.WGRAD_OVERLAP)})'
-                          if gs is not None else 'eager launches'),
+            'hip_graph': ((f'one hipGraph replay per step ({gs.n_graphs} capture(s): qagnn_amd.graphed.GraphedStep; side streams in the capture: '
+                           f'graph preparation {bool(gs.overlap and ops.PREP_OVERLAP)}, weight gradients {bool(gs.overlap and gs.wgrad_overlap and ops.WGRAD_OVERLAP)})'
+                           if gs is not None else 'eager launches') + (f'; {headline_choice}' if headline_choice else '')),
             'config': {'workload': f'{HEADLINE}: ' + wl['what'] + ', 5-layer GAT d=200 H=4, QAGNN decoder fwd+bwd (LM encoder excluded: random '
                                    f'sent_vecs), dropout {args.dropout}, train-mode BN',
                        'subgraphs_per_gpu': B, 'nodes': N, 'edges': E, 'edges_with_self_loops': Ep,
