@@ -498,6 +498,7 @@ class QAGNN(nn.Module):
         self.fc = MLP(concept_dim + sent_dim + concept_dim, fc_dim, 1, n_fc_layer, p_fc, layer_norm=True)
         self.dropout_e = nn.Dropout(p_emb)
         self.dropout_fc = nn.Dropout(p_fc)
+        self._input_plan = None  # ops.GatherPlan of cpt_transform's packed layouts (built on first use; not part of the state dict)
         if init_range > 0:
             self.apply(self._init_weights)
 
@@ -535,9 +536,14 @@ class QAGNN(nn.Module):
             # (:153-156) as one gather-GEMM + GELU/dropout pass, straight into the kernels' head-padded layout; context-node rows
             # (ridx = -1) take svec2nvec(sent_vecs) instead of an entity embedding
             L = head_layout(self.concept_dim, dev)
-            gnn_input = ops.concept_input(ce.emb.weight, ridx, L.pad(ce.cpt_transform.weight.t()),
-                                          L.pad(ce.cpt_transform.bias), L.pad(self.svec2nvec(sent_vecs)), n,
-                                          self.dropout_e.p, self.training)
+            # cpt_transform in the kernels' layouts (W^T and W, head-padded, + the padded bias) out of ONE gather (ops.GatherPlan)
+            # instead of a transpose, two pads and a transpose copy per step -- and their backward
+            if self._input_plan is None:
+                self._input_plan = ops.GatherPlan()
+            Wc_t, Wc, bc = self._input_plan((ce.cpt_transform.weight, ce.cpt_transform.bias),
+                                            lambda ids: [L.pad(ids[0].t()), L.pad(ids[0].t()).t().contiguous(), L.pad(ids[1])])
+            gnn_input = ops.concept_input(ce.emb.weight, ridx, Wc_t, bc, L.pad(self.svec2nvec(sent_vecs)), n,
+                                          self.dropout_e.p, self.training, Wc=Wc)
         else:
             gnn_input0 = self.activation(self.svec2nvec(sent_vecs)).unsqueeze(1)
             gnn_input1 = self.concept_emb(concept_ids[:, 1:] - 1, emb_data).to(dev)

@@ -567,11 +567,14 @@ class EdgeAttnFn(torch.autograd.Function):
         ctx.save_for_backward(KMQ, EkEm, a, alpha)
         ctx.graph, ctx.HP, ctx.qscale = graph, HP, qscale
         ctx.mark_non_differentiable(a)
+        ctx.set_materialize_grads(False)  # `a` gets no gradient: without this autograd zero-fills an [E', 4] tensor per layer and step
         return aggr, a
 
     @staticmethod
     @_bwd
     def backward(ctx, G, _da):
+        if G is None:
+            return None, None, None, None, None
         KMQ, EkEm, a, alpha = ctx.saved_tensors
         flush_wgrads(G)  # queued weight-gradient GEMMs go out on the side stream now: they run under the gather-bound kernels
         dKMQ, dEkEm = kernels().edge_attn_bwd(ctx.graph, KMQ, EkEm, ctx.HP, ctx.qscale, a, alpha, G.contiguous())
@@ -620,11 +623,14 @@ class GatMlpFn(torch.autograd.Function):
         ctx.cfg = (training, p, seed, R, apply_act)
         ctx.defer = _DEFER[0]
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)  # (no zero-filled stand-ins for the gradients of mean / var)
         return y, mean, var
 
     @staticmethod
     @_bwd
     def backward(ctx, dy, _dm, _dv):
+        if dy is None:
+            return (None,) * 19
         K = kernels()
         aggr, h1, out, mean, invstd, scale, shift, W1, W2, gamma, row_weight, W1t, W2t = ctx.saved_tensors
         training, p, seed, R, apply_act = ctx.cfg
@@ -762,11 +768,14 @@ class HopFn(torch.autograd.Function):
         ctx.acc = acc if acc is not None else (None, False, None, False)  # GradAcc of X / S and whether this hop returns the totals
         a = saved[1][0]
         ctx.mark_non_differentiable(a)
+        ctx.set_materialize_grads(False)  # (no zero-filled [E', 4] stand-in for the gradient of `a`)
         return y, a
 
     @staticmethod
     @_bwd
     def backward(ctx, dy, _da):
+        if dy is None:
+            return (None,) * 30
         K = kernels()
         graph, HP, qscale, batch_stats, eps, p, seed, apply_act, nprm = ctx.cfg
         t = ctx.saved_tensors
@@ -893,9 +902,9 @@ class ConceptInputFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed):
+    def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed, Wc=None):
         K = kernels()
-        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx, B1n=Wc_t.t().contiguous())
+        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx, B1n=Wc if Wc is not None else Wc_t.t().contiguous())
         B = ctx_pre.size(0)
         pre.view(B, n, -1)[:, 0] = ctx_pre
         ctx.save_for_backward(emb_w, rowidx, pre)
@@ -915,12 +924,14 @@ class ConceptInputFn(torch.autograd.Function):
         else:
             dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx), K.colsum(dpre)
         dbc = cs[0] - dctx.sum(0)  # the bias only acts on the entity rows (context-node rows were overwritten)
-        return None, None, dWc_t, dbc, dctx, None, None, None
+        return None, None, dWc_t, dbc, dctx, None, None, None, None
 
 
-def concept_input(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, training):
+def concept_input(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, training, Wc=None):
+    """Wc_t [in, DP], bc [DP]: cpt_transform in the kernels' layout; Wc [DP, in]: the same weight the other way round (optional: saves
+    a transpose copy per step when the caller packs both with one gather)."""
     p = float(p) if training else 0.0
-    return ConceptInputFn.apply(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, next_seed() if p > 0 else 0)
+    return ConceptInputFn.apply(emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, next_seed() if p > 0 else 0, Wc)
 
 
 QSCALE = lambda dh: 1.0 / math.sqrt(dh)  # noqa: E731  (query / sqrt(dim_per_head), modeling_qagnn.py:469)

@@ -133,7 +133,7 @@ PY
         python scripts/pmc_sq_by_kernel.py "$(find /tmp/sqp$i -name '*counter_collection.csv' | head -n 1)" 2>&1 | grep "nn_split\|Traceback\|Error" | head -n 20 >> gpurun_out/sqpmc.txt
       done; stamp sqpmc ;;
     census)   # kernel launches of one step by forward region (backward attributed through autograd sequence numbers)
-      timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 400 > gpurun_out/op_census.txt; stamp census ;;
+      timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 700 > gpurun_out/op_census.txt; stamp census ;;
     hostprof)
       timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt; stamp hostprof ;;
     cmd:*)
