@@ -445,3 +445,33 @@ def test_whole_stack_operator_equals_per_hop_path(case):
     assert torch.equal(l0, l1) and torch.equal(l0, l2)
     assert set(g0) == set(g1) and all(torch.equal(g0[k], g1[k]) for k in g0) and all(torch.equal(g0[k], g2[k]) for k in g0)
     assert all(torch.equal(b0[k], b1[k]) for k in b0)
+
+
+@pytest.mark.parametrize('d,nh', [(200, 2), (100, 2), (32, 4)])
+def test_pooling_head_packed_operands_equal_the_generic_form(d, nh):
+    """MultiheadAttPoolLayer with a HeadLayout takes both block-diagonal operands out of one gather, already in the head-padded layout
+    of the node rows (layers._packed_operands); without a layout it builds torch.block_diag per call.  Same function: outputs, attention
+    and every parameter gradient agree in float64 to rounding, on padded node rows with zero pads."""
+    from qagnn_amd.layers import MultiheadAttPoolLayer
+    torch.manual_seed(3)
+    b, l, dq = 3, 7, 24
+    L = ops.HeadLayout(d, 'cpu')
+    pool = MultiheadAttPoolLayer(nh, dq, d, dropout=0.0).double()
+    pool.attention.dropout.p = 0.0
+    q = torch.randn(b, dq, dtype=torch.float64)
+    k = torch.randn(b, l, d, dtype=torch.float64, requires_grad=True)
+    mask = torch.zeros(b, l, dtype=torch.bool)
+    mask[0, 4:] = True
+    res = []
+    for layout in (None, L):
+        pool.zero_grad()
+        k.grad = None
+        kk = L.pad(k) if layout is not None else k
+        out, attn = pool(q, kk, mask, layout=layout)
+        (out * torch.arange(1, out.numel() + 1, dtype=torch.float64).view_as(out)).sum().backward()
+        res.append((out.detach(), attn.detach(), k.grad.clone(), {n: p.grad.clone() for n, p in pool.named_parameters()}))
+    (o0, a0, gk0, g0), (o1, a1, gk1, g1) = res
+    assert torch.allclose(o0, o1, rtol=1e-12, atol=1e-13) and torch.allclose(a0, a1, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(gk0, gk1, rtol=1e-11, atol=1e-13)
+    for n in g0:  # (w_ks.bias shifts every score of a (sample, head) alike: its exact gradient is 0, both sides hold ~1e-14 of rounding)
+        assert torch.allclose(g0[n], g1[n], rtol=1e-11, atol=1e-12), n
