@@ -226,6 +226,9 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       NN_STAMP(kt, 3);
       gload(min(kt + 1, nkt - 1));  // in flight under the MFMAs; past the last tile: a redundant reload, never stored
       NN_STAMP(kt, 4);
+      // the wave in its MFMA phase goes first at the SIMD's issue port (over the co-resident block's wave, which is in its load / split
+      // phase): 3-6 % on the products alone, 0.1-0.4 % on the step (profiles/r3_run36_setprio.txt)
+      __builtin_amdgcn_s_setprio(1);
       bf16x8 af[SRT][3];
 #pragma unroll
       for (int i = 0; i < SRT; ++i)
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(STHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           acc[i][j] = c;
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       NN_STAMP(kt, 5);
     }
 
@@ -536,6 +540,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     gidx(t + 1);
     __syncthreads();
     gload(t + 1);  // in flight under the MFMAs; past the last tile: rows of the next chunk (or zeros), never stored
+    __builtin_amdgcn_s_setprio(1);  // (as in k_gemm_nn_split: the MFMA phase goes first)
     bf16x8 af[MT > 0 ? MT : 1][3];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -569,6 +574,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         accr[s] = c;
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
 #undef QAGNN_SIX
 

@@ -70,6 +70,13 @@ for arg in "$@"; do
         echo "== library: ${lib:-qagnn_amd/libqagnn_hip.so (shipped)}" >> gpurun_out/nn_ablate.txt
         python scripts/nn_micro_trace.py "$(find /tmp/nna -name '*kernel_trace.csv' | head -n 1)" --big >> gpurun_out/nn_ablate.txt 2>&1
       done; stamp nnabl ;;
+    nnvar)   # build variants of the NN split GEMM at M = 64 000 (tools/bin/libqagnn_hip_<name>.so, names in NNVAR)
+      for lib in "" $NNVAR; do
+        rm -rf /tmp/nna; mkdir -p /tmp/nna
+        ( cd /tmp && QAGNN_LIB=${lib:+$REPO/tools/bin/libqagnn_hip_$lib.so} timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nna -o m -- python "$REPO/tools/nn_micro.py" ) > /tmp/nna.log 2>&1
+        echo "== library: ${lib:-shipped}" >> gpurun_out/nn_variants.txt
+        python scripts/nn_micro_trace.py "$(find /tmp/nna -name '*kernel_trace.csv' | head -n 1)" --big >> gpurun_out/nn_variants.txt 2>&1
+      done; stamp nnvar ;;
     prof10)
       rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 0 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log
@@ -99,6 +106,17 @@ PY
         python -c "import json; d = json.load(open('/tmp/probe10.json')); print(d['ms_per_step'], d['hip_graph'])" >> gpurun_out/probe10.txt 2>&1
         grep -i "warn\|error\|GraphedStep" /tmp/probe10.err | cut -c1-400 | head -n 6 >> gpurun_out/probe10.txt
       done; stamp probe10 ;;
+    ablib:*)   # ablib:<name>  -- the shipped library vs tools/bin/libqagnn_hip_<name>.so, whole step, interleaved
+      name="${arg#ablib:}"
+      for lib in "" "$name" "" "$name"; do
+        echo "library: ${lib:-shipped}" >> gpurun_out/ablib_$name.txt
+        QAGNN_LIB=${lib:+$REPO/tools/bin/libqagnn_hip_$lib.so} timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 > /tmp/ab_line.txt
+        python - <<PY >> gpurun_out/ablib_$name.txt
+import json
+d = json.load(open('/tmp/ab_line.txt'))
+print(d['value'], d['ms_per_step'], d['repeat_ms_per_step'], d['breakdown_ms_per_step'], d['hip_graph'][-70:])
+PY
+      done; stamp "ablib:$name" ;;
     abq:*)   # abq:<questions>:<VAR>  -- interleaved A/B (0 1 0 1) of a switch at a given number of questions
       spec="${arg#abq:}"; q="${spec%%:*}"; var="${spec#*:}"
       for v in 0 1 0 1; do
