@@ -80,7 +80,7 @@ class _PlanGatherFn(torch.autograd.Function):
     @staticmethod
     @_fwd
     def forward(ctx, plan, *sources):
-        flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
+        flat = torch.cat([t.reshape(-1) for t in sources] + [plan.zeros[:1]])  # (the appended zero element: the plan's cached zeros, no fill)
         packed = flat.index_select(0, plan.idx)
         ctx.plan = plan
         ctx.src_shapes = [t.shape for t in sources]
