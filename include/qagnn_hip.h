@@ -161,6 +161,11 @@ int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, 
                       int32_t No, const float* a_scale, const float* a_shift /* BN+ReLU prologue on A, or NULL */,
                       const int64_t* a_rowidx /* [R] or NULL: row r of A is A[a_rowidx[r]], negative = zero row */,
                       int32_t accumulate, float* workspace, qagnn_stream_t stream);
+/* C [Ka1 + Ka2, No] = [A1 | A2]^T B (rows [0, Ka1) from A1, the rest from A2): the two weight gradients of a product with two A operands
+ * (modeling_qagnn.py:464-466 on [x ; extra]: dWx^T = X^T dK|dM|dQ, dWs^T = S^T dK|dM|dQ) in ONE split-K launch and one chunk sum where
+ * the bf16-split kernel takes the shapes, two qagnn_gemm_tn_f32 calls otherwise.  workspace: qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No). */
+int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
+                       float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream);
 /* Same, and additionally  bsum[g][no] = sum_r [grp(r) == g] B[r][no]  (groups in 1..4; b_rowidx NULL = one group): the
  * bias gradient (and the node-type-table gradient) of a Linear falls out of the weight-gradient GEMM's B tiles for free
  * instead of costing separate passes over dC. */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn_colsum_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 12  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace)
+ABI_VERSION = 13  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -80,6 +80,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
+    lib.qagnn_gemm_tn2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]
     lib.qagnn_gemm_tn_colsum_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
@@ -447,6 +448,23 @@ class HipKernels(metaclass=_GuardedMeta):
                                                colsum_groups, ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_gemm_tn_colsum_f32')
         return (out, bsum) if colsum_groups else out
+
+    def gemm_tn2(self, A1, A2, B, out=None):
+        """[A1 | A2]^T B -> [Ka1 + Ka2, No]: two weight gradients that share their B operand, one launch (qagnn_gemm_tn2_f32)."""
+        _chk2d(A1, 'A1'), _chk2d(A2, 'A2'), _chk2d(B, 'B')
+        Ka1, Ka2 = A1.size(1), A2.size(1)
+        R, No = B.shape
+        assert A1.size(0) == R and A2.size(0) == R
+        if out is None:
+            out = torch.empty((Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
+        else:
+            _chk2d(out, 'out')
+            assert out.shape == (Ka1 + Ka2, No)
+        ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
+        rc = self.lib.qagnn_gemm_tn2_f32(A1.data_ptr(), Ka1, Ka1, A2.data_ptr(), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No,
+                                         ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_gemm_tn2_f32')
+        return out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------
     def _colreduce(self, mode, X, X2, rowidx, groups, mean, invstd, scale, shift, nout, out_scale=1.0, roww=None, out=None):

@@ -15,6 +15,9 @@ bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affi
 int tn_split_chunk_rows(int R, int Ka, int No, int lo);
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
                     const int64_t* a_rowidx, int chunk_rows, hipStream_t stream);
+int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo);
+int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
+                     int chunk_rows, hipStream_t stream);
 
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \

@@ -818,6 +818,33 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
   return QAGNN_OK;
 }
 
+// C [Ka1 + Ka2, No] = [A1 | A2]^T B: the two weight gradients that share their B operand (X^T dK|dM|dQ and S^T dK|dM|dQ of a hop) as ONE
+// split-K launch and ONE chunk sum where the bf16-split kernel takes the shapes; otherwise two qagnn_gemm_tn_f32 calls.
+extern "C" int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
+                                  int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  QAGNN_REQUIRE(A1 && A2 && B && C && workspace, QAGNN_EINVAL, "gemm_tn2: null pointer");
+  QAGNN_REQUIRE(R > 0 && Ka1 > 0 && Ka2 > 0 && No > 0 && Ka1 % 4 == 0 && Ka2 % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
+                "gemm_tn2: bad sizes R=%d Ka1=%d Ka2=%d No=%d (Ka, No multiples of 4)", R, Ka1, Ka2, No);
+  QAGNN_REQUIRE(lda1 % 4 == 0 && lda2 % 4 == 0 && ldb % 4 == 0 && aligned16(A1) && aligned16(A2) && aligned16(B), QAGNN_EINVAL,
+                "gemm_tn2: operands must be 16-byte aligned with pitches multiple of 4");
+  const bool merged = tn_split_ok(R, Ka1, No, lda1, ldb, false, false) && tn_split_ok(R, Ka2, No, lda2, ldb, false, false) && ldc % 4 == 0 &&
+                      aligned16(C);
+  if (!merged) {
+    int rc = qagnn_gemm_tn_f32(A1, lda1, B, ldb, C, ldc, R, Ka1, No, nullptr, nullptr, nullptr, 0, workspace, stream_);
+    if (rc != QAGNN_OK) return rc;
+    return qagnn_gemm_tn_f32(A2, lda2, B, ldb, C + (int64_t)Ka1 * ldc, ldc, R, Ka2, No, nullptr, nullptr, nullptr, 0, workspace, stream_);
+  }
+  const int crows = tn_split2_chunk_rows(R, Ka1, Ka2, No, tn_split_min_chunk(R));
+  const int nchunks = cdiv(R, crows), Ka = Ka1 + Ka2;
+  int rc = launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream);
+  if (rc != QAGNN_OK) return rc;
+  const int64_t tot = (int64_t)Ka * No;
+  k_sum_chunks4<<<cdiv(tot / 4, 64), SC_G * 64, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, 0);
+  QAGNN_LAUNCH_CHECK("k_sum_chunks");
+  return QAGNN_OK;
+}
+
 extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, float* C, int32_t ldc, int32_t R,
                                  int32_t Ka, int32_t No, const float* a_scale, const float* a_shift, const int64_t* a_rowidx,
                                  int32_t accumulate, float* workspace, qagnn_stream_t stream_) {

@@ -424,7 +424,8 @@ __device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_e
 template <int KT, int NT, bool AFFINE, bool GATHER>
 __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_split(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
-    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const int64_t* __restrict__ a_rowidx) {
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const int64_t* __restrict__ a_rowidx,
+    const float* __restrict__ A2, int lda2, int Ka2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
   constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
   constexpr int MT = KT / 4, REM = KT % 4, RS = (REM * NT + 3) / 4;  // full strips per wave; leftover strips, shared tile by tile
@@ -438,7 +439,16 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   uint16_t* const Maj = A_MAJOR ? As : Bs;
   uint16_t* const Min = A_MAJOR ? Bs : As;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * BC, m0 = blockIdx.y * AC, chunk = blockIdx.z;
+  // Two A operands (A2 != nullptr): the product [A | A2]^T B, rows [0, Ka) of the output from A, rows [Ka, Ka + Ka2) from A2 -- the
+  // row tiles of A2 follow those of A in blockIdx.y, and such a block simply works on the other operand (one launch and one chunk sum
+  // for the two weight gradients that share dK|dM|dQ: X^T dKMQ and S^T dKMQ)
+  const int ka_total = Ka + (A2 ? Ka2 : 0);
+  int by = blockIdx.y, row_shift = 0;
+  if (A2 != nullptr) {
+    const int n1 = (Ka + AC - 1) / AC;
+    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
+  }
+  const int n0 = blockIdx.x * BC, m0 = by * AC, chunk = blockIdx.z;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
 
@@ -578,12 +588,12 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 #undef QAGNN_SIX
 
-  float* const Pc = P + (int64_t)chunk * Ka * No;
+  float* const Pc = P + (int64_t)chunk * ka_total * No;
   auto put = [&](int strip, int j, const f32x4s& c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + strip * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
-      if (row < Ka && col < No) Pc[(int64_t)row * No + col] = c[r];
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = c[r];
     }
   };
 #pragma unroll
@@ -599,7 +609,8 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
 template <int KT, int NT, bool AFFINE, bool GATHER = false>
 static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
-                             const float* sc, const float* sh, int chunk_rows, const int64_t* ridx = nullptr) {
+                             const float* sc, const float* sh, int chunk_rows, const int64_t* ridx = nullptr, const float* A2 = nullptr,
+                             int lda2 = 0, int Ka2 = 0) {
   constexpr size_t lds = (size_t)3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t);
   static bool raised[64] = {};
   int dev = 0;
@@ -609,7 +620,7 @@ static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int 
     if (e != hipSuccess) { set_error("gemm_tn_split: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
+  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx, A2, lda2, Ka2);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_split");
   return QAGNN_OK;
 }
@@ -634,6 +645,19 @@ int tn_split_chunk_rows(int R, int Ka, int No, int lo) {
   const int rows = (cdiv(R, target > 0 ? target : 1) + TKR - 1) / TKR * TKR;
   const int lo32 = (lo + TKR - 1) / TKR * TKR;
   return rows > lo32 ? rows : lo32;
+}
+// [A1 | A2]^T B in one launch: 112-row output tiles (the (7, 13) shape) over A1's columns, then over A2's
+int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
+  const int blocks_per_chunk = cdiv(No, 208) * (cdiv(Ka1, 112) + cdiv(Ka2, 112));
+  const int target = 2 * split_num_cus() / blocks_per_chunk;
+  const int rows = (cdiv(R, target > 0 ? target : 1) + TKR - 1) / TKR * TKR;
+  const int lo32 = (lo + TKR - 1) / TKR * TKR;
+  return rows > lo32 ? rows : lo32;
+}
+int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
+                     int chunk_rows, hipStream_t stream) {
+  dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
+  return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
                     const int64_t* ridx, int chunk_rows, hipStream_t stream) {

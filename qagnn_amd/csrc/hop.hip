@@ -126,7 +126,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
 
 extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t cls_part_rows) {
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
-  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
+  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, DP + SP, 3 * DP));
   // two sets of the buffers the weight-gradient stream reads (d out, d h1, d K|M|Q) + what the main stream keeps to itself
   return 2 * (2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP)) + up4((int64_t)N * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
          up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
@@ -202,7 +202,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   float* rs = w.take((int64_t)N * 4);
   float* cls_part = w.take(((int64_t)h->g->max_chunks + (int64_t)QAGNN_CLS_SLICES * h->g->C) * 2 * DP);
   int64_t tn = max64(qagnn_gemm_tn_workspace_elems(N, DP, DP), qagnn_gemm_tn_workspace_elems(N, DP, 3 * DP));
-  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, SP, 3 * DP));
+  if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, DP + SP, 3 * DP));
   float* tnws = w.take(tn);  // split-K partials: used by the weight-gradient products only, which are in order on one stream
   float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));  // column-reduction partials: main stream only
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
@@ -246,9 +246,13 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
                                   cls_part, stream));
   // projection: weight gradients, node-type-table gradient, data gradients
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
-  HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
-  if (SP > 0)
-    HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
+  if (SP > 0 && h->dWs_t == h->dWx_t + (int64_t)DP * 3 * DP) {  // the two gradients are one [DP + SP, 3 DP] matrix: one launch
+    HOP_TRY(qagnn_gemm_tn2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, tnws, wstream));
+  } else {
+    HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
+    if (SP > 0)
+      HOP_TRY(qagnn_gemm_tn_f32(h->S, SP, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, SP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
+  }
   if (SP > 0 && h->tab_col >= 0) {
     // the type indicators ride in S's padding columns: their rows of dWs_t ARE the type-table gradient
     QAGNN_REQUIRE(h->tab_col + h->T <= SP, QAGNN_EINVAL, "hop_bwd: tab_col=%d + T=%d exceeds SP=%d", h->tab_col, h->T, SP);

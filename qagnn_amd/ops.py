@@ -388,12 +388,18 @@ class LinearNNFn(torch.autograd.Function):
         want_tab, want_bias = has_tab and need[7], has_bias and need[6]
         if ctx.defer:  # weight gradients queued for the next edge backward (see defer_wgrads)
             jobs, dB1t, dB2t = [], None, None
-            if need[1]:
-                dB1t = _wg_empty(dC, (A1.size(1), dC.size(1)))
-                jobs.append(lambda: K.gemm_tn(A1, dC, out=dB1t))
-            if A2 is not None and need[4]:
-                dB2t = _wg_empty(dC, (A2.size(1), dC.size(1)))
-                jobs.append(lambda: K.gemm_tn(A2, dC, out=dB2t))
+            if need[1] and A2 is not None and need[4]:
+                # both weight gradients share dC: ONE split-K launch and one chunk sum into one [K1 + K2, No] buffer (qagnn_gemm_tn2_f32)
+                joint = _wg_empty(dC, (A1.size(1) + A2.size(1), dC.size(1)))
+                dB1t, dB2t = joint[:A1.size(1)], joint[A1.size(1):]
+                jobs.append(lambda: K.gemm_tn2(A1, A2, dC, out=joint))
+            else:
+                if need[1]:
+                    dB1t = _wg_empty(dC, (A1.size(1), dC.size(1)))
+                    jobs.append(lambda: K.gemm_tn(A1, dC, out=dB1t))
+                if A2 is not None and need[4]:
+                    dB2t = _wg_empty(dC, (A2.size(1), dC.size(1)))
+                    jobs.append(lambda: K.gemm_tn(A2, dC, out=dB2t))
             if want_tab and ctx.tabcol >= 0 and dB2t is not None and not want_bias:
                 drowtab = dB2t[ctx.tabcol:ctx.tabcol + G]  # (deferred with dB2t: its consumer, SplitColsFn.backward, joins the side stream)
             elif want_tab:  # consumed inside the graph (table GEMM backward): stays on the main stream
@@ -415,16 +421,20 @@ class LinearNNFn(torch.autograd.Function):
             if A2 is not None and need[3]:
                 dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
             return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
-        cs = None
+        cs = joint = None
         if FUSED_COLSUM and need[1] and (want_tab or want_bias):
             # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
             dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
         else:
-            dB1t = K.gemm_tn(A1, dC) if need[1] else None
+            joint = K.gemm_tn2(A1, A2, dC) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
+            dB1t = joint[:A1.size(1)] if joint is not None else (K.gemm_tn(A1, dC) if need[1] else None)
             tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
             if (want_tab or want_bias) and not tab_from_wgrad:
                 cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
-        dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
+        if joint is not None:
+            dB2t = joint[A1.size(1):]
+        else:
+            dB2t = K.gemm_tn(A2, dC) if (A2 is not None and need[4]) else None
         if want_tab and ctx.tabcol >= 0 and dB2t is not None and cs is None:
             cs = dB2t[ctx.tabcol:ctx.tabcol + G]
         if want_tab:
@@ -741,8 +751,11 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     dW1t = K.gemm_tn(aggr, dh1)
     daggr = K.gemm_nn(dh1, W1, B1n=W1t)
     dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
-    dWx_t = K.gemm_tn(X, dKMQ)
-    dWs_t = K.gemm_tn(S, dKMQ) if S is not None else None
+    if S is not None:  # one launch for both (qagnn_gemm_tn2_f32), like qagnn_hop_bwd_f32 when its two outputs are adjacent
+        joint = K.gemm_tn2(X, S, dKMQ)
+        dWx_t, dWs_t = joint[:X.size(1)], joint[X.size(1):]
+    else:
+        dWx_t, dWs_t = K.gemm_tn(X, dKMQ), None
     if dWs_t is not None and tab_col >= 0:
         dTT = dWs_t[tab_col:tab_col + TT.size(0)]  # (a view) rows of the type indicators in S (qagnn_hop_args.tab_col)
     else:

@@ -212,6 +212,11 @@ class EmuKernels:
             return C, self.colsum(B, b_rowidx, colsum_groups)
         return C
 
+    def gemm_tn2(self, A1, A2, B, out=None):
+        _chk(A1, A2, B, out)
+        C = torch.cat([A1, A2], 1).t() @ B
+        return C if out is None else out.copy_(C)
+
     def colsum(self, X, rowidx=None, groups=1, scale=1.0, roww=None, out=None):
         if roww is not None:
             X = X * roww.unsqueeze(1)

@@ -190,6 +190,28 @@ def test_gemm_tn(R, Ka, No, affine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('R,Ka1,Ka2,No', [(64000, 208, 112, 624), (2000, 208, 112, 624), (12800, 208, 208, 208), (5000, 208, 16, 624),
+                                          (700, 32, 16, 96), (1500, 100, 112, 208)])
+def test_gemm_tn_two_operands(R, Ka1, Ka2, No):
+    """qagnn_gemm_tn2_f32: [A1 | A2]^T B in one launch (the merged bf16-split launch where both shapes qualify, two plain calls
+    otherwise) == the two products, on the fp32 backward-error bound of test_gemm_tn; rows past the operands' widths never leak."""
+    g = torch.Generator().manual_seed(R + Ka1 + Ka2)
+    A1, A2, B = torch.randn(R, Ka1, generator=g), torch.randn(R, Ka2, generator=g), torch.randn(R, No, generator=g)
+    K = hip()
+    got = K.gemm_tn2(A1.cuda(), A2.cuda(), B.cuda()).cpu()
+    assert got.shape == (Ka1 + Ka2, No)
+    A = torch.cat([A1, A2], 1)
+    ref = A.double().t() @ B.double()
+    bound = 16 * EPS * (A.abs().double().t() @ B.abs().double()) + 1e-6
+    err = (got.double() - ref).abs()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+    # into a caller-provided buffer with a guard row behind it
+    buf = torch.full((Ka1 + Ka2 + 1, No), 7.0).cuda()
+    K.gemm_tn2(A1.cuda(), A2.cuda(), B.cuda(), out=buf[:Ka1 + Ka2])
+    assert torch.equal(buf[:Ka1 + Ka2].cpu(), got) and bool((buf[Ka1 + Ka2] == 7.0).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,V,K,No', [(3000, 500, 1024, 208), (129, 7, 32, 32), (20000, 100000, 1024, 208)])
 def test_gemm_with_fused_row_gather(M, V, K, No):
     """A-operand rows gathered from an embedding table inside the GEMM (a_rowidx), -1 = zero row; forward (NN) and
