@@ -159,7 +159,11 @@ def _tn_flops(A, B, **kw):
     return 2.0 * B.size(0) * A.size(1) * B.size(1)
 
 
-TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn']
+def _tn2_flops(A1, A2, B, **kw):
+    return 2.0 * B.size(0) * (A1.size(1) + A2.size(1)) * B.size(1)
+
+
+TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn', 'gemm_tn2']
 
 
 class Comm:
@@ -335,7 +339,7 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     off (both hide kernels from the events: see main()).  Returns per-step numbers."""
     timed.reset()
     timed.enabled = True
-    timed.active = {'gemm_nn', 'gemm_tn', 'edge_attn_bwd', 'edge_attn_fwd'}
+    timed.active = {'gemm_nn', 'gemm_tn', 'gemm_tn2', 'edge_attn_bwd', 'edge_attn_fwd'}
     overlap, fused, ops.WGRAD_OVERLAP, ops.FUSED_HOP = ops.WGRAD_OVERLAP, ops.FUSED_HOP, False, False
     try:
         for _ in range(n_steps):
@@ -344,10 +348,10 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     finally:
         ops.WGRAD_OVERLAP, ops.FUSED_HOP = overlap, fused
         timed.enabled = False
-    gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn')
-    flops = timed.work['gemm_nn'] + timed.work['gemm_tn']
+    gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn') + timed.total_ms('gemm_tn2')
+    flops = timed.work['gemm_nn'] + timed.work['gemm_tn'] + timed.work['gemm_tn2']
     return dict(gemm_ms=gemm_ms / n_steps, gemm_flops=flops / n_steps,
-                gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn'])) // n_steps,
+                gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn']) + len(timed.events['gemm_tn2'])) // n_steps,
                 edge_fwd_ms=timed.mean_ms('edge_attn_fwd')[0], edge_bwd_ms=timed.mean_ms('edge_attn_bwd')[0],
                 n_edge_fwd=timed.mean_ms('edge_attn_fwd')[1], n_edge_bwd=timed.mean_ms('edge_attn_bwd')[1])
 
@@ -521,7 +525,7 @@ def main():
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     comm = Comm(params, world, assignment=assignment)
-    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops})
+    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops})
     ops.set_kernels(timed)
     run, run_eager, gs = make_runner(model, b, nc, loss_weight, params, comm, args.graphs)
     headline_choice = make_runner.last_choice
@@ -639,7 +643,7 @@ def main():
                                       'achieved_algorithmic': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
                                       'timed_in': 'extra steps after the timed regions, weight-gradient overlap off (see source)'}},
             # the dense side of the step: every GEMM launch, algorithmic FLOPs of the products over their HIP-event time
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'all GEMM launches of the step (qagnn_gemm_nn_split_f32 / qagnn_gemm_nn_f32 / qagnn_gemm_tn_f32)',
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'all GEMM launches of the step (qagnn_gemm_nn_split_f32 / qagnn_gemm_nn_f32 / qagnn_gemm_tn_f32 / qagnn_gemm_tn2_f32)',
                               'achieved': round(gemm_tf, 1), 'unit': 'TFLOP/s',
                               'peak': round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), 'frac': round(gemm_tf / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
                               'peak_is': 'fp32-equivalent ceiling of the kernels that run: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per exact 3 x bf16 product',
