@@ -154,6 +154,14 @@ int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
  * row j = column j of B1 / B2); a->B1 / a->B2 are ignored.  K1, K2 multiples of 4 (any length; tiles are zero-filled). */
 int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                             qagnn_stream_t stream);
+/* The same with a caller-provided scratch buffer `ws` of `ws_bytes` >= qagnn_gemm_nn_pack_bytes(No, K1, K2) bytes (16-byte aligned,
+ * contents undefined before and after): large products (csrc/gemm_nn2.hip) first write B there ONCE, already split into its three
+ * bf16 images in the order the kernel's LDS wants them, and every row tile then streams it into LDS by DMA instead of repeating the
+ * split (19 % of the projection [N, 320] x [320, 624] at N = 64 000).  ws = NULL (or too small, or a small product) = qagnn_gemm_nn_split_f32.
+ * Same arithmetic per output element as the unpacked route: bit-identical results. */
+int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2);
+int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
+                               void* ws, int64_t ws_bytes, qagnn_stream_t stream);
 
 /* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) (includes room for the optional column sums of B) */
 int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);

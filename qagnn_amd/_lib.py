@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
@@ -24,7 +24,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 13  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32)
+ABI_VERSION = 14  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -77,6 +77,9 @@ def load_library(path=LIB_PATH):
     lib.qagnn_radam_step_f32.argtypes = [_i32, _vp, _vp, _vp, _vp, _vp] + [C.c_double] * 6 + [_i32, _vp]
     lib.qagnn_gemm_nn_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp]
     lib.qagnn_gemm_nn_split_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp]
+    lib.qagnn_gemm_nn_pack_bytes.restype = _i64
+    lib.qagnn_gemm_nn_pack_bytes.argtypes = [_i32, _i32, _i32]
+    lib.qagnn_gemm_nn_split_ws_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp, _i64, _vp]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
@@ -255,6 +258,7 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
+        self.PACK_MIN_M = int(os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))  # (the library applies the same threshold)
         self._side_streams = {}  # per device: the stream the natively sequenced hops put their weight-gradient products on
 
     # -- helpers -----------------------------------------------------------------------------------------------
@@ -422,7 +426,15 @@ class HipKernels(metaclass=_GuardedMeta):
                 _chk2d(B2n, 'B2n')
                 assert B2n.shape == (No, A2.size(1))
                 n2, ld2 = B2n.data_ptr(), B2n.size(1)
-            self._check(self.lib.qagnn_gemm_nn_split_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, self._stream()), 'qagnn_gemm_nn_split_f32')
+            if M >= self.PACK_MIN_M:
+                # large products: B is split ONCE into the kernel's LDS image order (scratch from the caching allocator, stream-ordered:
+                # the next product may reuse it), every row tile then streams it by DMA instead of repeating the split
+                ws_bytes = self.lib.qagnn_gemm_nn_pack_bytes(No, K1, A2.size(1) if A2 is not None else 0)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A1.device)
+                self._check(self.lib.qagnn_gemm_nn_split_ws_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, ws.data_ptr(), ws_bytes, self._stream()),
+                            'qagnn_gemm_nn_split_ws_f32')
+            else:
+                self._check(self.lib.qagnn_gemm_nn_split_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, self._stream()), 'qagnn_gemm_nn_split_f32')
             return (out, part) if colstats else out
         assert K1 % 16 == 0 and (A2 is None or A2.size(1) % 16 == 0), 'the fp32-MFMA kernel needs K to be a multiple of 16'
         self._check(self.lib.qagnn_gemm_nn_f32(C.byref(a), self._stream()), 'qagnn_gemm_nn_f32')

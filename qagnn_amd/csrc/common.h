@@ -19,6 +19,13 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo);
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
                      int chunk_rows, hipStream_t stream);
 
+// NN products, second kernel generation (gemm_nn2.hip): A fragments straight from global memory, B double-buffered in LDS
+bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2);
+int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream);
+int64_t nn2_pack_bytes(int No, int K1, int K2);
+bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes);
+int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream);
+
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \
     if (!(cond)) {                     \

@@ -1,0 +1,572 @@
+// NN products of the stack on the bf16 matrix cores by exact operand splitting (see gemm_split.hip for the arithmetic), second
+// kernel generation (round 4).  What changed against k_gemm_nn_split, and why (profiles/r3_run20_nn_sq_counters.txt: the matrix pipe
+// was 54 % busy, a wave spent 23 % parked on barriers and 41 % stalled at issue; every k-tile cost two barriers, an LDS round trip of
+// BOTH operands and ~370 VALU instructions per wave):
+//
+//  * The A operand (activations, streamed from HBM) never touches LDS.  A wave owns 32 rows of the output tile and nobody else
+//    reads them, so its lanes load the MFMA A fragments straight from global memory -- lane l: row l & 15, the 8 consecutive k of
+//    chunk l >> 4 = two 16-byte loads -- and split them in registers into the three bf16 fragments.  LDS traffic and the
+//    split / store work of the A tile (16 KB per k-tile and block) are gone, and so is the second barrier.
+//  * The B operand (weights, L2-resident) goes through LDS as before (all four waves need it), but DOUBLE-buffered and stored in
+//    FRAGMENT order: the image of (column tile j, piece p) is one 1-KB block holding each lane's 16 bytes at a lane-linear slot
+//    (XOR-permuted, below), so a fragment read is ONE conflict-free ds_read_b128 at base + immediate and the writes of the next
+//    tile can be issued between the MFMAs of the current one.  One barrier per k-tile.
+//  * The two K segments ([X | S]: K1 = 208, K2 = 112) are walked as ONE virtual K of 320 = 10 k-tiles (was 7 + 4 zero-padded tiles):
+//    the single tile that straddles the segments is loaded first, synchronously, in the prologue (two loads per lane, one of them
+//    answered with zeros by the bounds check, OR-ed); every tile of the steady-state loop lies in one segment and picks its buffer
+//    descriptor with scalar selects.
+//
+// LDS slot permutation.  Fragment lane l = (x = l & 15, c = l >> 4) keeps its 16 bytes at slot (x ^ 2c) + 16c of the block.
+// ds_read_b128 is serviced in four non-contiguous 16-lane groups (MI355X_MICROARCH.md, LDS), and every group then covers 16
+// different slots mod 16 (checked by enumeration in tests/test_host_logic_emu.py::test_nn2_lds_slots).  The writes are 8-byte halves
+// of a slot, ds_write_b64 is serviced in contiguous 16-lane groups with banks mod 32 (a 128-byte window): loader lanes 16g..16g+15
+// hold two weight rows (x = 2r, 2r + 1) times eight float4 (c = kq >> 1, half = kq & 1), i.e. slots {x ^ 2c} = 8 different values
+// mod 8, both halves each = every bank once.
+//
+// Shapes: block = 4 waves, 128 rows x NT*16 columns, wave = 32 rows x NT column tiles of v_mfma_f32_16x16x32_bf16 (2 x NT x 4
+// accumulator registers), k-tile 32; LDS 2 x NT x 3 KB (78 KB at NT = 13) => two blocks per CU, whose phases drift apart so that one
+// block's split work runs under the other's MFMAs.  Epilogue as in k_gemm_nn_split (16-row slabs through LDS, whole-row 16-byte stores;
+// bias / row table / accumulate / BatchNorm column statistics).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace qagnn {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+namespace nn2 {
+
+// QAGNN_NN2_ABL (tools/nn2_ablate.hip only; numerically wrong, timing only): bit 0 no loads in the steady loop, bit 1 no B split / store,
+// bit 2 no A split, bit 3 no barrier, bit 4 no fragment reads, bit 5 no MFMAs
+#ifndef QAGNN_NN2_ABL
+#define QAGNN_NN2_ABL 0
+#endif
+
+constexpr int BK = 32, BM = 128, WAVES = 4, THR = WAVES * 64;
+constexpr uint32_t OOB = 0x80000000u;  // beyond any operand this kernel is launched on: the buffer load answers with zeros
+
+__device__ __forceinline__ u32x4s bload(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+// x = h1 + h2 + h3 exactly, each h a bf16 number carried in the high half of a dword (see gemm_split.hip)
+__device__ __forceinline__ void split3(uint32_t u, uint32_t& h1, uint32_t& h2, uint32_t& h3) {
+  h1 = u & 0xFFFF0000u;
+  const float r1 = __builtin_bit_cast(float, u) - __builtin_bit_cast(float, h1);
+  h2 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+  const float r2 = r1 - __builtin_bit_cast(float, h2);
+  h3 = __builtin_bit_cast(uint32_t, r2);
+}
+__device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// 8 consecutive k of one row (two 16-byte loads) -> the three bf16x8 fragments
+template <bool AFFINE>
+__device__ __forceinline__ void split_frag(const u32x4s (&r)[2], bf16x8 (&f)[3], const float* __restrict__ sc, const float* __restrict__ sh, float lo) {
+  uint32_t h1[8], h2[8], h3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    uint32_t u = r[e >> 2][e & 3];
+    if constexpr (AFFINE) u = __builtin_bit_cast(uint32_t, fmaxf(fmaf(__builtin_bit_cast(float, u), sc[e], sh[e]), lo));
+    split3(u, h1[e], h2[e], h3[e]);
+  }
+  const u32x4s p1 = {pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]), pack_hi(h1[4], h1[5]), pack_hi(h1[6], h1[7])};
+  const u32x4s p2 = {pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]), pack_hi(h2[4], h2[5]), pack_hi(h2[6], h2[7])};
+  const u32x4s p3 = {pack_hi(h3[0], h3[1]), pack_hi(h3[2], h3[3]), pack_hi(h3[4], h3[5]), pack_hi(h3[6], h3[7])};
+  f[0] = __builtin_bit_cast(bf16x8, p1);
+  f[1] = __builtin_bit_cast(bf16x8, p2);
+  f[2] = __builtin_bit_cast(bf16x8, p3);
+}
+
+// one float4 of a weight row (4 consecutive k) -> 8 bytes per piece at `dst` (+ 1024 per piece)
+__device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s v) {
+  uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
+  split3(v[0], a1, a2, a3);
+  split3(v[1], b1, b2, b3);
+  split3(v[2], c1, c2, c3);
+  split3(v[3], d1, d2, d3);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi(a1, b1), pack_hi(c1, d1));
+  *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(pack_hi(a2, b2), pack_hi(c2, d2));
+  *reinterpret_cast<uint2*>(dst + 2048) = make_uint2(pack_hi(a3, b3), pack_hi(c3, d3));
+}
+
+#define QAGNN_NN2_SIX(C, AF, BF)                                          \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
+
+// ORDER 0: per column tile 12 MFMAs (hipcc interleaves the two row tiles' accumulate chains by itself), then the split work of a B
+// load round as one clump.  ORDER 1: the same instructions pinned as MFMA, 2 VALU, MFMA, 2 VALU, ... (sched_group_barrier).
+// PACKED: B arrives pre-split in the kernel's own LDS image order (k_pack_b below: [k-tile of the walk][column tile][piece][lane] x 16 B,
+// zero-filled past K and No), B1n = that buffer, ldn1 = column tiles per k-tile.  A k-tile of B is then NT * 3 contiguous KB that go
+// to LDS by DMA (global_load_lds, 1 KB per wave-instruction): no registers, no split arithmetic, no ds_write for B in the k-loop
+// (tools/nn2_ablate.hip: the in-kernel split of B costs 19 % of the projection, and it is repeated by all 500 row tiles).
+template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED>
+__global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn2(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
+                                                                                      int ldn1, const float* __restrict__ B2n, int ldn2,
+                                                                                      int ntiles) {
+  constexpr int BN = NT * 16;
+  constexpr int IMG = NT * 3 * 1024;   // bytes of one B image set: [column tile][piece][64 slots x 16 B]
+  constexpr int BR = (NT + 1) / 2;     // load rounds of the B tile: 32 weight rows (output columns) x 8 float4 per round
+  constexpr int PS = BN + 4, SLAB_ROWS = 16;
+  constexpr int SLAB_B = WAVES * SLAB_ROWS * PS * 4;
+  static_assert(SLAB_B + (STATS ? WAVES * 2 * BN * 4 : 0) <= 2 * IMG, "the epilogue reuses the k-loop's LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const aff = reinterpret_cast<float*>(smem + 2 * IMG);  // AFFINE: scale[KA] | shift[KA], KA = K1 rounded up to 32, zero-filled
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = a.M, No = a.No, K1 = a.K1, K2 = a.K2;
+  const int ncb = (No + BN - 1) / BN;
+  // the k-tile walk: [the tile that straddles the segments], the whole tiles of segment 1, the tiles of segment 2 from s2 on
+  const int r1 = K2 > 0 ? (K1 & 31) : 0;
+  const int mixi = r1 != 0 ? 1 : 0;
+  const int n1 = mixi ? (K1 >> 5) : ((K1 + 31) >> 5);
+  const int s2 = mixi ? 32 - r1 : 0;
+  const int n2 = K2 > s2 ? ((K2 - s2 + 31) >> 5) : 0;
+  const int nkt = mixi + n1 + n2;
+  const int KA = (K1 + 31) & ~31;
+
+  // all four operands through buffer descriptors (built once, wave-uniform); a null second segment gets an empty range
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A1), 0, M * a.lda1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A2), 0, K2 > 0 ? M * a.lda2 * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B1n), 0, No * ldn1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B2n), 0, K2 > 0 ? No * ldn2 * 4 : 0, 0x00020000);
+  const uint32_t bstep1 = 128u * (uint32_t)ldn1, bstep2 = 128u * (uint32_t)ldn2;  // bytes between the weight rows of two B load rounds
+  const unsigned char* const pk = reinterpret_cast<const unsigned char*>(B1n);   // PACKED
+
+  if constexpr (AFFINE) {  // once per block: the BatchNorm scale / shift of A1's columns
+    for (int i = tid; i < 2 * KA; i += THR) {
+      const int k = i < KA ? i : i - KA;
+      aff[i] = k < K1 ? (i < KA ? a.a_scale[k] : a.a_shift[k]) : 0.f;
+    }
+  }
+
+  const int ac = lane >> 4;                 // this lane's k chunk (8 k) of a tile, A side
+  const int nl = tid >> 3, kq = tid & 7;    // B loader: weight row of a round, float4 index inside the k-tile
+  // LDS byte offset of the loader's (row, float4) inside a round's two column tiles, and of the fragment reads (see the header)
+  const int bx = nl & 15, bc = kq >> 1;
+  const int wr_off = ((nl >> 4) * 3 * 64 + ((bx ^ (2 * bc)) + 16 * bc)) * 16 + (kq & 1) * 8;
+  const int rd_off = (((lane & 15) ^ (2 * ac)) + 16 * ac) * 16;
+  // the last load round of an odd NT covers one column tile only: the loaders of its second half (waves 2, 3) sit it out
+  const bool last_round_on = (NT & 1) == 0 || w < 2;
+
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int tile = a.xcd_remap ? xcd_remap(vb, ntiles) : vb;
+    const int m0 = (tile / ncb) * BM, n0 = (tile % ncb) * BN;
+    const int nvalid = min(BN, No - n0) - nl;  // load round q is inside the matrix for this loader iff 32 q < nvalid
+
+    f32x4s acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane byte offsets of the operand rows (the k position and B's load round come in as the scalar offset); rows outside: OOB
+    uint32_t arow1[2], arow2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + w * 32 + i * 16 + (lane & 15);
+      arow1[i] = row < M ? (uint32_t)row * (uint32_t)a.lda1 * 4u + (uint32_t)ac * 32u : OOB;
+      arow2[i] = row < M ? (uint32_t)row * (uint32_t)a.lda2 * 4u + (uint32_t)ac * 32u : OOB;
+    }
+    const uint32_t bbase1 = (uint32_t)(n0 + nl) * (uint32_t)ldn1 * 4u + (uint32_t)kq * 16u;
+    const uint32_t bbase2 = (uint32_t)(n0 + nl) * (uint32_t)ldn2 * 4u + (uint32_t)kq * 16u;
+
+    u32x4s ra[2][2], rb[PACKED ? 1 : BR];
+    bf16x8 af[2][3];
+
+    // loads of a tile that lies in one segment (steady state); `it` past the last tile: everything out of range, zeros
+#define QAGNN_NN2_GLOAD(IT)                                                                                              \
+    {                                                                                                                    \
+      const int u_ = (IT)-mixi;                                                                                          \
+      if (u_ < n1) {                                                                                                     \
+        const int kb_ = u_ * 32;                                                                                         \
+        if constexpr (!PACKED) {                                                                                         \
+          const uint32_t bo_ = kb_ + kq * 4 < K1 ? bbase1 : OOB;                                                         \
+          _Pragma("unroll") for (int q = 0; q < BR; ++q)                                                                 \
+              rb[q] = bload(rB1, q * 32 < nvalid ? bo_ : OOB, (uint32_t)kb_ * 4u + (uint32_t)q * bstep1);                \
+        }                                                                                                                \
+        const bool ain_ = kb_ + ac * 8 < K1;                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+          const uint32_t off_ = ain_ ? arow1[i] : OOB;                                                                   \
+          ra[i][0] = bload(rA1, off_, (uint32_t)kb_ * 4u);                                                               \
+          ra[i][1] = bload(rA1, off_, (uint32_t)kb_ * 4u + 16u);                                                         \
+        }                                                                                                                \
+      } else {                                                                                                           \
+        const int kb_ = s2 + (u_ - n1) * 32;                                                                             \
+        if constexpr (!PACKED) {                                                                                         \
+          const uint32_t bo_ = kb_ + kq * 4 < K2 ? bbase2 : OOB;                                                         \
+          _Pragma("unroll") for (int q = 0; q < BR; ++q)                                                                 \
+              rb[q] = bload(rB2, q * 32 < nvalid ? bo_ : OOB, (uint32_t)kb_ * 4u + (uint32_t)q * bstep2);                \
+        }                                                                                                                \
+        const bool ain_ = kb_ + ac * 8 < K2;                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+          const uint32_t off_ = ain_ ? arow2[i] : OOB;                                                                   \
+          ra[i][0] = bload(rA2, off_, (uint32_t)kb_ * 4u);                                                               \
+          ra[i][1] = bload(rA2, off_, (uint32_t)kb_ * 4u + 16u);                                                         \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }
+    // PACKED: the NT * 3 KB of k-tile IT -> the image BUF by DMA, the 1-KB blocks dealt out over the waves
+#define QAGNN_NN2_GLDS(IT, BUF)                                                                                          \
+    {                                                                                                                    \
+      const unsigned char* src_ = pk + ((int64_t)(IT) * ldn1 + n0 / 16) * 3072 + lane * 16;                              \
+      _Pragma("unroll") for (int b = 0; b < (NT * 3 + WAVES - 1) / WAVES; ++b) {                                         \
+        const int blk_ = w + b * WAVES;                                                                                  \
+        if (blk_ < NT * 3)                                                                                               \
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + blk_ * 1024),         \
+                                           (__attribute__((address_space(3))) void*)((BUF) + blk_ * 1024), 16, 0, 0);    \
+      }                                                                                                                  \
+    }
+    // one load round of B -> the image `BUF` (uniform condition: see last_round_on)
+#define QAGNN_NN2_STORE_B(Q, BUF)                                                       \
+    {                                                                                   \
+      if constexpr (!PACKED) {                                                          \
+        if ((Q) + 1 < BR || last_round_on) store_b4((BUF) + wr_off + (Q) * (2 * 3 * 1024), rb[Q]); \
+      }                                                                                 \
+    }
+    // IT: the tile the fragments belong to.  AFFINE applies to segment 1 only: a segment-2 chunk gets scale 1, shift 0 and the floor
+    // -inf instead of 0, i.e. passes through unchanged; k past K1 reads the zero fill (relu(0 * x + 0) = 0)
+#define QAGNN_NN2_SPLIT_A(IT)                                                                                            \
+    {                                                                                                                    \
+      if constexpr (AFFINE) {                                                                                            \
+        const int u_ = (IT)-mixi;                                                                                        \
+        const bool mixt_ = mixi && (IT) == 0;                                                                            \
+        const bool s1_ = mixt_ ? (ac * 8 < r1) : (u_ < n1);                                                              \
+        const int k_ = min(mixt_ ? K1 - r1 + ac * 8 : u_ * 32 + ac * 8, KA - 8);                                         \
+        const float4 c0 = ld4(aff + k_), c1 = ld4(aff + k_ + 4), h0 = ld4(aff + KA + k_), h1 = ld4(aff + KA + k_ + 4);   \
+        const float sc[8] = {s1_ ? c0.x : 1.f, s1_ ? c0.y : 1.f, s1_ ? c0.z : 1.f, s1_ ? c0.w : 1.f,                     \
+                             s1_ ? c1.x : 1.f, s1_ ? c1.y : 1.f, s1_ ? c1.z : 1.f, s1_ ? c1.w : 1.f};                    \
+        const float sh[8] = {s1_ ? h0.x : 0.f, s1_ ? h0.y : 0.f, s1_ ? h0.z : 0.f, s1_ ? h0.w : 0.f,                     \
+                             s1_ ? h1.x : 0.f, s1_ ? h1.y : 0.f, s1_ ? h1.z : 0.f, s1_ ? h1.w : 0.f};                    \
+        const float lo = s1_ ? 0.f : -INFINITY;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) split_frag<true>(ra[i], af[i], sc, sh, lo);                        \
+      } else {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) split_frag<false>(ra[i], af[i], nullptr, nullptr, 0.f);            \
+      }                                                                                                                  \
+    }
+    // the MFMAs of one k-tile out of the image CUR; STORE: the next tile's B rows (loaded at the top of this iteration) go to the
+    // image NXT behind the LAST BR column tiles, one load round each.  Fragments are read one column tile ahead, nothing else moves
+    // across column tiles.
+#define QAGNN_NN2_MFMA_TILE(CUR, NXT, STORE)                                                                             \
+    {                                                                                                                    \
+      __builtin_amdgcn_s_setprio(1);                                                                                     \
+      bf16x8 bfa[3], bfb[3];                                                                                             \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) bfa[p] = *reinterpret_cast<const bf16x8*>((CUR) + p * 1024 + rd_off); \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                   \
+        bf16x8(&bf)[3] = (j & 1) ? bfb : bfa;                                                                            \
+        bf16x8(&bn)[3] = (j & 1) ? bfa : bfb;                                                                            \
+        if (j + 1 < NT && !(QAGNN_NN2_ABL & 16)) {                                                                       \
+          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                  \
+              bn[p] = *reinterpret_cast<const bf16x8*>((CUR) + ((j + 1) * 3 + p) * 1024 + rd_off);                       \
+        }                                                                                                                \
+        if constexpr (!(QAGNN_NN2_ABL & 32)) {                                                                           \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            f32x4s c = acc[i][j];                                                                                        \
+            QAGNN_NN2_SIX(c, af[i], bf)                                                                                  \
+            acc[i][j] = c;                                                                                               \
+          }                                                                                                              \
+        } else {                                                                                                         \
+          _Pragma("unroll") for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(bf[p]));                                   \
+        }                                                                                                                \
+        if ((STORE) && j >= NT - BR) QAGNN_NN2_STORE_B(j - (NT - BR), NXT)                                               \
+        if constexpr (ORDER == 1) { /* one MFMA, two VALU, ... instead of 12 MFMAs and a clump of 24 split instructions */ \
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                                             \
+          _Pragma("unroll") for (int r = 0; r < 12; ++r) {                                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                           \
+          }                                                                                                              \
+          __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                                                             \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+      }                                                                                                                  \
+      __builtin_amdgcn_s_setprio(0);                                                                                     \
+    }
+
+    __syncthreads();  // the previous output tile's slab reads (and the scale / shift fill) are done
+    // ---- prologue: tile 0 into image 0 / the fragment registers, tile 1 in flight
+    if (mixi) {
+      // the straddling tile: k in [K1 - r1, K1) of segment 1, then [0, 32 - r1) of segment 2 (nn2_ok: K2 >= 32 - r1).  One 64-bit
+      // flat load per destination, the segment chosen per lane; rows past M and columns past No read the last valid row instead
+      // (their products are never stored), so nothing needs zeroing and no second set of registers is in flight
+      const int kbq = kq * 4, kaq = ac * 8;
+      const bool b1 = kbq < r1, a1 = kaq < r1;
+      if constexpr (!PACKED) {
+#pragma unroll
+        for (int q = 0; q < BR; ++q) {
+          const int64_t col = min(n0 + nl + q * 32, No - 1);
+          const float* p = b1 ? B1n + col * ldn1 + (K1 - r1 + kbq) : B2n + col * ldn2 + (kbq - r1);
+          rb[q] = *reinterpret_cast<const u32x4s*>(p);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int64_t row = min(m0 + w * 32 + i * 16 + (lane & 15), M - 1);
+        const float* p = a1 ? a.A1 + row * a.lda1 + (K1 - r1 + kaq) : a.A2 + row * a.lda2 + (kaq - r1);
+        ra[i][0] = *reinterpret_cast<const u32x4s*>(p);
+        ra[i][1] = *reinterpret_cast<const u32x4s*>(p + 4);
+      }
+    } else {
+      QAGNN_NN2_GLOAD(0)
+    }
+    if constexpr (PACKED) {
+      QAGNN_NN2_GLDS(0, smem)
+    } else {
+#pragma unroll
+      for (int q = 0; q < BR; ++q) QAGNN_NN2_STORE_B(q, smem)
+    }
+    QAGNN_NN2_SPLIT_A(0)
+    __syncthreads();
+    // Steady state.  The loads of tile it + 1 are issued at the TOP of iteration it and consumed inside it (B behind the last column
+    // tiles, A after the MFMAs): no load is in flight across the loop's back edge -- with the loads issued at the bottom, hipcc put
+    // copies of their destination registers (and with them an s_waitcnt vmcnt(0)) right behind the barrier of every k-tile.
+    for (int it = 0; it + 1 < nkt; ++it) {
+      unsigned char* const cur = smem + (it & 1) * IMG;
+      unsigned char* const nxt = smem + ((it & 1) ^ 1) * IMG;
+      if constexpr (PACKED && !(QAGNN_NN2_ABL & 2)) QAGNN_NN2_GLDS(it + 1, nxt)
+      if constexpr (!(QAGNN_NN2_ABL & 1)) QAGNN_NN2_GLOAD(it + 1)
+      QAGNN_NN2_MFMA_TILE(cur, nxt, !PACKED && !(QAGNN_NN2_ABL & 2))   // + tile it + 1's B rows -> nxt
+      if constexpr (!(QAGNN_NN2_ABL & 4)) QAGNN_NN2_SPLIT_A(it + 1)  // tile it + 1's A fragments (the MFMAs above were the last readers of af)
+      if constexpr (!(QAGNN_NN2_ABL & 8)) __syncthreads();  // nxt is complete; everybody is done reading cur
+    }
+    {
+      unsigned char* const cur = smem + ((nkt - 1) & 1) * IMG;
+      QAGNN_NN2_MFMA_TILE(cur, cur, false)
+    }
+#undef QAGNN_NN2_GLOAD
+#undef QAGNN_NN2_GLDS
+#undef QAGNN_NN2_STORE_B
+#undef QAGNN_NN2_SPLIT_A
+#undef QAGNN_NN2_MFMA_TILE
+
+    // ---- epilogue: transpose 16 rows at a time through the wave's LDS slab, then whole-row 16-byte stores
+    float* const St = reinterpret_cast<float*>(smem) + w * SLAB_ROWS * PS;
+    float (*const cstat)[2][BN] = reinterpret_cast<float (*)[2][BN]>(smem + SLAB_B);
+    constexpr int ROW_F4 = BN / 4, TILE_F4 = SLAB_ROWS * ROW_F4, ST_IT = (TILE_F4 + 63) / 64;
+    constexpr int SC = (BN + 63) / 64;
+    float x0r[SC], s1[SC], s2v[SC];
+#pragma unroll
+    for (int cc = 0; cc < SC; ++cc) x0r[cc] = s1[cc] = s2v[cc] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __syncthreads();  // k-loop reads (first pass) / the previous pass's slab reads are done before the slab is overwritten
+      const int lr0 = (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[(lr0 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
+      __syncthreads();
+      if constexpr (STATS) {
+        const float* const S0 = reinterpret_cast<const float*>(smem);  // row 0 of wave 0's first slab = the tile's first row
+#pragma unroll
+        for (int cc = 0; cc < SC; ++cc) {
+          const int c = lane + cc * 64;
+          if (c < BN && n0 + c < No) {
+            const float bcv = a.bias ? a.bias[n0 + c] : 0.f;
+            if (i == 0) x0r[cc] = S0[c] + bcv;
+            const int rows = M - (m0 + (w * 2 + i) * 16);
+            float v[SLAB_ROWS];
+#pragma unroll
+            for (int r = 0; r < SLAB_ROWS; ++r) v[r] = St[r * PS + c];
+#pragma unroll
+            for (int r = 0; r < SLAB_ROWS; ++r) {
+              const float dlt = r < rows ? (v[r] + bcv) - x0r[cc] : 0.f;
+              s1[cc] += dlt;
+              s2v[cc] = fmaf(dlt, dlt, s2v[cc]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int itx = 0; itx < ST_IT; ++itx) {
+        const int idx = lane + itx * 64;
+        if (idx >= TILE_F4) break;
+        const int slr = idx / ROW_F4, c4 = idx % ROW_F4;
+        const int row = m0 + (w * 2 + i) * 16 + slr, col = n0 + c4 * 4;
+        if (row >= M || col >= No) continue;
+        float4 v = ld4(St + slr * PS + c4 * 4);
+        if (a.bias) v = add4(v, ld4(a.bias + col));
+        if (a.rowtab) v = add4(v, ld4(a.rowtab + (int64_t)a.rowidx[row] * a.ldt + col));
+        float* dst = a.C + (int64_t)row * a.ldc + col;
+        if (a.accumulate) v = add4(v, ld4(dst));
+        st4(dst, v);
+      }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int cc = 0; cc < SC; ++cc) {
+        const int c = lane + cc * 64;
+        if (c < BN) { cstat[w][0][c] = s1[cc]; cstat[w][1][c] = s2v[cc]; }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < No) {  // thread (w, lane) = column w * 64 + lane: its own x0r[w] is that column's shift
+        float x0c = x0r[0];
+#pragma unroll
+        for (int cc = 1; cc < SC; ++cc) x0c = (w == cc) ? x0r[cc] : x0c;
+        float* const pt = a.colstat_part + (int64_t)(tile / ncb) * 3 * No + n0 + tid;
+        pt[0] = x0c;
+        pt[No] = (cstat[0][0][tid] + cstat[1][0][tid]) + (cstat[2][0][tid] + cstat[3][0][tid]);
+        pt[2 * No] = (cstat[0][1][tid] + cstat[1][1][tid]) + (cstat[2][1][tid] + cstat[3][1][tid]);
+      }
+    }
+  }
+}
+#undef QAGNN_NN2_SIX
+
+static int num_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED>
+static int launch_i(const qagnn_gemm_nn_args& b, const float* B1n, int ldn1, const float* B2n, int ldn2, int grid, int ntiles, hipStream_t stream) {
+  const size_t lds = (size_t)2 * NT * 3 * 1024 + (AFFINE ? (size_t)2 * ((b.K1 + 31) & ~31) * 4 : 0);
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (lds > 64 * 1024 && !raised[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    if (e != hipSuccess) { set_error("gemm_nn2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
+    raised[dev & 63] = true;
+  }
+  k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED><<<grid, THR, lds, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  QAGNN_LAUNCH_CHECK("k_gemm_nn2");
+  return QAGNN_OK;
+}
+
+// PACKED: B1n = the packed buffer, ldn1 = its column tiles per k-tile
+template <int NT, int ORDER, bool PACKED = false>
+static int launch_nt(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
+  qagnn_gemm_nn_args b = a;
+  b.xcd_remap = 1;
+  const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, BM);
+  const int cap = (num_cus() * 2) & ~7;
+  const int grid = ntiles < cap ? ntiles : cap;
+  if constexpr (NT == 13 || NT == 7 || NT == 4 || NT == 2) {
+    if (a.colstat_part) return launch_i<NT, false, true, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  }
+  if (a.a_scale) return launch_i<NT, true, false, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  return launch_i<NT, false, false, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+}
+
+// B [No][K1] | [No][K2] (k contiguous) -> the packed image of PACKED kernels: block ((it * NJ + j) * 3 + p) of 1 KB holds, for lane
+// l = (x = l & 15, c = l >> 4), at slot (x ^ 2c) + 16c, the piece-p halves of B[k = position(it, 8 c .. 8 c + 7)][n = 16 j + x]; `it` walks the k-tiles in the
+// kernel's order (the straddling tile first).  One wave per block of three pieces; zeros past K and past No.
+__global__ __launch_bounds__(256) void k_pack_b(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2,
+                                               int No, int NJ, int nkt, unsigned char* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), it = blockIdx.y;
+  if (j >= NJ) return;
+  const int r1 = K2 > 0 ? (K1 & 31) : 0;
+  const int mixi = r1 != 0 ? 1 : 0;
+  const int n1 = mixi ? (K1 >> 5) : ((K1 + 31) >> 5);
+  const int s2 = mixi ? 32 - r1 : 0;
+  const int kk = (lane >> 4) * 8, n = j * 16 + (lane & 15);
+  const float* src = nullptr;  // the 8 consecutive k of this lane, or nullptr = zeros
+  if (n < No) {
+    if (mixi && it == 0) {
+      if (kk < r1) src = B1n + (int64_t)n * ldn1 + (K1 - r1 + kk);
+      else if (kk - r1 < K2) src = B2n + (int64_t)n * ldn2 + (kk - r1);
+    } else {
+      const int u = it - mixi;
+      if (u < n1) {
+        if (u * 32 + kk < K1) src = B1n + (int64_t)n * ldn1 + (u * 32 + kk);
+      } else {
+        const int k2 = s2 + (u - n1) * 32 + kk;
+        if (k2 < K2) src = B2n + (int64_t)n * ldn2 + k2;
+      }
+    }
+  }
+  u32x4s r[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  if (src) {
+    r[0] = *reinterpret_cast<const u32x4s*>(src);
+    r[1] = *reinterpret_cast<const u32x4s*>(src + 4);
+  }
+  bf16x8 f[3];
+  split_frag<false>(r, f, nullptr, nullptr, 0.f);
+  // (the slot permutation of the in-kernel loader, so that both kinds of image are read with the same fragment offsets)
+  unsigned char* dst = out + ((int64_t)it * NJ + j) * 3072 + (((lane & 15) ^ (2 * (lane >> 4))) + 16 * (lane >> 4)) * 16;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * 1024) = f[p];
+}
+
+static int walk_tiles(int K1, int K2) {
+  const int r1 = K2 > 0 ? (K1 & 31) : 0;
+  const int mixi = r1 != 0 ? 1 : 0;
+  const int n1 = mixi ? (K1 >> 5) : ((K1 + 31) >> 5);
+  const int s2 = mixi ? 32 - r1 : 0;
+  const int n2 = K2 > s2 ? ((K2 - s2 + 31) >> 5) : 0;
+  return mixi + n1 + n2;
+}
+
+}  // namespace nn2
+
+int64_t nn2_pack_bytes(int No, int K1, int K2);
+
+// QAGNN_NN2: 0 = k_gemm_nn_split everywhere (A/B switch), 1 = k_gemm_nn2 with the in-kernel split of B, 2 = the same with the fine
+// MFMA / VALU interleave pinned, 3 (default) = B packed once per product (k_pack_b) wherever the caller hands over a workspace and
+// the product has at least QAGNN_NN2_PACK_MIN_M rows, the in-kernel split otherwise
+int nn2_mode() {
+  static const int v = getenv("QAGNN_NN2") ? atoi(getenv("QAGNN_NN2")) : 3;
+  return v;
+}
+bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes) {
+  static const int min_m = getenv("QAGNN_NN2_PACK_MIN_M") ? atoi(getenv("QAGNN_NN2_PACK_MIN_M")) : 8192;
+  return nn2_mode() == 3 && a.M >= min_m && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2);
+}
+
+// what the second-generation kernel takes: no fused row gather, 32-bit operand offsets, segments that are multiples of 8
+bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
+  const int64_t lim = (int64_t)0x7FFFFFFF;
+  if (nn2_mode() == 0 || a.a_rowidx) return false;
+  if (a.K1 % 8 != 0 || a.K2 % 8 != 0) return false;
+  if ((int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.No * ldn1 * 4 >= lim) return false;
+  if (a.K2 > 0 && ((int64_t)a.M * a.lda2 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim)) return false;
+  if (a.K2 > 0 && (a.K1 & 31) != 0 && a.K2 < 32 - (a.K1 & 31)) return false;  // (the straddling tile must lie inside segment 2)
+  if (a.a_scale && a.K1 > 256) return false;  // (the scale / shift vectors live in LDS next to the two B images)
+  return true;
+}
+
+int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
+  const bool il = nn2_mode() == 2;
+#define QAGNN_NN2_CASE(N) \
+  case N: return il ? nn2::launch_nt<N, 1>(a, B1n, ldn1, B2n, ldn2, stream) : nn2::launch_nt<N, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+  switch (nt) {
+    QAGNN_NN2_CASE(13)
+    QAGNN_NN2_CASE(8)
+    QAGNN_NN2_CASE(7)
+    QAGNN_NN2_CASE(4)
+    default: return il ? nn2::launch_nt<2, 1>(a, B1n, ldn1, B2n, ldn2, stream) : nn2::launch_nt<2, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+  }
+#undef QAGNN_NN2_CASE
+}
+
+// bytes of the packed image of B for one product (13 column tiles of slack: the last column block of a k-tile reads its full width)
+int64_t nn2_pack_bytes(int No, int K1, int K2) { return ((int64_t)nn2::walk_tiles(K1, K2) * cdiv(No, 16) + 13) * 3072; }
+
+// pack B into `ws` (>= nn2_pack_bytes), then the PACKED kernel: two launches
+int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream) {
+  const int NJ = cdiv(a.No, 16), nkt = nn2::walk_tiles(a.K1, a.K2);
+  nn2::k_pack_b<<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
+  QAGNN_LAUNCH_CHECK("k_pack_b");
+  const float* pk = reinterpret_cast<const float*>(ws);
+  switch (nt) {
+    case 13: return nn2::launch_nt<13, 0, true>(a, pk, NJ, nullptr, 0, stream);
+    case 8: return nn2::launch_nt<8, 0, true>(a, pk, NJ, nullptr, 0, stream);
+    case 7: return nn2::launch_nt<7, 0, true>(a, pk, NJ, nullptr, 0, stream);
+    case 4: return nn2::launch_nt<4, 0, true>(a, pk, NJ, nullptr, 0, stream);
+    default: return nn2::launch_nt<2, 0, true>(a, pk, NJ, nullptr, 0, stream);
+  }
+}
+
+}  // namespace qagnn

@@ -679,8 +679,15 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
 
 using namespace qagnn;
 
+extern "C" int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2) { return nn2_pack_bytes(No, K1, K2); }
+
 extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                                        qagnn_stream_t stream_) {
+  return qagnn_gemm_nn_split_ws_f32(a, B1n, ldn1, B2n, ldn2, nullptr, 0, stream_);
+}
+
+extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
+                                          void* ws, int64_t ws_bytes, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(a && a->A1 && B1n && a->C, QAGNN_EINVAL, "gemm_nn_split: null pointer");
   QAGNN_REQUIRE(a->M > 0 && a->No > 0 && a->K1 >= 4, QAGNN_EINVAL, "gemm_nn_split: bad sizes M=%d No=%d K1=%d", a->M, a->No, a->K1);
@@ -718,6 +725,13 @@ extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float*
     for (int ci = 0; ci < 3 && row_tiles * cdiv(a->No, nt * 16) < want; ++ci)
       if (cands[ci] < nt) nt = cands[ci];
     if (small_nt > 0 && small_nt < nt) nt = small_nt;
+  }
+  if (nn2_ok(*a, ldn1, ldn2)) {
+    if (ws && nn2_packed_ok(*a, ws_bytes)) {
+      QAGNN_REQUIRE(aligned16(ws), QAGNN_EINVAL, "gemm_nn_split: the pack workspace must be 16-byte aligned");
+      return launch_nn2_packed(nt, *a, B1n, ldn1, B2n, ldn2, ws, stream);
+    }
+    return launch_nn2(nt, *a, B1n, ldn1, B2n, ldn2, stream);
   }
   switch (nt) {
     case 13: return launch_split<13>(*a, B1n, ldn1, B2n, ldn2, stream);

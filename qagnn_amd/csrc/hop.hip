@@ -57,15 +57,19 @@ using namespace qagnn;
     if (rc__ != QAGNN_OK) return rc__; \
   } while (0)
 
+// scratch for the packed B image of a hop's NN products (qagnn_gemm_nn_split_ws_f32), in floats: sized for the projection
+// [DP | <= DP] -> 3 DP, the largest of them; one buffer, the products of a hop are in order on the main stream
+static int64_t hop_pack_elems(int DP) { return up4((qagnn_gemm_nn_pack_bytes(3 * DP, DP, DP) + 3) / 4); }
+
 extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP) {
-  return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
+  return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP)) + hop_pack_elems(DP);
 }
 
 // NN product through the kernel family the caller asked for (qagnn_hop_args.gemm_split): the bf16-split kernel takes B in its
 // [No][K] layout, which the hop holds for every weight (W and W^T both arrive packed)
 static int hop_nn(const qagnn_hop_args* h, const qagnn_gemm_nn_args* a, const float* B1n, int ldn1, const float* B2n, int ldn2,
-                  qagnn_stream_t stream) {
-  if (h->gemm_split && a->K1 % 4 == 0 && a->K2 % 4 == 0) return qagnn_gemm_nn_split_f32(a, B1n, ldn1, B2n, ldn2, stream);
+                  float* pkws, int64_t pk_elems, qagnn_stream_t stream) {
+  if (h->gemm_split && a->K1 % 4 == 0 && a->K2 % 4 == 0) return qagnn_gemm_nn_split_ws_f32(a, B1n, ldn1, B2n, ldn2, pkws, pk_elems * 4, stream);
   return qagnn_gemm_nn_f32(a, stream);
 }
 
@@ -75,6 +79,8 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   Carver w{h->ws, h->ws + h->ws_elems};
   float* score = w.take((int64_t)Ep * 4);
   float* crws = w.take(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
+  const int64_t pk_elems = hop_pack_elems(DP);
+  float* pkws = w.take(pk_elems);
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_fwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   float* mean = h->stats, *var = h->stats + DP, *invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
 
@@ -84,7 +90,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   if (SP > 0) { ga.A2 = h->S; ga.lda2 = SP; ga.K2 = SP; ga.B2 = h->Ws_t; ga.ldb2 = 3 * DP; }
   ga.C = h->KMQ; ga.ldc = 3 * DP; ga.M = N; ga.No = 3 * DP;
   ga.rowtab = h->TT; ga.ldt = 3 * DP; ga.rowidx = h->ntype;
-  HOP_TRY(hop_nn(h, &ga, h->Wx, DP, SP > 0 ? h->Ws : nullptr, SP, stream));
+  HOP_TRY(hop_nn(h, &ga, h->Wx, DP, SP > 0 ? h->Ws : nullptr, SP, pkws, pk_elems, stream));
   // attention + aggregation (:442, 455-484)
   HOP_TRY(qagnn_edge_attn_fwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP, stream));
   // mlp: Linear -> BatchNorm1d -> ReLU -> Linear (:443, 408); BN + ReLU are folded into the second GEMM's operand load
@@ -93,7 +99,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   // batch statistics as a by-product of this GEMM's epilogue where the split kernel can provide them (same rule as ops.GatMlpFn)
   const bool fused_stats = h->batch_stats && h->gemm_split && DP > 192 && DP <= 208;
   if (fused_stats) g1.colstat_part = crws;
-  HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, stream));
+  HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, pkws, pk_elems, stream));
   const double Rd = (double)N;
   const float unbias = (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0));
   if (fused_stats) {
@@ -118,7 +124,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
   g2.a_scale = scale; g2.a_shift = shift;
-  HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, stream));
+  HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, pkws, pk_elems, stream));
   if (h->apply_act)  // X' = dropout(GELU(out))  (:48-49)
     HOP_TRY(qagnn_gelu_dropout_fwd_f32(h->out, h->y, (int64_t)N * DP, h->p_drop, h->seed, stream));
   return QAGNN_OK;
@@ -129,7 +135,7 @@ extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t 
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, DP + SP, 3 * DP));
   // two sets of the buffers the weight-gradient stream reads (d out, d h1, d K|M|Q) + what the main stream keeps to itself
   return 2 * (2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP)) + up4((int64_t)N * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
-         up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));
+         up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4)) + hop_pack_elems(DP);
 }
 
 namespace qagnn {
@@ -205,6 +211,8 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, DP + SP, 3 * DP));
   float* tnws = w.take(tn);  // split-K partials: used by the weight-gradient products only, which are in order on one stream
   float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));  // column-reduction partials: main stream only
+  const int64_t pk_elems = hop_pack_elems(DP);
+  float* pkws = w.take(pk_elems);  // packed B images of the data-gradient products: main stream only
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
   const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
@@ -230,7 +238,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   }
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
-  HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, stream));
+  HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, pkws, pk_elems, stream));
   // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
   HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufC, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
@@ -240,7 +248,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufC, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   qagnn_gemm_nn_args gg = {};
   gg.A1 = bufC; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
-  HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, stream));
+  HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, pkws, pk_elems, stream));
   // attention backward
   HOP_TRY(qagnn_edge_attn_bwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs,
                                   cls_part, stream));
@@ -274,13 +282,13 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
     gx.accumulate = h->accumulate_dX;
-    HOP_TRY(hop_nn(h, &gx, h->Wx_t, 3 * DP, nullptr, 0, stream));
+    HOP_TRY(hop_nn(h, &gx, h->Wx_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   if (SP > 0 && h->dS) {
     qagnn_gemm_nn_args gs = {};
     gs.A1 = dKMQ; gs.lda1 = 3 * DP; gs.K1 = 3 * DP; gs.B1 = h->Ws; gs.ldb1 = SP; gs.C = h->dS; gs.ldc = SP; gs.M = N; gs.No = SP;
     gs.accumulate = h->accumulate_dS;
-    HOP_TRY(hop_nn(h, &gs, h->Ws_t, 3 * DP, nullptr, 0, stream));
+    HOP_TRY(hop_nn(h, &gs, h->Ws_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   return QAGNN_OK;
 }

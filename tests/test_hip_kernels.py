@@ -124,7 +124,13 @@ def _bound(absA, absB, extra=0.0):
 
 
 GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (130, 112, 0, 112), (513, 32, 32, 96),
-               (64, 64, 0, 64), (3, 16, 0, 4), (20000, 208, 208, 624)]
+               (64, 64, 0, 64), (3, 16, 0, 4), (20000, 208, 208, 624),
+               # round 4 (k_gemm_nn2): the projection's [208 | 112] walk with the straddling tile, a straddling tile with a short
+               # first segment, odd row / column counts under every column-tile width, a k-tile tail, and a shape it declines (K2 < 32 - K1 % 32)
+               (64000, 208, 112, 624), (2000, 208, 112, 624), (500, 40, 56, 208), (1000, 624, 0, 112), (260, 224, 0, 320), (129, 8, 24, 16),
+               (300, 200, 8, 320),
+               # at and above the row count where B is packed once (k_pack_b + DMA-fed kernel): one segment, a k-tile tail, narrow outputs
+               (9000, 208, 0, 208), (8192, 624, 0, 112), (10000, 40, 56, 200)]
 
 
 @pytest.mark.gpu
@@ -134,6 +140,8 @@ GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (
 def test_gemm_nn(M, K1, K2, No, variant, split):
     """split=True: the same product through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way operand splitting, B handed
     over in its [No, K] layout as well) -- held to the SAME fp32 backward-error bound as the fp32-MFMA kernel."""
+    if not split and (K1 % 16 or K2 % 16):
+        pytest.skip('the fp32-MFMA kernel takes K in multiples of 16')
     g = torch.Generator().manual_seed(M + K1 + No)
     A1, B1 = torch.randn(M, K1, generator=g), torch.randn(K1, No, generator=g)
     A2 = torch.randn(M, K2, generator=g) if K2 else None

@@ -475,3 +475,73 @@ def test_pooling_head_packed_operands_equal_the_generic_form(d, nh):
     assert torch.allclose(gk0, gk1, rtol=1e-11, atol=1e-13)
     for n in g0:  # (w_ks.bias shifts every score of a (sample, head) alike: its exact gradient is 0, both sides hold ~1e-14 of rounding)
         assert torch.allclose(g0[n], g1[n], rtol=1e-11, atol=1e-12), n
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# k_gemm_nn2 (csrc/gemm_nn2.hip): the index arithmetic of the kernel restated in numpy -- the LDS slot permutation (reads and writes
+# touch every bank once per hardware lane group), the loader -> fragment correspondence, and the walk over the two K segments.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _nn2_slot(x, c):
+    return (x ^ (2 * c)) + 16 * c
+
+
+def test_nn2_lds_slots():
+    # ds_read_b128: four NON-contiguous 16-lane groups (MI355X_MICROARCH.md, LDS); a group is conflict-free iff its 16 lanes hit 16
+    # different 16-byte slots modulo the 256-byte bank row
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+              [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63]]
+    for grp in groups:
+        slots = {_nn2_slot(lane & 15, lane >> 4) % 16 for lane in grp}
+        assert len(slots) == 16
+    assert sorted(_nn2_slot(lane & 15, lane >> 4) for lane in range(64)) == list(range(64))  # a permutation of the block's 64 slots
+    # ds_write_b64: contiguous 16-lane groups, banks modulo 32 dwords (128 bytes = 8 slots x 2 halves): loader lanes 16 g .. 16 g + 15
+    for tid0 in range(0, 256, 16):
+        banks = set()
+        for tid in range(tid0, tid0 + 16):
+            nl, kq = tid >> 3, tid & 7
+            byte = ((nl >> 4) * 3 * 64 + _nn2_slot(nl & 15, kq >> 1)) * 16 + (kq & 1) * 8
+            banks.add((byte // 8) % 16)
+        assert len(banks) == 16
+
+
+@pytest.mark.parametrize('NT,K1,K2', [(13, 208, 112), (13, 208, 0), (7, 624, 0), (4, 40, 56), (2, 8, 24), (13, 224, 32), (8, 16, 0)])
+def test_nn2_tile_walk_and_fragment_correspondence(NT, K1, K2):
+    """Every (segment, k) is multiplied exactly once, A and B agree on what sits at each position of a k-tile, and the lane that
+    reads slot s of column tile j finds the 8 numbers the MFMA B operand wants (B[k = 8 c + e][n = 16 j + x])."""
+    r1 = (K1 & 31) if K2 > 0 else 0
+    mixi = 1 if r1 else 0
+    n1 = (K1 >> 5) if mixi else (K1 + 31) >> 5
+    s2 = 32 - r1 if mixi else 0
+    n2 = (K2 - s2 + 31) >> 5 if K2 > s2 else 0
+    nkt = mixi + n1 + n2
+    assert not (K2 > 0 and r1 and K2 < 32 - r1), 'nn2_ok() declines this shape'
+
+    def position(it, kk):  # (segment, k) at position kk of tile it, or None (zero fill) -- A side: kk = 8 * chunk + e; B side: 4 * kq + e
+        if mixi and it == 0:
+            return (1, K1 - r1 + kk) if kk < r1 else ((2, kk - r1) if kk - r1 < K2 else None)
+        u = it - mixi
+        if u < n1:
+            return (1, u * 32 + kk) if u * 32 + kk < K1 else None
+        k2 = s2 + (u - n1) * 32 + kk
+        return (2, k2) if k2 < K2 else None
+
+    seen = [position(it, kk) for it in range(nkt) for kk in range(32)]
+    seen = [p for p in seen if p is not None]
+    assert sorted(seen) == [(1, k) for k in range(K1)] + [(2, k) for k in range(K2)]
+    assert all(position(nkt + d, kk) is None for d in (0, 1) for kk in range(32))  # the loads issued past the last tile read zeros
+    # loader -> LDS image -> fragment lane
+    BR = (NT + 1) // 2
+    img = {}
+    for tid in range(256):
+        nl, kq = tid >> 3, tid & 7
+        for q in range(BR):
+            if q + 1 < BR or (NT & 1) == 0 or (tid >> 6) < 2:
+                byte = ((nl >> 4) * 3 * 64 + _nn2_slot(nl & 15, kq >> 1)) * 16 + (kq & 1) * 8 + q * 2 * 3 * 1024
+                for e in range(4):
+                    assert byte + 2 * e not in img
+                    img[byte + 2 * e] = (nl + 32 * q, 4 * kq + e)  # (column of the tile, position in the k-tile)
+    assert len(img) == NT * 16 * 32 and max(img) < NT * 3 * 1024
+    for j in range(NT):
+        for lane in range(64):
+            rd = _nn2_slot(lane & 15, lane >> 4) * 16 + j * 3 * 1024
+            assert [img[rd + 2 * e] for e in range(8)] == [(16 * j + (lane & 15), 8 * (lane >> 4) + e) for e in range(8)]
