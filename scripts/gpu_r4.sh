@@ -148,7 +148,7 @@ PY
         i=$((i+1)); rm -rf /tmp/sqp$i; mkdir -p /tmp/sqp$i
         ( cd /tmp && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/sqp$i -o p -- python "$REPO/tools/nn_micro.py" ) > gpurun_out/sqpmc$i.log 2>&1
         tail -n 3 gpurun_out/sqpmc$i.log > /tmp/x && mv /tmp/x gpurun_out/sqpmc$i.log
-        python scripts/pmc_sq_by_kernel.py "$(find /tmp/sqp$i -name '*counter_collection.csv' | head -n 1)" 2>&1 | grep "nn_split\|Traceback\|Error" | head -n 20 >> gpurun_out/sqpmc.txt
+        python scripts/pmc_sq_by_kernel.py "$(find /tmp/sqp$i -name '*counter_collection.csv' | head -n 1)" 2>&1 | grep "nn_split\|nn2\|pack_b\|Traceback\|Error" | head -n 20 >> gpurun_out/sqpmc.txt
       done; stamp sqpmc ;;
     census)   # kernel launches of one step by forward region (backward attributed through autograd sequence numbers)
       timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 700 > gpurun_out/op_census.txt; stamp census ;;
