@@ -74,6 +74,10 @@ WORKLOADS = {
                            what='MedQA-USMLE per-GPU shard of 128 x 4 over 8 GPUs: 16 questions x 4 = 64 subgraphs, 34 relations, ~3 k-edge '
                                 'graphs, no node scores, 768-d SapBERT table and sentence vectors (run_qagnn__medqa_usmle.sh:16-21)'),
 }
+# configs[1] once more with the entity table at its upstream size (tzw.ent.npy: 799 273 x 1024 fp32 = 3.3 GB, utils/layers.py:572-588):
+# the row gather of the input stage then walks a table 8x the headline's 100 000 rows (--n-concept), i.e. well past L2 + Infinity Cache
+WORKLOADS['configs[1]/full_entity_table'] = dict(WORKLOADS['configs[1]'], n_concept=799273,
+                                                 what=WORKLOADS['configs[1]']['what'] + '; entity table 799 273 x 1024 (3.3 GB, the upstream size)')
 HEADLINE = 'configs[1]'
 
 
@@ -101,21 +105,30 @@ def batch_from_lists(wl, cids, nt, ns, al, ei, et, seed):
 def build_model(cls_module, wl, n_concept, p=0.2, seed=0):
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(1234)
-    table = torch.randn(n_concept, wl['concept_in'], generator=g) * 0.1
+    big = n_concept > 400000  # the 3.3 GB table: random rows are drawn on the device by the caller (fill_table), not on the host
+    table = torch.empty(n_concept, wl['concept_in']) if big else torch.randn(n_concept, wl['concept_in'], generator=g) * 0.1
     model = cls_module.QAGNN(None, K_LAYERS, N_NTYPE, wl['n_etype'], wl['sent_dim'], n_concept, D, wl['concept_in'], 2, 200, 0, p, p, p,
                              pretrained_concept_emb=table, freeze_ent_emb=True, init_range=0.02)
     # init_range=0.02 re-initialises the embedding too (reference _init_weights quirk); restore the "pretrained" table
-    model.concept_emb.emb.weight.data.copy_(table)
+    if not big:
+        model.concept_emb.emb.weight.data.copy_(table)
     return model
+
+
+def fill_table(model, n_concept):
+    """The entity table of a `big` build_model(): N(0, 0.1) rows drawn on the device."""
+    if n_concept > 400000:
+        model.concept_emb.emb.weight.data.normal_(0.0, 0.1, generator=torch.Generator(device=model.concept_emb.emb.weight.device).manual_seed(1234))
 
 
 class TimedKernels:
     """Proxy around the kernel provider that brackets selected calls with HIP events on the launch stream."""
 
-    def __init__(self, inner, names, work=None):
+    def __init__(self, inner, names, work=None, useful=None):
         self._inner, self._names = inner, set(names)
         self.name = inner.name
         self._work_fn = work or {}
+        self._useful_fn = useful or {}
         self.enabled = False
         self.active = set(names)  # subset of names currently bracketed (keeps the timed region's instrumentation minimal)
         self.reset()
@@ -123,6 +136,7 @@ class TimedKernels:
     def reset(self):
         self.events = {n: [] for n in self._names}
         self.work = {n: 0.0 for n in self._names}   # e.g. FLOPs, accumulated per timed call by work[name](*args, **kwargs)
+        self.useful = {n: 0.0 for n in self._names}  # the same without the layout padding (see _dense)
 
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
@@ -139,6 +153,8 @@ class TimedKernels:
             self.events[attr].append((e0, e1))
             if attr in self._work_fn:
                 self.work[attr] += self._work_fn[attr](*a, **kw)
+            if attr in self._useful_fn:
+                self.useful[attr] += self._useful_fn[attr](*a, **kw)
             return out
         return wrapped
 
@@ -161,6 +177,34 @@ def _tn_flops(A, B, **kw):
 
 def _tn2_flops(A1, A2, B, **kw):
     return 2.0 * B.size(0) * (A1.size(1) + A2.size(1)) * B.size(1)
+
+
+# The operands the kernels see are head-padded: d = 200 is stored as DP = 208 (4 heads x 52), K|M|Q as 624 for 600, the score
+# embedding S as 112 columns for d/2 = 100 (+ 4 node-type indicator columns that exist for a by-product gradient, + padding).
+# `_dense` maps an operand width back to the width of the reference's tensor, so that the USEFUL FLOPs of a product -- the ones the
+# reference formulation also has -- can be reported beside the FLOPs the launch executes.
+_DP = 4 * ((D // 4 + 3) // 4 * 4)
+
+
+def _dense(x):
+    if x % _DP == 0:
+        return x // _DP * D
+    if x == (D // 2 + N_NTYPE + 15) // 16 * 16 and x != D // 2:  # S: [N, SP] holds d/2 score-embedding columns
+        return D // 2
+    return x
+
+
+def _nn_useful(A1, B1, A2=None, B2=None, **kw):
+    rows = kw['a_rowidx'].numel() if kw.get('a_rowidx') is not None else A1.size(0)
+    return 2.0 * rows * (_dense(B1.size(0)) + (_dense(B2.size(0)) if B2 is not None else 0)) * _dense(B1.size(1))
+
+
+def _tn_useful(A, B, **kw):
+    return 2.0 * B.size(0) * _dense(A.size(1)) * _dense(B.size(1))
+
+
+def _tn2_useful(A1, A2, B, **kw):
+    return 2.0 * B.size(0) * (_dense(A1.size(1)) + _dense(A2.size(1))) * _dense(B.size(1))
 
 
 TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn', 'gemm_tn2']
@@ -260,10 +304,11 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
 # kernels one qagnn_edge_attn_fwd_f32 call launches (substring of the demangled name): their FETCH_SIZE / WRITE_SIZE add up to
 # the forward edge stage's traffic per launch
 EDGE_FWD_KERNELS = ('qagnn::k_edge_scores', 'qagnn::k_edge_aggregate', 'qagnn::k_edge_fwd_', 'qagnn::k_edge_iso')
+EDGE_BWD_KERNELS = ('qagnn::k_edge_bwd_', 'qagnn::k_cls_reduce', 'qagnn::k_cls_scatter')  # (k_cls_reduce matches k_cls_reduce2 too)
 PMC_CAL_KERNEL = 'k_gelu_dropout<false>'  # reads and writes exactly N*DP*4 bytes: checks the counter units in the same run
 
 
-def measure_edge_traffic(args, N, DP):
+def measure_edge_traffic(args, N, DP):  # (also leaves the backward stage's bytes per launch in measure_edge_traffic.backward)
     """HBM-side bytes per qagnn_edge_attn_fwd_f32 launch from two rocprofv3 --pmc passes over a short child run of this script
     (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and WRITE_SIZE need separate passes; gfx950 tallies 128-byte reads at 64 B, so
     FETCH is doubled; --pmc is combined with --kernel-trace only).  Returns (bytes or None, description)."""
@@ -307,6 +352,9 @@ def measure_edge_traffic(args, N, DP):
     exact = N * DP * 4 / 1024.0
     cal_f, cal_w = kib('FETCH_SIZE', PMC_CAL_KERNEL), kib('WRITE_SIZE', PMC_CAL_KERNEL)
     cal = f'; calibration on {PMC_CAL_KERNEL} ({exact:.0f} KiB each way): FETCH {cal_f:.0f} KiB (x2), WRITE {cal_w:.0f} KiB' if cal_f > 0 else ''
+    bfetch = sum(kib('FETCH_SIZE', n) for n in EDGE_BWD_KERNELS)
+    bwrite = sum(kib('WRITE_SIZE', n) for n in EDGE_BWD_KERNELS)
+    measure_edge_traffic.backward = int((2.0 * bfetch + bwrite) * 1024) if bfetch > 0 and bwrite > 0 else None
     return int((2.0 * fetch + write) * 1024), ('measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over a '
                                                '2-step child run; mean per launch summed over the kernels of qagnn_edge_attn_fwd_f32, FETCH doubled (gfx950 tallies '
                                                '128-B reads at 64 B)' + cal)
@@ -350,7 +398,8 @@ def instrumented_pass(run_step, timed, sync, n_steps):
         timed.enabled = False
     gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn') + timed.total_ms('gemm_tn2')
     flops = timed.work['gemm_nn'] + timed.work['gemm_tn'] + timed.work['gemm_tn2']
-    return dict(gemm_ms=gemm_ms / n_steps, gemm_flops=flops / n_steps,
+    useful = timed.useful['gemm_nn'] + timed.useful['gemm_tn'] + timed.useful['gemm_tn2']
+    return dict(gemm_ms=gemm_ms / n_steps, gemm_flops=flops / n_steps, gemm_useful_flops=useful / n_steps,
                 gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn']) + len(timed.events['gemm_tn2'])) // n_steps,
                 edge_fwd_ms=timed.mean_ms('edge_attn_fwd')[0], edge_bwd_ms=timed.mean_ms('edge_attn_bwd')[0],
                 n_edge_fwd=timed.mean_ms('edge_attn_fwd')[1], n_edge_bwd=timed.mean_ms('edge_attn_bwd')[1])
@@ -395,6 +444,7 @@ def gpu_small_batch(wl, args, dev, questions=2, steps=30, warmup=5):
     nc = wl['nc']
     b = to_device(make_batch(wl, questions, seed=123, n_concept=args.n_concept), dev, not args.edge_lists, nc)
     model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    fill_table(model, args.n_concept)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     run, _, gs = make_runner(model, b, nc, 1.0, params, None, args.graphs)
@@ -409,8 +459,10 @@ def gpu_small_batch(wl, args, dev, questions=2, steps=30, warmup=5):
 def secondary_config(name, wl, args, dev, timed):
     """One of the other single-GPU configurations: throughput, where the time goes, host-bound or not, CPU oracle beside it."""
     nc, n = wl['nc'], wl['n']
-    b = to_device(make_batch(wl, wl['questions'], seed=2000, n_concept=args.n_concept), dev, not args.edge_lists, nc)
-    model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    n_concept = wl.get('n_concept', args.n_concept)
+    b = to_device(make_batch(wl, wl['questions'], seed=2000, n_concept=n_concept), dev, not args.edge_lists, nc)
+    model = build_model(MQ, wl, n_concept, p=args.dropout).to(dev)
+    fill_table(model, n_concept)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     run, run_eager, gs = make_runner(model, b, nc, 1.0, params, None, args.graphs)
@@ -422,14 +474,14 @@ def secondary_config(name, wl, args, dev, timed):
     ins = instrumented_pass(run_eager, timed, torch.cuda.synchronize, 2)
     B = wl['questions'] * nc
     E = b['ei'].size(1)
-    out = dict(workload=wl['what'], subgraphs=B, nodes=B * n, edges=E, value=round(B * steps / dt, 1), unit='QA-subgraphs/s',
+    out = dict(workload=wl['what'], subgraphs=B, nodes=B * n, edges=E, n_concept=n_concept, value=round(B * steps / dt, 1), unit='QA-subgraphs/s',
                ms_per_step=round(dt / steps * 1e3, 3), host_enqueue_ms_per_step=round(enq / steps * 1e3, 3),
                host_bound=bool(enq > 0.9 * dt), hip_graph=gs is not None, edge_fwd_ms_per_step=round(ins['edge_fwd_ms'] * K_LAYERS, 3),
                edge_bwd_ms_per_step=round(ins['edge_bwd_ms'] * K_LAYERS, 3), gemm_ms_per_step=round(ins['gemm_ms'], 3),
                gemm_tflops=round(ins['gemm_flops'] / (ins['gemm_ms'] * 1e-3) / 1e12, 1) if ins['gemm_ms'] > 0 else 0.0)
     del model, b, run, run_eager, gs
     torch.cuda.empty_cache()
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and 'n_concept' not in wl:  # (the full-table entry repeats configs[1]: no second CPU leg)
         small = gpu_small_batch(wl, args, dev, steps=20, warmup=4)
         cpu = cpu_oracle(wl, budget_s=4.0)
         out['small_batch'] = small
@@ -522,10 +574,12 @@ def main():
         my_questions = args.questions
     b = to_device(host_batch, dev, not args.edge_lists, nc)
     model = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    fill_table(model, args.n_concept)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     comm = Comm(params, world, assignment=assignment)
-    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops})
+    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops},
+                         useful={'gemm_nn': _nn_useful, 'gemm_tn': _tn_useful, 'gemm_tn2': _tn2_useful})
     ops.set_kernels(timed)
     run, run_eager, gs = make_runner(model, b, nc, loss_weight, params, comm, args.graphs)
     headline_choice = make_runner.last_choice
@@ -594,8 +648,10 @@ def main():
         n_lone = int((deg == 0).sum().item())
         compulsory = (N - n_lone) * 3 * DP * 4 + n_lone * DP * 4 + Ep * 10 + N * DP * 4 + 2 * Ep * 16
         traffic, traffic_source = None, None
+        measure_edge_traffic.backward = None
         if world == 1 and not args.no_pmc and not args.pmc_child:
             traffic, traffic_source = measure_edge_traffic(args, N, DP)
+        bwd_traffic = measure_edge_traffic.backward
         if traffic is None:
             why = traffic_source
             pmc_path = os.path.join(ROOT, 'profiles', 'pmc_edge_fwd.json')
@@ -636,10 +692,19 @@ def main():
                                  'the HBM interface.  The per-edge row gathers of the SURVEY 8d byte model are re-reads served by L1/L2; they are '
                                  'reported as achieved_algorithmic and are not an HBM fraction',
                          'algorithmic_bytes_per_launch': alg_fwd, 'achieved_algorithmic': round(achieved_alg, 1),
+                         'frac_algorithmic': round(achieved_alg / HBM_PEAK_GBS, 4),
+                         'frac_algorithmic_is': 'SURVEY 8d contractual figure: (E\' * 2410 + N * 800) algorithmic bytes / launch duration / 8 TB/s.  '
+                                                'Above 1 it cannot be an HBM fraction: the per-edge row gathers are L1/L2 re-reads (see `frac` for bytes '
+                                                'that cross the HBM interface)',
                          'avg_launch_ms': round(fwd_ms, 4), 'launches_timed': n_fwd,
                          'backward': {'algorithmic_bytes_per_launch': alg_bwd, 'avg_launch_ms': round(bwd_ms, 4), 'launches_timed': n_bwd,
                                       'compulsory_bytes_per_launch': bwd_comp,
-                                      'achieved': round(bwd_comp / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
+                                      'traffic': bwd_traffic,
+                                      'traffic_source': ('the same two rocprofv3 --pmc passes as the forward figure (mean per launch summed over the '
+                                                         'kernels of qagnn_edge_attn_bwd_f32, FETCH doubled)' if bwd_traffic else None),
+                                      'traffic_over_compulsory': round(bwd_traffic / bwd_comp, 3) if bwd_traffic else None,
+                                      'achieved': round(max(bwd_comp, bwd_traffic or 0) / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
+                                      'frac': round(min(max(bwd_comp, bwd_traffic or 0) / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 1.0), 4) if bwd_ms > 0 else 0.0,
                                       'achieved_algorithmic': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
                                       'timed_in': 'extra steps after the timed regions, weight-gradient overlap off (see source)'}},
             # the dense side of the step: every GEMM launch, algorithmic FLOPs of the products over their HIP-event time
@@ -649,6 +714,11 @@ def main():
                               'peak_is': 'fp32-equivalent ceiling of the kernels that run: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per exact 3 x bf16 product',
                               'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'frac_of_fp32_mfma_peak': round(gemm_tf / MFMA_F32_PEAK_TFLOPS, 4),
                               'gflop_per_step': round(gemm_flops / 1e9, 1), 'ms_per_step': round(gemm_ms, 3),
+                              'useful_gflop_per_step': round(ins['gemm_useful_flops'] / 1e9, 1),
+                              'achieved_useful': round(ins['gemm_useful_flops'] / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
+                              'frac_useful': round(ins['gemm_useful_flops'] / (gemm_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4) if gemm_ms > 0 else 0.0,
+                              'useful_is': 'FLOPs of the same products at the reference\'s tensor widths (d = 200 for the stored 208, K|M|Q 600 for 624, the '
+                                           'score embedding 100 for 112): `achieved` counts what the launches execute on head-padded operands',
                               'launches_per_step': ins['gemm_launches'],
                               'timed_in': f'{GEMM_STEPS} extra steps after the timed regions (HIP events around every launch)',
                               'note': 'fp32-equivalent FLOPs.  The NN products run as six bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per '
