@@ -255,8 +255,7 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
     launch (qagnn_amd.graphed.GraphedStep: static input buffers refilled before every replay, true edge counts read on the device,
     dropout masks advanced per replay); the collectives stay outside the graph."""
     run_eager = lambda: step(model, b, nc, loss_weight, params, comm)  # noqa: E731
-    if use_graph == 'auto' and comm is not None and comm.world > 1:
-        use_graph = '0'  # multi-rank runs stay on eager launches unless --graphs 1 asks otherwise (replay + RCCL has not been measured)
+    multi = comm is not None and comm.world > 1
     can_graph = isinstance(b['adj'], data_utils.PackedGraphBatch)
     picked = None
     make_runner.last_choice = ''
@@ -273,10 +272,13 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
         return run_eager, run_eager, None
     gs = graphed.GraphedStep(model, nc)
 
+    def run_local():
+        return gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], loss_weight)[0]
+
     def run():
-        logits, _ = gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], loss_weight)
+        logits = run_local()
         if comm is not None:
-            comm(logits.view(-1, nc))
+            comm(logits.view(-1, nc))  # the collectives stay OUTSIDE the graph, on the same stream, behind the replay
     if picked == 'measured':
         def ms_of(fn, n=6):
             for _ in range(3):
@@ -287,15 +289,27 @@ def make_runner(model, b, nc, loss_weight, params, comm, use_graph):
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
-        t_eager = ms_of(run_eager)
+        # Both forms are timed WITHOUT the collectives (a rank whose capture fails would otherwise leave its peers waiting inside an
+        # all-reduce), then the ranks agree: replay only if every rank could capture, on the slowest rank's timings.
+        t_eager = ms_of(lambda: step(model, b, nc, loss_weight, params, None))
+        ok, why = 1.0, ''
         try:
-            t_replay = ms_of(run)
+            t_replay = ms_of(run_local)
         except Exception as e:  # a capture that fails at this size (memory, an unsupported node) must not cost the run: eager launches
-            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {str(e)[:200]}); eager launches', file=sys.stderr)
+            why = f'{type(e).__name__}: {str(e)[:200]}'
+            print(f'[bench] hipGraph capture failed ({why}); eager launches', file=sys.stderr)
             torch.cuda.synchronize()
-            make_runner.last_choice = 'replay not available (capture failed)'
+            ok, t_replay = 0.0, float('inf')
+        if multi:
+            import torch.distributed as dist
+            t = torch.tensor([t_eager, min(t_replay, 1e9), -ok], device=b['nt'].device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_eager, t_replay, ok = float(t[0]), float(t[1]), -float(t[2])
+        if ok < 1.0:
+            make_runner.last_choice = 'replay not available (capture failed' + (' on some rank' if multi else '') + ')'
             return run_eager, run_eager, None
-        make_runner.last_choice = f'chosen by measurement: eager {t_eager:.3f} ms vs replay {t_replay:.3f} ms per step over 6 steps each'
+        make_runner.last_choice = (f'chosen by measurement: eager {t_eager:.3f} ms vs replay {t_replay:.3f} ms per step over 6 steps each'
+                                   + (' (without the collectives, max over ranks)' if multi else ''))
         if t_eager <= t_replay:
             return run_eager, run_eager, None
     return run, run_eager, gs
@@ -729,6 +743,7 @@ def main():
         }
         if world > 1:
             out['comm_ms_per_step'] = round(comm_ms, 4)
+            out['comm_fraction_of_step'] = round(comm_ms / (dt / args.steps * 1e3), 4)
             out['comm_is'] = 'RCCL all-reduce(sum) of the flat 11.4 MB gradient bucket + logits all-gather, HIP events on the compute stream (rank 0)'
             out['rank_ms_per_step'] = {'min': round(dt_min / args.steps * 1e3, 3), 'max': round(dt / args.steps * 1e3, 3)}
             if balance is not None:

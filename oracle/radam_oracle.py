@@ -34,3 +34,23 @@ def radam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
             p = p + dtype(-weight_decay * lr) * p
         p = p + dtype(-step_size * lr) * m
     return p, m, v
+
+
+def transformers_adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.0, correct_bias=True, dtype=np.float64):
+    """One update of `transformers.AdamW` -- the class the reference imports for `--optim adamw` (utils/optimization_utils.py:3, :103).
+    It is a THIRD-PARTY dependency that is not under /root/reference: transformers == 3.4.0 (pinned in the reference's README.md; the
+    class was later deprecated and removed, it is not in the transformers of this image).  Restated from the published algorithm of
+    that release (src/transformers/optimization.py, AdamW.step): first / second moments, eps added to the UNcorrected sqrt(v), the
+    bias corrections folded into the step size, decoupled weight decay applied to the already-updated parameter.  Parity unpinned for
+    this function (no golden vector of the third-party class exists in the reference); tests hold qagnn_amd's AdamW to it."""
+    p, g, m, v = (np.asarray(x, dtype=dtype) for x in (p, g, m, v))
+    m = m * dtype(beta1) + dtype(1.0 - beta1) * g
+    v = v * dtype(beta2) + dtype(1.0 - beta2) * g * g
+    denom = np.sqrt(v) + dtype(eps)
+    step_size = lr
+    if correct_bias:
+        step_size = step_size * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    p = p + dtype(-step_size) * (m / denom)
+    if weight_decay > 0.0:
+        p = p + dtype(-lr * weight_decay) * p
+    return p, m, v

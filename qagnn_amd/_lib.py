@@ -140,16 +140,32 @@ class _ErrWatch:
 
     def __init__(self):
         self.pending = []
+        self.sink = None  # while a hipGraph is being captured (graphed.GraphedStep): the flag tensors the captured launches write
 
     def watch(self, flags, what, reset=None):
         """`reset`: a persistent flag tensor to clear once its error has been reported (per-call flag arrays need none)."""
         if torch.cuda.is_current_stream_capturing():
+            # no copy / event inside a capture; the capturing step keeps the (static) flag tensors and hands them to after_replay()
+            # behind every replay, so a bad batch raises one step late under replay exactly as it does on the eager path
+            if self.sink is not None:
+                self.sink.append((flags, what, reset))
             return
         host = torch.empty(4, dtype=torch.int32, pin_memory=True)
         host.copy_(flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, host, what, reset))
+        if VALIDATE:
+            self.poll(block=True)
+
+    def after_replay(self, watched):
+        """Behind graph.replay(): the flag words the replayed launches wrote -> pinned host memory (async) + an event, as watch()."""
+        for flags, what, reset in watched:
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((ev, host, what, reset))
         if VALIDATE:
             self.poll(block=True)
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 // masks while forward and backward of one replay still agree.  With the epoch at 0 (eager use) the seeds are used as passed.
 const unsigned long long* seed_epoch_ptr();  // device address of the current device's epoch word (elementwise.hip)
 __device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const unsigned long long* __restrict__ epoch) {
-  return seed + (uint64_t)epoch[0] * 0xD1B54A32D192ED03ull;
+  return epoch ? seed + (uint64_t)epoch[0] * 0xD1B54A32D192ED03ull : seed;  // (null: the epoch word could not be resolved -- epoch 0)
 }
 
 // counter-based uniform in [0,1): splitmix64 finaliser over (seed, element index); same value in fwd and bwd

@@ -15,7 +15,13 @@ What makes it legitimate for TRAINING (a new batch every step, not a replay of o
     captured step advances as its last launch (qagnn_seed_epoch_advance), torch's own nn.Dropout registers its philox state with
     the graph: replay k draws masks no other replay draws;
   * BatchNorm running statistics and batch counters are updated by the captured kernels in place, once per replay;
-  * gradients land in static `.grad` tensors (re-attached after every replay), ready for any optimiser.
+  * gradients land in static `.grad` tensors (re-attached after every replay), ready for any optimiser; `accumulate=True` adds them
+    into the parameters' running `.grad` instead (the reference accumulates `loss.backward()` over mini-batches of 2 questions before
+    each `optimizer.step()`, qagnn.py:252-266), and `sent_vecs.requires_grad` makes the step return d loss / d sent_vecs for the LM
+    encoder's backward (the reference backpropagates into the encoder after `unfreeze_epoch`);
+  * input validation -- the flag words the captured preparation kernels write (out-of-range edge endpoint / relation / node type /
+    concept id, clamped on the device) are copied to the host behind every replay and looked at before the next one
+    (_lib.ERR_WATCH): a corrupt batch raises one step late, as on the eager path.
 
 The captured work is exactly the eager step's launch sequence (same kernels, same order, side streams included): results are
 bit-identical to the eager path on the same capacity-laid-out batch (tests/test_graphed.py).
@@ -37,7 +43,8 @@ def edge_capacity(E, floor=1024):
 
 
 class _Captured:
-    __slots__ = ('graph', 'sent', 'cids', 'nt', 'ns', 'al', 'labels', 'blob', 'lw', 'packed', 'logits', 'attn', 'loss', 'grads', 'replays')
+    __slots__ = ('graph', 'sent', 'cids', 'nt', 'ns', 'al', 'labels', 'blob', 'lw', 'packed', 'logits', 'attn', 'loss', 'grads', 'replays',
+                 'params', 'watched', 'sent_grad')
 
 
 class GraphedStep:
@@ -46,11 +53,15 @@ class GraphedStep:
     graph as a data_utils.PackedGraphBatch (device or host buffer), labels [B / num_choice].
 
     loss = cross_entropy(logits.view(-1, nc), labels) * loss_weight  (the reference's mini-batch loss, qagnn.py:257-261);
-    after the call every trainable parameter's .grad holds this step's gradient (NOT accumulated: zero_grad is implicit)."""
+    after the call every trainable parameter's .grad holds this step's gradient (zero_grad implicit), or -- accumulate=True -- the
+    running sum of the window's steps (the first step of a window is the one that finds .grad None, e.g. after
+    optimizer.zero_grad(set_to_none=True)).  sent_vecs.requires_grad: `step.sent_grad` holds d loss / d sent_vecs afterwards.
+    The set of trainable parameters is read at every call (freeze_net / unfreeze_net change it): one capture per set."""
 
     def __init__(self, model, num_choice, capacity=edge_capacity, warmup=2):
         self.model, self.nc, self.capacity, self.warmup = model, int(num_choice), capacity, int(warmup)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.sent_grad = None
         self.dev = self.params[0].device
         assert self.dev.type == 'cuda', 'GraphedStep captures a HIP graph: the model must live on the GPU'
         self._captured = {}
@@ -70,14 +81,19 @@ class GraphedStep:
         return logits, attn, loss
 
     def _key(self, sent, cids, packed):
-        return (cids.size(0), cids.size(1), sent.size(1), int(self.capacity(packed.E)), bool(self.model.training))
+        trainable = tuple(i for i, p in enumerate(self.model.parameters()) if p.requires_grad)
+        return (cids.size(0), cids.size(1), sent.size(1), int(self.capacity(packed.E)), bool(self.model.training), bool(sent.requires_grad),
+                hash(trainable))
 
     def _capture(self, key, args):
-        B, n, sent_dim, e_cap, _ = key
+        B, n, sent_dim, e_cap, _, sent_rg, _ = key
         sent, cids, nt, ns, al, packed, labels, lw = args
         dev, K = self.dev, ops.kernels()
+        from ._lib import ERR_WATCH
         c = _Captured()
-        c.sent = torch.empty((B, sent_dim), dtype=torch.float32, device=dev)
+        c.params = [p for p in self.model.parameters() if p.requires_grad]
+        c.watched, c.sent_grad = [], None
+        c.sent = torch.empty((B, sent_dim), dtype=torch.float32, device=dev, requires_grad=sent_rg)
         c.cids = torch.empty((B, n), dtype=torch.long, device=dev)
         c.nt = torch.empty((B, n), dtype=torch.long, device=dev)
         c.ns = torch.empty((B, n, 1), dtype=torch.float32, device=dev)
@@ -100,32 +116,40 @@ class GraphedStep:
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(self.warmup):
-                    for p in self.params:
+                    for p in c.params:
                         p.grad = None
+                    c.sent.grad = None
                     self._step(c)
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             with torch.no_grad():
                 for b, v in saved:
                     b.copy_(v)
-            for p in self.params:
+            for p in c.params:
                 p.grad = None
+            c.sent.grad = None
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             c.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(c.graph, pool=self._pool):
-                c.logits, c.attn, c.loss = self._step(c)
-                K.seed_epoch_advance(1)  # the next replay draws different dropout masks
+            ERR_WATCH.sink = c.watched  # the flag tensors of the captured preparation kernels (kept alive, read behind every replay)
+            try:
+                with torch.cuda.graph(c.graph, pool=self._pool):
+                    c.logits, c.attn, c.loss = self._step(c)
+                    K.seed_epoch_advance(1)  # the next replay draws different dropout masks
+            finally:
+                ERR_WATCH.sink = None
         finally:
             ops.WGRAD_OVERLAP, ops.PREP_OVERLAP = old
-        c.grads = [p.grad for p in self.params]
+        c.grads = [p.grad for p in c.params]
+        c.sent_grad = c.sent.grad if sent_rg else None
         assert all(g is not None for g in c.grads), 'a trainable parameter received no gradient during capture'
         self._captured[key] = c
         return c
 
     def _load(self, c, args):
         sent, cids, nt, ns, al, packed, labels, lw = args
-        c.sent.copy_(sent, non_blocking=True)
+        with torch.no_grad():
+            c.sent.copy_(sent, non_blocking=True)
         c.cids.copy_(cids, non_blocking=True)
         c.nt.copy_(nt, non_blocking=True)
         c.ns.copy_(ns.reshape(c.ns.shape), non_blocking=True)
@@ -136,7 +160,7 @@ class GraphedStep:
         assert nwords <= c.blob.numel() and packed.E <= c.packed.e_cap and packed.B == c.packed.B and packed.n == c.packed.n
         c.blob[:nwords].copy_(packed.buf, non_blocking=True)
 
-    def __call__(self, sent_vecs, concept_ids, node_type_ids, node_scores, adj_lengths, packed, labels, loss_weight=1.0):
+    def __call__(self, sent_vecs, concept_ids, node_type_ids, node_scores, adj_lengths, packed, labels, loss_weight=1.0, accumulate=False):
         assert isinstance(packed, PackedGraphBatch), 'GraphedStep takes the graph as load-time blobs (data_utils.PackedGraphBatch)'
         args = (sent_vecs, concept_ids, node_type_ids, node_scores, adj_lengths, packed, labels, loss_weight)
         key = self._key(sent_vecs, concept_ids, packed)
@@ -154,10 +178,27 @@ class GraphedStep:
                     self.overlap = False
                     torch.cuda.synchronize(self.dev)
                     c = self._capture(key, args)
+            from ._lib import ERR_WATCH
+            ERR_WATCH.poll()  # the previous replays' validation flags that have landed: a corrupt batch raises here, one step late
             self._load(c, args)
             c.graph.replay()
             c.replays += 1
-        for p, g in zip(self.params, c.grads):
+            ERR_WATCH.after_replay(c.watched)
+            self.params, self.sent_grad = c.params, c.sent_grad
+            if accumulate:
+                # the static gradients are overwritten by the next replay: the window's sum lives in tensors of its own
+                dst, src = [], []
+                static = {id(g) for cc in self._captured.values() for g in cc.grads}  # a .grad that IS one of these holds one step
+                for p, g in zip(c.params, c.grads):
+                    if p.grad is None or id(p.grad) in static:
+                        p.grad = g.clone()
+                    else:
+                        dst.append(p.grad)
+                        src.append(g)
+                if dst:
+                    torch._foreach_add_(dst, src)
+                return c.logits, c.loss
+        for p, g in zip(c.params, c.grads):
             p.grad = g
         return c.logits, c.loss
 

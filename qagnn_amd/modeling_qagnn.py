@@ -266,13 +266,17 @@ class GATConvE(nn.Module):
     N_PACKED = 18
 
     def hop(self, Xp, extra_p, graph, tab, L, apply_act, p_drop, typed=None, packed=None, tables=None, acc=None, tab_col=-1):
-        cols = (tab_col, L.ones_col)  # (type-indicator column of S, ones column of relu(bn(h1))): by-product gradients, see ops
         """Head-padded core of forward(): returns (next Xp [N, DP], attention a [E', 4] in source order).
 
         `extra_p` [N, DP] is a generic node_feature_extra; with `typed = (temb [T, d/2], node_type [N], S [N, SP])` the
         decomposed form is used instead (see packed_projection_typed).  `packed` = this layer's pack_build() outputs
         when the caller packed all layers with one gather; `tables` = (TT [T, 3DP], EkEm [C, 2DP]) when the caller also
         computed this layer's node-type and edge-class tables (for all layers at once)."""
+        cols = (tab_col, L.ones_col)  # (type-indicator column of S, ones column of relu(bn(h1))): by-product gradients, see ops
+        # the by-product type-table gradient is a view of a (possibly deferred) weight-gradient product: only SplitColsFn, the consumer
+        # of tables computed OUTSIDE the hop, joins the side stream before reading it
+        assert tab_col < 0 or tables is not None, 'tab_col >= 0 needs the node-type table of the caller (tables=...), see ops.wgrad_scope'
+
         if typed is None:
             W_t, W_nt, bias = self.packed_projection(L)
             KMQ = ops.linear_nn(Xp, W_t[0], W_nt[0], extra_p, W_t[1], W_nt[1], bias=bias)

@@ -189,7 +189,11 @@ FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '0') == '1'
 # gradients, GatherPlan's backward (plus an end-of-backward engine callback as a safety net).  Rules that make this safe:
 #   * only operators created inside `wgrad_scope()` defer, and the stack guarantees that every weight operand there comes
 #     straight out of GatherPlan, so nothing on the main stream reads a deferred gradient before the join;
-#   * gradients consumed inside the graph (the node-type-table gradient) are never deferred;
+#   * a gradient consumed inside the graph is either computed on the main stream (the grouped column reduction over dC when
+#     QAGNN_BYPRODUCT_GRADS=0) or -- the default -- handed out as a VIEW of a deferred weight-gradient product (the node-type-table
+#     gradient = rows [tab_col, tab_col + T) of S^T dC, LinearNNFn.tabcol) whose ONE consumer, SplitColsFn.backward, joins the side
+#     stream before it reads; hop() refuses the combination "table gradient as a by-product" + "tables computed inside the hop"
+#     (torch.addmm would read the view without a join);
 #   * outputs are allocated on the main stream up front; every input of a queued launch is kept alive until the join, so
 #     the caching allocator cannot hand its memory to a main-stream kernel while the side stream still reads it.
 WGRAD_OVERLAP = _os.environ.get('QAGNN_WGRAD_OVERLAP', '1') == '1'
@@ -468,7 +472,9 @@ def type_indicators(S, ntype, col0, T):
     (41 us + a 19-27 us final stage at 64 000 rows).  The gradient that flows back into S is zeroed at the indicator positions by
     scatter's own backward."""
     assert col0 + T <= S.size(1)
-    return S.scatter(1, (ntype.view(-1, 1) + col0), 1.0)
+    # the kernels clamp a node type outside [0, T) to T - 1 and report it through ERR_WATCH: the indicator must follow the same rule,
+    # or an invalid id would land in a later padding column (or past SP) and dTT would silently lose that row's contribution
+    return S.scatter(1, (ntype.clamp(0, T - 1).view(-1, 1) + col0), 1.0)
 
 
 class SplitColsFn(torch.autograd.Function):
@@ -528,6 +534,19 @@ def _rank():
         else:
             return int(_os.environ.get('RANK', '0'))  # not cached: the group may be initialised later
     return _rank_salt[0]
+
+
+def manual_seed(seed):
+    """Seed everything a run's dropout masks depend on: torch's generators, this module's per-process call counter and -- on every
+    visible GPU -- the library's device-side seed EPOCH (the word a replayed hipGraph advances, qagnn_seed_epoch_advance; it is
+    device state that torch.manual_seed does not know about, and it is not part of a checkpoint: a resumed run that wants the masks
+    of the original run calls manual_seed again and replays from there)."""
+    torch.manual_seed(seed)
+    _seed_counter[0] = 0
+    if torch.cuda.is_available() and _K is not None and getattr(_K, 'name', '') == 'hip':
+        for d in range(torch.cuda.device_count()):
+            with torch.cuda.device(d):
+                _K.seed_epoch_set(0)
 
 
 def next_seed():

@@ -11,7 +11,6 @@ import math
 
 import torch
 from torch.optim import SGD, Adam
-from torch.optim import AdamW as _TorchAdamW
 from torch.optim.optimizer import Optimizer
 
 
@@ -30,15 +29,69 @@ def radam_step_size(step, beta1, beta2, degenerated_to_sgd=True):
     return n_sma, step_size
 
 
-class AdamW(_TorchAdamW):
-    """`transformers.AdamW` as the reference imports it (utils/optimization_utils.py:3; removed from current transformers): the
-    decoupled-weight-decay update of torch.optim.AdamW with THAT class's defaults -- eps = 1e-6 and weight_decay = 0.0, not
-    torch's 1e-8 / 0.01.  The reference's driver sets weight_decay per parameter group and never passes eps (qagnn.py:196-206),
-    so `--optim adamw` trains with eps = 1e-6 there and must do so here."""
+class AdamW(Optimizer):
+    """`transformers.AdamW` as the reference imports it (utils/optimization_utils.py:3; transformers == 3.4.0 is pinned in the
+    reference's README, the class has since been removed from transformers): its defaults -- eps = 1e-6, weight_decay = 0.0,
+    correct_bias = True -- AND its update rule, which is not torch.optim.AdamW's:
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, **kwargs):
-        kwargs.pop('correct_bias', None)  # transformers' switch; True (its default) is what torch implements
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kwargs)
+        m <- b1 m + (1 - b1) g;   v <- b2 v + (1 - b2) g^2
+        p <- p - lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)        (eps is added to the UNcorrected sqrt(v): an effective
+        p <- p - lr * weight_decay * p                                           eps of eps / sqrt(1 - b2^t), ~30x larger at t = 1;
+                                                                                 the decay uses the parameter AFTER the Adam update)
+
+    torch's class divides sqrt(v) by sqrt(1 - b2^t) before adding eps and applies the decay first.  The reference's driver sets
+    weight_decay per parameter group and never passes eps (qagnn.py:196-206).  State layout as transformers': `step`, `exp_avg`,
+    `exp_avg_sq` per parameter.  One multi-tensor (foreach) op sequence per group."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            by_step = {}  # parameters that share a step count share their scalar factors
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['exp_avg'] = torch.zeros_like(p)
+                    state['exp_avg_sq'] = torch.zeros_like(p)
+                state['step'] += 1
+                by_step.setdefault(state['step'], []).append(p)
+            for t, ps in by_step.items():
+                grads = [p.grad for p in ps]
+                m = [self.state[p]['exp_avg'] for p in ps]
+                v = [self.state[p]['exp_avg_sq'] for p in ps]
+                torch._foreach_mul_(m, beta1)
+                torch._foreach_add_(m, grads, alpha=1.0 - beta1)
+                torch._foreach_mul_(v, beta2)
+                torch._foreach_addcmul_(v, grads, grads, value=1.0 - beta2)
+                denom = torch._foreach_sqrt(v)
+                torch._foreach_add_(denom, group['eps'])
+                step_size = group['lr']
+                if group['correct_bias']:
+                    step_size = step_size * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+                torch._foreach_addcdiv_(ps, m, denom, value=-step_size)
+                if group['weight_decay'] > 0.0:
+                    torch._foreach_mul_(ps, 1.0 - group['lr'] * group['weight_decay'])  # p <- p + (-lr wd) p, one rounding per element
+        return loss
 
 
 class RAdam(Optimizer):

@@ -99,6 +99,40 @@ class GradBucket:
         return self.flat.numel()
 
 
+def sync_batchnorm_running_stats(model, group=None):
+    """Average the BatchNorm running statistics over the ranks, in place (optional, at epoch end or before a
+    checkpoint is written).
+
+    Under question sharding every rank runs BatchNorm on its own shard -- exactly the reference's gradient accumulation with
+    mbs = bs / world (qagnn.py:252-266: batch statistics per mini-batch) -- so the replicas' running_mean / running_var drift apart by
+    the sampling noise of their shards while their PARAMETERS stay identical (summed gradients).  A checkpoint written by rank 0 would
+    carry rank 0's statistics only; averaging first makes the checkpoint independent of which rank writes it and uses all shards'
+    batches.  One flat all-reduce of every running_mean | running_var (a few KB); num_batches_tracked is the same on every rank (one
+    step = one batch everywhere) and is left alone.  Returns the number of floats reduced (0: no BatchNorm buffers / one rank)."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    bufs = []
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.running_mean is not None:
+            bufs += [m.running_mean, m.running_var]
+    seen, uniq = set(), []
+    for t in bufs:  # the edge encoder's BatchNorm is ONE module shared by all k layers (modeling_qagnn.py:30): reduce it once
+        if id(t) not in seen:
+            seen.add(id(t))
+            uniq.append(t)
+    if world == 1 or not uniq:
+        return 0
+    flat = torch.cat([t.detach().reshape(-1).float() for t in uniq])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
+    off = 0
+    with torch.no_grad():
+        for t in uniq:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    return flat.numel()
+
+
 def allreduce_gradients(params, group=None):
     """Sum the gradients of `params` across ranks through one flat bucket (in place) without a persistent bucket: the
     gradients are copied into a temporary flat buffer and back (p.grad keeps its identity).  Prefer GradBucket in a training

@@ -131,16 +131,40 @@ def test_fused_radam_decoder_tensor_list_vs_float64(step, wd):
         np.testing.assert_allclose(p.detach().cpu().numpy(), rp, rtol=2e-6, atol=1e-7)
 
 
-def test_adamw_keeps_the_defaults_of_the_class_the_reference_imports():
-    """The reference's OPTIMIZER_CLASSES['adamw'] is transformers.AdamW (utils/optimization_utils.py:3, 103): eps 1e-6, weight_decay 0.
-    Its driver never passes eps (qagnn.py:196-206), so the mirror must default to the same values, not to torch's 1e-8 / 0.01."""
+def test_adamw_keeps_the_defaults_and_the_update_rule_of_the_class_the_reference_imports():
+    """The reference's OPTIMIZER_CLASSES['adamw'] is transformers.AdamW (utils/optimization_utils.py:3, 103; transformers 3.4.0): eps
+    1e-6, weight_decay 0, and an update rule that differs from torch.optim.AdamW's (eps added to the uncorrected sqrt(v), decay after the
+    Adam update).  Its driver never passes eps (qagnn.py:196-206).  Held to oracle.radam_oracle.transformers_adamw_step in float64."""
+    import numpy as np
     import torch
+    from oracle import radam_oracle as RO
     p = torch.nn.Parameter(torch.ones(3))
     opt = OU.OPTIMIZER_CLASSES['adamw']([{'params': [p], 'weight_decay': 0.01, 'lr': 1e-3}])
     g = opt.param_groups[0]
-    assert g['eps'] == 1e-6 and g['weight_decay'] == 0.01 and g['betas'] == (0.9, 0.999)
+    assert g['eps'] == 1e-6 and g['weight_decay'] == 0.01 and g['betas'] == (0.9, 0.999) and g['correct_bias'] is True
     assert OU.OPTIMIZER_CLASSES['adamw']([p], lr=1e-3).param_groups[0]['weight_decay'] == 0.0
     p.grad = torch.full((3,), 0.5)
-    opt.step()  # first step of Adam with bias correction: p -= lr * (wd * p + g / (|g| + eps))
-    want = 1.0 - 1e-3 * 0.01 * 1.0 - 1e-3 * 0.5 / (0.5 + 1e-6)
+    opt.step()
+    # first step by hand: m = 0.05, sqrt(v) = 0.5 sqrt(0.001); p -= lr sqrt(0.001) / 0.1 * m / (sqrt(v) + eps); then p -= lr wd p
+    upd = 1e-3 * (0.001 ** 0.5) / 0.1 * 0.05 / (0.5 * 0.001 ** 0.5 + 1e-6)
+    want = (1.0 - upd) * (1.0 - 1e-3 * 0.01)
     assert torch.allclose(p.detach(), torch.full((3,), want), rtol=0, atol=1e-7)
+    torch_first = 1.0 - 1e-3 * 0.01 - 1e-3 * 0.5 / (0.5 + 1e-6)   # what torch.optim.AdamW(eps=1e-6) does on the same step
+    assert abs(want - torch_first) > 5e-8  # the two rules are not the same rule (eps / sqrt(1 - b2^t) ~ 3e-5 here)
+    # several steps, two groups with different decay, against the float64 restatement
+    gen = torch.Generator().manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(7, 5, generator=gen)), torch.nn.Parameter(torch.randn(11, generator=gen))]
+    opt = OU.AdamW([{'params': [ps[0]], 'weight_decay': 0.01}, {'params': [ps[1]], 'weight_decay': 0.0}], lr=2e-3)
+    ref = [(q.detach().double().numpy().copy(), np.zeros(q.shape), np.zeros(q.shape)) for q in ps]
+    for step in range(1, 8):
+        for q in ps:
+            q.grad = torch.randn(q.shape, generator=gen) * (0.1 if step % 2 else 1e-4)  # small gradients: where eps placement matters
+        opt.step()
+        ref = [RO.transformers_adamw_step(rp, q.grad.double().numpy(), rm, rv, step, 2e-3, weight_decay=wd)
+               for (rp, rm, rv), q, wd in zip(ref, ps, (0.01, 0.0))]
+        for q, (rp, rm, rv) in zip(ps, ref):
+            st = opt.state[q]
+            assert st['step'] == step
+            np.testing.assert_allclose(st['exp_avg'].numpy(), rm, rtol=3e-6, atol=1e-9)
+            np.testing.assert_allclose(st['exp_avg_sq'].numpy(), rv, rtol=3e-6, atol=1e-12)
+            np.testing.assert_allclose(q.detach().numpy(), rp, rtol=3e-6, atol=2e-7)

@@ -90,6 +90,23 @@ def _worker(rank, world, port, q):
     params2 = [p for p in model2.parameters() if p.requires_grad]
     parallel.GradBucket(params2).allreduce()
     z2 = parallel.scatter_logits_by_assignment(parallel.allgather_logits(logits2), parts)
+    # ---- BatchNorm running statistics: per-shard after a training forward (different on the two ranks), averaged by
+    #      sync_batchnorm_running_stats(); the edge encoder's BatchNorm is one module shared by all layers and must be reduced once ----
+    names = [k for k, _ in model2.named_buffers() if k.endswith('running_mean') or k.endswith('running_var')]
+    pre = {k: v.clone() for k, v in model2.named_buffers() if k in names}
+    gathered = {}
+    for k in names:
+        both = [torch.empty_like(pre[k]) for _ in range(world)]
+        dist.all_gather(both, pre[k])
+        gathered[k] = both
+    assert any(not torch.equal(gathered[k][0], gathered[k][1]) for k in names), 'the shards should leave different statistics'
+    n_bn = parallel.sync_batchnorm_running_stats(model2)
+    dup = [k for k, _ in model2.named_buffers(remove_duplicate=False) if k.endswith('running_mean') or k.endswith('running_var')]
+    assert len(dup) > len(names)  # the shared edge encoder shows up under every layer ...
+    assert n_bn == sum(pre[k].numel() for k in names)  # ... and is reduced once
+    for k, v in model2.named_buffers():
+        if k in names:
+            assert torch.allclose(v, sum(gathered[k]) / world, rtol=1e-6, atol=1e-7), k
     if rank == 0:
         q.put(res + (parts, z2.numpy(), {k: p.grad.numpy().copy() for k, p in model2.named_parameters() if p.grad is not None}))
     dist.barrier()
