@@ -76,6 +76,9 @@ def make_records(n_samples, seed=0, shape='csqa', n_rel=17, n_concept_vocab=1000
       'csqa_max' 199 concepts, 990 KG edges (the <=200 nodes / <=2k edges worst case of north_star)
       'medqa'    100..199 concepts, ~1500 KG edges, no node scores (cid2score None), 15 relations
       'tiny'     3..12 concepts, 0..15 KG edges (edge cases: empty graphs, 1 concept, ...)
+      'hub'      249 concepts of which 60 Q + 25 A (the context node gets 85 out-edges and 85 in-edges: a > 64-degree segment),
+                 2 900 Zipf-distributed KG edges = ~5.8 k directed edges with hub concepts -- the loader's comment case of a
+                 249-node graph (reference utils/data_utils.py:103) that it truncates to n = 200 node slots (:117)
     """
     rng = np.random.default_rng(seed)
     recs = []
@@ -94,6 +97,8 @@ def make_records(n_samples, seed=0, shape='csqa', n_rel=17, n_concept_vocab=1000
             m = int(rng.integers(100, 200))
             recs.append(make_record(rng, m, int(rng.integers(3, 20)), int(rng.integers(1, 4)),
                                     1500, 15, n_concept_vocab, zipf, with_scores=False))
+        elif shape == 'hub':
+            recs.append(make_record(rng, 249, 60, 25, 2900, n_rel, n_concept_vocab, zipf=True))
         elif shape == 'tiny':
             m = int(rng.integers(1, 13))
             nq = int(rng.integers(1, max(2, m // 2 + 1)))

@@ -140,6 +140,24 @@ def test_oracle_parity_odd_shapes(train):
     oracle_vs_package(case)
 
 
+@pytest.mark.parametrize('train', [True, False])
+def test_oracle_parity_hub_node_and_truncated_graph(train):
+    """Inside QAGNN.forward, not only in the kernel tests: a context node with 85 out- and in-edges (a > 64-degree softmax segment
+    takes the edge kernels' hub path), Zipf hub concepts, and a 249-concept / ~5.8 k-edge graph that the loader truncates to
+    n = 200 node slots, dropping the edges of the cut concepts (reference utils/data_utils.py:103, :117)."""
+    case = dict(shape='hub', nq=2, nc=3, n=200, n_rel=17, std=0.6, train=train, seed=57,
+                cfg=helpers.model_cfg(d=200, k=5, sent_dim=64, n_concept=3000, concept_in_dim=32))
+    args, _ = _case_args(case)
+    ei_list = args[5] if isinstance(args[5], (list, tuple)) else None
+    al = args[4]
+    assert int(al.max()) == 200, 'the graphs must be truncated at n = 200'
+    src = args[5][0] if not ei_list else None
+    if src is not None:  # batched edge_index: the context node of subgraph 0 is row 0
+        assert int((src == 0).sum()) > 64, 'the context node must have a > 64-edge segment'
+    report = oracle_vs_package(case)
+    assert max(report.values()) < helpers.MAX_ALLOWED
+
+
 BIG_TRAIN_CASES = {
     # train-mode fwd+bwd at the largest sizes the CPU oracle handles in seconds (SURVEY 8d), n = 200, d = 200, 5 layers:
     'configs1_csqa_b40': dict(shape='csqa', nq=8, nc=5, n=200, n_rel=17, std=0.6, train=True, seed=41,
@@ -358,23 +376,32 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
 # (concept_emb.cpt_transform.weight, at the bottom of the network), 5-7e-3 on a handful of bottom-of-network tensors, < 5e-3 elsewhere.
 # The tight per-tensor statement stays with the float64 yardstick at B = 40 / 24 / 16 above.
 BENCH_SIZE_BAR, BENCH_SIZE_KINK_BAR = 1.5e-2, 2e-2
+BENCH_SIZE_MEDIAN_BAR = 2e-3  # median over the gradient tensors that are not BatchNorm affine parameters (round 4; measured: see profiles/)
 # ---------------------------------------------------------------------------------------------------------------------------------
 _BENCH_SIZE = {}
+# (workload of BASELINE.json) -> questions, choices, record shape, relations, edge types, input width.  configs[2] at 64 x 4 = 256
+# subgraphs: the full 128 x 4 needs ~50 GB of autograd state on the host; configs[4]/gpu is the MedQA shard as bench.py runs it.
+BENCH_WORKLOADS = {
+    'configs1_csqa_320': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024),
+    'configs2_obqa_256': dict(nq=64, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024),
+    'configs4_medqa_64': dict(nq=16, nc=4, shape='medqa', n_rel=15, n_etype=34, dim=768),
+}
 
 
-def _bench_size_case():
+def _bench_size_case(workload='configs1_csqa_320'):
     """Inputs + the fp32 CPU oracle's logits and gradients (computed once per session: ~30 GB of autograd state, tens of seconds)."""
-    if _BENCH_SIZE:
-        return _BENCH_SIZE
+    if workload in _BENCH_SIZE:
+        return _BENCH_SIZE[workload]
     from oracle import qagnn_oracle as O
-    nq, nc, n = 64, 5, 200
+    wl = BENCH_WORKLOADS[workload]
+    nq, nc, n = wl['nq'], wl['nc'], 200
     B = nq * nc
-    cfg = helpers.model_cfg(d=200, k=5, sent_dim=1024, n_concept=20000, concept_in_dim=1024)
-    recs = synthetic.make_records(B, seed=91, shape='csqa', n_rel=17, n_concept_vocab=20000)
+    cfg = helpers.model_cfg(d=200, k=5, n_etype=wl['n_etype'], sent_dim=wl['dim'], n_concept=20000, concept_in_dim=wl['dim'])
+    recs = synthetic.make_records(B, seed=91, shape=wl['shape'], n_rel=wl['n_rel'], n_concept_vocab=20000)
     _, cids, nt, ns, al, ei, et, _ = data_utils.records_to_tensors(recs, n, nc)
     bei, bet = data_utils.batch_graph(ei, et, n)
     g = torch.Generator().manual_seed(92)
-    sv = torch.randn(B, 1024, generator=g)
+    sv = torch.randn(B, wl['dim'], generator=g)
     labels = torch.randint(0, nc, (nq,), generator=g)
     torch.manual_seed(0)
     omodel = O.build_qagnn(cfg)
@@ -383,39 +410,43 @@ def _bench_size_case():
     omodel.train()
     ologits, _ = omodel(sv, cids, nt, ns, al, (bei, bet))
     torch.nn.functional.cross_entropy(ologits.view(nq, nc), labels).backward()
-    _BENCH_SIZE.update(cfg=cfg, inputs=(sv, cids, nt, ns, al, bei, bet), labels=labels, ei=ei, et=et, nt=nt,
-                       logits=ologits.detach(), grads={k: p.grad for k, p in omodel.named_parameters() if p.grad is not None},
-                       bufs={k: b.detach().clone() for k, b in omodel.named_buffers()})
-    return _BENCH_SIZE
+    _BENCH_SIZE[workload] = dict(cfg=cfg, wl=wl, inputs=(sv, cids, nt, ns, al, bei, bet), labels=labels, ei=ei, et=et, nt=nt,
+                                 logits=ologits.detach(), grads={k: p.grad for k, p in omodel.named_parameters() if p.grad is not None},
+                                 bufs={k: b.detach().clone() for k, b in omodel.named_buffers()})
+    del omodel
+    return _BENCH_SIZE[workload]
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize('variant', ['default', 'poison', 'blobs', 'native'])
-def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
+@pytest.mark.parametrize('variant,workload', [('default', 'configs1_csqa_320'), ('poison', 'configs1_csqa_320'), ('blobs', 'configs1_csqa_320'),
+                                              ('native', 'configs1_csqa_320'), ('blobs', 'configs2_obqa_256'), ('blobs', 'configs4_medqa_64')])
+def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch):
     """default: int64 edge lists; poison: deferred weight gradients start as NaN (a reader that runs before the side-stream join
     would carry the NaN into a gradient); blobs: the graph arrives as load-time blobs, as in bench.py's default mode; native: the
     natively sequenced stack (qagnn_stack_{fwd,bwd}_f32, what the host-bound batches take) at this size, where its weight-gradient
     stream (qagnn_hop_args.side_stream) really lags the data-gradient chain by a hop -- the two buffer sets earn their keep here."""
     import re
     from qagnn_amd import modeling_qagnn as MQ
-    ref = _bench_size_case()
-    cfg, nq, nc, n = ref['cfg'], 64, 5, 200
+    ref = _bench_size_case(workload)
+    cfg, wl, n = ref['cfg'], ref['wl'], 200
+    nq, nc, n_etype = wl['nq'], wl['nc'], wl['n_etype']
+    big = nq * nc * n >= 32768  # the composed path + weight-gradient side stream (the MedQA shard takes the native stack: host-bound size)
     if variant == 'poison':
         monkeypatch.setattr(ops, 'WGRAD_POISON', True)
     if variant == 'native':
         monkeypatch.setattr(ops, 'FUSED_HOP', True)
         assert ops.FUSED_STACK and ops.use_fused_hop(nq * nc * n)
-    else:
+    elif big:
         assert not ops.use_fused_hop(nq * nc * n), 'this test is about the composed path + weight-gradient overlap'
     assert ops.WGRAD_OVERLAP
     torch.manual_seed(0)
-    model = MQ.QAGNN(None, cfg['k'], 4, 38, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
+    model = MQ.QAGNN(None, cfg['k'], 4, n_etype, cfg['sent_dim'], cfg['n_concept'], 200, cfg['concept_in_dim'], 2, 200, 0, 0.0, 0.0, 0.0)
     helpers.det_fill_(model, 7, 0.6)
     model.pooler.dropout.p = model.pooler.attention.dropout.p = 0.0
     model = model.cuda().train()
     sv, cids, nt, ns, al, bei, bet = cu(*ref['inputs'])
     if variant == 'blobs':
-        store = data_utils.GraphBlobStore.build(ref['ei'], ref['et'], ref['nt'], 38, 4)
+        store = data_utils.GraphBlobStore.build(ref['ei'], ref['et'], ref['nt'], n_etype, 4)
         buf, Bb, E = store.pack(list(range(nq * nc)))
         adj = data_utils.PackedGraphBatch(buf.cuda(), Bb, E, store, list(range(nq * nc)), nc)
     else:
@@ -424,14 +455,14 @@ def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
     logits, _ = model(sv, cids, nt, ns, al, adj)
     torch.nn.functional.cross_entropy(logits.view(nq, nc), ref['labels'].cuda()).backward()
     torch.cuda.synchronize()
-    if variant != 'native':
+    if variant != 'native' and big:
         assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the path bench.py times'
     # forward bar 5e-4 of the logits' scale (1e-4 at the small cases): both sides are fp32, and at N = 64 000 rows x 5 layers of
     # train-mode BatchNorm each is ~1e-4 from exact arithmetic (measured 1.4e-4 between them)
-    helpers._close(logits.detach().cpu(), ref['logits'], what='B=320 train-mode logits', rtol=5e-4, atol=1e-5)
+    helpers._close(logits.detach().cpu(), ref['logits'], what=f'{workload} train-mode logits', rtol=5e-4, atol=1e-5)
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(grads) == set(ref['grads'])
-    worst, n_checked, fails = (0.0, None), 0, []
+    worst, n_checked, fails, rel_plain = (0.0, None), 0, [], []
     for k, gref in ref['grads'].items():
         assert torch.isfinite(grads[k]).all(), f'{k}: non-finite gradient ({variant})'
         # besides the usual null gradients: cross-entropy over a question's choices is invariant to a constant added to all of its
@@ -442,14 +473,23 @@ def test_bench_size_train_step_matches_the_oracle(variant, monkeypatch):
         err = (grads[k].cpu() - gref).abs().max().item()
         bar = BENCH_SIZE_KINK_BAR if re.search(r'(mlp|edge_encoder)\.1\.(weight|bias)$', k) else BENCH_SIZE_BAR
         n_checked += 1
+        if bar == BENCH_SIZE_BAR:
+            rel_plain.append(err / (scale + 1e-30))
         if err / (scale + 1e-30) > worst[0]:
             worst = (err / (scale + 1e-30), k)
         if err > bar * scale + 1e-9:
             fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.0e})')
     if helpers.REPORT:
         with open(helpers.REPORT, 'a') as f:
-            f.write(f'bench-size B=320 train [{variant}] vs fp32 oracle: {n_checked} tensors, worst {worst[0]:.3e} of scale ({worst[1]})\n')
+            rs = sorted(rel_plain)
+            f.write(f'bench-size {workload} train [{variant}] vs fp32 oracle: {n_checked} tensors, worst {worst[0]:.3e} of scale ({worst[1]}); '
+                    f'tensors off a BatchNorm: median {rs[len(rs) // 2]:.2e}, 90th percentile {rs[int(len(rs) * 0.9)]:.2e}, '
+                    f'{sum(r <= 1e-3 for r in rs)} of {len(rs)} within 1e-3\n')
     assert n_checked >= 60 and not fails, fails[:10]
+    # the per-tensor bars above leave room for ReLU-kink flips (a different subgradient on a handful of the 64 M BatchNorm outputs moves
+    # everything upstream of it); what is NOT a kink must still be fp32-accurate: the typical tensor sits far below them
+    rs = sorted(rel_plain)
+    assert rs[len(rs) // 2] <= BENCH_SIZE_MEDIAN_BAR, f'median error of the tensors off a BatchNorm: {rs[len(rs) // 2]:.2e}'
     for bname, b in model.named_buffers():
         helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=5e-4, atol=1e-6, what='buffer ' + bname)  # the forward bar: statistics of activations that agree to ~1e-4
 

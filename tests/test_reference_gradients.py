@@ -4,8 +4,9 @@ reconstruction, nothing fitted to the candidate:
 
     |g - g_ref| <= BAR * max(|g_ref| elementwise, max|g_ref|) + 1e-6 + 6 x (the reference's own re-ordering noise)
 
-BAR = FIXED_GRAD_BAR = 5e-3 for every tensor except the affine parameters of a BatchNorm in front of a ReLU (`mlp.1.*`,
-`edge_encoder.1.*`), which get KINK_BAR = 1e-2.  Why not tighter: of the ~1e6 BatchNorm outputs of a case a handful lie within
+BAR = FIXED_GRAD_BAR_HIP = 1e-3 on the GPU (round 4; 5e-3 for the torch emulation of the kernels on the CPU, whose rounding differs
+more) for every tensor except the affine parameters of a BatchNorm in front of a ReLU (`mlp.1.*`, `edge_encoder.1.*`), which get
+KINK_BAR = 1e-2.  Why not tighter: of the ~1e6 BatchNorm outputs of a case a handful lie within
 fp32 rounding of 0, two fp32 implementations put some of them on different sides of the ReLU (a different subgradient at a kink,
 not an arithmetic error), and each such element changes those column sums by one whole upstream-gradient element and everything
 upstream of the layer in proportion.  Measured on the torch emulation of the kernels (same formulas, other rounding) over all 27
@@ -29,12 +30,13 @@ import torch
 import helpers
 from qagnn_amd import ops
 
-FIXED_GRAD_BAR = 5e-3
+FIXED_GRAD_BAR = 5e-3      # the torch emulation of the kernels (CPU test below): measured worst 2.9e-3 off a BatchNorm
+FIXED_GRAD_BAR_HIP = 1e-3  # the shipped HIP path (`-m gpu`): measured worst 3.9e-4 off a BatchNorm (profiles/r3_run4_direct_gradients_vs_reference.txt)
 KINK_BAR = 1e-2
 CASES = list(helpers.GOLDEN_CASES.keys())
 
 
-def check_gradients_against_fixture(fix, prefix, grads, train, what=''):
+def check_gradients_against_fixture(fix, prefix, grads, train, what='', fixed_bar=FIXED_GRAD_BAR):
     """grads: name -> tensor (parameter names, or '::key' for an input gradient stored without the prefix).  Returns the number of
     tensors compared."""
     n, worst = 0, (0.0, None)
@@ -43,7 +45,7 @@ def check_gradients_against_fixture(fix, prefix, grads, train, what=''):
             continue
         key = name[2:] if name.startswith('::') else prefix + name
         assert (key in fix) or (key + '::head' in fix), f'{what}: the fixture has no {key}'
-        bar = KINK_BAR if re.search(r'(mlp|edge_encoder)\.1\.(weight|bias)$', name) else FIXED_GRAD_BAR
+        bar = KINK_BAR if re.search(r'(mlp|edge_encoder)\.1\.(weight|bias)$', name) else fixed_bar
         err = helpers.check_stored(fix, key, g, rtol=bar, atol=1e-6)
         scale = helpers._stored_scale(fix, key)
         if scale > 0 and err / scale > worst[0]:
@@ -55,7 +57,7 @@ def check_gradients_against_fixture(fix, prefix, grads, train, what=''):
     return n
 
 
-def run_section(case, section, device):
+def run_section(case, section, device, fixed_bar=FIXED_GRAD_BAR):
     from test_host_logic_emu import build, golden_inputs
     fix = helpers.load_golden(case)
     c = helpers.GOLDEN_CASES[case]
@@ -67,7 +69,7 @@ def run_section(case, section, device):
         logits, _ = model(sv, cids, nt, ns, al, (ei, et))
         (logits * torch.linspace(0.5, 1.5, B, device=device).view(B, 1)).sum().backward()
         grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
-        return check_gradients_against_fixture(fix, 'grad::', grads, c['train'], what=f'{case} grad')
+        return check_gradients_against_fixture(fix, 'grad::', grads, c['train'], what=f'{case} grad', fixed_bar=fixed_bar)
     if section == 'mpgrad':
         nsc = nsc * (torch.arange(n) < al.cpu().unsqueeze(1)).float().unsqueeze(2)
         Hg = H.to(device).requires_grad_(True)
@@ -76,7 +78,7 @@ def run_section(case, section, device):
         (out * wg).sum().backward()
         grads = {k: p.grad for k, p in model.gnn.named_parameters() if p.grad is not None}
         grads['::mp_dH'] = Hg.grad
-        return check_gradients_against_fixture(fix, 'mpgrad::', grads, c['train'], what=f'{case} mpgrad')
+        return check_gradients_against_fixture(fix, 'mpgrad::', grads, c['train'], what=f'{case} mpgrad', fixed_bar=fixed_bar)
     layer = model.gnn.gnn_layers[0]
     xg = x.to(device).requires_grad_(True)
     out = layer(xg, ei, et, nt.view(-1), extra.to(device))
@@ -84,7 +86,7 @@ def run_section(case, section, device):
     (out * wl).sum().backward()
     grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
     grads['::layer_dx'] = xg.grad
-    return check_gradients_against_fixture(fix, 'layergrad::', grads, c['train'], what=f'{case} layergrad')
+    return check_gradients_against_fixture(fix, 'layergrad::', grads, c['train'], what=f'{case} layergrad', fixed_bar=fixed_bar)
 
 
 MIN_TENSORS = {'grad': 40, 'mpgrad': 30, 'layergrad': 8}
@@ -96,7 +98,7 @@ MIN_TENSORS = {'grad': 40, 'mpgrad': 30, 'layergrad': 8}
 def test_hip_gradients_equal_the_reference_gradients(case, section):
     ops.set_kernels(None)
     k = helpers.GOLDEN_CASES[case]['cfg']['k']
-    n = run_section(case, section, 'cuda')
+    n = run_section(case, section, 'cuda', fixed_bar=FIXED_GRAD_BAR_HIP)
     assert ops.kernels().name == 'hip'
     assert n >= (MIN_TENSORS[section] if k >= 5 else MIN_TENSORS[section] // 2), n
 
