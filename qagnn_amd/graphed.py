@@ -108,6 +108,7 @@ class GraphedStep:
         # warm-up outside the capture (lazy initialisation: operand-packing plans, LDS attribute raises, allocator pools), on a side
         # stream as torch's capture recipe asks; module buffers (BatchNorm running statistics, batch counters) are put back afterwards
         saved = [(b, b.detach().clone()) for b in self.model.buffers()]
+        held = [p.grad for p in c.params]  # a capture in the middle of an accumulation window must not lose the window's gradients
         old = ops.WGRAD_OVERLAP, ops.PREP_OVERLAP
         ops.WGRAD_OVERLAP = ops.WGRAD_OVERLAP and self.wgrad_overlap and self.overlap
         ops.PREP_OVERLAP = ops.PREP_OVERLAP and self.overlap
@@ -142,6 +143,8 @@ class GraphedStep:
             ops.WGRAD_OVERLAP, ops.PREP_OVERLAP = old
         c.grads = [p.grad for p in c.params]
         c.sent_grad = c.sent.grad if sent_rg else None
+        for p, g in zip(c.params, held):
+            p.grad = g
         assert all(g is not None for g in c.grads), 'a trainable parameter received no gradient during capture'
         self._captured[key] = c
         return c
