@@ -369,7 +369,8 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
 # (ops.WGRAD_OVERLAP) -- a different code path from the natively sequenced stack the smaller train-mode cases take.  Dropout is off
 # (it cannot be replayed on the oracle); everything else is the bench's step.
 # Bars (fixed, nothing read off the candidate): logits 5e-4 of scale; every gradient tensor 1.5e-2 of its scale (2e-2 for the affine
-# parameters of a BatchNorm in front of a ReLU).  Why not the 5e-3 of the 10-subgraph cases: this batch has 64 M BatchNorm outputs,
+# parameters of a BatchNorm in front of a ReLU) or 6 x the REFERENCE's own re-ordering noise on that tensor, whichever is larger (round 4:
+# the oracle is run a second time on the edge-permuted batch, see _bench_size_case).  Why not the 5e-3 of the 10-subgraph cases: this batch has 64 M BatchNorm outputs,
 # ~1e-6 of them within fp32 rounding of the ReLU kink, i.e. dozens of elements per layer on which two correct fp32 implementations
 # choose different subgradients; each moves every gradient upstream of it.  Measured HIP vs the fp32 oracle: 7.2e-3 of scale at worst
 # (concept_emb.cpt_transform.weight, at the bottom of the network), 5-7e-3 on a handful of bottom-of-network tensors, < 5e-3 elsewhere.
@@ -406,12 +407,26 @@ def _bench_size_case(workload='configs1_csqa_320'):
     helpers.det_fill_(omodel, 7, 0.6)
     omodel.pooler.dropout.p = omodel.pooler.attention.dropout.p = 0.0
     omodel.train()
+    state0 = {k: v.detach().clone() for k, v in omodel.state_dict().items()}
     ologits, _ = omodel(sv, cids, nt, ns, al, (bei, bet))
     torch.nn.functional.cross_entropy(ologits.view(nq, nc), labels).backward()
+    grads = {k: p.grad.detach().clone() for k, p in omodel.named_parameters() if p.grad is not None}
+    bufs = {k: b.detach().clone() for k, b in omodel.named_buffers()}
+    ologits = ologits.detach().clone()
+    # The reference's OWN sensitivity at this size (as tests/golden/make_golden.py measures it for the small cases): the same oracle,
+    # same weights, same batch, with the edge list permuted -- only the summation order of its index_add / scatter changes, i.e. fp32
+    # rounding -- flips some of the ReLU kinks among the tens of millions of BatchNorm outputs and moves every gradient upstream of them.
+    # A candidate cannot be asked to sit closer to run 1 than the reference's run 2 does.
+    omodel.load_state_dict(state0)
+    for p in omodel.parameters():
+        p.grad = None
+    perm = torch.randperm(bei.size(1), generator=torch.Generator().manual_seed(93))
+    l2, _ = omodel(sv, cids, nt, ns, al, (bei[:, perm], bet[perm]))
+    torch.nn.functional.cross_entropy(l2.view(nq, nc), labels).backward()
+    noise = {k: (p.grad - grads[k]).abs().max().item() for k, p in omodel.named_parameters() if p.grad is not None}
     _BENCH_SIZE[workload] = dict(cfg=cfg, wl=wl, inputs=(sv, cids, nt, ns, al, bei, bet), labels=labels, ei=ei, et=et, nt=nt,
-                                 logits=ologits.detach(), grads={k: p.grad for k, p in omodel.named_parameters() if p.grad is not None},
-                                 bufs={k: b.detach().clone() for k, b in omodel.named_buffers()})
-    del omodel
+                                 logits=ologits, grads=grads, bufs=bufs, noise=noise, logit_noise=(l2.detach() - ologits).abs().max().item())
+    del omodel, l2
     return _BENCH_SIZE[workload]
 
 
@@ -477,14 +492,16 @@ def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch
             rel_plain.append(err / (scale + 1e-30))
         if err / (scale + 1e-30) > worst[0]:
             worst = (err / (scale + 1e-30), k)
-        if err > bar * scale + 1e-9:
-            fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.0e})')
+        if err > max(bar * scale, 6.0 * ref['noise'][k]) + 1e-9:
+            fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.0e}, the reference\'s own re-ordering noise '
+                         f'{ref["noise"][k] / (scale + 1e-30):.2e})')
     if helpers.REPORT:
         with open(helpers.REPORT, 'a') as f:
             rs = sorted(rel_plain)
             f.write(f'bench-size {workload} train [{variant}] vs fp32 oracle: {n_checked} tensors, worst {worst[0]:.3e} of scale ({worst[1]}); '
                     f'tensors off a BatchNorm: median {rs[len(rs) // 2]:.2e}, 90th percentile {rs[int(len(rs) * 0.9)]:.2e}, '
-                    f'{sum(r <= 1e-3 for r in rs)} of {len(rs)} within 1e-3\n')
+                    f'{sum(r <= 1e-3 for r in rs)} of {len(rs)} within 1e-3; the reference against its own edge-permuted run: worst '
+                    f'{max(ref["noise"][k] / (g.abs().max().item() + 1e-30) for k, g in ref["grads"].items() if not helpers.has_null_gradient(k, True)):.2e} of scale\n')
     assert n_checked >= 60 and not fails, fails[:10]
     # (the report line above also carries the median / 90th percentile over the tensors off a BatchNorm: at 64 M BatchNorm outputs the
     # kink flips of the top layers move EVERY tensor below them -- measured median 4.6e-3 at 320 subgraphs -- so no tighter typical-case
