@@ -166,6 +166,18 @@ PY
         ( cd /tmp && QAGNN_NN2=$v timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nnm -o m -- python "$REPO/tools/nn_micro.py" --small ) > /tmp/nnm.log 2>&1
         python scripts/nn_micro_trace.py "$(find /tmp/nnm -name '*kernel_trace.csv' | head -n 1)" >> gpurun_out/nn2_micro_small.txt 2>&1
       done; stamp nn2small ;;
+    edgepmc)   # what bounds the edge kernels: TA / TD busy, L1 and L2 hit rates, issue stalls (three passes; --pmc with --kernel-trace only)
+      i=0; files=""
+      for ctrs in "GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max TD_TD_BUSY_sum TCC_HIT_sum TCC_MISS_sum" \
+                  "GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUFFER_READ_WAVEFRONTS_sum" \
+                  "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS"; do
+        i=$((i+1)); rm -rf /tmp/ep$i; mkdir -p /tmp/ep$i
+        ( cd /tmp && timeout 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/ep$i -o p -- python "$REPO/bench.py" --steps 2 --warmup 1 --repeats 1 --graphs 0 --no-cpu-baseline --no-pmc --no-configs ) > gpurun_out/edgepmc$i.log 2>&1
+        tail -n 3 gpurun_out/edgepmc$i.log > /tmp/x && mv /tmp/x gpurun_out/edgepmc$i.log
+        files="$files $(find /tmp/ep$i -name '*counter_collection.csv' | head -n 1)"
+      done
+      python scripts/pmc_edge_counters.py $files > gpurun_out/edge_counters.txt 2>&1
+      stamp edgepmc ;;
     cmd:*)
       c="${arg#cmd:}"
       bash -c "$c" > gpurun_out/cmd.log 2>&1; echo "cmd exit $?" >> gpurun_out/summary.txt; stamp "cmd" ;;
