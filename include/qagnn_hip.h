@@ -160,6 +160,18 @@ int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32
  * split (19 % of the projection [N, 320] x [320, 624] at N = 64 000).  ws = NULL (or too small, or a small product) = qagnn_gemm_nn_split_f32.
  * Same arithmetic per output element as the unpacked route: bit-identical results. */
 int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2);
+/* All B operands of a step's large NN products packed in ONE launch, ahead of the products: `d[i]` names a weight in its [No][K]
+ * layout(s) exactly as the product will pass it (B1n / ldn1 / K1, B2n / ldn2 / K2, No); the images go to `out`
+ * (>= qagnn_gemm_nn_prepack_bytes(d, n) bytes, 16-byte aligned) and are REGISTERED under `tag` (!= 0, replaces the tag's earlier
+ * entries): qagnn_gemm_nn_split_f32 / _ws_f32 recognise a registered operand by its pointers and sizes and skip their own packing.
+ * Contract: the fp32 weights and `out` stay alive and unchanged until qagnn_gemm_nn_prepack_clear(tag) or the next prepack under the
+ * same tag (the module mirror packs behind its operand-packing gather every forward and holds both tensors).  Entries that the
+ * packed kernels do not take (K not a multiple of 8, ...) are skipped silently: their products pack per call as before.  Host-side
+ * registry, mutex-protected; clear(0) empties it. */
+typedef struct qagnn_pack_desc { const float* B1n; int32_t ldn1; int32_t K1; const float* B2n; int32_t ldn2; int32_t K2; int32_t No; } qagnn_pack_desc;
+int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n);
+int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, void* out, int64_t out_bytes, int64_t tag, qagnn_stream_t stream);
+int qagnn_gemm_nn_prepack_clear(int64_t tag);
 int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                                void* ws, int64_t ws_bytes, qagnn_stream_t stream);
 

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_nn_prepack_bytes', 'qagnn_gemm_nn_prepack_f32',
+           'qagnn_gemm_nn_prepack_clear', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
@@ -24,7 +25,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 14  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer)
+ABI_VERSION = 14  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear})
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -35,6 +36,10 @@ class qagnn_graph(C.Structure):
                                     'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
                 [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
+
+
+class qagnn_pack_desc(C.Structure):
+    _fields_ = [('B1n', _vp), ('ldn1', _i32), ('K1', _i32), ('B2n', _vp), ('ldn2', _i32), ('K2', _i32), ('No', _i32)]
 
 
 class qagnn_gemm_nn_args(C.Structure):
@@ -80,6 +85,10 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_nn_pack_bytes.restype = _i64
     lib.qagnn_gemm_nn_pack_bytes.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_nn_split_ws_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp, _i64, _vp]
+    lib.qagnn_gemm_nn_prepack_bytes.restype = _i64
+    lib.qagnn_gemm_nn_prepack_bytes.argtypes = [C.POINTER(qagnn_pack_desc), _i32]
+    lib.qagnn_gemm_nn_prepack_f32.argtypes = [C.POINTER(qagnn_pack_desc), _i32, _vp, _i64, _i64, _vp]
+    lib.qagnn_gemm_nn_prepack_clear.argtypes = [_i64]
     lib.qagnn_gemm_tn_workspace_elems.restype = _i64
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
@@ -389,6 +398,27 @@ class HipKernels(metaclass=_GuardedMeta):
     def colstats_supported(self, M, K1, No):
         """Can gemm_nn(..., colstats=True) deliver per-tile column statistics for this shape?  (the bf16-split kernel, 193..208 columns)"""
         return self.gemm_split and 192 < No <= 208 and K1 % 4 == 0 and M * max(K1, No) * 4 < 2 ** 31 - 1
+
+    def prepack(self, pairs, tag):
+        """Pack the B operands of the coming large NN products in ONE launch (qagnn_gemm_nn_prepack_f32) and register them under `tag`:
+        pairs = [(B1n, B2n or None), ...], each weight in its [No, K] layout exactly as gemm_nn() will receive it.  Returns what must
+        stay alive (and unchanged) until the tag is cleared or packed again: the packed buffer and the weights themselves."""
+        descs = (qagnn_pack_desc * len(pairs))()
+        for d, (b1, b2) in zip(descs, pairs):
+            _chk2d(b1, 'B1n')
+            d.B1n, d.ldn1, d.K1, d.No = b1.data_ptr(), b1.size(1), b1.size(1), b1.size(0)
+            if b2 is not None:
+                _chk2d(b2, 'B2n')
+                assert b2.size(0) == b1.size(0)
+                d.B2n, d.ldn2, d.K2 = b2.data_ptr(), b2.size(1), b2.size(1)
+        nbytes = self.lib.qagnn_gemm_nn_prepack_bytes(descs, len(pairs))
+        out = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=pairs[0][0].device)
+        self._check(self.lib.qagnn_gemm_nn_prepack_f32(descs, len(pairs), out.data_ptr(), out.numel(), int(tag), self._stream()),
+                    'qagnn_gemm_nn_prepack_f32')
+        return out, [t for pr in pairs for t in pr if t is not None]
+
+    def prepack_clear(self, tag=0):
+        self.lib.qagnn_gemm_nn_prepack_clear(int(tag))
 
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
                 out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None, colstats=False):

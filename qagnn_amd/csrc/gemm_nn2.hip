@@ -462,10 +462,9 @@ static int launch_nt(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, co
 // B [No][K1] | [No][K2] (k contiguous) -> the packed image of PACKED kernels: block ((it * NJ + j) * 3 + p) of 1 KB holds, for lane
 // l = (x = l & 15, c = l >> 4), at slot (x ^ 2c) + 16c, the piece-p halves of B[k = position(it, 8 c .. 8 c + 7)][n = 16 j + x]; `it` walks the k-tiles in the
 // kernel's order (the straddling tile first).  One wave per block of three pieces; zeros past K and past No.
-__global__ __launch_bounds__(256) void k_pack_b(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2,
-                                               int No, int NJ, int nkt, unsigned char* __restrict__ out) {
+__device__ __forceinline__ void pack_b_wave(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2, int No,
+                                            int NJ, int it, int j, unsigned char* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), it = blockIdx.y;
   if (j >= NJ) return;
   const int r1 = K2 > 0 ? (K1 & 31) : 0;
   const int mixi = r1 != 0 ? 1 : 0;
@@ -498,6 +497,25 @@ __global__ __launch_bounds__(256) void k_pack_b(const float* __restrict__ B1n, i
   unsigned char* dst = out + ((int64_t)it * NJ + j) * 3072 + (((lane & 15) ^ (2 * (lane >> 4))) + 16 * (lane >> 4)) * 16;
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * 1024) = f[p];
+}
+
+__global__ __launch_bounds__(256) void k_pack_b(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2,
+                                               int No, int NJ, int nkt, unsigned char* __restrict__ out) {
+  pack_b_wave(B1n, ldn1, K1, B2n, ldn2, K2, No, NJ, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), out);
+}
+
+// The same for up to PACK_MAX weights in ONE launch (qagnn_gemm_nn_prepack_f32: all B operands of a training step's large NN products,
+// packed right behind the operand-packing gather; 39 pack launches per step of the 320-subgraph batch become one).  The descriptors
+// travel as kernel arguments (3.4 KB): nothing to upload, and a captured graph replays them as they are.
+constexpr int PACK_MAX = 60;
+struct PackOne { const float* B1n; const float* B2n; long long out_off; int ldn1, K1, ldn2, K2, No, NJ, jb, blk0; };  // jb = ceil(NJ / 4)
+struct PackArgs { int n; int nblk; PackOne d[PACK_MAX]; };
+__global__ __launch_bounds__(256) void k_pack_b_multi(PackArgs a, unsigned char* __restrict__ out) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.d[i + 1].blk0) ++i;  // wave-uniform walk over <= 60 entries
+  const PackOne& d = a.d[i];
+  const int lb = (int)blockIdx.x - d.blk0;
+  pack_b_wave(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, lb / d.jb, (lb % d.jb) * 4 + (threadIdx.x >> 6), out + d.out_off);
 }
 
 static int walk_tiles(int K1, int K2) {
@@ -569,4 +587,94 @@ int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Registry of pre-packed B images (qagnn_gemm_nn_prepack_f32): (B1n, B2n, K1, K2, No, pitches) -> packed image.  The caller keeps the
+// fp32 weights and the packed buffer alive -- and unchanged -- until it clears or replaces the tag; qagnn_gemm_nn_split*_f32 look a
+// product's B operand up here first.  Host-side only (a handful of entries, one mutex).
+// ------------------------------------------------------------------------------------------------------------
 }  // namespace qagnn
+#include <mutex>
+#include <vector>
+namespace qagnn {
+struct PrepackEntry { long long tag; const float* B1n; const float* B2n; int ldn1, K1, ldn2, K2, No; const void* pk; };
+static std::mutex g_prepack_mu;
+static std::vector<PrepackEntry> g_prepack;
+
+const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No) {
+  std::lock_guard<std::mutex> lk(g_prepack_mu);
+  for (const PrepackEntry& e : g_prepack)
+    if (e.B1n == B1n && e.K1 == K1 && e.No == No && e.ldn1 == ldn1 && e.K2 == K2 && (K2 == 0 || (e.B2n == B2n && e.ldn2 == ldn2))) return e.pk;
+  return nullptr;
+}
+
+static bool prepack_takes(const qagnn_pack_desc& d) {
+  if (!d.B1n || d.No <= 0 || d.K1 < 8 || d.K1 % 8 != 0 || d.K2 < 0 || d.K2 % 8 != 0 || d.ldn1 < d.K1 || d.ldn1 % 4 != 0 || !aligned16(d.B1n)) return false;
+  if (d.K2 > 0 && (!d.B2n || d.ldn2 < d.K2 || d.ldn2 % 4 != 0 || !aligned16(d.B2n))) return false;
+  if (d.K2 > 0 && (d.K1 & 31) != 0 && d.K2 < 32 - (d.K1 & 31)) return false;  // (nn2_ok: the straddling tile must lie inside segment 2)
+  return true;
+}
+
+int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream) {
+  const int NJ = cdiv(a.No, 16);
+  const float* p = reinterpret_cast<const float*>(pk);
+  switch (nt) {
+    case 13: return nn2::launch_nt<13, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 8: return nn2::launch_nt<8, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 7: return nn2::launch_nt<7, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 4: return nn2::launch_nt<4, 0, true>(a, p, NJ, nullptr, 0, stream);
+    default: return nn2::launch_nt<2, 0, true>(a, p, NJ, nullptr, 0, stream);
+  }
+}
+}  // namespace qagnn
+
+using namespace qagnn;
+
+extern "C" int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n) {
+  int64_t tot = 0;
+  for (int i = 0; i < n; ++i)
+    if (prepack_takes(d[i])) tot += nn2_pack_bytes(d[i].No, d[i].K1, d[i].K2);
+  return tot;
+}
+
+extern "C" int qagnn_gemm_nn_prepack_clear(int64_t tag) {
+  std::lock_guard<std::mutex> lk(g_prepack_mu);
+  for (size_t i = 0; i < g_prepack.size();) {
+    if (tag == 0 || g_prepack[i].tag == tag) { g_prepack[i] = g_prepack.back(); g_prepack.pop_back(); }
+    else ++i;
+  }
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, void* out, int64_t out_bytes, int64_t tag, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(d && n > 0 && out && tag != 0 && aligned16(out), QAGNN_EINVAL, "gemm_nn_prepack: bad arguments");
+  QAGNN_REQUIRE(out_bytes >= qagnn_gemm_nn_prepack_bytes(d, n), QAGNN_EINVAL, "gemm_nn_prepack: the buffer of %lld bytes is too small", (long long)out_bytes);
+  qagnn_gemm_nn_prepack_clear(tag);
+  std::vector<PrepackEntry> fresh;
+  int64_t off = 0;
+  for (int i0 = 0; i0 < n;) {  // one launch per PACK_MAX weights
+    nn2::PackArgs pa;
+    pa.n = 0;
+    pa.nblk = 0;
+    int i = i0;
+    for (; i < n && pa.n < nn2::PACK_MAX; ++i) {
+      if (!prepack_takes(d[i])) continue;
+      nn2::PackOne& o = pa.d[pa.n++];
+      o.B1n = d[i].B1n; o.B2n = d[i].K2 > 0 ? d[i].B2n : nullptr; o.ldn1 = d[i].ldn1; o.K1 = d[i].K1; o.ldn2 = d[i].ldn2; o.K2 = d[i].K2; o.No = d[i].No;
+      o.NJ = cdiv(d[i].No, 16);
+      o.jb = cdiv(o.NJ, 4);
+      o.blk0 = pa.nblk;
+      o.out_off = off;
+      pa.nblk += o.jb * nn2::walk_tiles(o.K1, o.K2);
+      fresh.push_back(PrepackEntry{(long long)tag, o.B1n, o.B2n, o.ldn1, o.K1, o.ldn2, o.K2, o.No, static_cast<const unsigned char*>(out) + off});
+      off += nn2_pack_bytes(o.No, o.K1, o.K2);
+    }
+    if (pa.n > 0) {
+      nn2::k_pack_b_multi<<<pa.nblk, 256, 0, (hipStream_t)stream_>>>(pa, static_cast<unsigned char*>(out));
+      QAGNN_LAUNCH_CHECK("k_pack_b_multi");
+    }
+    i0 = i;
+  }
+  std::lock_guard<std::mutex> lk(g_prepack_mu);
+  g_prepack.insert(g_prepack.end(), fresh.begin(), fresh.end());
+  return QAGNN_OK;
+}

@@ -727,6 +727,8 @@ extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const flo
     if (small_nt > 0 && small_nt < nt) nt = small_nt;
   }
   if (nn2_ok(*a, ldn1, ldn2)) {
+    // B pre-packed by the caller (qagnn_gemm_nn_prepack_f32: one launch for all weights of a step)?
+    if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return launch_nn2_prepacked(nt, *a, pk, stream);
     if (ws && nn2_packed_ok(*a, ws_bytes)) {
       QAGNN_REQUIRE(aligned16(ws), QAGNN_EINVAL, "gemm_nn_split: the pack workspace must be 16-byte aligned");
       return launch_nn2_packed(nt, *a, B1n, ldn1, B2n, ldn2, ws, stream);

@@ -441,6 +441,14 @@ class QAGNN_Message_Passing(nn.Module):
         per_layer, extras = self.pack_all(L)
         Vh_t, Vh, Vx_t, Vx, bVh, bVx, Wes_t, Wes, bes, We_t_all, We_all, be_all, Wtype_all, bias_all = extras[:14]
         Hp = H if padded_input else L.pad(H.reshape(bs * n, d))
+        # the weight operands of this forward's (and its backward's) large NN products, split into the kernels' bf16 images with ONE
+        # launch (ops.prepack_weights): per hop the projection [Wx | Ws], its two data-gradient products, and both ways of the mlp's two
+        # Linears; the output layer [Vh | Vx] and the score embedding
+        pairs = []
+        for pk in per_layer:
+            pairs += [(pk[1], pk[3]), (pk[0], None), (pk[2], None), (pk[9], None), (pk[8], None), (pk[14], None), (pk[13], None)]
+        pairs += [(Vh, Vx), (Vh_t, None), (Vx_t, None), (Wes, None)]
+        ops.prepack_weights(self, pairs, bs * n)
         # Every weight operand below comes straight out of pack_all (GatherPlan), whose backward is the only reader of its
         # gradient: the operators may queue their weight-gradient GEMMs and run them under the edge backward kernels.
         with ops.wgrad_scope():

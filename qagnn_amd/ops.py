@@ -336,6 +336,28 @@ def graph_prep_async(adj, node_type, n_etype, n_ntype, block_n):
     return graph, (lambda: torch.cuda.current_stream(dev).wait_stream(side))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# B operands of the large NN products, packed once per forward.  The bf16-split NN kernel wants its weight operand split into three
+# bf16 images in LDS order (csrc/gemm_nn2.hip); done per product that is one extra launch in front of each of the ~39 large NN
+# products of a step (0.18 ms of kernel time and as many host calls at 320 subgraphs).  The stack therefore packs ALL of them with one
+# launch right behind the operand-packing gather and registers them with the library, which recognises a registered operand by its
+# pointers.  `owner` (a module) holds the packed buffer and the weights until its next forward replaces them: a registered pointer
+# always names live, unchanged memory.
+PREPACK = _os.environ.get('QAGNN_PREPACK', '1') == '1'
+PREPACK_MIN_ROWS = int(_os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))
+
+
+def prepack_weights(owner, pairs, rows):
+    """pairs = [(B1n, B2n or None), ...] in their [No, K] layouts, as the products of this forward (and its backward) will pass them."""
+    K = kernels()
+    if not (PREPACK and rows >= PREPACK_MIN_ROWS and pairs and pairs[0][0].is_cuda and hasattr(K, 'prepack')):
+        return
+    owner._qagnn_prepacked = K.prepack(pairs, id(owner))  # (replaces, and thereby releases, what the previous forward registered)
+    if not getattr(owner, '_qagnn_prepack_finalizer', None):
+        import weakref
+        owner._qagnn_prepack_finalizer = weakref.finalize(owner, K.prepack_clear, id(owner))
+
+
 class GradAcc:
     """Running gradient of ONE tensor that several operators of the stack read (the score embedding S: every hop; the stack
     input: hop 0 and the output GEMM).  Autograd would give each reader its own [N, .] gradient and add them with elementwise

@@ -730,3 +730,37 @@ def test_gemm_column_statistics_and_bn_stats_finalize(M):
     assert torch.allclose(rm.cpu().double(), rm0.double() + 0.1 * (mean64[pos] - rm0.double()), rtol=1e-5, atol=1e-6)
     assert torch.allclose(rv.cpu().double(), rv0.double() + 0.1 * (var64[pos] * unb - rv0.double()), rtol=1e-5, atol=1e-6)
     assert int(nbt) == 8
+
+
+@pytest.mark.gpu
+def test_prepacked_weights_are_found_by_pointer_and_change_no_bit():
+    """qagnn_gemm_nn_prepack_f32: several weights packed in one launch and registered; a product whose B operand is registered takes
+    the registered image (no pack launch of its own) and must give the same bits as the per-call route; after prepack_clear the
+    registry is empty again.  Includes a two-segment weight with the straddling k-tile and one the packed kernels decline (K % 8)."""
+    K = hip()
+    g = torch.Generator().manual_seed(77)
+    M = 9000
+    shapes = [(208, 112, 624), (624, 0, 208), (208, 0, 208), (36, 0, 64)]
+    ws = []
+    for K1, K2, No in shapes:
+        B1 = torch.randn(K1, No, generator=g).cuda()
+        B2 = torch.randn(K2, No, generator=g).cuda() if K2 else None
+        ws.append((B1, B2, B1.t().contiguous(), B2.t().contiguous() if K2 else None))
+    K.prepack_clear(0)
+    want = []
+    for (K1, K2, No), (B1, B2, B1n, B2n) in zip(shapes, ws):
+        A1 = torch.randn(M, K1, generator=g).cuda()
+        A2 = torch.randn(M, K2, generator=g).cuda() if K2 else None
+        want.append((A1, A2, K.gemm_nn(A1, B1, A2, B2, B1n=B1n, B2n=B2n)))
+    keep = K.prepack([(w[2], w[3]) for w in ws], tag=4242)
+    for (A1, A2, ref), (B1, B2, B1n, B2n) in zip(want, ws):
+        got = K.gemm_nn(A1, B1, A2, B2, B1n=B1n, B2n=B2n)
+        assert torch.equal(got, ref)
+    # a registered pointer with OTHER sizes is not a hit
+    B1, B2, B1n, B2n = ws[2]
+    half = K.gemm_nn(want[2][0][:, :104].contiguous(), B1[:104].contiguous(), B1n=B1n[:, :104].contiguous())
+    assert torch.isfinite(half).all()
+    K.prepack_clear(4242)
+    del keep
+    got = K.gemm_nn(want[0][0], ws[0][0], want[0][1], ws[0][1], B1n=ws[0][2], B2n=ws[0][3])
+    assert torch.equal(got, want[0][2])
