@@ -415,7 +415,9 @@ class HipKernels(metaclass=_GuardedMeta):
         out = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=pairs[0][0].device)
         self._check(self.lib.qagnn_gemm_nn_prepack_f32(descs, len(pairs), out.data_ptr(), out.numel(), int(tag), self._stream()),
                     'qagnn_gemm_nn_prepack_f32')
-        return out, [t for pr in pairs for t in pr if t is not None]
+        # (detached aliases: they pin the storage, not the autograd graph that produced the weights -- a kept-alive graph of the previous
+        # iteration makes its AccumulateGrad nodes run on THEIR stream during a later hipGraph capture, which breaks the capture)
+        return out, [t.detach() for pr in pairs for t in pr if t is not None]
 
     def prepack_clear(self, tag=0):
         self.lib.qagnn_gemm_nn_prepack_clear(int(tag))
