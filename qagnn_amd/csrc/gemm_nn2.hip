@@ -40,12 +40,12 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 namespace nn2 {
 
 // QAGNN_NN2_ABL (tools/nn2_ablate.hip only; numerically wrong, timing only): bit 0 no loads in the steady loop, bit 1 no B split / store,
-// bit 2 no A split, bit 3 no barrier, bit 4 no fragment reads, bit 5 no MFMAs
+// bit 2 no A split, bit 3 no barrier, bit 4 no fragment reads, bit 5 no MFMAs, bit 6 no stores of the result
 #ifndef QAGNN_NN2_ABL
 #define QAGNN_NN2_ABL 0
 #endif
 
-constexpr int BK = 32, BM = 128, WAVES = 4, THR = WAVES * 64;
+constexpr int BK = 32;
 constexpr uint32_t OOB = 0x80000000u;  // beyond any operand this kernel is launched on: the buffer load answers with zeros
 
 __device__ __forceinline__ u32x4s bload(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
@@ -92,6 +92,13 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
   *reinterpret_cast<uint2*>(dst + 2048) = make_uint2(pack_hi(a3, b3), pack_hi(c3, d3));
 }
 
+#define QAGNN_NN2_SIX_T(C, AF, BF)                                        \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[2], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[2], AF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[0], C, 0, 0, 0);
 #define QAGNN_NN2_SIX(C, AF, BF)                                          \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
@@ -106,18 +113,52 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
 // zero-filled past K and No), B1n = that buffer, ldn1 = column tiles per k-tile.  A k-tile of B is then NT * 3 contiguous KB that go
 // to LDS by DMA (global_load_lds, 1 KB per wave-instruction): no registers, no split arithmetic, no ds_write for B in the k-loop
 // (tools/nn2_ablate.hip: the in-kernel split of B costs 19 % of the projection, and it is repeated by all 500 row tiles).
-template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED>
-__global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn2(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
-                                                                                      int ldn1, const float* __restrict__ B2n, int ldn2,
-                                                                                      int ntiles) {
+//
+// WV = 8 (PACKED only): the STAGGERED block.  Two 4-wave blocks that share a CU run in lockstep (same work, fair arbitration; neither a
+// static priority for one of them nor an initial skew of up to 6 000 cycles changes the kernel time, tools/cu_census.hip and
+// profiles/r4_run16_nn2_stagger.txt), so their MFMA phases coincide and so do their load / split phases: the matrix pipe idles while
+// both split.  Here ONE block of 8 waves owns the CU (256 rows), two waves per SIMD, one of each SIMD's pair in phase group 0 and the
+// other in group 1, and every k-tile is two barrier-separated phases per wave:
+//     N: split the A fragments of tile t out of the raw registers, issue the loads of tile t + 1 (A) and this wave's share of the DMA
+//        of B tile t + 1 + g, read the first two column tiles' B fragments;      M: the 12 NT MFMAs of tile t, fragment reads only.
+// Group 1 passes one extra barrier before its first phase and group 0 one after its last, so at every moment one wave of a SIMD is in
+// M and the other in N: the matrix pipe sees one uninterrupted MFMA stream, the split / load work runs under it.  B is shared by all
+// 8 waves (half the DMA instructions per wave) in a ring of THREE images: tile t is read in the global phases 2t .. 2t + 2 (group 0:
+// end of N_t and M_t, group 1 one phase later), group 0 issues its share of tile t's DMA in its N_(t-1) (phase 2t - 2) and waits for it
+// at the end of M_(t-1); group 1 would be too late there and issues in ITS N_(t-2) (phase 2t - 3; the image's previous tenant, tile t - 3,
+// was last read in phase 2t - 4).  The loop's back edge sits right after the barrier that ends M: every load issued in the previous N has
+// had a whole M phase to land, so nothing is in flight across it.
+template <int NT, bool STATS, int WV>
+constexpr int nn2_lds_bytes(int aff_bytes) {
+  const int ring = (WV == 8 ? 3 : 2) * NT * 3 * 1024 + aff_bytes;
+  const int epi = WV * 16 * (NT * 16 + 4) * 4 + (STATS ? WV * 2 * NT * 16 * 4 : 0);
+  return ring > epi ? ring : epi;
+}
+
+template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED, int WV = 4>
+__global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn2(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
+                                                                                          int ldn1, const float* __restrict__ B2n, int ldn2,
+                                                                                          int ntiles) {
+  static_assert(WV == 4 || (WV == 8 && PACKED), "the staggered block takes B by DMA only");
+  static_assert(!(AFFINE && STATS), "no product needs both");
+  constexpr bool STAG = WV == 8;
+  // DIRECT: the MFMAs are issued with their operands swapped (the transposed 16 x 16 tile: lane (x, c) then holds FOUR CONSECUTIVE
+  // COLUMNS 4c .. 4c + 3 of row x), so the epilogue stores its accumulators straight from the registers -- 16 rows x 64 bytes per
+  // instruction, column tiles j and j + 1 completing each other's 128-byte lines -- without the LDS transpose and its four barriers.
+  // That leaves LDS free at the end of a tile: the first loads of the NEXT tile are issued in front of the stores, and the stores
+  // (address-predicated buffer stores, a fixed 2 NT per wave, so that s_waitcnt vmcnt(2 NT) means "everything older has landed") drain
+  // under the next tile's k-loop.  With one block per CU nothing else would run under either.
+  constexpr bool DIRECT = STAG && !STATS;
+  constexpr int THR = WV * 64, BM = WV * 32;
   constexpr int BN = NT * 16;
   constexpr int IMG = NT * 3 * 1024;   // bytes of one B image set: [column tile][piece][64 slots x 16 B]
+  constexpr int RING_B = (STAG ? 3 : 2) * IMG;
   constexpr int BR = (NT + 1) / 2;     // load rounds of the B tile: 32 weight rows (output columns) x 8 float4 per round
   constexpr int PS = BN + 4, SLAB_ROWS = 16;
-  constexpr int SLAB_B = WAVES * SLAB_ROWS * PS * 4;
-  static_assert(SLAB_B + (STATS ? WAVES * 2 * BN * 4 : 0) <= 2 * IMG, "the epilogue reuses the k-loop's LDS");
+  constexpr int SLAB_B = WV * SLAB_ROWS * PS * 4;
+  static_assert(SLAB_B + (STATS ? WV * 2 * BN * 4 : 0) <= (AFFINE ? RING_B : nn2_lds_bytes<NT, STATS, WV>(0)), "the epilogue reuses the k-loop's LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const aff = reinterpret_cast<float*>(smem + 2 * IMG);  // AFFINE: scale[KA] | shift[KA], KA = K1 rounded up to 32, zero-filled
+  float* const aff = reinterpret_cast<float*>(smem + RING_B);  // AFFINE: scale[KA] | shift[KA], KA = K1 rounded up to 32, zero-filled
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,9 +197,37 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // the last load round of an odd NT covers one column tile only: the loaders of its second half (waves 2, 3) sit it out
   const bool last_round_on = (NT & 1) == 0 || w < 2;
 
+  // STAG: the phase group of this wave.  256 registers per wave = two waves per SIMD; the first wave to arrive on a SIMD joins group 0,
+  // the second group 1 (any split is correct -- the groups only decide who is in which phase -- an even one is what overlaps)
+  int g = 0;
+  if constexpr (STAG) {
+    int* const cnt = reinterpret_cast<int*>(smem);
+    if (tid < 4) cnt[tid] = 0;
+    __syncthreads();
+    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // HW_ID[5:4] = SIMD_ID
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&cnt[simd], 1);
+    g = __builtin_amdgcn_readfirstlane(slot) & 1;
+    __syncthreads();
+  }
+
+  int tile = 0, m0 = 0, n0 = 0;
+  uint32_t arow1[2], arow2[2];  // per-lane byte offsets of the operand rows (the k position comes in as the scalar offset); rows outside: OOB
+#define QAGNN_NN2_SET_TILE(VB)                                                                                           \
+  {                                                                                                                      \
+    tile = a.xcd_remap ? xcd_remap((VB), ntiles) : (VB);                                                                 \
+    m0 = (tile / ncb) * BM;                                                                                              \
+    n0 = (tile % ncb) * BN;                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                      \
+      const int row = m0 + w * 32 + i * 16 + (lane & 15);                                                                \
+      arow1[i] = row < M ? (uint32_t)row * (uint32_t)a.lda1 * 4u + (uint32_t)ac * 32u : OOB;                             \
+      arow2[i] = row < M ? (uint32_t)row * (uint32_t)a.lda2 * 4u + (uint32_t)ac * 32u : OOB;                             \
+    }                                                                                                                    \
+  }
+  bool loaded = false;  // DIRECT: this tile's first loads were issued in front of the previous tile's stores
+  u32x4s ra[2][2];
   for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-    const int tile = a.xcd_remap ? xcd_remap(vb, ntiles) : vb;
-    const int m0 = (tile / ncb) * BM, n0 = (tile % ncb) * BN;
+    if (!loaded) QAGNN_NN2_SET_TILE(vb)
     const int nvalid = min(BN, No - n0) - nl;  // load round q is inside the matrix for this loader iff 32 q < nvalid
 
     f32x4s acc[2][NT];
@@ -167,18 +236,10 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4s){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane byte offsets of the operand rows (the k position and B's load round come in as the scalar offset); rows outside: OOB
-    uint32_t arow1[2], arow2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = m0 + w * 32 + i * 16 + (lane & 15);
-      arow1[i] = row < M ? (uint32_t)row * (uint32_t)a.lda1 * 4u + (uint32_t)ac * 32u : OOB;
-      arow2[i] = row < M ? (uint32_t)row * (uint32_t)a.lda2 * 4u + (uint32_t)ac * 32u : OOB;
-    }
     const uint32_t bbase1 = (uint32_t)(n0 + nl) * (uint32_t)ldn1 * 4u + (uint32_t)kq * 16u;
     const uint32_t bbase2 = (uint32_t)(n0 + nl) * (uint32_t)ldn2 * 4u + (uint32_t)kq * 16u;
 
-    u32x4s ra[2][2], rb[PACKED ? 1 : BR];
+    u32x4s rb[PACKED ? 1 : BR];
     bf16x8 af[2][3];
 
     // loads of a tile that lies in one segment (steady state); `it` past the last tile: everything out of range, zeros
@@ -217,8 +278,8 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define QAGNN_NN2_GLDS(IT, BUF)                                                                                          \
     {                                                                                                                    \
       const unsigned char* src_ = pk + ((int64_t)(IT) * ldn1 + n0 / 16) * 3072 + lane * 16;                              \
-      _Pragma("unroll") for (int b = 0; b < (NT * 3 + WAVES - 1) / WAVES; ++b) {                                         \
-        const int blk_ = w + b * WAVES;                                                                                  \
+      _Pragma("unroll") for (int b = 0; b < (NT * 3 + WV - 1) / WV; ++b) {                                               \
+        const int blk_ = w + b * WV;                                                                                     \
         if (blk_ < NT * 3)                                                                                               \
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + blk_ * 1024),         \
                                            (__attribute__((address_space(3))) void*)((BUF) + blk_ * 1024), 16, 0, 0);    \
@@ -289,32 +350,183 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_setprio(0);                                                                                     \
     }
 
-    __syncthreads();  // the previous output tile's slab reads (and the scale / shift fill) are done
+    // STAG: the B fragments of column tile J of the image at LDS address ADDR (+ this lane's slot); the MFMAs of one k-tile with the
+    // fragments read TWO column tiles ahead (a ring of three register sets; sets 0 and 1 arrive in flight from the N phase), so that the
+    // one wave of the SIMD that is in its M phase never waits for LDS.  Reads and waits are inline assembly: hipcc's own counter waits for
+    // lgkmcnt(0) every third column tile -- right behind three fresh reads -- where lgkmcnt(6) is what the data flow needs.  The raw
+    // barriers: the compiler must not add its vmcnt(0), the loads issued in N land under M.
+#define QAGNN_NN2_FRAG(DST, ADDR, J)                                                                                     \
+    {                                                                                                                    \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                      \
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"(((J) * 3 + p) * 1024));           \
+    }
+    // the fragments of column tile j are the oldest reads in flight; behind them: tiles j + 1 and j + 2 (LDS returns in order)
+#define QAGNN_NN2_FRAG_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]))
+#define QAGNN_NN2_MFMA_TILE3(ADDR)                                                                                       \
+    {                                                                                                                    \
+      __builtin_amdgcn_s_setprio(1);                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                   \
+        bf16x8(&bf)[3] = bfr[j % 3];                                                                                     \
+        if (j + 2 < NT) {                                                                                                \
+          QAGNN_NN2_FRAG(bfr[(j + 2) % 3], ADDR, j + 2)                                                                  \
+          QAGNN_NN2_FRAG_WAIT(bf, 6);                                                                                    \
+        } else if (j + 1 < NT) {                                                                                         \
+          QAGNN_NN2_FRAG_WAIT(bf, 3);                                                                                    \
+        } else {                                                                                                         \
+          QAGNN_NN2_FRAG_WAIT(bf, 0);                                                                                    \
+        }                                                                                                                \
+        if constexpr (!(QAGNN_NN2_ABL & 32)) {                                                                           \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            f32x4s c = acc[i][j];                                                                                        \
+            if constexpr (DIRECT) { QAGNN_NN2_SIX_T(c, af[i], bf) } else { QAGNN_NN2_SIX(c, af[i], bf) }                  \
+            acc[i][j] = c;                                                                                               \
+          }                                                                                                              \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+      }                                                                                                                  \
+      __builtin_amdgcn_s_setprio(0);                                                                                     \
+    }
+    // (no lgkmcnt wait in front of the N phase's barrier: the fragment reads stay in flight across it and the compiler's own counter
+    // stays exact; sched_barrier: the split arithmetic must not sink behind the barrier into the M phase)
+#define QAGNN_NN2_BAR                            \
+    {                                            \
+      __builtin_amdgcn_sched_barrier(0);         \
+      asm volatile("s_barrier" ::: "memory");    \
+      __builtin_amdgcn_sched_barrier(0);         \
+    }
+#define QAGNN_NN2_BAR_VMN /* everything but the last 2 NT vector-memory operations (the previous tile's stores) has landed */ \
+    {                                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                                   \
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(2 * NT) : "memory");                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    }
+#define QAGNN_NN2_BAR_VM                                         \
+    {                                                            \
+      __builtin_amdgcn_sched_barrier(0);                         \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); \
+      __builtin_amdgcn_sched_barrier(0);                         \
+    }
+
+    // the first loads of a tile: A of k-tile 0 into the raw registers (B too without PACKED); STAG: B tile 0 (and group 1's share of
+    // tile 1) by DMA.  The straddling tile: k in [K1 - r1, K1) of segment 1, then [0, 32 - r1) of segment 2 (nn2_ok: K2 >= 32 - r1).  One
+    // 64-bit flat load per destination, the segment chosen per lane; rows past M and columns past No read the last valid row instead
+    // (their products are never stored), so nothing needs zeroing and no second set of registers is in flight
+#define QAGNN_NN2_FIRST_LOADS                                                                                            \
+    {                                                                                                                    \
+      if (mixi) {                                                                                                        \
+        const int kbq = kq * 4, kaq = ac * 8;                                                                            \
+        const bool b1 = kbq < r1, a1 = kaq < r1;                                                                         \
+        if constexpr (!PACKED) {                                                                                         \
+          _Pragma("unroll") for (int q = 0; q < BR; ++q) {                                                               \
+            const int64_t col = min(n0 + nl + q * 32, No - 1);                                                           \
+            const float* p = b1 ? B1n + col * ldn1 + (K1 - r1 + kbq) : B2n + col * ldn2 + (kbq - r1);                    \
+            rb[q] = *reinterpret_cast<const u32x4s*>(p);                                                                 \
+          }                                                                                                              \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+          const int64_t row = min(m0 + w * 32 + i * 16 + (lane & 15), M - 1);                                            \
+          const float* p = a1 ? a.A1 + row * a.lda1 + (K1 - r1 + kaq) : a.A2 + row * a.lda2 + (kaq - r1);                \
+          ra[i][0] = *reinterpret_cast<const u32x4s*>(p);                                                                \
+          ra[i][1] = *reinterpret_cast<const u32x4s*>(p + 4);                                                            \
+        }                                                                                                                \
+      } else {                                                                                                           \
+        QAGNN_NN2_GLOAD(0)                                                                                               \
+      }                                                                                                                  \
+      if constexpr (STAG) {                                                                                              \
+        QAGNN_NN2_GLDS(0, smem)                                                                                          \
+        if (g == 1 && nkt > 1) QAGNN_NN2_GLDS(1, smem + IMG)                                                             \
+      }                                                                                                                  \
+    }
+
+    if constexpr (!DIRECT) __syncthreads();  // the previous output tile's slab reads (and the scale / shift fill) are done
     // ---- prologue: tile 0 into image 0 / the fragment registers, tile 1 in flight
-    if (mixi) {
-      // the straddling tile: k in [K1 - r1, K1) of segment 1, then [0, 32 - r1) of segment 2 (nn2_ok: K2 >= 32 - r1).  One 64-bit
-      // flat load per destination, the segment chosen per lane; rows past M and columns past No read the last valid row instead
-      // (their products are never stored), so nothing needs zeroing and no second set of registers is in flight
-      const int kbq = kq * 4, kaq = ac * 8;
-      const bool b1 = kbq < r1, a1 = kaq < r1;
-      if constexpr (!PACKED) {
-#pragma unroll
-        for (int q = 0; q < BR; ++q) {
-          const int64_t col = min(n0 + nl + q * 32, No - 1);
-          const float* p = b1 ? B1n + col * ldn1 + (K1 - r1 + kbq) : B2n + col * ldn2 + (kbq - r1);
-          rb[q] = *reinterpret_cast<const u32x4s*>(p);
-        }
+    if (!loaded) QAGNN_NN2_FIRST_LOADS
+    if constexpr (STAG) {
+      if (loaded) {
+        QAGNN_NN2_BAR_VMN           // (the previous tile's stores stay in flight)
+      } else {
+        QAGNN_NN2_BAR_VM            // tile 0 (and group 1's share of tile 1) has landed
       }
+      if (g == 1) QAGNN_NN2_BAR     // group 1 runs one phase behind from here on
+      bf16x8 bfr[3][3];
+      const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (uint32_t)rd_off;
+      for (int it = 0; it < nkt; ++it) {
+        const uint32_t cur = lds0 + (uint32_t)((it % 3) * IMG);
+        // N: fragments of tile it, loads of tile it + 1 (A) / it + 1 + g (this wave's share of B)
+        if ((QAGNN_NN2_ABL & 4) == 0 || it == 0) QAGNN_NN2_SPLIT_A(it)
+        QAGNN_NN2_FRAG(bfr[0], cur, 0)
+        if constexpr (NT > 1) QAGNN_NN2_FRAG(bfr[1], cur, 1)
+        if constexpr (!(QAGNN_NN2_ABL & 1)) {
+          if (it + 1 < nkt) QAGNN_NN2_GLOAD(it + 1)
+        }
+        if constexpr (!(QAGNN_NN2_ABL & 2)) {
+          const int tb = it + 1 + g;
+          if (tb < nkt) QAGNN_NN2_GLDS(tb, smem + (tb % 3) * IMG)
+        }
+        QAGNN_NN2_BAR
+        // M
+        QAGNN_NN2_MFMA_TILE3(cur)
+        QAGNN_NN2_BAR_VM  // this wave's loads of the N phase have landed; the other group moves on to its M
+      }
+      if (g == 0) QAGNN_NN2_BAR
+      if constexpr (DIRECT) {
+        // ---- the next tile's first loads (every wave is past its last fragment read: the ring is free), then this tile's stores
+        const int em0 = m0, en0 = n0;
+        loaded = vb + (int)gridDim.x < ntiles;
+        if (loaded) {
+          QAGNN_NN2_SET_TILE(vb + (int)gridDim.x)
+          QAGNN_NN2_FIRST_LOADS
+        }
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, M * a.ldc * 4, 0x00020000);
+        const int c4 = 4 * (lane >> 4);
+        // product + bias + table row + old value, in the slab epilogue's order; every kind of addend is fetched for all column tiles
+        // at once (a column past No reads the last four columns instead and is not stored: No % 4 == 0), and ALL addends are in
+        // before the first store is issued -- waiting for a load behind a store would wait for the store's acknowledgement too
+        uint32_t crow[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int64_t row = min(m0 + w * 32 + i * 16 + (lane & 15), M - 1);
-        const float* p = a1 ? a.A1 + row * a.lda1 + (K1 - r1 + kaq) : a.A2 + row * a.lda2 + (kaq - r1);
-        ra[i][0] = *reinterpret_cast<const u32x4s*>(p);
-        ra[i][1] = *reinterpret_cast<const u32x4s*>(p + 4);
+        for (int i = 0; i < 2; ++i) {
+          const int row = em0 + w * 32 + i * 16 + (lane & 15);
+          const bool rok = row < M;
+          crow[i] = rok ? (uint32_t)row * (uint32_t)a.ldc * 4u : OOB;
+          f32x4s t[NT];
+          if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(a.bias + min(en0 + j * 16 + c4, No - 4)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+          }
+          if (a.rowtab) {
+            const float* const trow = a.rowtab + (int64_t)a.rowidx[rok ? row : 0] * a.ldt;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(trow + min(en0 + j * 16 + c4, No - 4)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+          }
+          if (a.accumulate) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int col = en0 + j * 16 + c4;
+              t[j] = __builtin_bit_cast(f32x4s, bload(rC, rok && col < No ? crow[i] + (uint32_t)col * 4u : OOB, 0u));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int col = en0 + j * 16 + c4;
+            const uint32_t off = crow[i] != OOB && col < No ? crow[i] + (uint32_t)col * 4u : OOB;
+            if constexpr (QAGNN_NN2_ABL & 64) {
+              if (acc[i][j][0] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
+            }
+          }
+        continue;
       }
     } else {
-      QAGNN_NN2_GLOAD(0)
-    }
     if constexpr (PACKED) {
       QAGNN_NN2_GLDS(0, smem)
     } else {
@@ -339,7 +551,16 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       unsigned char* const cur = smem + ((nkt - 1) & 1) * IMG;
       QAGNN_NN2_MFMA_TILE(cur, cur, false)
     }
+    }
+#undef QAGNN_NN2_FRAG
+#undef QAGNN_NN2_FRAG_WAIT
+#undef QAGNN_NN2_MFMA_TILE3
+#undef QAGNN_NN2_BAR
+#undef QAGNN_NN2_BAR_VM
+#undef QAGNN_NN2_BAR_VMN
+#undef QAGNN_NN2_FIRST_LOADS
 #undef QAGNN_NN2_GLOAD
+#undef QAGNN_NN2_SET_TILE
 #undef QAGNN_NN2_GLDS
 #undef QAGNN_NN2_STORE_B
 #undef QAGNN_NN2_SPLIT_A
@@ -363,7 +584,8 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 4; ++r) St[(lr0 + r) * PS + j * 16 + (lane & 15)] = acc[i][j][r];
       __syncthreads();
       if constexpr (STATS) {
-        const float* const S0 = reinterpret_cast<const float*>(smem);  // row 0 of wave 0's first slab = the tile's first row
+        // row 0 of the first slab of this wave's 128-row statistics tile (wave 0's, or wave 4's in a 256-row block) = the tile's first row
+        const float* const S0 = reinterpret_cast<const float*>(smem) + (w & ~3) * SLAB_ROWS * PS;
 #pragma unroll
         for (int cc = 0; cc < SC; ++cc) {
           const int c = lane + cc * 64;
@@ -395,7 +617,11 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (a.rowtab) v = add4(v, ld4(a.rowtab + (int64_t)a.rowidx[row] * a.ldt + col));
         float* dst = a.C + (int64_t)row * a.ldc + col;
         if (a.accumulate) v = add4(v, ld4(dst));
-        st4(dst, v);
+        if constexpr (QAGNN_NN2_ABL & 64) {
+          if (v.x == 1.2345e-30f) st4(dst, v);
+        } else {
+          st4(dst, v);
+        }
       }
     }
     if constexpr (STATS) {
@@ -405,19 +631,24 @@ __global__ __launch_bounds__(THR) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (c < BN) { cstat[w][0][c] = s1[cc]; cstat[w][1][c] = s2v[cc]; }
       }
       __syncthreads();
-      if (tid < BN && n0 + tid < No) {  // thread (w, lane) = column w * 64 + lane: its own x0r[w] is that column's shift
+      // one partial per 128 rows (the contract of colstat_part): thread (hw, lane) of half `hf` = column hw * 64 + lane of that half,
+      // its own x0r[hw] is that column's shift
+      const int hw = w & 3, hf = w >> 2, col = hw * 64 + lane;
+      if (col < BN && n0 + col < No && m0 + hf * 128 < M) {
         float x0c = x0r[0];
 #pragma unroll
-        for (int cc = 1; cc < SC; ++cc) x0c = (w == cc) ? x0r[cc] : x0c;
-        float* const pt = a.colstat_part + (int64_t)(tile / ncb) * 3 * No + n0 + tid;
+        for (int cc = 1; cc < SC; ++cc) x0c = (hw == cc) ? x0r[cc] : x0c;
+        float* const pt = a.colstat_part + ((int64_t)(tile / ncb) * (WV / 4) + hf) * 3 * No + n0 + col;
+        const int w0 = hf * 4;
         pt[0] = x0c;
-        pt[No] = (cstat[0][0][tid] + cstat[1][0][tid]) + (cstat[2][0][tid] + cstat[3][0][tid]);
-        pt[2 * No] = (cstat[0][1][tid] + cstat[1][1][tid]) + (cstat[2][1][tid] + cstat[3][1][tid]);
+        pt[No] = (cstat[w0][0][col] + cstat[w0 + 1][0][col]) + (cstat[w0 + 2][0][col] + cstat[w0 + 3][0][col]);
+        pt[2 * No] = (cstat[w0][1][col] + cstat[w0 + 1][1][col]) + (cstat[w0 + 2][1][col] + cstat[w0 + 3][1][col]);
       }
     }
   }
 }
 #undef QAGNN_NN2_SIX
+#undef QAGNN_NN2_SIX_T
 
 static int num_cus() {
   static int n = [] {
@@ -428,35 +659,36 @@ static int num_cus() {
   return n;
 }
 
-template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED>
+template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED, int WV>
 static int launch_i(const qagnn_gemm_nn_args& b, const float* B1n, int ldn1, const float* B2n, int ldn2, int grid, int ntiles, hipStream_t stream) {
-  const size_t lds = (size_t)2 * NT * 3 * 1024 + (AFFINE ? (size_t)2 * ((b.K1 + 31) & ~31) * 4 : 0);
+  const size_t lds = nn2_lds_bytes<NT, STATS, WV>(AFFINE ? 2 * ((b.K1 + 31) & ~31) * 4 : 0);
+  constexpr int lds_max = nn2_lds_bytes<NT, STATS, WV>(AFFINE ? 2 * 256 * 4 : 0);  // (nn2_ok: K1 <= 256 with a scale / shift)
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (lds > 64 * 1024 && !raised[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+  if (lds_max > 64 * 1024 && !raised[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e != hipSuccess) { set_error("gemm_nn2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED><<<grid, THR, lds, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED, WV><<<grid, WV * 64, lds, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
   QAGNN_LAUNCH_CHECK("k_gemm_nn2");
   return QAGNN_OK;
 }
 
-// PACKED: B1n = the packed buffer, ldn1 = its column tiles per k-tile
-template <int NT, int ORDER, bool PACKED = false>
+// PACKED: B1n = the packed buffer, ldn1 = its column tiles per k-tile.  WV = 8: the staggered 256-row block, one per CU.
+template <int NT, int ORDER, bool PACKED = false, int WV = 4>
 static int launch_nt(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
   qagnn_gemm_nn_args b = a;
   b.xcd_remap = 1;
-  const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, BM);
-  const int cap = (num_cus() * 2) & ~7;
+  const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, WV * 32);
+  const int cap = (num_cus() * (WV == 8 ? 1 : 2)) & ~7;
   const int grid = ntiles < cap ? ntiles : cap;
   if constexpr (NT == 13 || NT == 7 || NT == 4 || NT == 2) {
-    if (a.colstat_part) return launch_i<NT, false, true, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+    if (a.colstat_part) return launch_i<NT, false, true, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
   }
-  if (a.a_scale) return launch_i<NT, true, false, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
-  return launch_i<NT, false, false, ORDER, PACKED>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  if (a.a_scale) return launch_i<NT, true, false, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  return launch_i<NT, false, false, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
 }
 
 // B [No][K1] | [No][K2] (k contiguous) -> the packed image of PACKED kernels: block ((it * NJ + j) * 3 + p) of 1 KB holds, for lane
@@ -532,15 +764,37 @@ static int walk_tiles(int K1, int K2) {
 int64_t nn2_pack_bytes(int No, int K1, int K2);
 
 // QAGNN_NN2: 0 = k_gemm_nn_split everywhere (A/B switch), 1 = k_gemm_nn2 with the in-kernel split of B, 2 = the same with the fine
-// MFMA / VALU interleave pinned, 3 (default) = B packed once per product (k_pack_b) wherever the caller hands over a workspace and
-// the product has at least QAGNN_NN2_PACK_MIN_M rows, the in-kernel split otherwise
+// MFMA / VALU interleave pinned, 3 = B packed once per product (k_pack_b) wherever the caller hands over a workspace and
+// the product has at least QAGNN_NN2_PACK_MIN_M rows, the in-kernel split otherwise, 4 (default) = 3 with the staggered 8-wave block
+// wherever a packed product has at least one 256-row tile per CU
 int nn2_mode() {
-  static const int v = getenv("QAGNN_NN2") ? atoi(getenv("QAGNN_NN2")) : 3;
+  static const int v = getenv("QAGNN_NN2") ? atoi(getenv("QAGNN_NN2")) : 4;
   return v;
 }
 bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes) {
   static const int min_m = getenv("QAGNN_NN2_PACK_MIN_M") ? atoi(getenv("QAGNN_NN2_PACK_MIN_M")) : 8192;
-  return nn2_mode() == 3 && a.M >= min_m && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2);
+  return nn2_mode() >= 3 && a.M >= min_m && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2);
+}
+// Measured at M = 64 000 (tools/nn2_ablate.hip, profiles/r4_run16_nn2_stagger.txt), 4-wave blocks -> staggered block:
+// [208|112] -> 624 141 -> 122 us, 624 -> 208 96..101 -> 79, but 208 -> 208 38 -> 39 and 624 -> 112 (NT = 7) 53 -> 54: with one block per
+// CU nothing runs under a tile's first loads, and the last tiles' stores are a tail at HBM speed, which 10 k-tiles of 13 column tiles
+// amortise and 7 k-tiles or 7 column tiles do not.
+static bool nn2_staggered(int nt, const qagnn_gemm_nn_args& a) {
+  return nn2_mode() >= 4 && nt >= 8 && nn2::walk_tiles(a.K1, a.K2) >= 10 && (int64_t)cdiv(a.No, nt * 16) * cdiv(a.M, 256) * 10 >= nn2::num_cus() * 9;
+}
+// the PACKED kernel on an image `p` of B (NJ column tiles per k-tile)
+static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p, int NJ, hipStream_t stream) {
+  if (nn2_staggered(nt, a)) {
+    if (nt == 13) return nn2::launch_nt<13, 0, true, 8>(a, p, NJ, nullptr, 0, stream);
+    return nn2::launch_nt<8, 0, true, 8>(a, p, NJ, nullptr, 0, stream);
+  }
+  switch (nt) {
+    case 13: return nn2::launch_nt<13, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 8: return nn2::launch_nt<8, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 7: return nn2::launch_nt<7, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 4: return nn2::launch_nt<4, 0, true>(a, p, NJ, nullptr, 0, stream);
+    default: return nn2::launch_nt<2, 0, true>(a, p, NJ, nullptr, 0, stream);
+  }
 }
 
 // what the second-generation kernel takes: no fused row gather, 32-bit operand offsets, segments that are multiples of 8
@@ -548,7 +802,7 @@ bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
   const int64_t lim = (int64_t)0x7FFFFFFF;
   if (nn2_mode() == 0 || a.a_rowidx) return false;
   if (a.K1 % 8 != 0 || a.K2 % 8 != 0) return false;
-  if ((int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.No * ldn1 * 4 >= lim) return false;
+  if ((int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.M * a.ldc * 4 >= lim) return false;
   if (a.K2 > 0 && ((int64_t)a.M * a.lda2 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim)) return false;
   if (a.K2 > 0 && (a.K1 & 31) != 0 && a.K2 < 32 - (a.K1 & 31)) return false;  // (the straddling tile must lie inside segment 2)
   if (a.a_scale && a.K1 > 256) return false;  // (the scale / shift vectors live in LDS next to the two B images)
@@ -577,14 +831,7 @@ int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int
   const int NJ = cdiv(a.No, 16), nkt = nn2::walk_tiles(a.K1, a.K2);
   nn2::k_pack_b<<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
   QAGNN_LAUNCH_CHECK("k_pack_b");
-  const float* pk = reinterpret_cast<const float*>(ws);
-  switch (nt) {
-    case 13: return nn2::launch_nt<13, 0, true>(a, pk, NJ, nullptr, 0, stream);
-    case 8: return nn2::launch_nt<8, 0, true>(a, pk, NJ, nullptr, 0, stream);
-    case 7: return nn2::launch_nt<7, 0, true>(a, pk, NJ, nullptr, 0, stream);
-    case 4: return nn2::launch_nt<4, 0, true>(a, pk, NJ, nullptr, 0, stream);
-    default: return nn2::launch_nt<2, 0, true>(a, pk, NJ, nullptr, 0, stream);
-  }
+  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(ws), NJ, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -615,15 +862,7 @@ static bool prepack_takes(const qagnn_pack_desc& d) {
 }
 
 int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream) {
-  const int NJ = cdiv(a.No, 16);
-  const float* p = reinterpret_cast<const float*>(pk);
-  switch (nt) {
-    case 13: return nn2::launch_nt<13, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 8: return nn2::launch_nt<8, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 7: return nn2::launch_nt<7, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 4: return nn2::launch_nt<4, 0, true>(a, p, NJ, nullptr, 0, stream);
-    default: return nn2::launch_nt<2, 0, true>(a, p, NJ, nullptr, 0, stream);
-  }
+  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(pk), cdiv(a.No, 16), stream);
 }
 }  // namespace qagnn
 

@@ -93,6 +93,17 @@ d = json.load(open('/tmp/ab_line.txt'))
 print(d['value'], d['ms_per_step'], d['repeat_ms_per_step'], d['breakdown_ms_per_step'])
 PY
       done; stamp "ab:$var" ;;
+    abv:*)   # abv:VAR:a:b -- interleaved A/B of two VALUES of an environment switch
+      IFS=: read -r _ var va vb <<< "$arg"
+      for v in $va $vb $va $vb; do
+        echo "$var=$v" >> gpurun_out/ab_$var.txt
+        env $var=$v timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 > /tmp/ab_line.txt
+        python - <<PY >> gpurun_out/ab_$var.txt
+import json
+d = json.load(open('/tmp/ab_line.txt'))
+print(d['value'], d['ms_per_step'], d['repeat_ms_per_step'], d['breakdown_ms_per_step'])
+PY
+      done; stamp "abv:$var" ;;
     ab10:*)
       var="${arg#ab10:}"
       for v in 0 1 0 1; do

@@ -130,7 +130,10 @@ GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (
                (64000, 208, 112, 624), (2000, 208, 112, 624), (500, 40, 56, 208), (1000, 624, 0, 112), (260, 224, 0, 320), (129, 8, 24, 16),
                (300, 200, 8, 320),
                # at and above the row count where B is packed once (k_pack_b + DMA-fed kernel): one segment, a k-tile tail, narrow outputs
-               (9000, 208, 0, 208), (8192, 624, 0, 112), (10000, 40, 56, 200)]
+               (9000, 208, 0, 208), (8192, 624, 0, 112), (10000, 40, 56, 200),
+               # the staggered 8-wave block (>= 10 k-tiles, one 256-row tile per CU or more): ragged last row tile, a column tail, the
+               # 8-column-tile block (and one it leaves to the 4-wave blocks: 7 column tiles); the projection above walks three tiles per block (stores of one tile under the loads of the next)
+               (63901, 624, 0, 208), (61003, 320, 0, 200), (60001, 320, 8, 112), (60100, 320, 0, 128)]
 
 
 @pytest.mark.gpu

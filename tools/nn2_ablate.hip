@@ -65,13 +65,15 @@ int main(int argc, char** argv) {
       const int64_t wsb = qagnn::nn2_pack_bytes(sh.No, sh.K1, sh.K2);
       CK(hipMalloc(&ws, wsb));
       const int NJ = (sh.No + 15) / 16;
-      for (int alone = 0; alone < 2; ++alone) {
+      for (int alone = 0; alone < 3; ++alone) {  // 2: the staggered 8-wave block
         for (int i = 0; i < 3; ++i) qagnn::launch_nn2_packed(nt, a, B1n, sh.K1, B2n, sh.K2, ws, st);
         CK(hipStreamSynchronize(st));
         const int reps = 30;
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < reps; ++i) {
           if (!alone) qagnn::launch_nn2_packed(nt, a, B1n, sh.K1, B2n, sh.K2, ws, st);
+          else if (alone == 2 && nt == 13) qagnn::nn2::launch_nt<13, 0, true, 8>(a, (const float*)ws, NJ, nullptr, 0, st);
+          else if (alone == 2) continue;  // (the staggered block is built for 13 and 8 column tiles)
           else if (nt == 13) qagnn::nn2::launch_nt<13, 0, true>(a, (const float*)ws, NJ, nullptr, 0, st);
           else qagnn::nn2::launch_nt<7, 0, true>(a, (const float*)ws, NJ, nullptr, 0, st);
         }
@@ -80,7 +82,7 @@ int main(int argc, char** argv) {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
-        printf("  %-22s %s  %8.1f us  %7.1f TFLOP/s fp32-eq\n", sh.name, alone ? "packed, product only" : "packed, pack+product", us,
+        printf("  %-22s %s  %8.1f us  %7.1f TFLOP/s fp32-eq\n", sh.name, alone == 2 ? "staggered, product only" : alone ? "packed, product only" : "packed, pack+product", us,
                2.0 * M * (sh.K1 + sh.K2) * sh.No / us / 1e6);
       }
       CK(hipFree(ws));
