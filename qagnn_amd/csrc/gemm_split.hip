@@ -19,6 +19,8 @@
 // in registers, under the MFMAs), two blocks per CU.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace qagnn {
@@ -607,6 +609,344 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_gemm_tn_ws (round 4): the same product with the work of a CU divided by KIND instead of by output.  Where k_gemm_tn_split runs at
+// 44 % of the matrix pipe (187 us for the [X | S]^T dKMQ product of the 320-subgraph batch): per k-tile a block spends ~2 200 cycles of
+// MFMAs, ~2 000 cycles of VALU work (split + transpose of 320 x 32 numbers) and ~1 900 cycles of LDS traffic, in barrier-separated
+// phases, and the two blocks of a CU run in lockstep (same work, fair arbitration), so the three resources are used one after the other.
+// Here ONE block of 8 waves owns the CU, one COMPUTE wave and one PRODUCER wave per SIMD:
+//   * the four compute waves own the KT x NT output tiles exactly as the four waves of k_gemm_tn_split do (strips of the 13-wide
+//     operand stay in registers; the (7, 13) shape mirrored, so that it reads 42 fragments per k-tile like the (13, 7) one instead of
+//     100), and do nothing but fragment reads (issued two column tiles ahead, counted waits) and MFMAs;
+//   * the four producer waves load the NEXT k-tile's rows of both operands (one unified space of float4 columns [A | B]: 80 columns =
+//     5 task-waves of 64 tasks, four fixed and the fifth rotating over the producers), split and transpose them into the OTHER of two
+//     LDS images (2 x 77 KB), and issue the loads of the tile after that;
+//   * one barrier per k-tile.  The roles are taken by arrival order on each SIMD (HW_ID), so that every SIMD holds one wave of each
+//     kind: the matrix pipe sees an MFMA stream, the vector ALU the split arithmetic, at the same time.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WTHR = 512;
+// QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
+// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either
+#ifndef QAGNN_TNW_ABL
+#define QAGNN_TNW_ABL 0
+#endif
+
+// store_task with a per-lane floor (AFF: relu for the lanes of A, -inf = pass-through for the lanes of B)
+template <bool AFF>
+__device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh, float lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = j == 0 ? r[i].x : j == 1 ? r[i].y : j == 2 ? r[i].z : r[i].w;
+      if (AFF) {
+        const float s_ = j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w, h = j == 0 ? sh.x : j == 1 ? sh.y : j == 2 ? sh.z : sh.w;
+        v = fmaxf(fmaf(v, s_, h), lo);
+      }
+      x[i] = v;
+    }
+    store_col8(img + off + j * TCP, img_elems, x);
+  }
+}
+
+template <int KT, int NT, bool AFFINE>
+__global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_ws(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const float* __restrict__ A2, int lda2, int Ka2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_tw[];
+  constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
+  constexpr int IMG_EL = 3 * (A_EL + B_EL), IMG_B = IMG_EL * 2;  // one k-tile's image: [A: piece][column][32 rows + pad] | [B: ...]
+  constexpr bool MAJ_A = KT >= NT;                                // the operand whose strips a compute wave keeps in registers
+  constexpr int MAJT = MAJ_A ? KT : NT, MINT = MAJ_A ? NT : KT;
+  constexpr int MT = MAJT / 4, REM = MAJT % 4, RS = (REM * MINT + 3) / 4;
+  constexpr int MAJ_PIECE = (MAJ_A ? A_EL : B_EL) * 2, MIN_PIECE = (MAJ_A ? B_EL : A_EL) * 2;  // bytes between the pieces of an operand
+  constexpr int STRIP_B = 16 * TCP * 2;                                                        // bytes of one 16-column strip
+  constexpr int NC4 = (AC + BC) / 4, NTW = (NC4 + 15) / 16;                                    // float4 columns of [A | B], task-waves
+  static_assert(MT >= 1 && NTW >= 4 && NTW <= 8, "shapes: (13, 7) and (7, 13)");
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int ka_total = Ka + (A2 ? Ka2 : 0);
+  int by = blockIdx.y, row_shift = 0;
+  if (A2 != nullptr) {
+    const int n1 = (Ka + AC - 1) / AC;
+    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
+  }
+  const int n0 = blockIdx.x * BC, m0 = by * AC, chunk = blockIdx.z;
+  const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
+  const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
+
+  // roles: the first wave to arrive on a SIMD computes, the second produces; should the hardware ever place the waves otherwise
+  // (not 4 + 4), waves 0-3 compute and 4-7 produce -- correct either way, only the overlap is lost
+  int* const ctl = reinterpret_cast<int*>(smem_tw + 2 * IMG_B);
+  if (tid < 8) ctl[tid] = 0;
+  __syncthreads();
+  int role, idx;
+  {
+    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // HW_ID[5:4] = SIMD_ID
+    int v = 0;
+    if (lane == 0) v = atomicAdd(&ctl[simd], 1);
+    role = __builtin_amdgcn_readfirstlane(v) & 1;
+    if (lane == 0) v = atomicAdd(&ctl[4 + role], 1);
+    idx = __builtin_amdgcn_readfirstlane(v);
+    __syncthreads();
+    if (ctl[4] != 4 || ctl[5] != 4) { role = w >> 2; idx = w & 3; }
+  }
+#define QAGNN_TNW_BAR                                                  \
+  {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  }
+  __syncthreads();  // (ctl is read; the images may be written)
+
+  const int ntile4 = (ntile + 3) & ~3;  // both roles run whole groups of four k-tiles (the producers' loop is unrolled by four)
+  if (role == 1) {
+    // ---------------------------------------------------------------- producer
+    // Everything about a producer's k-tile is a compile-time constant of (its index, the tile's position in a group of four): which
+    // task-waves it holds (its own; the rotating fifth on tile T iff (idx - T) % 4 == 0), which operand(s) their columns lie in, how
+    // many loads that makes.  hipcc then counts its vmcnt waits exactly; with the same facts behind uniform branches it waited for
+    // vmcnt(0) in front of every split -- i.e. for the loads it had just issued for the tile after (3.1 us per k-tile instead of 1.2).
+    // Loads and stores run past the chunk's last tile unconditionally (rows past R read zeros, rows of the next chunk land in an
+    // image nobody reads).
+    auto produce = [&](auto IDXC) {
+      constexpr int IDX = decltype(IDXC)::value;
+      const int g = lane & 3;
+      const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, R * lda * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, R * ldb * 4, 0x00020000);
+      constexpr uint32_t OOB = 0x80000000u;  // (+ any offset of this kernel stays out of range: the load answers with zeros)
+      const uint32_t ldA4 = (uint32_t)lda * 4u, ldB4 = (uint32_t)ldb * 4u;
+      constexpr int TW[2] = {IDX, 4};
+      constexpr bool HAS_A[2] = {TW[0] * 16 < AC / 4, TW[1] * 16 < AC / 4};
+      constexpr bool HAS_B[2] = {TW[0] * 16 + 15 >= AC / 4, TW[1] * 16 + 15 >= AC / 4};
+      uint32_t voA[2], voB[2];
+      int off[2], iel[2];
+      float4 sc[2], sh[2];
+      float lo[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c4u = TW[k] * 16 + (lane >> 2);
+        const bool act = c4u < NC4 && (k == 0 || NTW > 4);
+        const bool isA = c4u < AC / 4;
+        const int c4 = isA ? c4u : c4u - AC / 4;
+        voA[k] = act && isA && m0 + c4 * 4 < Ka ? (uint32_t)(r_beg + g * 8) * ldA4 + (uint32_t)(m0 + c4 * 4) * 4u : OOB;
+        voB[k] = act && !isA && n0 + c4 * 4 < No ? (uint32_t)(r_beg + g * 8) * ldB4 + (uint32_t)(n0 + c4 * 4) * 4u : OOB;
+        iel[k] = isA ? A_EL : B_EL;
+        off[k] = act ? (isA ? 0 : 3 * A_EL) + c4 * 4 * TCP + ((g ^ ((c4 ^ (c4 >> 1)) & 1)) << 3) : -1;
+        sc[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lo[k] = -INFINITY;
+        if (AFFINE && isA && act) {
+          const int cc = min(m0 + c4 * 4, Ka - 4);
+          sc[k] = ld4(a_scale + cc);
+          sh[k] = ld4(a_shift + cc);
+          lo[k] = 0.f;
+        }
+      }
+      // two register sets per task slot: the loads of tile t + 2 are issued BEFORE the split work of tile t + 1 and have a whole
+      // k-tile to land (even tiles in set a, odd tiles in set b)
+      float4 r1a[8], r2a[8], r1b[8], r2b[8];
+      if constexpr ((QAGNN_TNW_ABL & 2) != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r1a[i] = r2a[i] = r1b[i] = r2b[i] = make_float4(1.f + lane, 2.f, 3.f, 4.f);
+      }
+      // the rows of tile T of task slot K -> the registers RR (a task-wave that straddles the end of A asks both operands and ORs)
+#define QAGNN_TNW_LOAD1(T, K, RR)                                                                          \
+      {                                                                                                    \
+        const uint32_t a_ = voA[K] + (uint32_t)(T) * (TKR * ldA4), b_ = voB[K] + (uint32_t)(T) * (TKR * ldB4); \
+        if constexpr (HAS_A[K] && HAS_B[K]) {                                                              \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
+            const u32x4s x_ = __builtin_bit_cast(u32x4s, bload4(rsA, a_ + (uint32_t)i * ldA4)) |           \
+                              __builtin_bit_cast(u32x4s, bload4(rsB, b_ + (uint32_t)i * ldB4));            \
+            RR[i] = __builtin_bit_cast(float4, x_);                                                        \
+          }                                                                                                \
+        } else if constexpr (HAS_A[K]) {                                                                   \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) RR[i] = bload4(rsA, a_ + (uint32_t)i * ldA4);      \
+        } else {                                                                                           \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) RR[i] = bload4(rsB, b_ + (uint32_t)i * ldB4);      \
+        }                                                                                                  \
+      }
+      // TP: the tile's position modulo 4 (t itself is a multiple of 4)
+#define QAGNN_TNW_LOAD(T, TP, R1, R2)                                                                      \
+      if constexpr (!(QAGNN_TNW_ABL & 2)) {                                                                \
+        QAGNN_TNW_LOAD1(T, 0, R1)                                                                          \
+        if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) QAGNN_TNW_LOAD1(T, 1, R2)                        \
+      }
+#define QAGNN_TNW_STORE(T, TP, R1, R2)                                                                     \
+      if constexpr (!(QAGNN_TNW_ABL & 1)) {                                                                \
+        uint16_t* const img_ = reinterpret_cast<uint16_t*>(smem_tw) + ((TP)&1) * IMG_EL;                   \
+        if (off[0] >= 0) store_task_lo<AFFINE>(img_, iel[0], off[0], R1, sc[0], sh[0], lo[0]);             \
+        if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) {                                                \
+          if (off[1] >= 0) store_task_lo<AFFINE>(img_, iel[1], off[1], R2, sc[1], sh[1], lo[1]);           \
+        }                                                                                                  \
+      }
+      QAGNN_TNW_LOAD(0, 0, r1a, r2a)
+      QAGNN_TNW_LOAD(1, 1, r1b, r2b)
+      QAGNN_TNW_STORE(0, 0, r1a, r2a)
+      QAGNN_TNW_BAR
+      for (int t = 0; t < ntile4; t += 4) {
+        QAGNN_TNW_LOAD(t + 2, 2, r1a, r2a)   // compute: tile t
+        QAGNN_TNW_STORE(t + 1, 1, r1b, r2b)  // (the compute waves read the other image)
+        QAGNN_TNW_BAR
+        QAGNN_TNW_LOAD(t + 3, 3, r1b, r2b)   // compute: tile t + 1
+        QAGNN_TNW_STORE(t + 2, 2, r1a, r2a)
+        QAGNN_TNW_BAR
+        QAGNN_TNW_LOAD(t + 4, 0, r1a, r2a)   // compute: tile t + 2
+        QAGNN_TNW_STORE(t + 3, 3, r1b, r2b)
+        QAGNN_TNW_BAR
+        QAGNN_TNW_LOAD(t + 5, 1, r1b, r2b)   // compute: tile t + 3
+        QAGNN_TNW_STORE(t + 4, 0, r1a, r2a)
+        QAGNN_TNW_BAR
+      }
+#undef QAGNN_TNW_LOAD
+#undef QAGNN_TNW_LOAD1
+#undef QAGNN_TNW_STORE
+    };
+    switch (idx) {
+      case 0: produce(std::integral_constant<int, 0>{}); break;
+      case 1: produce(std::integral_constant<int, 1>{}); break;
+      case 2: produce(std::integral_constant<int, 2>{}); break;
+      default: produce(std::integral_constant<int, 3>{}); break;
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute
+  const int ci = idx;
+  f32x4s acc[MT][MINT], accr[RS > 0 ? RS : 1];
+#pragma unroll
+  for (int s_ = 0; s_ < MT; ++s_)
+#pragma unroll
+    for (int n = 0; n < MINT; ++n) acc[s_][n] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < RS; ++q) accr[q] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+
+  const int rd_off = (lane & 15) * TCP + (((lane >> 4) ^ ((((lane & 15) >> 2) ^ ((lane & 15) >> 3)) & 1)) << 3);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_tw + (uint32_t)rd_off * 2u;
+  const uint32_t maj0 = lds0 + (MAJ_A ? 0u : (uint32_t)(3 * A_EL * 2)) + (uint32_t)(ci * STRIP_B);  // this wave's first strip
+  const uint32_t min0 = lds0 + (MAJ_A ? (uint32_t)(3 * A_EL * 2) : 0u);
+  // the leftover strips' tiles, dealt out one by one: tile q = ci + 4 s -> (strip 4 MT + q / MINT, minor tile q % MINT)
+  uint32_t rem_maj[RS > 0 ? RS : 1], rem_min[RS > 0 ? RS : 1];
+#pragma unroll
+  for (int s_ = 0; s_ < RS; ++s_) {
+    const int q = ci + 4 * s_;
+    rem_maj[s_] = lds0 + (MAJ_A ? 0u : (uint32_t)(3 * A_EL * 2)) + (uint32_t)((4 * MT + q / MINT) * STRIP_B);
+    rem_min[s_] = min0 + (uint32_t)((q % MINT) * STRIP_B);
+  }
+#define QAGNN_TNW_FRAG(DST, ADDR, OFF, PIECE)                                                                            \
+  {                                                                                                                      \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                        \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"((OFF) + p * (PIECE)));              \
+  }
+#define QAGNN_TNW_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]))
+#define QAGNN_TNW_SIX(C, AF, BF)                                          \
+  if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[1]), "v"(AF[2]), "v"(BF[0]), "v"(BF[1]), "v"(BF[2])); } else { \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0); }
+
+  QAGNN_TNW_BAR  // image 0 is complete
+  for (int t = 0; t < ntile4; ++t) {
+    if (t >= ntile) {  // (the producers' group of four is not over)
+      QAGNN_TNW_BAR
+      continue;
+    }
+    if constexpr ((QAGNN_TNW_ABL & 8) != 0) {
+      QAGNN_TNW_BAR
+      continue;
+    }
+    const uint32_t cur = (uint32_t)((t & 1) * IMG_B);
+    const uint32_t amaj = maj0 + cur, amin = min0 + cur;
+    bf16x8 mf[MT][3], nf[3][3];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s_ = 0; s_ < MT; ++s_) QAGNN_TNW_FRAG(mf[s_], amaj, s_ * 4 * STRIP_B, MAJ_PIECE)
+    QAGNN_TNW_FRAG(nf[0], amin, 0, MIN_PIECE)
+    if constexpr (MINT > 1) QAGNN_TNW_FRAG(nf[1], amin, STRIP_B, MIN_PIECE)
+#pragma unroll
+    for (int n = 0; n < MINT; ++n) {
+      bf16x8(&bfn)[3] = nf[n % 3];
+      if (n + 2 < MINT) {
+        QAGNN_TNW_FRAG(nf[(n + 2) % 3], amin, (n + 2) * STRIP_B, MIN_PIECE)
+        QAGNN_TNW_WAIT(bfn, 6);
+      } else if (n + 1 < MINT) {
+        QAGNN_TNW_WAIT(bfn, 3);
+      } else {
+        QAGNN_TNW_WAIT(bfn, 0);
+      }
+      if (n == 0) {  // (the strips' fragments are older than every minor fragment: landed with the first wait)
+#pragma unroll
+        for (int s_ = 0; s_ < MT; ++s_) asm volatile("" : "+v"(mf[s_][0]), "+v"(mf[s_][1]), "+v"(mf[s_][2]));
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < MT; ++s_) {  // small terms first
+        f32x4s c = acc[s_][n];
+        if constexpr (MAJ_A) { QAGNN_TNW_SIX(c, mf[s_], bfn) } else { QAGNN_TNW_SIX(c, bfn, mf[s_]) }
+        acc[s_][n] = c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < RS; ++s_) {
+      if (ci + 4 * s_ < REM * MINT) {  // wave-uniform
+        bf16x8 ar[3], br[3];
+        QAGNN_TNW_FRAG(ar, rem_maj[s_] + cur, 0, MAJ_PIECE)
+        QAGNN_TNW_FRAG(br, rem_min[s_] + cur, 0, MIN_PIECE)
+        QAGNN_TNW_WAIT(ar, 0);
+        asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
+        f32x4s c = accr[s_];
+        if constexpr (MAJ_A) { QAGNN_TNW_SIX(c, ar, br) } else { QAGNN_TNW_SIX(c, br, ar) }
+        accr[s_] = c;
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    QAGNN_TNW_BAR
+  }
+#undef QAGNN_TNW_FRAG
+#undef QAGNN_TNW_WAIT
+#undef QAGNN_TNW_SIX
+#undef QAGNN_TNW_BAR
+
+  float* const Pc = P + (int64_t)chunk * ka_total * No;
+  auto put = [&](int maj_strip, int min_tile, const f32x4s& c) {
+    const int rstrip = MAJ_A ? maj_strip : min_tile, ctile = MAJ_A ? min_tile : maj_strip;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + rstrip * 16 + (lane >> 4) * 4 + r, col = n0 + ctile * 16 + (lane & 15);
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = c[r];
+    }
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < MT; ++s_)
+#pragma unroll
+    for (int n = 0; n < MINT; ++n) put(ci + 4 * s_, n, acc[s_][n]);
+#pragma unroll
+  for (int s_ = 0; s_ < RS; ++s_) {
+    const int q = ci + 4 * s_;
+    if (q < REM * MINT) put(4 * MT + q / MINT, q % MINT, accr[s_]);
+  }
+}
+
+template <int KT, int NT, bool AFFINE>
+static int launch_tn_ws_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
+                          const float* sc, const float* sh, int chunk_rows, const float* A2 = nullptr, int lda2 = 0, int Ka2 = 0) {
+  constexpr size_t lds = (size_t)2 * 3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t) + 64;
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (!raised[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_ws<KT, NT, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("gemm_tn_ws: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
+    raised[dev & 63] = true;
+  }
+  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, A2, lda2, Ka2);
+  QAGNN_LAUNCH_CHECK("k_gemm_tn_ws");
+  return QAGNN_OK;
+}
+
 template <int KT, int NT, bool AFFINE, bool GATHER = false>
 static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
                              const float* sc, const float* sh, int chunk_rows, const int64_t* ridx = nullptr, const float* A2 = nullptr,
@@ -654,9 +994,18 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
   const int lo32 = (lo + TKR - 1) / TKR * TKR;
   return rows > lo32 ? rows : lo32;
 }
+// QAGNN_TN_WS: 0 = k_gemm_tn_split everywhere, 1 (default) = k_gemm_tn_ws for the two-operand product [X | S]^T dKMQ (36 k-tiles per
+// block: 201 -> 171 us at 64 000 rows), 2 = for every product it takes.  Measured with 8 - 24 k-tiles per block (tools/tn_ablate.hip,
+// profiles/r4_run17_tn_ws.txt): 208 x 624 115 -> 126 us, 208 x 208 43 -> 57, 112 x 624 72 -> 74 -- one block per CU leaves a block's
+// first loads and its partial-sum stores uncovered, which only a long chunk amortises.
+static int tn_ws_mode() {
+  static const int v = getenv("QAGNN_TN_WS") ? atoi(getenv("QAGNN_TN_WS")) : 1;
+  return v;
+}
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
                      int chunk_rows, hipStream_t stream) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
+  if (tn_ws_mode() >= 1) return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
@@ -664,6 +1013,16 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
   if (ridx) {
     dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
     return launch_tn_split_i<13, 7, false, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
+  }
+  if (tn_ws_mode() >= 2) {
+    if (tn_split_wide_b(Ka)) {
+      dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
+      return sc ? launch_tn_ws_i<7, 13, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
+                : launch_tn_ws_i<7, 13, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
+    }
+    dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
+    return sc ? launch_tn_ws_i<13, 7, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
+              : launch_tn_ws_i<13, 7, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
   }
   if (tn_split_wide_b(Ka)) {
     dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));

@@ -222,6 +222,28 @@ def test_gemm_tn_two_operands(R, Ka1, Ka2, No):
     assert torch.equal(buf[:Ka1 + Ka2].cpu(), got) and bool((buf[Ka1 + Ka2] == 7.0).all())
 
 
+# The GEMM kernel families that an environment switch selects once per process (the library reads it at its first call), each through
+# the SAME tests above in an interpreter of its own: QAGNN_TN_WS=2 the warp-specialised weight-gradient kernel (k_gemm_tn_ws) for every
+# product it takes (by default only the two-operand product runs on it), QAGNN_TN_WS=0 k_gemm_tn_split everywhere, QAGNN_NN2=3 the
+# 4-wave packed blocks where the staggered 8-wave block would run, QAGNN_NN2=1 the in-kernel split of B.
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('env,sel', [('QAGNN_TN_WS=2', 'test_gemm_tn'), ('QAGNN_TN_WS=0', 'test_gemm_tn'),
+                                     ('QAGNN_NN2=3', 'test_gemm_nn and (64000 or 63901 or 61003 or 60100)'),
+                                     ('QAGNN_NN2=1', 'test_gemm_nn and (64000 or 9000 or 8192 or 10000)')])
+def test_gemm_kernel_families(env, sel):
+    import subprocess
+    import sys
+    if os.environ.get('QAGNN_VARIANT_CHILD'):
+        pytest.skip('already inside a variant run')
+    child_env = dict(os.environ, QAGNN_VARIANT_CHILD='1', **dict(kv.split('=') for kv in env.split()))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q', '-x', '-p', 'no:cacheprovider', '-k', sel],
+                       env=child_env, cwd=helpers.ROOT, capture_output=True, text=True, timeout=800)
+    tail = (r.stdout or '')[-1500:] + (r.stderr or '')[-500:]
+    assert r.returncode == 0, f'{env}:\n{tail}'
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, tail
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,V,K,No', [(3000, 500, 1024, 208), (129, 7, 32, 32), (20000, 100000, 1024, 208)])
 def test_gemm_with_fused_row_gather(M, V, K, No):

@@ -8,6 +8,9 @@ Tolerances: forward values 1e-4 of the tensor's max magnitude (+ the reference's
 tensor on the float64 yardstick of tests/helpers.py (F64Ref): |hip - f64| <= 3 |fp32 oracle - f64| + 1e-6 scale, which
 comes to <= 6e-4 of a tensor's scale on every case here and is asserted to stay below 1 %.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -368,14 +371,19 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
 # the composed per-kernel path with the weight-gradient GEMMs queued onto a side stream under the edge backward
 # (ops.WGRAD_OVERLAP) -- a different code path from the natively sequenced stack the smaller train-mode cases take.  Dropout is off
 # (it cannot be replayed on the oracle); everything else is the bench's step.
-# Bars (fixed, nothing read off the candidate): logits 5e-4 of scale; every gradient tensor 1.5e-2 of its scale (2e-2 for the affine
-# parameters of a BatchNorm in front of a ReLU) or 6 x the REFERENCE's own re-ordering noise on that tensor, whichever is larger (round 4:
-# the oracle is run a second time on the edge-permuted batch, see _bench_size_case).  Why not the 5e-3 of the 10-subgraph cases: this batch has 64 M BatchNorm outputs,
-# ~1e-6 of them within fp32 rounding of the ReLU kink, i.e. dozens of elements per layer on which two correct fp32 implementations
-# choose different subgradients; each moves every gradient upstream of it.  Measured HIP vs the fp32 oracle: 7.2e-3 of scale at worst
-# (concept_emb.cpt_transform.weight, at the bottom of the network), 5-7e-3 on a handful of bottom-of-network tensors, < 5e-3 elsewhere.
+# Bars (fixed, nothing read off the candidate): logits 5e-4 of scale (1e-3 for the two workloads added in round 4); every gradient tensor
+# within the LARGEST of three yardsticks: (a) 1.5e-2 of its scale (2e-2 for the affine parameters of a BatchNorm in front of a ReLU);
+# (b) 6 x the REFERENCE's own re-ordering noise on that tensor (the oracle run a second time on the edge-permuted batch, _bench_size_case);
+# (c) 4 x the distance between the reference's fp32 and float64 runs on that tensor (committed fixture
+# tests/golden/bench_size_f64_yardstick.json + its script).  Why not the 5e-3 of the 10-subgraph cases: this batch has 64 M BatchNorm
+# outputs, ~1e-6 of them within fp32 rounding of the ReLU kink, i.e. dozens of elements per layer on which two correct fp32
+# implementations choose different subgradients; each moves every gradient upstream of it.  Measured HIP vs the fp32 oracle at 320 CSQA
+# subgraphs: 9e-3 of scale at worst, median 4.6e-3 (the fp32 oracle against its own float64 run: up to 1.1e-2); at 256 OpenBookQA-shaped
+# subgraphs (ill-conditioned by the 0.6-sigma fill): median 1.2e-2, while the fp32 oracle sits a median 2.9e-2 from its float64 run.
 # The tight per-tensor statement stays with the float64 yardstick at B = 40 / 24 / 16 above.
 BENCH_SIZE_BAR, BENCH_SIZE_KINK_BAR = 1.5e-2, 2e-2
+# per workload, per gradient tensor: max |fp32 oracle - float64 oracle| on the same weights and batch (committed fixture + its script)
+F64_YARDSTICK = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bench_size_f64_yardstick.json')))
 # ---------------------------------------------------------------------------------------------------------------------------------
 _BENCH_SIZE = {}
 # (workload of BASELINE.json) -> questions, choices, record shape, relations, edge types, input width.  configs[2] at 64 x 4 = 256
@@ -492,9 +500,17 @@ def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch
             rel_plain.append(err / (scale + 1e-30))
         if err / (scale + 1e-30) > worst[0]:
             worst = (err / (scale + 1e-30), k)
-        if err > max(bar * scale, 6.0 * ref['noise'][k]) + 1e-9:
-            fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.0e}, the reference\'s own re-ordering noise '
-                         f'{ref["noise"][k] / (scale + 1e-30):.2e})')
+        # the third yardstick (tests/golden/make_bench_size_yardstick.py): how far the fp32 reference itself is from its own float64 run
+        # on this tensor -- a candidate is not asked to sit closer to the fp32 run than the fp32 run sits to exact arithmetic
+        # (OpenBookQA-shaped batch: median 2.9e-2 of scale, the HIP path 1.2e-2; CSQA 320: up to 1.1e-2; MedQA 64: ~1e-5, never the larger)
+        # -- the criterion of the small cases (helpers.F64Ref: |hip - f64| <= 3 |fp32 - f64|) restated against the fp32 run, because
+        # the float64 tensors (16 MB per workload) do not travel: |hip - fp32| <= |hip - f64| + |f64 - fp32| <= 4 |fp32 - f64|.
+        # Measured on the OpenBookQA batch: one tensor (layer 3's mlp.0.weight, one flipped kink = one changed outer product) at
+        # 3.04 x its yardstick, two at 1.4 x, everything else below 1 x
+        yard = 4.0 * F64_YARDSTICK.get(workload, {}).get(k, 0.0)
+        if err > max(bar * scale, 6.0 * ref['noise'][k], yard) + 1e-9:
+            fails.append(f'{k}: {err / (scale + 1e-30):.2e} of scale (bar {bar:.1e}, the reference\'s own re-ordering noise '
+                         f'{ref["noise"][k] / (scale + 1e-30):.2e}, 4 x the fp32 reference against float64 {yard / (scale + 1e-30):.2e})')
     if helpers.REPORT:
         with open(helpers.REPORT, 'a') as f:
             rs = sorted(rel_plain)
