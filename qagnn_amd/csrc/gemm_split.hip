@@ -445,12 +445,22 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   // row tiles of A2 follow those of A in blockIdx.y, and such a block simply works on the other operand (one launch and one chunk sum
   // for the two weight gradients that share dK|dM|dQ: X^T dKMQ and S^T dKMQ)
   const int ka_total = Ka + (A2 ? Ka2 : 0);
-  int by = blockIdx.y, row_shift = 0;
+  // XCD-aware block order (chunk_rows < 0: off; see k_gemm_tn_ws): the blocks of one chunk on one XCD
+  int bx = blockIdx.x, by = blockIdx.y, chunk = blockIdx.z, row_shift = 0;
+  if (chunk_rows < 0) {
+    chunk_rows = -chunk_rows;
+  } else {
+    const int lin = bx + (int)gridDim.x * (by + (int)gridDim.y * chunk);
+    const int v = xcd_remap(lin, (int)(gridDim.x * gridDim.y * gridDim.z));
+    bx = v % (int)gridDim.x;
+    by = (v / (int)gridDim.x) % (int)gridDim.y;
+    chunk = v / (int)(gridDim.x * gridDim.y);
+  }
   if (A2 != nullptr) {
     const int n1 = (Ka + AC - 1) / AC;
     if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
   }
-  const int n0 = blockIdx.x * BC, m0 = by * AC, chunk = blockIdx.z;
+  const int n0 = bx * BC, m0 = by * AC;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
 
@@ -624,9 +634,14 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 //   * one barrier per k-tile.  The roles are taken by arrival order on each SIMD (HW_ID), so that every SIMD holds one wave of each
 //     kind: the matrix pipe sees an MFMA stream, the vector ALU the split arithmetic, at the same time.
 // ------------------------------------------------------------------------------------------------------------
+// QAGNN_TN_XCD=0: the weight-gradient blocks in launch order (A/B switch)
+static bool tn_xcd() {
+  static const int v = getenv("QAGNN_TN_XCD") ? atoi(getenv("QAGNN_TN_XCD")) : 1;
+  return v != 0;
+}
 constexpr int WTHR = 512;
 // QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
-// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either
+// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them
 #ifndef QAGNN_TNW_ABL
 #define QAGNN_TNW_ABL 0
 #endif
@@ -667,12 +682,24 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const int ka_total = Ka + (A2 ? Ka2 : 0);
-  int by = blockIdx.y, row_shift = 0;
+  // XCD-aware block order (chunk_rows < 0: off): the blocks of one chunk read the same rows of A and B, so they belong on ONE XCD,
+  // next to each other in time -- in launch order they are dealt out over all eight L2s and every operand row crosses the fabric once
+  // per block that uses it (744 MB instead of 242 MB for the two-operand product: the kernel ran at the speed of those re-reads)
+  int bx = blockIdx.x, by = blockIdx.y, chunk = blockIdx.z, row_shift = 0;
+  if (chunk_rows < 0) {
+    chunk_rows = -chunk_rows;
+  } else {
+    const int lin = bx + (int)gridDim.x * (by + (int)gridDim.y * chunk);
+    const int v = xcd_remap(lin, (int)(gridDim.x * gridDim.y * gridDim.z));
+    bx = v % (int)gridDim.x;
+    by = (v / (int)gridDim.x) % (int)gridDim.y;
+    chunk = v / (int)(gridDim.x * gridDim.y);
+  }
   if (A2 != nullptr) {
     const int n1 = (Ka + AC - 1) / AC;
     if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
   }
-  const int n0 = blockIdx.x * BC, m0 = by * AC, chunk = blockIdx.z;
+  const int n0 = bx * BC, m0 = by * AC;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
   const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
 
@@ -773,7 +800,12 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) QAGNN_TNW_LOAD1(T, 1, R2)                        \
       }
 #define QAGNN_TNW_STORE(T, TP, R1, R2)                                                                     \
-      if constexpr (!(QAGNN_TNW_ABL & 1)) {                                                                \
+      if constexpr ((QAGNN_TNW_ABL & 16) != 0) { /* wait for the tile's loads, do nothing with them */     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(R1[i].x), "v"(R1[i].w));       \
+        if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) {                                                \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(R2[i].x), "v"(R2[i].w));     \
+        }                                                                                                  \
+      } else if constexpr (!(QAGNN_TNW_ABL & 1)) {                                                         \
         uint16_t* const img_ = reinterpret_cast<uint16_t*>(smem_tw) + ((TP)&1) * IMG_EL;                   \
         if (off[0] >= 0) store_task_lo<AFFINE>(img_, iel[0], off[0], R1, sc[0], sh[0], lo[0]);             \
         if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) {                                                \
@@ -942,7 +974,7 @@ static int launch_tn_ws_i(dim3 grid, hipStream_t stream, const float* A, int lda
     if (e != hipSuccess) { set_error("gemm_tn_ws: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, A2, lda2, Ka2);
+  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, A2, lda2, Ka2);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_ws");
   return QAGNN_OK;
 }
@@ -960,7 +992,8 @@ static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int 
     if (e != hipSuccess) { set_error("gemm_tn_split: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx, A2, lda2, Ka2);
+  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, ridx, A2,
+                                                                       lda2, Ka2);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_split");
   return QAGNN_OK;
 }
