@@ -74,8 +74,10 @@ typedef struct qagnn_graph {
   int32_t* n_chunks;           /* [1] device scalar */
   int32_t* chunkptr;           /* [n_groups*C+1] first chunk of pair g*C + c */
   int32_t max_chunks;          /* Ep / QAGNN_CLS_CHUNK + n_groups*C + 1 */
-  int32_t* err;                /* [4] device flags: [0] = 1: an index was out of range (it was clamped);
-                                  [1] = 1: some edge leaves its block of block_n consecutive node rows */
+  int32_t* err;                /* [16]; [0..3] device flags: [0] = 1: an index was out of range (it was clamped);
+                                  [1] = 1: some edge leaves its block of block_n consecutive node rows;
+                                  [4..12] the XCD partition of the node-side edge kernels: XCD k walks the 4-node blocks
+                                  [err[4 + k], err[5 + k]), an eighth of the batch's edge work each (csrc/graph_prep.hip) */
   int32_t block_n;             /* 0, or the node-block size the graph was checked against (subgraph = n consecutive rows) */
   int32_t n_groups;            /* position groups of the class order */
 } qagnn_graph;

@@ -58,6 +58,17 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return base + slot;
 }
 
+// The balanced form for the node-side edge kernels (graph_prep.hip: k_xcd_partition): XCD k walks the 4-node blocks
+// [base[k], base[k + 1]); the grid is 8 x edge_xcd_cap(N) blocks and a block past its XCD's run has nothing to do (-1).
+__host__ __device__ __forceinline__ int edge_xcd_cap(int N) {
+  const int per = (((N + 3) >> 2) + 7) >> 3;
+  return (per * 5 + 3) >> 2;  // 1.25 x an equal share
+}
+__device__ __forceinline__ int xcd_remap_balanced(int b, const int* __restrict__ base) {
+  const int xcd = b & 7, lb = base[xcd] + (b >> 3);
+  return lb < base[xcd + 1] ? lb : -1;
+}
+
 // Dropout seeds under hipGraph replay.  Every dropout launch takes its seed BY VALUE, which a captured graph would replay verbatim:
 // the same keep masks in every training step.  The kernels therefore mix one device-resident word -- the seed EPOCH, one per device,
 // 0 unless a caller advances it -- into the seed; a captured step ends with qagnn_seed_epoch_advance(), so each replay draws new

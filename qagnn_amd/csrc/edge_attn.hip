@@ -61,10 +61,11 @@ __device__ __forceinline__ Lane lane_info(int HP) {
   L.voff = L.act ? (uint32_t)L.off * 4u : OOB_OFF;
   return L;
 }
-// node handled by this wave: 4 waves per block, blocks remapped so an XCD owns a contiguous node range
-__device__ __forceinline__ int wave_node() {
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  return __builtin_amdgcn_readfirstlane(lb * 4 + (threadIdx.x >> 6));
+// node handled by this wave: 4 waves per block, blocks remapped so that an XCD owns a contiguous node range holding an eighth of the
+// batch's edges (xcd_base: qagnn_graph.err + 4, written by the graph preparation); INT_MAX = a block past its XCD's run
+__device__ __forceinline__ int wave_node(const int* __restrict__ xcd_base) {
+  const int lb = xcd_remap_balanced(blockIdx.x, xcd_base);
+  return __builtin_amdgcn_readfirstlane(lb < 0 ? 0x7FFFFFFF : lb * 4 + (threadIdx.x >> 6));
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
                                                      const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
                                                      const float* __restrict__ EkEm, int lde, int HP, float qscale,
                                                      float* __restrict__ score, float* __restrict__ a, float* __restrict__ alpha,
-                                                     int N, int C) {
+                                                     int N, int C, const int* __restrict__ xcd_base) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  const int s = wave_node();
+  const int s = wave_node(xcd_base);
   if (s >= N) return;
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
   const int cnt = end - beg;
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
                                                         const int* __restrict__ cls_t, const int* __restrict__ pos_t,
                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
                                                         int lde, int HP, const float* __restrict__ alpha,
-                                                        float* __restrict__ aggr, int lda, int N, int C) {
+                                                        float* __restrict__ aggr, int lda, int N, int C, const int* __restrict__ xcd_base) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  const int t = wave_node();
+  const int t = wave_node(xcd_base);
   if (t >= N) return;
   const Lane L = lane_info(HP);
   const int DP = 4 * HP;
@@ -278,9 +279,10 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
                                                        const float* __restrict__ EkEm, int lde, int HP,
                                                        const float* __restrict__ a, const float* __restrict__ alpha,
                                                        const float* __restrict__ G, int ldg, float* __restrict__ dKMQ,
-                                                       float* __restrict__ ga, float* __restrict__ rs, int N, int C) {
+                                                       float* __restrict__ ga, float* __restrict__ rs, int N, int C,
+                                                       const int* __restrict__ xcd_base) {
   __shared__ float4 slab[3][4][SLAB_ROWS];  // a | alpha | ga of the current chunk
-  const int s = wave_node();
+  const int s = wave_node(xcd_base);
   if (s >= N) return;
   const Lane L = lane_info(HP);
   const int DP = 4 * HP;
@@ -339,9 +341,10 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
                                                        const int* __restrict__ cls_s, const float* __restrict__ KMQ, int ldk,
                                                        const float* __restrict__ EkEm, int lde, int HP, float qscale,
                                                        const float* __restrict__ a, float* __restrict__ dKMQ,
-                                                       float* __restrict__ ga, const float* __restrict__ rs, int N, int C) {
+                                                       float* __restrict__ ga, const float* __restrict__ rs, int N, int C,
+                                                       const int* __restrict__ xcd_base) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  const int s = wave_node();
+  const int s = wave_node(xcd_base);
   if (s >= N) return;
   const Lane L = lane_info(HP);
   const int DP = 4 * HP;
@@ -385,9 +388,10 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
 
 __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
                                                       const int* __restrict__ pos_t, const float* __restrict__ KMQ, int ldk,
-                                                      int HP, const float* __restrict__ gsb, float* __restrict__ dKMQ, int N) {
+                                                      int HP, const float* __restrict__ gsb, float* __restrict__ dKMQ, int N,
+                                                      const int* __restrict__ xcd_base) {
   __shared__ float4 slab[4][SLAB_ROWS];
-  const int t = wave_node();
+  const int t = wave_node(xcd_base);
   if (t >= N) return;
   const Lane L = lane_info(HP);
   const int DP = 4 * HP;
@@ -542,10 +546,10 @@ static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
                 "edge_attn_fwd: bad output arguments");
-  const int nb = cdiv(g->N, 4);
-  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C);
+  const int nb = 8 * edge_xcd_cap(g->N);  // (8 runs of at most edge_xcd_cap blocks: see k_xcd_partition)
+  k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
-  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C);
+  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_aggregate");
   return QAGNN_OK;
 }
@@ -568,12 +572,12 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
   QAGNN_REQUIRE((int64_t)g->N * ldg * 4 < (int64_t)OOB_OFF, QAGNN_EUNSUPPORTED, "edge_attn_bwd: G exceeds 2 GiB");
   const int DP2 = 8 * HP;
   QAGNN_REQUIRE(DP2 / 4 <= 1024, QAGNN_EUNSUPPORTED, "edge_attn_bwd: HP too large");
-  const int nb = cdiv(g->N, 4);
-  k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N, g->C);
+  const int nb = 8 * edge_xcd_cap(g->N);  // (8 runs of at most edge_xcd_cap blocks: see k_xcd_partition)
+  k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N, g->C, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_src1");
-  k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N, g->C);
+  k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N, g->C, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_src2");
-  k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N);
+  k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_tgt");
   k_edge_bwd_cls<<<cdiv(g->max_chunks, 4), 256, 0, stream>>>(g->n_chunks, g->chunk_beg, g->chunk_len, g->src_c, g->tgt_c, g->pos_c,
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part, g->N);

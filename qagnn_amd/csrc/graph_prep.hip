@@ -9,6 +9,8 @@
 // self loops) and :476-479 (out-degree); PyG's implicit grouping in softmax()/scatter().
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace qagnn {
@@ -382,9 +384,59 @@ static inline void cls_groups(int Ep, int* nblk, int* gb, int* NG) {
 
 static inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
+// The node-side edge kernels walk 4 nodes per block with block b on XCD b % 8 (common.h: xcd_remap gives every XCD one contiguous
+// run of blocks, so that a subgraph's rows stay in one L2).  Equal RUNS are not equal WORK: with 400..2000 edges per subgraph the eight
+// runs of a 320-subgraph batch differ by +-9 % in edges and every edge kernel lasts as long as its heaviest XCD (measured by re-ordering
+// the questions of the bench batch into equal-edge eighths: forward edge stage -5.6 %, backward -3.7 %).  base[0..8]: run k =
+// blocks [base[k], base[k + 1]) holds 1/8 of the work, no run longer than `cap` blocks (the grids are 8 x cap).  Work of a node = its
+// out-edges + 1/4 for the node itself (a row whose only edge is its self loop takes the degree-1 fast paths): in units of 1/4,
+// 4 rowptr_s[i] - 3 i up to node i -- the prefix sum is there already, one binary search per boundary.  On the bench batch the
+// heaviest run carries 1.078 x the mean with equal runs and 1.002 x with these.  balance = 0: equal runs.
+__global__ void k_xcd_partition(const int* __restrict__ rowptr_s, int N, int cap, int balance, int* __restrict__ base) {
+  const int nbk = (N + 3) >> 2, lane = threadIdx.x;
+  int cand = 0;
+  if (lane >= 1 && lane <= 7) {
+    if (balance) {
+      const long long W = 4ll * rowptr_s[N] - 3ll * N, target = (W * lane + 7) / 8;
+      int lo = 0, hi = nbk;  // smallest lb with work(lb) >= target
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1, nd = min(4 * mid, N);
+        if (4ll * rowptr_s[nd] - 3ll * nd >= target) hi = mid; else lo = mid + 1;
+      }
+      cand = lo;
+    } else {
+      const int q = nbk >> 3, r = nbk & 7;
+      cand = lane < r ? lane * (q + 1) : r * (q + 1) + (lane - r) * q;
+    }
+  }
+  __shared__ int c[8];
+  if (lane < 8) c[lane] = cand;
+  __syncthreads();
+  if (lane == 0) {
+    int prev = 0;
+    base[0] = 0;
+    for (int k = 1; k < 8; ++k) {
+      int b = c[k];
+      b = min(b, prev + cap);            // no run longer than the grid provides for
+      b = max(b, nbk - (8 - k) * cap);   // ... and the runs behind this boundary can still cover the rest
+      b = max(b, prev);
+      base[k] = b;
+      prev = b;
+    }
+    base[8] = nbk;
+  }
+}
+
 }  // namespace qagnn
 
 using namespace qagnn;
+
+static int xcd_partition(qagnn_graph* g, hipStream_t stream) {
+  static const int balance = getenv("QAGNN_EDGE_XCD_BALANCE") ? atoi(getenv("QAGNN_EDGE_XCD_BALANCE")) : 1;
+  k_xcd_partition<<<1, 64, 0, stream>>>(g->rowptr_s, g->N, edge_xcd_cap(g->N), balance, g->err + 4);
+  QAGNN_LAUNCH_CHECK("k_xcd_partition");
+  return QAGNN_OK;
+}
 
 // carve `storage` into the arrays of *g plus scratch (layout shared by qagnn_graph_prep_blocked and qagnn_graph_from_blobs)
 struct carved {
@@ -411,7 +463,7 @@ static carved carve(qagnn_graph* g, int32_t* storage, int N, int E, int R, int T
   cv.nch = take(cv.pairs + 1);
   g->cls_count = take(C);
   g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
-  g->n_chunks = take(4); g->err = take(4);
+  g->n_chunks = take(4); g->err = take(16);  // err[4 .. 12]: the XCD partition of the node blocks (k_xcd_partition)
   // ---- scratch; the zero-initialised region comes first (cls_count, which sits just before it, must be zero too) ----
   cv.cnt_s = take(N); cv.cnt_t = take(N);
   cv.es = take(Ep); cv.et = take(Ep); cv.ec = take(Ep);
@@ -457,7 +509,7 @@ extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, in
   tot += 4 * up4(pairs + 1);  // gc_cnt, gcptr, chunkptr, nch scratch
   tot += up4(C);              // cls_count
   tot += 3 * up4(maxch);      // chunk tables
-  tot += 2 * up4(4);          // n_chunks, err
+  tot += up4(4) + up4(16);    // n_chunks, err (+ the XCD partition)
   tot += 2 * up4(N);          // cnt_s, cnt_t
   tot += 6 * up4(Ep);         // es et ec tmp_s tmp_t srcpos
   tot += up4(nblk * C);       // per-block class histograms
@@ -502,6 +554,8 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   k_payload<<<cdiv(Ep, TB), TB, 0, stream>>>(es, et, ec, g->eid_s, eid_t, srcpos, g->tgt_s, g->src_s, g->cls_s, g->src_t,
                                               g->tgt_t, g->cls_t, g->pos_t, Ep);
   QAGNN_LAUNCH_CHECK("k_payload");
+  int rc = xcd_partition(g, stream);
+  if (rc != QAGNN_OK) return rc;
   return class_pass(g, hist, gc_cnt, gcptr, nch, nblk, gb, NG, pairs, stream);
 }
 
@@ -524,5 +578,7 @@ extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const in
                                                                            g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t, g->tgt_t,
                                                                            g->cls_t, g->pos_t, g->err);
   QAGNN_LAUNCH_CHECK("k_blob_assemble");
+  int rc = xcd_partition(g, stream);
+  if (rc != QAGNN_OK) return rc;
   return class_pass(g, cv.hist, cv.gc_cnt, cv.gcptr, cv.nch, cv.nblk, cv.gb, cv.NG, cv.pairs, stream);
 }

@@ -102,6 +102,39 @@ def test_graph_prep_bit_exact(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,skew', [(64000, 'subgraphs'), (2000, 'subgraphs'), (777, 'front'), (16, 'none'), (5, 'none')])
+def test_graph_prep_xcd_partition(N, skew):
+    """qagnn_graph.err[4 .. 12]: eight contiguous runs of 4-node blocks that cover every node once, none longer than the grids of the
+    node-side edge kernels provide for (8 x 1.25 equal shares), each holding an eighth of the work 4 (out-edges) + 1 per node -- within
+    10 % where the cap and the block granularity allow it.  (That the kernels then visit every node is what every edge-kernel test checks.)"""
+    g_ = torch.Generator().manual_seed(N)
+    if skew == 'subgraphs':   # subgraphs of 200 node slots with 400 .. 2000 edges each, like the bench batch
+        n, nsub = 200, N // 200
+        e_per = torch.randint(400, 2001, (nsub,), generator=g_)
+        src = torch.cat([torch.randint(0, n, (int(e),), generator=g_) + i * n for i, e in enumerate(e_per)])
+        tgt = (src // n) * n + torch.randint(0, n, (src.numel(),), generator=g_)
+    elif skew == 'front':     # every edge in the first tenth of the nodes
+        src = torch.randint(0, max(N // 10, 1), (8 * N,), generator=g_)
+        tgt = torch.randint(0, N, (8 * N,), generator=g_)
+    else:
+        src = torch.randint(0, N, (3 * N,), generator=g_)
+        tgt = torch.randint(0, N, (3 * N,), generator=g_)
+    ei, et, nt = torch.stack([src, tgt]), torch.randint(0, 3, (src.numel(),), generator=g_), torch.randint(0, 2, (N,), generator=g_)
+    g = hip().graph_prep(ei.cuda(), et.cuda(), nt.cuda(), 3, 2)
+    base = g.array('err', 16)[4:13].cpu().tolist()
+    nbk, per = (N + 3) // 4, ((N + 3) // 4 + 7) // 8
+    cap = (per * 5 + 3) // 4
+    assert base[0] == 0 and base[8] == nbk and all(0 <= base[k + 1] - base[k] <= cap for k in range(8)), base
+    rowptr = g.array('rowptr_s', N + 1).cpu().long()
+    work = [4 * int(rowptr[min(4 * b, N)]) - 3 * min(4 * b, N) for b in base]
+    loads = [work[k + 1] - work[k] for k in range(8)]
+    if skew == 'subgraphs' and N >= 64000:  # (ten subgraphs over eight runs: the cap binds there too)
+        assert max(loads) <= 1.10 * sum(loads) / 8, loads
+    if skew == 'front':       # the cap binds: the first runs are as long as allowed, the rest still cover every block
+        assert base[1] - base[0] <= cap and sum(loads) == work[8]
+
+
+@pytest.mark.gpu
 def test_graph_prep_flags_out_of_range_indices():
     ei, et, nt, R, T = rand_graph(7, 30, 100)
     ei[0, 5] = 1000
