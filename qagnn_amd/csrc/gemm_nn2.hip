@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // That leaves LDS free at the end of a tile: the first loads of the NEXT tile are issued in front of the stores, and the stores
   // (address-predicated buffer stores, a fixed 2 NT per wave, so that s_waitcnt vmcnt(2 NT) means "everything older has landed") drain
   // under the next tile's k-loop.  With one block per CU nothing else would run under either.
-  constexpr bool DIRECT = STAG && !STATS;
+  constexpr bool DIRECT = PACKED && !STATS;  // (the 4-wave packed blocks store the same way, without the early loads)
   constexpr int THR = WV * 64, BM = WV * 32;
   constexpr int BN = NT * 16;
   constexpr int IMG = NT * 3 * 1024;   // bytes of one B image set: [column tile][piece][64 slots x 16 B]
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if constexpr (!(QAGNN_NN2_ABL & 32)) {                                                                           \
           _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             f32x4s c = acc[i][j];                                                                                        \
-            QAGNN_NN2_SIX(c, af[i], bf)                                                                                  \
+            if constexpr (DIRECT) { QAGNN_NN2_SIX_T(c, af[i], bf) } else { QAGNN_NN2_SIX(c, af[i], bf) }                  \
             acc[i][j] = c;                                                                                               \
           }                                                                                                              \
         } else {                                                                                                         \
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }                                                                                                                  \
     }
 
-    if constexpr (!DIRECT) __syncthreads();  // the previous output tile's slab reads (and the scale / shift fill) are done
+    if constexpr (!(DIRECT && STAG)) __syncthreads();  // the previous output tile's slab / last-image reads (and the scale / shift fill) are done
     // ---- prologue: tile 0 into image 0 / the fragment registers, tile 1 in flight
     if (!loaded) QAGNN_NN2_FIRST_LOADS
     if constexpr (STAG) {
@@ -469,63 +469,6 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         QAGNN_NN2_BAR_VM  // this wave's loads of the N phase have landed; the other group moves on to its M
       }
       if (g == 0) QAGNN_NN2_BAR
-      if constexpr (DIRECT) {
-        // ---- the next tile's first loads (every wave is past its last fragment read: the ring is free), then this tile's stores
-        const int em0 = m0, en0 = n0;
-        loaded = vb + (int)gridDim.x < ntiles;
-        if (loaded) {
-          QAGNN_NN2_SET_TILE(vb + (int)gridDim.x)
-          QAGNN_NN2_FIRST_LOADS
-        }
-        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, M * a.ldc * 4, 0x00020000);
-        const int c4 = 4 * (lane >> 4);
-        // product + bias + table row + old value, in the slab epilogue's order; every kind of addend is fetched for all column tiles
-        // at once (a column past No reads the last four columns instead and is not stored: No % 4 == 0), and ALL addends are in
-        // before the first store is issued -- waiting for a load behind a store would wait for the store's acknowledgement too
-        uint32_t crow[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = em0 + w * 32 + i * 16 + (lane & 15);
-          const bool rok = row < M;
-          crow[i] = rok ? (uint32_t)row * (uint32_t)a.ldc * 4u : OOB;
-          f32x4s t[NT];
-          if (a.bias) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(a.bias + min(en0 + j * 16 + c4, No - 4)));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
-          }
-          if (a.rowtab) {
-            const float* const trow = a.rowtab + (int64_t)a.rowidx[rok ? row : 0] * a.ldt;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(trow + min(en0 + j * 16 + c4, No - 4)));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
-          }
-          if (a.accumulate) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const int col = en0 + j * 16 + c4;
-              t[j] = __builtin_bit_cast(f32x4s, bload(rC, rok && col < No ? crow[i] + (uint32_t)col * 4u : OOB, 0u));
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int col = en0 + j * 16 + c4;
-            const uint32_t off = crow[i] != OOB && col < No ? crow[i] + (uint32_t)col * 4u : OOB;
-            if constexpr (QAGNN_NN2_ABL & 64) {
-              if (acc[i][j][0] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
-            }
-          }
-        continue;
-      }
     } else {
     if constexpr (PACKED) {
       QAGNN_NN2_GLDS(0, smem)
@@ -551,6 +494,65 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       unsigned char* const cur = smem + ((nkt - 1) & 1) * IMG;
       QAGNN_NN2_MFMA_TILE(cur, cur, false)
     }
+    }
+    if constexpr (DIRECT) {
+      // ---- STAG: the next tile's first loads (every wave is past its last fragment read: the ring is free); then this tile's stores
+      const int em0 = m0, en0 = n0;
+      if constexpr (STAG) {
+        loaded = vb + (int)gridDim.x < ntiles;
+        if (loaded) {
+          QAGNN_NN2_SET_TILE(vb + (int)gridDim.x)
+          QAGNN_NN2_FIRST_LOADS
+        }
+      }
+      const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, M * a.ldc * 4, 0x00020000);
+      const int c4 = 4 * (lane >> 4);
+      // product + bias + table row + old value, in the slab epilogue's order; every kind of addend is fetched for all column tiles
+      // at once (a column past No reads the last four columns instead and is not stored: No % 4 == 0), and ALL addends are in
+      // before the first store is issued -- waiting for a load behind a store would wait for the store's acknowledgement too
+      uint32_t crow[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = em0 + w * 32 + i * 16 + (lane & 15);
+        const bool rok = row < M;
+        crow[i] = rok ? (uint32_t)row * (uint32_t)a.ldc * 4u : OOB;
+        f32x4s t[NT];
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(a.bias + min(en0 + j * 16 + c4, No - 4)));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+        }
+        if (a.rowtab) {
+          const float* const trow = a.rowtab + (int64_t)a.rowidx[rok ? row : 0] * a.ldt;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) t[j] = __builtin_bit_cast(f32x4s, ld4(trow + min(en0 + j * 16 + c4, No - 4)));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+        }
+        if (a.accumulate) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int col = en0 + j * 16 + c4;
+            t[j] = __builtin_bit_cast(f32x4s, bload(rC, rok && col < No ? crow[i] + (uint32_t)col * 4u : OOB, 0u));
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] += t[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = en0 + j * 16 + c4;
+          const uint32_t off = crow[i] != OOB && col < No ? crow[i] + (uint32_t)col * 4u : OOB;
+          if constexpr (QAGNN_NN2_ABL & 64) {
+            if (acc[i][j][0] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[i][j]), rC, (int)off, 0, 0);
+          }
+        }
+      continue;
     }
 #undef QAGNN_NN2_FRAG
 #undef QAGNN_NN2_FRAG_WAIT
