@@ -244,6 +244,29 @@ int qagnn_pool_attn_fwd_f32(const float* u, const float* cvec, const float* K, i
 int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t ldk, int32_t B, int32_t n, int32_t NH, int32_t Cc, float inv_temp,
                             float p, uint64_t seed, const float* attn, const float* attn_d, const float* dz, const float* dattn_d,
                             float* dK, int32_t lddk, float* du, float* dc, qagnn_stream_t stream);
+/* The rest of the head behind the pooling, one workgroup per subgraph (reference utils/layers.py:366-371: the value projection of the
+ * pooled rows + `self.dropout`; modeling_qagnn.py:178-182 with fc_layer_num = 0: `concat = dropout_fc(cat(graph_vecs, sent_vecs, Z_vecs))`,
+ * `logits = fc(concat)`):
+ *   out[b]    = Wv_h z[b,h] + bv_h sum_l attn[b,h,l]                 z, attn: outputs of qagnn_pool_attn_fwd_f32 (attn = its attn_d)
+ *   logits[b] = < drop_fc([ drop_pool(out[b]) | sent[b] | Z[b] ]), w_fc > + b_fc
+ * BDv [NH*DP][NH*dv]: blockdiag(Wv_h^T) at the head-padded positions of the node features; H + b*ldh = row 0 of subgraph b in the
+ * head-padded GNN output (4 GAT heads of d/4 features in DP/4 slots each), Z[b] its d dense features; w_fc [NH*dv + Ds + d].
+ * Saved for the backward: out [B][NH*dv] (before dropout), asum [B][NH].  Masks are counter-based (seed_pool / seed_fc + the seed epoch).
+ * Backward: dz [B][NH][DP], dattn [B][NH][n] (the gradient through sum_l attn), dout [B][NH*dv] (dBDv = z^T dout), dsent [B][Ds] or
+ * NULL, dZ [B][DP] (padded, to be added to row 0 of the pooling's dK: qagnn_add_row0_f32), and part [B][ldp >= L + NH*dv + 1], L = NH*dv + Ds + d:
+ * per subgraph the addends of d w_fc | d bv | d b_fc, whose column sums are those gradients.
+ * QAGNN_EUNSUPPORTED outside NH <= 4, NH*dv <= 256, DP <= 256. */
+int qagnn_head_post_fwd_f32(const float* z, const float* attn, const float* BDv, const float* bv, const float* sent, const float* H, int64_t ldh,
+                            const float* w_fc, const float* b_fc, int32_t B, int32_t NH, int32_t DP, int32_t dv, int32_t n, int32_t Ds, int32_t d,
+                            float p_pool, float p_fc, uint64_t seed_pool, uint64_t seed_fc, float* out, float* asum, float* logits,
+                            qagnn_stream_t stream);
+int qagnn_head_post_bwd_f32(const float* dlogits, const float* out, const float* asum, const float* BDv, const float* bv, const float* sent,
+                            const float* H, int64_t ldh, const float* w_fc, int32_t B, int32_t NH, int32_t DP, int32_t dv, int32_t n, int32_t Ds,
+                            int32_t d, float p_pool, float p_fc, uint64_t seed_pool, uint64_t seed_fc, float* dz, float* dattn, float* dout,
+                            float* dsent, float* dZ, float* part, int32_t ldp /* row pitch of part, >= L + NH*dv + 1; extra columns are zeroed */,
+                            qagnn_stream_t stream);
+/* dK[b*ld_sub + j] += dZ[b*Cc + j]: the gradient of each subgraph's row 0 that the head reads directly, into the pooling's dK */
+int qagnn_add_row0_f32(float* dK, int64_t ld_sub, const float* dZ, int32_t B, int32_t Cc, qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 /* qagnn_bn_relu_bwd_f32 with the column sums of its OUTPUT as a by-product (the bias gradient of the Linear in front of the

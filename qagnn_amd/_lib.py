@@ -19,13 +19,13 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
-           'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32',
+           'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 14  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear})
+ABI_VERSION = 15  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -107,6 +107,11 @@ def load_library(path=LIB_PATH):
     lib.qagnn_bn_relu_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_bwd_f32.argtypes = [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
+    lib.qagnn_head_post_fwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64,
+                                            _vp, _vp, _vp, _vp]
+    lib.qagnn_head_post_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64,
+                                            _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
+    lib.qagnn_add_row0_f32.argtypes = [_vp, _i64, _vp, _i32, _i32, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
@@ -625,6 +630,51 @@ class HipKernels(metaclass=_GuardedMeta):
                                               dc.data_ptr(), self._stream())
         self._check(rc, 'qagnn_pool_attn_bwd_f32')
         return dK, du, dc
+
+    HEAD_LIMITS = (4, 256, 256)  # heads, NH * dv, DP of qagnn_head_post_{fwd,bwd}_f32
+
+    def head_post_fwd(self, z, attn, BDv, bv, sent, K3, d, w_fc, b_fc, p_pool, p_fc, seed_pool, seed_fc):
+        """z [B, NH, DP], attn [B, NH, n] (after dropout), BDv [NH*DP, NH*dv], bv [NH*dv], sent [B, Ds], K3 [B, n, DP] (row 0 of every
+        subgraph is read), w_fc [NH*dv + Ds + d], b_fc [1] -> logits [B], out [B, NH*dv] (before dropout), asum [B, NH]."""
+        B, NH, DP = z.shape
+        n, NO, Ds = attn.size(2), BDv.size(1), sent.size(1)
+        for t in (z, attn, BDv, bv, sent, K3, w_fc, b_fc):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert K3.shape == (B, n, DP) and BDv.size(0) == NH * DP and NO % NH == 0 and w_fc.numel() == NO + Ds + d and sent.size(0) == B
+        out = torch.empty((B, NO), dtype=torch.float32, device=z.device)
+        asum = torch.empty((B, NH), dtype=torch.float32, device=z.device)
+        logits = torch.empty((B,), dtype=torch.float32, device=z.device)
+        rc = self.lib.qagnn_head_post_fwd_f32(z.data_ptr(), attn.data_ptr(), BDv.data_ptr(), bv.data_ptr(), sent.data_ptr(), K3.data_ptr(), n * DP,
+                                              w_fc.data_ptr(), b_fc.data_ptr(), B, NH, DP, NO // NH, n, Ds, d, float(p_pool), float(p_fc),
+                                              int(seed_pool), int(seed_fc), out.data_ptr(), asum.data_ptr(), logits.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_head_post_fwd_f32')
+        return logits, out, asum
+
+    def head_post_bwd(self, dlogits, out, asum, BDv, bv, sent, K3, d, w_fc, p_pool, p_fc, seed_pool, seed_fc, n, need_dsent):
+        """-> dz [B, NH, DP], dattn [B, NH, n], dout [B, NH*dv], dsent [B, Ds] or None, dZ [B, DP], part [B, L + NH*dv + 1]"""
+        B, NO = out.shape
+        NH, DP, Ds = asum.size(1), K3.size(2), sent.size(1)
+        assert dlogits.is_contiguous() and dlogits.numel() == B
+        dev = out.device
+        dz = torch.empty((B, NH, DP), dtype=torch.float32, device=dev)
+        dattn = torch.empty((B, NH, n), dtype=torch.float32, device=dev)
+        dout = torch.empty((B, NO), dtype=torch.float32, device=dev)
+        dsent = torch.empty((B, Ds), dtype=torch.float32, device=dev) if need_dsent else None
+        dZ = torch.empty((B, DP), dtype=torch.float32, device=dev)
+        part = torch.empty((B, (NO + Ds + d + NO + 1 + 3) // 4 * 4), dtype=torch.float32, device=dev)  # (pitch: a multiple of 4 for the column sums)
+        rc = self.lib.qagnn_head_post_bwd_f32(dlogits.data_ptr(), out.data_ptr(), asum.data_ptr(), BDv.data_ptr(), bv.data_ptr(), sent.data_ptr(),
+                                              K3.data_ptr(), n * DP, w_fc.data_ptr(), B, NH, DP, NO // NH, n, Ds, d, float(p_pool), float(p_fc),
+                                              int(seed_pool), int(seed_fc), dz.data_ptr(), dattn.data_ptr(), dout.data_ptr(), _ptr(dsent),
+                                              dZ.data_ptr(), part.data_ptr(), part.size(1), self._stream())
+        self._check(rc, 'qagnn_head_post_bwd_f32')
+        return dz, dattn, dout, dsent, dZ, part
+
+    def add_row0(self, dK, dZ):
+        """dK [B, n, Cc] (contiguous): dK[:, 0, :] += dZ [B, Cc], in place."""
+        B, n, Cc = dK.shape
+        assert dK.is_contiguous() and dZ.is_contiguous() and dZ.shape == (B, Cc)
+        self._check(self.lib.qagnn_add_row0_f32(dK.data_ptr(), n * Cc, dZ.data_ptr(), B, Cc, self._stream()), 'qagnn_add_row0_f32')
+        return dK
 
     def gelu_dropout_fwd(self, X, p, seed):
         assert X.is_contiguous() and X.dtype == torch.float32

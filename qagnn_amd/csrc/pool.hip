@@ -207,6 +207,134 @@ __global__ __launch_bounds__(64 * POOL_W) void k_pool_bwd(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The rest of the head behind the pooling (reference utils/layers.py:366-371 + modeling_qagnn.py:178-182 with fc_layer_num = 0):
+//     out[b]    = dropout_p1( Wv_h z[b,h] + bv_h sum_l attn[b,h,l] )                     (the value projection of the pooled rows)
+//     logits[b] = < dropout_p2( [ out[b] | sent_vecs[b] | Z[b] ] ), w_fc > + b_fc        (Z = row 0 of the subgraph, dense part)
+// One workgroup of 256 threads per subgraph each way instead of ~10 + ~20 stock elementwise / reduction / cat kernels: at the
+// reference's mini-batch of 10 subgraphs a training step IS its ~300 kernel launches.  BDv is the block-diagonal value projection
+// in the padded node layout ([NH * DP][NO], NO = NH * dv <= 256; qagnn_amd/layers.py), read column-wise by consecutive threads.
+// The dropout masks are counter-based (uniform01) like every other mask of this library: backward regenerates them from the seeds.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int HEAD_T = 256;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
+  v = wave_sum(v);
+  __syncthreads();  // (red may still be read from the previous reduction)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dense feature k of a GNN row -> its position in the head-padded row (4 GAT heads of dh features, HP slots each)
+__device__ __forceinline__ int padded_pos(int k, int dh, int HP) { return (k / dh) * HP + (k % dh); }
+
+__global__ __launch_bounds__(HEAD_T) void k_head_post_fwd(const float* __restrict__ z, const float* __restrict__ attn, const float* __restrict__ BDv,
+                                                         const float* __restrict__ bv, const float* __restrict__ sent, const float* __restrict__ H,
+                                                         int64_t ldh, const float* __restrict__ w, const float* __restrict__ bfc, int NH, int DP, int dv,
+                                                         int n, int Ds, int d, int dh, int HP, float p1, float p2, uint64_t seed1, uint64_t seed2,
+                                                         const unsigned long long* __restrict__ epoch, float* __restrict__ out,
+                                                         float* __restrict__ asum, float* __restrict__ logits) {
+  __shared__ float zs[POOL_MAXH * 256], outd[HEAD_T], as[POOL_MAXH], red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, NO = NH * dv, L = NO + Ds + d;
+  if (p1 > 0.f) seed1 = epoch_seed(seed1, epoch);
+  if (p2 > 0.f) seed2 = epoch_seed(seed2, epoch);
+  for (int i = tid; i < NH * DP; i += HEAD_T) zs[i] = z[(int64_t)b * NH * DP + i];
+  for (int h = 0; h < NH; ++h) {
+    float s_ = 0.f;
+    for (int l = tid; l < n; l += HEAD_T) s_ += attn[((int64_t)b * NH + h) * n + l];
+    s_ = block_sum_256(s_, red);
+    if (tid == 0) { as[h] = s_; asum[b * NH + h] = s_; }
+  }
+  __syncthreads();
+  if (tid < NO) {
+    const int h = tid / dv;
+    const float* col = BDv + (int64_t)h * DP * NO + tid;
+    float acc = 0.f;
+    for (int j = 0; j < DP; ++j) acc = fmaf(zs[h * DP + j], col[(int64_t)j * NO], acc);
+    acc = fmaf(bv[tid], as[h], acc);
+    out[(int64_t)b * NO + tid] = acc;
+    const float keep = (p1 > 0.f && uniform01(seed1, (uint64_t)b * NO + tid) < p1) ? 0.f : 1.f / (1.f - p1);
+    outd[tid] = p1 > 0.f ? acc * keep : acc;
+  }
+  __syncthreads();
+  const float inv2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f;
+  const float* Hb = H + (int64_t)b * ldh;
+  float part = 0.f;
+  for (int k = tid; k < L; k += HEAD_T) {
+    const float v = k < NO ? outd[k] : k < NO + Ds ? sent[(int64_t)b * Ds + (k - NO)] : Hb[padded_pos(k - NO - Ds, dh, HP)];
+    const float keep = (p2 > 0.f && uniform01(seed2, (uint64_t)b * L + k) < p2) ? 0.f : inv2;
+    part = fmaf(v * keep, w[k], part);
+  }
+  part = block_sum_256(part, red);
+  if (tid == 0) logits[b] = part + bfc[0];
+}
+
+// part [B][PW >= L + NO + 1]: per subgraph the addends of d w_fc (L), d bv (NO) and d b_fc (1); their column sums are the gradients
+__global__ __launch_bounds__(HEAD_T) void k_head_post_bwd(const float* __restrict__ dlogits, const float* __restrict__ out, const float* __restrict__ asum,
+                                                         const float* __restrict__ BDv, const float* __restrict__ bv, const float* __restrict__ sent,
+                                                         const float* __restrict__ H, int64_t ldh, const float* __restrict__ w, int NH, int DP, int dv,
+                                                         int n, int Ds, int d, int dh, int HP, float p1, float p2, uint64_t seed1, uint64_t seed2,
+                                                         const unsigned long long* __restrict__ epoch, float* __restrict__ dz,
+                                                         float* __restrict__ dattn, float* __restrict__ dout, float* __restrict__ dsent,
+                                                         float* __restrict__ dZ, float* __restrict__ part, int PW) {
+  __shared__ float douts[HEAD_T], red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, NO = NH * dv, L = NO + Ds + d;
+  if (p1 > 0.f) seed1 = epoch_seed(seed1, epoch);
+  if (p2 > 0.f) seed2 = epoch_seed(seed2, epoch);
+  const float dl = dlogits[b];
+  const float inv1 = p1 > 0.f ? 1.f / (1.f - p1) : 1.f, inv2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f;
+  const float* Hb = H + (int64_t)b * ldh;
+  float* pb = part + (int64_t)b * PW;
+  for (int j = tid; j < 4 * HP; j += HEAD_T) dZ[(int64_t)b * 4 * HP + j] = 0.f;  // (the pads of the row stay zero)
+  __syncthreads();
+  for (int k = tid; k < L; k += HEAD_T) {
+    const float keep2 = (p2 > 0.f && uniform01(seed2, (uint64_t)b * L + k) < p2) ? 0.f : inv2;
+    const float dc = dl * w[k] * keep2;
+    float v;
+    if (k < NO) {
+      const float keep1 = (p1 > 0.f && uniform01(seed1, (uint64_t)b * NO + k) < p1) ? 0.f : inv1;
+      v = out[(int64_t)b * NO + k] * keep1;
+      const float g = dc * keep1;
+      douts[k] = g;
+      dout[(int64_t)b * NO + k] = g;
+      pb[L + k] = g * asum[b * NH + k / dv];
+    } else if (k < NO + Ds) {
+      v = sent[(int64_t)b * Ds + (k - NO)];
+      if (dsent) dsent[(int64_t)b * Ds + (k - NO)] = dc;
+    } else {
+      const int pos = padded_pos(k - NO - Ds, dh, HP);
+      v = Hb[pos];
+      dZ[(int64_t)b * 4 * HP + pos] = dc;
+    }
+    pb[k] = dl * v * keep2;
+  }
+  if (tid == 0) pb[L + NO] = dl;
+  if (tid >= 1 && L + NO + tid < PW) pb[L + NO + tid] = 0.f;  // (the pitch's padding columns)
+  __syncthreads();
+  for (int q = tid; q < NH * DP; q += HEAD_T) {
+    const int h = q / DP;
+    const float* row = BDv + (int64_t)q * NO + h * dv;
+    float acc = 0.f;
+    for (int i = 0; i < dv; ++i) acc = fmaf(row[i], douts[h * dv + i], acc);
+    dz[(int64_t)b * NH * DP + q] = acc;
+  }
+  for (int h = 0; h < NH; ++h) {
+    float s_ = 0.f;
+    for (int i = tid; i < dv; i += HEAD_T) s_ = fmaf(douts[h * dv + i], bv[h * dv + i], s_);
+    s_ = block_sum_256(s_, red);
+    for (int l = tid; l < n; l += HEAD_T) dattn[((int64_t)b * NH + h) * n + l] = s_;
+  }
+}
+
+// dK[b][0][:] += dZ[b][:] (the gradient of the subgraph's context row that the head reads directly)
+__global__ void k_add_row0(float* __restrict__ dK, int64_t ldk_sub, const float* __restrict__ dZ, int Cc, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Cc) return;
+  const int b = i / Cc, j = i - b * Cc;
+  dK[(int64_t)b * ldk_sub + j] += dZ[i];
+}
+
 }  // namespace qagnn
 
 using namespace qagnn;
@@ -242,5 +370,48 @@ extern "C" int qagnn_pool_attn_bwd_f32(const float* u, const float* K, int32_t l
   if (int rc = pool_check("pool_attn_bwd", B, n, NH, Cc, ldk, p)) return rc;
   k_pool_bwd<<<B, 64 * POOL_W, 0, stream>>>(u, K, ldk, n, NH, Cc, inv_temp, p, seed, seed_epoch_ptr(), attn, attn_d, dz, dattn_d, dK, lddk, du, dc);
   QAGNN_LAUNCH_CHECK("k_pool_bwd");
+  return QAGNN_OK;
+}
+
+static int head_check(const char* who, int B, int NH, int DP, int dv, int n, int Ds, int d) {
+  QAGNN_REQUIRE(B > 0 && NH >= 1 && NH <= POOL_MAXH && dv > 0 && NH * dv <= HEAD_T && DP > 0 && DP <= 256 && DP % 4 == 0 && n > 0 && Ds >= 0 && d > 0 &&
+                    d % 4 == 0 && DP >= d && (DP / 4) >= (d / 4),
+                QAGNN_EUNSUPPORTED, "%s: sizes outside what the head kernels take (B=%d NH=%d DP=%d dv=%d n=%d Ds=%d d=%d)", who, B, NH, DP, dv, n, Ds, d);
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_head_post_fwd_f32(const float* z, const float* attn, const float* BDv, const float* bv, const float* sent, const float* H,
+                                       int64_t ldh, const float* w_fc, const float* b_fc, int32_t B, int32_t NH, int32_t DP, int32_t dv, int32_t n,
+                                       int32_t Ds, int32_t d, float p_pool, float p_fc, uint64_t seed_pool, uint64_t seed_fc, float* out, float* asum,
+                                       float* logits, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(z && attn && BDv && bv && (sent || Ds == 0) && H && w_fc && b_fc && out && asum && logits, QAGNN_EINVAL, "head_post_fwd: null pointer");
+  QAGNN_REQUIRE(p_pool >= 0.f && p_pool < 1.f && p_fc >= 0.f && p_fc < 1.f, QAGNN_EINVAL, "head_post_fwd: dropout probabilities");
+  int rc = head_check("head_post_fwd", B, NH, DP, dv, n, Ds, d);
+  if (rc != QAGNN_OK) return rc;
+  k_head_post_fwd<<<B, HEAD_T, 0, (hipStream_t)stream_>>>(z, attn, BDv, bv, sent, H, ldh, w_fc, b_fc, NH, DP, dv, n, Ds, d, d / 4, DP / 4, p_pool, p_fc,
+                                                         seed_pool, seed_fc, seed_epoch_ptr(), out, asum, logits);
+  QAGNN_LAUNCH_CHECK("k_head_post_fwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_head_post_bwd_f32(const float* dlogits, const float* out, const float* asum, const float* BDv, const float* bv, const float* sent,
+                                       const float* H, int64_t ldh, const float* w_fc, int32_t B, int32_t NH, int32_t DP, int32_t dv, int32_t n,
+                                       int32_t Ds, int32_t d, float p_pool, float p_fc, uint64_t seed_pool, uint64_t seed_fc, float* dz, float* dattn,
+                                       float* dout, float* dsent, float* dZ, float* part, int32_t ldp, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(dlogits && out && asum && BDv && bv && (sent || Ds == 0) && H && w_fc && dz && dattn && dout && dZ && part, QAGNN_EINVAL,
+                "head_post_bwd: null pointer");
+  int rc = head_check("head_post_bwd", B, NH, DP, dv, n, Ds, d);
+  if (rc != QAGNN_OK) return rc;
+  QAGNN_REQUIRE(ldp >= NH * dv + Ds + d + NH * dv + 1 && ldp <= NH * dv + Ds + d + NH * dv + 1 + 255, QAGNN_EINVAL, "head_post_bwd: pitch of part");
+  k_head_post_bwd<<<B, HEAD_T, 0, (hipStream_t)stream_>>>(dlogits, out, asum, BDv, bv, sent, H, ldh, w_fc, NH, DP, dv, n, Ds, d, d / 4, DP / 4, p_pool, p_fc,
+                                                         seed_pool, seed_fc, seed_epoch_ptr(), dz, dattn, dout, dsent, dZ, part, ldp);
+  QAGNN_LAUNCH_CHECK("k_head_post_bwd");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_add_row0_f32(float* dK, int64_t ld_sub, const float* dZ, int32_t B, int32_t Cc, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(dK && dZ && B > 0 && Cc > 0, QAGNN_EINVAL, "add_row0: bad arguments");
+  k_add_row0<<<cdiv(B * Cc, 256), 256, 0, (hipStream_t)stream_>>>(dK, ld_sub, dZ, Cc, B);
+  QAGNN_LAUNCH_CHECK("k_add_row0");
   return QAGNN_OK;
 }

@@ -94,7 +94,7 @@ class MultiheadAttPoolLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self._plan = None  # ops.GatherPlan of the block-diagonal operands (built on first use; not part of the state dict)
 
-    def forward(self, q, k, mask=None, layout=None):
+    def forward(self, q, k, mask=None, layout=None, head=None):
         """q [b, d_q], k [b, l, d_k], mask [b, l] -> (pooled [b, n_head*d_v], attn [n_head*b, l] head-major).
 
         Same function as the reference (utils/layers.py:344-371), re-associated so that the two [b*l, d] x [d, d]
@@ -110,6 +110,16 @@ class MultiheadAttPoolLayer(nn.Module):
         qs = qs2.view(b, nh, dk)
         c = (qs * self.w_ks.bias.view(nh, dk)).sum(2)
         from . import ops
+        if head is not None:
+            # the caller's whole head (value projection, both dropouts, concatenation, the one-output Linear) behind this pooling as
+            # ONE autograd node (ops.HeadFn): head = (sent_vecs, fc weight [1, nh*dv + d_q + d], fc bias [1], d, p_fc)
+            sent, w_fc, b_fc, d, p_fc = head
+            BDk, BDv = self._packed_operands(layout)
+            u = torch.mm(qs2, BDk).view(b, nh, layout.DP)
+            m = mask if mask is not None else torch.zeros(b, l, dtype=torch.bool, device=k.device)
+            logits, attn = ops.head(u, c, k, m, 1.0 / self.attention.temperature, self.attention.dropout.p, BDv, self.w_vs.bias, sent, w_fc, b_fc, d,
+                                    self.dropout.p, p_fc, self.training)
+            return logits, attn.transpose(0, 1).reshape(nh * b, l)
         if layout is not None:
             # The per-head products run as ONE plain matmul against a block-diagonal weight (the batched form runs, and differentiates,
             # as batch-of-2 bmm calls for which rocBLAS picks 48 us kernels at these sizes).  Both block-diagonal operands come out of

@@ -565,6 +565,15 @@ class QAGNN(nn.Module):
         if join_graph is not None:
             join_graph()
         gnn_output = self.gnn(gnn_input, adj, node_type_ids, node_scores, graph=graph, padded_input=fused_input, padded_output=True)
+        pl, fc = self.pooler, self.fc
+        if (fc.num_layers == 0 and fc.output_size == 1 and gnn_output.is_contiguous() and gnn_output.size(2) == Lh.DP
+                and ops.head_supported(pl.n_head, pl.d_v, Lh.DP, n)):
+            # (:178-182) pooling, value projection, both dropouts, concatenation and the one-output Linear as one autograd node
+            lin = fc.layers[0]
+            logits, pool_attn = pl(sent_vecs, gnn_output, mask, layout=Lh, head=(sent_vecs, lin.weight, lin.bias, self.concept_dim, self.dropout_fc.p))
+            if cache_output:
+                self.concept_ids, self.adj, self.pool_attn = concept_ids, adj, pool_attn
+            return logits, pool_attn
         Z_vecs = Lh.unpad(gnn_output[:, 0])
         graph_vecs, pool_attn = self.pooler(sent_vecs, gnn_output, mask, layout=Lh)
         if cache_output:

@@ -343,6 +343,7 @@ def graph_prep_async(adj, node_type, n_etype, n_ntype, block_n):
 # launch right behind the operand-packing gather and registers them with the library, which recognises a registered operand by its
 # pointers.  `owner` (a module) holds the packed buffer and the weights until its next forward replaces them: a registered pointer
 # always names live, unchanged memory.
+HEAD_FUSED = _os.environ.get('QAGNN_HEAD_FUSED', '1') == '1'  # the head behind the pooling as two kernels each way (0 = stock torch ops: A/B switch)
 PREPACK = _os.environ.get('QAGNN_PREPACK', '1') == '1'
 PREPACK_MIN_ROWS = int(_os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))
 
@@ -937,6 +938,59 @@ class PoolAttnFn(torch.autograd.Function):
 def pool_attention(u, cvec, K3, mask, inv_temp, p, training):
     p = float(p) if training else 0.0
     return PoolAttnFn.apply(u, cvec, K3, mask, inv_temp, p, next_seed() if p > 0 else 0)
+
+
+class HeadFn(torch.autograd.Function):
+    """Pooling + everything behind it as ONE autograd node (reference utils/layers.py:344-371 and modeling_qagnn.py:178-182 with
+    fc_layer_num = 0):  logits[b] = < drop_fc([ drop_pool(Wv pool(K3[b]) + bv sum attn) | sent[b] | K3[b, 0] ]), w_fc > + b_fc.
+    Forward = qagnn_pool_attn_fwd_f32 + qagnn_head_post_fwd_f32; backward = qagnn_head_post_bwd_f32, one column sum for
+    d w_fc | d bv | d b_fc, one product for d BDv, qagnn_pool_attn_bwd_f32, and the context row's direct gradient added into the
+    pooling's dK in place (autograd's slice backward would zero-fill and add a second [B, n, DP] tensor: 53 MB each at 320 subgraphs)."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, u, cvec, K3, mask, inv_temp, p_attn, seed_attn, BDv, bv, sent, w_fc, b_fc, d, p_pool, p_fc, seed_pool, seed_fc):
+        Kn = kernels()
+        u, cvec, K3, sent = u.contiguous(), cvec.contiguous(), K3.contiguous(), sent.contiguous()
+        BDv, bv, w1, b_fc = BDv.contiguous(), bv.contiguous(), w_fc.reshape(-1).contiguous(), b_fc.contiguous()
+        attn, attn_d, z = Kn.pool_attn_fwd(u, cvec, K3, mask.contiguous(), inv_temp, p_attn, seed_attn)
+        logits, out, asum = Kn.head_post_fwd(z, attn_d, BDv, bv, sent, K3, d, w1, b_fc, p_pool, p_fc, seed_pool, seed_fc)
+        ctx.save_for_backward(u, K3, attn, attn_d, z, out, asum, BDv, bv, sent, w1)
+        ctx.cfg = (inv_temp, p_attn, seed_attn, d, p_pool, p_fc, seed_pool, seed_fc, w_fc.shape)
+        ctx.mark_non_differentiable(attn_d)
+        return logits.unsqueeze(1), attn_d
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, dlogits, _dattn_unused):
+        u, K3, attn, attn_d, z, out, asum, BDv, bv, sent, w1 = ctx.saved_tensors
+        inv_temp, p_attn, seed_attn, d, p_pool, p_fc, seed_pool, seed_fc, w_shape = ctx.cfg
+        Kn = kernels()
+        B, NO = out.shape
+        Ds, n = sent.size(1), attn.size(2)
+        L = NO + Ds + d
+        dz, dattn, dout, dsent, dZ, part = Kn.head_post_bwd(dlogits.reshape(-1).contiguous(), out, asum, BDv, bv, sent, K3, d, w1, p_pool, p_fc,
+                                                            seed_pool, seed_fc, n, ctx.needs_input_grad[9])
+        cols = Kn.colsum(part)[0]
+        dBDv = torch.mm(z.reshape(B, -1).t(), dout) if ctx.needs_input_grad[7] else None
+        dK, du, dc = Kn.pool_attn_bwd(u, K3, inv_temp, p_attn, seed_attn, attn, attn_d, dz, dattn)
+        Kn.add_row0(dK, dZ)
+        return (du, dc, dK, None, None, None, None, dBDv, cols[L:L + NO], dsent, cols[:L].reshape(w_shape), cols[L + NO:L + NO + 1],
+                None, None, None, None, None)
+
+
+def head_supported(nh, dv, width, n):
+    K = kernels()
+    lim = getattr(K, 'HEAD_LIMITS', None)
+    return (HEAD_FUSED and lim is not None and nh <= lim[0] and nh * dv <= lim[1] and width <= lim[2] and width % 4 == 0
+            and pool_attention_supported(nh, width, n))
+
+
+def head(u, cvec, K3, mask, inv_temp, p_attn, BDv, bv, sent, w_fc, b_fc, d, p_pool, p_fc, training):
+    """(logits [B, 1], attn_d [B, NH, n]); see HeadFn."""
+    p_attn, p_pool, p_fc = (float(p_attn), float(p_pool), float(p_fc)) if training else (0.0, 0.0, 0.0)
+    return HeadFn.apply(u, cvec, K3, mask, inv_temp, p_attn, next_seed() if p_attn > 0 else 0, BDv, bv, sent, w_fc, b_fc, int(d),
+                        p_pool, p_fc, next_seed() if p_pool > 0 else 0, next_seed() if p_fc > 0 else 0)
 
 
 def pool_attention_supported(nh, width, n):

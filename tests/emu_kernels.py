@@ -289,6 +289,49 @@ class EmuKernels:
         dK = torch.bmm((attn * keep).transpose(1, 2), dz) + torch.bmm(ds.transpose(1, 2), u)
         return dK, torch.bmm(ds, K), ds.sum(2)
 
+    HEAD_LIMITS = (4, 256, 256)
+
+    @staticmethod
+    def _head_pos(d, DP, dev):
+        k = torch.arange(d, device=dev)
+        return (k // (d // 4)) * (DP // 4) + k % (d // 4)
+
+    def head_post_fwd(self, z, attn, BDv, bv, sent, K3, d, w_fc, b_fc, p_pool, p_fc, seed_pool, seed_fc):
+        B, NH, DP = z.shape
+        NO = BDv.size(1)
+        asum = attn.sum(2)
+        out = z.reshape(B, NH * DP) @ BDv + bv * asum.repeat_interleave(NO // NH, 1)
+        outd = out * self._pool_keep(out.shape, p_pool, seed_pool, out)
+        Z = K3[:, 0][:, self._head_pos(d, DP, z.device)]
+        cat = torch.cat([outd, sent, Z], 1)
+        catd = cat * self._pool_keep(cat.shape, p_fc, seed_fc, cat)
+        return catd @ w_fc + b_fc, out, asum
+
+    def head_post_bwd(self, dlogits, out, asum, BDv, bv, sent, K3, d, w_fc, p_pool, p_fc, seed_pool, seed_fc, n, need_dsent):
+        B, NO = out.shape
+        NH, DP, Ds = asum.size(1), K3.size(2), sent.size(1)
+        L = NO + Ds + d
+        k1 = self._pool_keep(out.shape, p_pool, seed_pool, out)
+        pos = self._head_pos(d, DP, out.device)
+        cat = torch.cat([out * k1, sent, K3[:, 0][:, pos]], 1)
+        k2 = self._pool_keep(cat.shape, p_fc, seed_fc, cat)
+        dl = dlogits.reshape(B, 1)
+        dcat = dl * w_fc.reshape(1, L) * k2
+        dout = dcat[:, :NO] * k1
+        dZ = torch.zeros(B, DP, dtype=out.dtype, device=out.device)
+        dZ[:, pos] = dcat[:, NO + Ds:]
+        dz = (dout @ BDv.t()).reshape(B, NH, DP)
+        dasum = (dout * bv).reshape(B, NH, NO // NH).sum(2)
+        part = torch.zeros(B, (L + NO + 1 + 3) // 4 * 4, dtype=out.dtype, device=out.device)
+        part[:, :L] = dl * cat * k2
+        part[:, L:L + NO] = dout * asum.repeat_interleave(NO // NH, 1)
+        part[:, L + NO] = dlogits.reshape(B)
+        return dz, dasum.unsqueeze(2).expand(B, NH, n).contiguous(), dout, (dcat[:, NO:NO + Ds].contiguous() if need_dsent else None), dZ, part
+
+    def add_row0(self, dK, dZ):
+        dK[:, 0, :] += dZ
+        return dK
+
     def gelu_dropout_fwd(self, X, p, seed):
         return _gelu(X) * self._keep(X, p, seed)
 

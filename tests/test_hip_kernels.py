@@ -500,6 +500,43 @@ def test_pool_attention_forward_backward(B, n, NH, Cc, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,n,NH,DP,dv,Ds,d,p1,p2', [(7, 200, 2, 208, 100, 1024, 200, 0.0, 0.0), (5, 200, 2, 208, 100, 1024, 200, 0.1, 0.2),
+                                                     (3, 37, 4, 32, 8, 20, 32, 0.3, 0.0), (2, 300, 1, 256, 64, 0, 100, 0.0, 0.4),
+                                                     (320, 200, 2, 208, 100, 768, 200, 0.1, 0.2)])
+def test_head_post_forward_backward(B, n, NH, DP, dv, Ds, d, p1, p2):
+    """qagnn_head_post_{fwd,bwd}_f32 + qagnn_add_row0_f32 against the float64 emulation (same counter-based masks)."""
+    g = torch.Generator().manual_seed(B * 100 + n + NH)
+    NO, L = NH * dv, NH * dv + Ds + d
+    z, attn = torch.randn(B, NH, DP, generator=g), torch.rand(B, NH, n, generator=g) / n
+    BDv, bv = torch.randn(NH * DP, NO, generator=g) * 0.1, torch.randn(NO, generator=g)
+    for h in range(NH):  # block diagonal, as qagnn_amd.layers builds it: head h's rows reach head h's outputs only
+        BDv[h * DP:(h + 1) * DP, :h * dv] = 0
+        BDv[h * DP:(h + 1) * DP, (h + 1) * dv:] = 0
+    sent, K3 = torch.randn(B, Ds, generator=g), torch.randn(B, n, DP, generator=g)
+    w, bfc, dl = torch.randn(L, generator=g) * 0.1, torch.randn(1, generator=g), torch.randn(B, generator=g)
+    K, s1, s2 = hip(), 4711, 815
+    cu = lambda t: t.cuda()  # noqa: E731
+    logits, out, asum = K.head_post_fwd(cu(z), cu(attn), cu(BDv), cu(bv), cu(sent), cu(K3), d, cu(w), cu(bfc), p1, p2, s1, s2)
+    dd = lambda t: t.double()  # noqa: E731
+    r_logits, r_out, r_asum = EMU.head_post_fwd(dd(z), dd(attn), dd(BDv), dd(bv), dd(sent), dd(K3), d, dd(w), dd(bfc), p1, p2, s1, s2)
+    tol = dict(rtol=2e-4, atol=2e-5)
+    assert torch.allclose(out.cpu().double(), r_out, **tol) and torch.allclose(asum.cpu().double(), r_asum, **tol)
+    assert torch.allclose(logits.cpu().double(), r_logits, rtol=2e-4, atol=2e-4)
+    for need_dsent in (True, False):
+        got = K.head_post_bwd(cu(dl), out, asum, cu(BDv), cu(bv), cu(sent), cu(K3), d, cu(w), p1, p2, s1, s2, n, need_dsent and Ds > 0)
+        ref = EMU.head_post_bwd(dd(dl), r_out, r_asum, dd(BDv), dd(bv), dd(sent), dd(K3), d, dd(w), p1, p2, s1, s2, n, need_dsent and Ds > 0)
+        for name, a, b_ in zip(('dz', 'dattn', 'dout', 'dsent', 'dZ', 'part'), got, ref):
+            assert (a is None) == (b_ is None), name
+            if a is not None:
+                assert torch.allclose(a.cpu().double(), b_, rtol=2e-4, atol=2e-5 * max(1.0, b_.abs().max().item())), name
+    dK = torch.randn(B, n, DP, generator=g)
+    got = K.add_row0(cu(dK), got[4]).cpu()
+    want = dK.clone()
+    want[:, 0] += ref[4].float()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6) and torch.equal(got[:, 1:], dK[:, 1:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name,HP,mode', [('csqa_b10', 52, 'train'), ('csqa_b10', 52, 'eval'), ('small_train', 8, 'train'),
                                           ('rand_hub', 52, 'train_noact'), ('medqa_b8', 52, 'train_noS'), ('big', 52, 'train'),
                                           ('big_pad', 52, 'train')])
