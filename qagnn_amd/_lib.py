@@ -19,13 +19,13 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
-           'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32',
+           'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32', 'qagnn_gather_multi_f32', 'qagnn_gather_multi_sum_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 15  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32)
+ABI_VERSION = 15  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -36,6 +36,13 @@ class qagnn_graph(C.Structure):
                                     'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
                 [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
+
+
+GATHER_MAX = 160
+
+
+class qagnn_gather_tabs(C.Structure):
+    _fields_ = [('p', _vp * GATHER_MAX), ('pre', _i32 * (GATHER_MAX + 1)), ('len', _i32 * GATHER_MAX), ('n', _i32)]
 
 
 class qagnn_pack_desc(C.Structure):
@@ -112,6 +119,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_head_post_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64,
                                             _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_add_row0_f32.argtypes = [_vp, _i64, _vp, _i32, _i32, _vp]
+    lib.qagnn_gather_multi_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _vp, _i32, _vp]
+    lib.qagnn_gather_multi_sum_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _i32, _i32, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
@@ -668,6 +677,39 @@ class HipKernels(metaclass=_GuardedMeta):
                                               dZ.data_ptr(), part.data_ptr(), part.size(1), self._stream())
         self._check(rc, 'qagnn_head_post_bwd_f32')
         return dz, dattn, dout, dsent, dZ, part
+
+    GATHER_MAX = GATHER_MAX
+
+    @staticmethod
+    def _gather_tabs(tensors, starts, lens):
+        """tensors: fp32 tensors or None; starts: first element of each in the virtual concatenation (+ the total at the end)"""
+        t = qagnn_gather_tabs()
+        t.n = len(tensors)
+        for i, x in enumerate(tensors):
+            if x is not None:
+                assert x.is_contiguous() and x.dtype == torch.float32
+                t.p[i] = x.data_ptr()
+            t.len[i] = lens[i]
+        for i, v in enumerate(starts):
+            t.pre[i] = v
+        return t
+
+    def gather_multi(self, sources, starts, idx):
+        """out[i] = cat(sources)[idx[i]] without the cat (an index >= the total gives 0); idx int32 on the device"""
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and len(sources) <= GATHER_MAX
+        out = torch.empty(idx.numel(), dtype=torch.float32, device=idx.device)
+        t = self._gather_tabs(sources, starts, [s.numel() for s in sources])
+        self._check(self.lib.qagnn_gather_multi_f32(C.byref(t), idx.data_ptr(), out.data_ptr(), idx.numel(), self._stream()), 'qagnn_gather_multi_f32')
+        return out
+
+    def gather_multi_sum(self, grads, starts, lens, inv):
+        """out[s] = sum_k virtual_cat(grads)[inv[k, s]] (grads: tensors or None; slice k occupies [starts[k], starts[k + 1]), lens[k] real)"""
+        assert inv.dtype == torch.int32 and inv.is_contiguous() and inv.dim() == 2 and len(grads) <= GATHER_MAX
+        out = torch.empty(inv.size(1), dtype=torch.float32, device=inv.device)
+        t = self._gather_tabs(grads, starts, lens)
+        self._check(self.lib.qagnn_gather_multi_sum_f32(C.byref(t), inv.data_ptr(), inv.size(0), inv.size(1), out.data_ptr(), self._stream()),
+                    'qagnn_gather_multi_sum_f32')
+        return out
 
     def add_row0(self, dK, dZ):
         """dK [B, n, Cc] (contiguous): dK[:, 0, :] += dZ [B, Cc], in place."""

@@ -80,8 +80,12 @@ class _PlanGatherFn(torch.autograd.Function):
     @staticmethod
     @_fwd
     def forward(ctx, plan, *sources):
-        flat = torch.cat([t.reshape(-1) for t in sources] + [plan.zeros[:1]])  # (the appended zero element: the plan's cached zeros, no fill)
-        packed = flat.index_select(0, plan.idx)
+        K = plan.kernels_for(sources)
+        if K is not None:  # one launch over the tensors where they lie (qagnn_gather_multi_f32)
+            packed = K.gather_multi([t.contiguous() for t in sources], plan.src_starts, plan.idx32)
+        else:
+            flat = torch.cat([t.reshape(-1) for t in sources] + [plan.zeros[:1]])  # (the appended zero element: the plan's cached zeros, no fill)
+            packed = flat.index_select(0, plan.idx)
         ctx.plan = plan
         ctx.src_shapes = [t.shape for t in sources]
         ctx.set_materialize_grads(False)  # operands without a gradient arrive as None, not as ~50 freshly zero-filled tensors
@@ -92,6 +96,18 @@ class _PlanGatherFn(torch.autograd.Function):
     def backward(ctx, *grads):
         plan = ctx.plan
         join_wgrads(next((g for g in grads if g is not None), None))  # the packed operands' gradients may still be in flight
+        K = plan.kernels_for(grads)
+        if K is not None and any(g is not None for g in grads):  # one launch: every source element sums its packed copies' gradients
+            gsrc = K.gather_multi_sum([None if g is None else g.contiguous() for g in grads], plan.pack_starts, [n for _, n, _ in plan.slices],
+                                      plan.inv32)
+            out, off = [], 0
+            for shape in ctx.src_shapes:
+                n = 1
+                for v in shape:
+                    n *= v
+                out.append(gsrc[off:off + n].view(shape))
+                off += n
+            return (None,) + tuple(out)
         parts = []
         z = plan.zeros  # cached zeros: operands that received no gradient (the non-transposed weight copies) cost no fill kernel
         for g, (a, n, shape), n4 in zip(grads, plan.slices, plan.padded):
@@ -158,6 +174,26 @@ class GatherPlan:
         for k in range(max(K, 1)):
             take = order[torch.clamp(starts + k, max=order.numel() - 1)]
             self.inv.append(torch.where(counts > k, take, torch.full_like(take, pos)))
+        # the same maps for the one-launch kernels (qagnn_gather_multi{,_sum}_f32): int32 indices, element offsets of the tensors
+        self.idx32 = self.idx.to(torch.int32)
+        self.inv32 = torch.stack(self.inv).to(torch.int32).contiguous()
+        self.src_starts, a = [0], 0
+        for t in sources:
+            a += t.numel()
+            self.src_starts.append(a)
+        self.pack_starts = [a for a, _, _ in self.slices] + [pos]
+        self.n_sources, self.fits = len(sources), total < 2 ** 31 - 1 and pos < 2 ** 31 - 1
+
+    def kernels_for(self, tensors):
+        """the provider's one-launch gather, where it has one and the tables fit its kernel arguments"""
+        if not GATHER_FUSED or not self.fits:
+            return None
+        K = kernels()
+        lim = getattr(K, 'GATHER_MAX', 0)
+        if self.n_sources > lim or len(self.slices) > lim:
+            return None
+        t0 = next((t for t in tensors if t is not None), None)
+        return K if t0 is not None and t0.dtype == torch.float32 and (t0.is_cuda or K.name != 'hip') else None
 
     def __call__(self, sources, build):
         sig = tuple((tuple(t.shape), str(t.device), t.dtype) for t in sources)
@@ -343,6 +379,7 @@ def graph_prep_async(adj, node_type, n_etype, n_ntype, block_n):
 # launch right behind the operand-packing gather and registers them with the library, which recognises a registered operand by its
 # pointers.  `owner` (a module) holds the packed buffer and the weights until its next forward replaces them: a registered pointer
 # always names live, unchanged memory.
+GATHER_FUSED = _os.environ.get('QAGNN_GATHER_FUSED', '1') == '1'  # GatherPlan through qagnn_gather_multi{,_sum}_f32 (0 = cat + index_select: A/B switch)
 HEAD_FUSED = _os.environ.get('QAGNN_HEAD_FUSED', '1') == '1'  # the head behind the pooling as two kernels each way (0 = stock torch ops: A/B switch)
 PREPACK = _os.environ.get('QAGNN_PREPACK', '1') == '1'
 PREPACK_MIN_ROWS = int(_os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))

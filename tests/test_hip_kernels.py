@@ -500,6 +500,29 @@ def test_pool_attention_forward_backward(B, n, NH, Cc, p):
 
 
 @pytest.mark.gpu
+def test_gather_plan_kernels_equal_the_torch_path(monkeypatch):
+    """qagnn_gather_multi_f32 / qagnn_gather_multi_sum_f32 through ops.GatherPlan against its cat + index_select form, bit for bit; then a
+    plan of 150 tensors (the table limit is 160) with a million elements."""
+    from qagnn_amd import ops as O
+    from test_host_logic_emu import _gather_plan_case, _run_gather_plan
+    O.set_kernels(None)
+    srcs, build = _gather_plan_case('cuda')
+    o1, g1 = _run_gather_plan(srcs, build, True, monkeypatch)
+    o0, g0 = _run_gather_plan(srcs, build, False, monkeypatch)
+    for a, b in zip(o1 + list(g1), o0 + list(g0)):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(9)
+    big = [torch.randn(int(n), generator=g).cuda().requires_grad_(True) for n in torch.randint(2000, 12000, (150,), generator=g)]
+
+    def build_big(ids):
+        return [torch.cat([ids[i].flip(0), ids[(i + 1) % 150][:100]]) for i in range(150)]
+    a1, b1 = _run_gather_plan(big, build_big, True, monkeypatch)
+    a0, b0 = _run_gather_plan(big, build_big, False, monkeypatch)
+    for x, y in zip(a1 + list(b1), a0 + list(b0)):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,n,NH,DP,dv,Ds,d,p1,p2', [(7, 200, 2, 208, 100, 1024, 200, 0.0, 0.0), (5, 200, 2, 208, 100, 1024, 200, 0.1, 0.2),
                                                      (3, 37, 4, 32, 8, 20, 32, 0.3, 0.0), (2, 300, 1, 256, 64, 0, 100, 0.0, 0.4),
                                                      (320, 200, 2, 208, 100, 768, 200, 0.1, 0.2)])

@@ -545,3 +545,44 @@ def test_nn2_tile_walk_and_fragment_correspondence(NT, K1, K2):
         for lane in range(64):
             rd = _nn2_slot(lane & 15, lane >> 4) * 16 + j * 3 * 1024
             assert [img[rd + 2 * e] for e in range(8)] == [(16 * j + (lane & 15), 8 * (lane >> 4) + e) for e in range(8)]
+
+
+def _gather_plan_case(dev):
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(7, 5, generator=g), torch.randn(11, generator=g), torch.randn(3, 4, generator=g), torch.randn(6, generator=g)]
+    srcs = [t.to(dev).requires_grad_(True) for t in srcs]
+
+    def build(ids):
+        a, b, c, d = ids
+        return [torch.nn.functional.pad(a.t(), (0, 1)), torch.cat([b, b[:3]]), c, a[:2], torch.zeros_like(d[:5])]  # (d is never used: zero gradient)
+    return srcs, build
+
+
+def _run_gather_plan(srcs, build, fused, monkeypatch):
+    from qagnn_amd import ops as O
+    monkeypatch.setattr(O, 'GATHER_FUSED', fused)
+    plan = O.GatherPlan()
+    outs = plan(srcs, build)
+    w = [torch.arange(o.numel(), dtype=o.dtype, device=o.device).view_as(o) * 0.01 + 1 for o in outs]
+    loss = sum((o * wi).sum() for o, wi in zip(outs[:3], w[:3]))  # outputs 3 and 4 get no gradient
+    grads = torch.autograd.grad(loss, srcs, allow_unused=True)
+    return [o.detach() for o in outs], grads
+
+
+def test_gather_plan_one_launch_kernels_equal_the_cat_and_gather_path(monkeypatch):
+    """ops.GatherPlan through the provider's gather_multi / gather_multi_sum (one launch each way over the tensors where they lie) against
+    its cat + index_select form: same packed operands, same source gradients (absent packed gradients, alignment padding and an unused
+    source included), bit for bit -- the sums run in the same order."""
+    from emu_kernels import EmuKernels
+    old = ops.set_kernels(EmuKernels())
+    try:
+        srcs, build = _gather_plan_case('cpu')
+        o1, g1 = _run_gather_plan(srcs, build, True, monkeypatch)
+        o0, g0 = _run_gather_plan(srcs, build, False, monkeypatch)
+        for a, b in zip(o1, o0):
+            assert torch.equal(a, b)
+        for a, b in zip(g1, g0):
+            assert (a is None and b is None) or torch.equal(a, b)
+        assert torch.equal(g1[3], torch.zeros_like(g1[3]))
+    finally:
+        ops.set_kernels(old)
