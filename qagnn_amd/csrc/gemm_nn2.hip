@@ -23,10 +23,18 @@
 // hold two weight rows (x = 2r, 2r + 1) times eight float4 (c = kq >> 1, half = kq & 1), i.e. slots {x ^ 2c} = 8 different values
 // mod 8, both halves each = every bank once.
 //
-// Shapes: block = 4 waves, 128 rows x NT*16 columns, wave = 32 rows x NT column tiles of v_mfma_f32_16x16x32_bf16 (2 x NT x 4
-// accumulator registers), k-tile 32; LDS 2 x NT x 3 KB (78 KB at NT = 13) => two blocks per CU, whose phases drift apart so that one
-// block's split work runs under the other's MFMAs.  Epilogue as in k_gemm_nn_split (16-row slabs through LDS, whole-row 16-byte stores;
-// bias / row table / accumulate / BatchNorm column statistics).
+//  * (the straddling tile, as built: one 64-bit flat load per destination with the segment chosen per lane -- see QAGNN_NN2_FIRST_LOADS)
+//
+// Shapes: a wave = 32 rows x NT column tiles of v_mfma_f32_16x16x32_bf16 (2 x NT x 4 accumulator registers), k-tile 32.
+//   WV = 4: block = 128 rows x NT*16 columns, LDS 2 x NT x 3 KB (78 KB at NT = 13) => two blocks per CU.  They do NOT drift apart as
+//     hoped: blocks b and b + 256 share a CU and run in lockstep (tools/cu_census.hip, profiles/r4_run16_nn2_stagger.txt), so the parts
+//     of a k-tile add up instead of overlapping -- which is what the WV = 8 form below is for.
+//   WV = 8 (PACKED, >= 10 k-tiles, >= 8 column tiles, >= one 256-row tile per CU): the staggered block, see the comment at the kernel.
+//   PACKED: B arrives pre-split in the kernel's LDS image order (k_pack_b / k_pack_b_multi: once per product, or once per training step
+//     for all weights through the registry of qagnn_gemm_nn_prepack_f32) and goes to LDS by DMA.
+// Epilogues: PACKED without column statistics stores straight from the accumulators (the MFMAs are issued with their operands swapped,
+// so that a lane holds four consecutive columns of a row); the others go through 16-row LDS slabs as in k_gemm_nn_split (whole-row
+// 16-byte stores; bias / row table / accumulate / BatchNorm column statistics).
 #include <stdlib.h>
 
 #include "common.h"
