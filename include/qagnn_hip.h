@@ -268,15 +268,16 @@ int qagnn_head_post_bwd_f32(const float* dlogits, const float* out, const float*
 /* dK[b*ld_sub + j] += dZ[b*Cc + j]: the gradient of each subgraph's row 0 that the head reads directly, into the pooling's dK */
 int qagnn_add_row0_f32(float* dK, int64_t ld_sub, const float* dZ, int32_t B, int32_t Cc, qagnn_stream_t stream);
 /* Weight packing of the module mirror (qagnn_amd.ops.GatherPlan; no reference counterpart: the reference multiplies by nn.Linear weights
- * in place, the kernels of this library want them transposed / head-padded / concatenated).  qagnn_gather_multi_f32: out[i] = element
- * idx[i] of the virtual concatenation of the n tensors p[0..n) (tensor k holds elements [pre[k], pre[k + 1]); an index outside
- * [0, pre[n]) gives 0).  qagnn_gather_multi_sum_f32: out[s] = sum over k < K, in that order, of element inv[k][s] of the virtual
- * concatenation, where tensor k occupies [pre[k], pre[k + 1]) but only its first len[k] elements are real (the rest, and a NULL p[k],
- * read as 0): the backward of the packing, its packed gradients being separate, possibly absent tensors. */
+ * in place, the kernels of this library want them transposed / head-padded / concatenated).  qagnn_gather_multi_f32: out[i] =
+ * p[tid[i]][off[i]], 0 where tid[i] < 0 -- which tensor and which element a packed position comes from is fixed when the plan is built,
+ * only the tensors' addresses change from call to call.  qagnn_gather_multi_sum_f32: out[s] = sum over k < K, in that order, of
+ * p[tid[k][s]][off[k][s]] (tid < 0 or a NULL p[.]: 0), tid / off being [K][S]: the backward of the packing, its packed gradients being
+ * separate, possibly absent tensors. */
 #define QAGNN_GATHER_MAX 160
-typedef struct qagnn_gather_tabs { const float* p[QAGNN_GATHER_MAX]; int32_t pre[QAGNN_GATHER_MAX + 1]; int32_t len[QAGNN_GATHER_MAX]; int32_t n; } qagnn_gather_tabs;
-int qagnn_gather_multi_f32(const qagnn_gather_tabs* t, const int32_t* idx, float* out, int32_t total, qagnn_stream_t stream);
-int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* inv, int32_t K, int32_t S, float* out, qagnn_stream_t stream);
+typedef struct qagnn_gather_tabs { const float* p[QAGNN_GATHER_MAX]; int32_t n; } qagnn_gather_tabs;
+int qagnn_gather_multi_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, float* out, int32_t total, qagnn_stream_t stream);
+int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, int32_t K, int32_t S, float* out,
+                               qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 /* qagnn_bn_relu_bwd_f32 with the column sums of its OUTPUT as a by-product (the bias gradient of the Linear in front of the

@@ -42,7 +42,7 @@ GATHER_MAX = 160
 
 
 class qagnn_gather_tabs(C.Structure):
-    _fields_ = [('p', _vp * GATHER_MAX), ('pre', _i32 * (GATHER_MAX + 1)), ('len', _i32 * GATHER_MAX), ('n', _i32)]
+    _fields_ = [('p', _vp * GATHER_MAX), ('n', _i32)]
 
 
 class qagnn_pack_desc(C.Structure):
@@ -119,8 +119,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_head_post_bwd_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _u64,
                                             _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_add_row0_f32.argtypes = [_vp, _i64, _vp, _i32, _i32, _vp]
-    lib.qagnn_gather_multi_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _vp, _i32, _vp]
-    lib.qagnn_gather_multi_sum_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _i32, _i32, _vp, _vp]
+    lib.qagnn_gather_multi_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _vp, _vp, _i32, _vp]
+    lib.qagnn_gather_multi_sum_f32.argtypes = [C.POINTER(qagnn_gather_tabs), _vp, _vp, _i32, _i32, _vp, _vp]
     lib.qagnn_edge_attn_fwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]
     lib.qagnn_edge_attn_bwd_f32.argtypes = [C.POINTER(qagnn_graph), _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32,
                                             _vp, _vp, _vp, _vp, _vp, _vp]
@@ -681,34 +681,32 @@ class HipKernels(metaclass=_GuardedMeta):
     GATHER_MAX = GATHER_MAX
 
     @staticmethod
-    def _gather_tabs(tensors, starts, lens):
-        """tensors: fp32 tensors or None; starts: first element of each in the virtual concatenation (+ the total at the end)"""
+    def _gather_tabs(tensors):
         t = qagnn_gather_tabs()
         t.n = len(tensors)
         for i, x in enumerate(tensors):
             if x is not None:
                 assert x.is_contiguous() and x.dtype == torch.float32
                 t.p[i] = x.data_ptr()
-            t.len[i] = lens[i]
-        for i, v in enumerate(starts):
-            t.pre[i] = v
         return t
 
-    def gather_multi(self, sources, starts, idx):
-        """out[i] = cat(sources)[idx[i]] without the cat (an index >= the total gives 0); idx int32 on the device"""
-        assert idx.dtype == torch.int32 and idx.is_contiguous() and len(sources) <= GATHER_MAX
-        out = torch.empty(idx.numel(), dtype=torch.float32, device=idx.device)
-        t = self._gather_tabs(sources, starts, [s.numel() for s in sources])
-        self._check(self.lib.qagnn_gather_multi_f32(C.byref(t), idx.data_ptr(), out.data_ptr(), idx.numel(), self._stream()), 'qagnn_gather_multi_f32')
+    def gather_multi(self, sources, tid, off):
+        """out[i] = sources[tid[i]].flat[off[i]] (tid < 0: 0); tid / off int32 on the device"""
+        assert tid.dtype == torch.int32 and off.dtype == torch.int32 and tid.is_contiguous() and off.is_contiguous() and len(sources) <= GATHER_MAX
+        out = torch.empty(tid.numel(), dtype=torch.float32, device=tid.device)
+        t = self._gather_tabs(sources)
+        self._check(self.lib.qagnn_gather_multi_f32(C.byref(t), tid.data_ptr(), off.data_ptr(), out.data_ptr(), tid.numel(), self._stream()),
+                    'qagnn_gather_multi_f32')
         return out
 
-    def gather_multi_sum(self, grads, starts, lens, inv):
-        """out[s] = sum_k virtual_cat(grads)[inv[k, s]] (grads: tensors or None; slice k occupies [starts[k], starts[k + 1]), lens[k] real)"""
-        assert inv.dtype == torch.int32 and inv.is_contiguous() and inv.dim() == 2 and len(grads) <= GATHER_MAX
-        out = torch.empty(inv.size(1), dtype=torch.float32, device=inv.device)
-        t = self._gather_tabs(grads, starts, lens)
-        self._check(self.lib.qagnn_gather_multi_sum_f32(C.byref(t), inv.data_ptr(), inv.size(0), inv.size(1), out.data_ptr(), self._stream()),
-                    'qagnn_gather_multi_sum_f32')
+    def gather_multi_sum(self, grads, tid, off):
+        """out[s] = sum_k grads[tid[k, s]].flat[off[k, s]] (tid < 0 or an absent gradient: 0); tid / off [K, S] int32"""
+        assert tid.dtype == torch.int32 and off.dtype == torch.int32 and tid.is_contiguous() and off.is_contiguous() and tid.dim() == 2
+        assert len(grads) <= GATHER_MAX
+        out = torch.empty(tid.size(1), dtype=torch.float32, device=tid.device)
+        t = self._gather_tabs(grads)
+        self._check(self.lib.qagnn_gather_multi_sum_f32(C.byref(t), tid.data_ptr(), off.data_ptr(), tid.size(0), tid.size(1), out.data_ptr(),
+                                                        self._stream()), 'qagnn_gather_multi_sum_f32')
         return out
 
     def add_row0(self, dK, dZ):

@@ -435,83 +435,52 @@ extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, i
 }
 
 // ---- weight packing without the concatenations (qagnn_amd.ops.GatherPlan) ------------------------------------------------------
-// Forward: out[i] = element idx[i] of the VIRTUAL concatenation of the source tensors (index >= the total: 0) -- the tensors stay where
-// they are, their addresses travel in the kernel arguments.  Backward: for every source element s the sum, in fixed order k = 0..K-1,
-// of the packed-gradient elements inv[k][s] (a position past the packed total, inside a slice's alignment padding, or inside a slice
-// whose gradient is absent contributes 0), the packed gradients being separate tensors as autograd hands them over.
+// Forward: out[i] = p[tid[i]][off[i]] (tid < 0: 0) -- the source tensors stay where they are, their addresses travel in the kernel
+// arguments, and which tensor / which element a packed position comes from was worked out once when the plan was built.  Backward: for
+// every source element s the sum, in fixed order k = 0..K-1, of the packed-gradient elements (tid[k][s], off[k][s]) (tid < 0 or an
+// absent gradient tensor: 0), the packed gradients being separate tensors as autograd hands them over.
 // Was: torch.cat + index_select forward; cat of ~90 gradient slices + K index_selects + K - 1 adds backward.
-__global__ __launch_bounds__(256) void k_gather_multi(qagnn_gather_tabs t, const int* __restrict__ idx, float* __restrict__ out, int total) {
+__global__ __launch_bounds__(256) void k_gather_multi(qagnn_gather_tabs t, const int* __restrict__ tid, const int* __restrict__ off,
+                                                     float* __restrict__ out, int total) {
   __shared__ const float* ps[QAGNN_GATHER_MAX];
-  __shared__ int pre[QAGNN_GATHER_MAX + 1];
-  for (int i = threadIdx.x; i <= t.n; i += blockDim.x) {
-    pre[i] = t.pre[i];
-    if (i < t.n) ps[i] = t.p[i];
-  }
+  for (int i = threadIdx.x; i < t.n; i += blockDim.x) ps[i] = t.p[i];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int g = idx[i];
-  float v = 0.f;
-  if (g >= 0 && g < pre[t.n]) {
-    int lo = 0, hi = t.n - 1;  // the last tensor whose first element is <= g
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (pre[mid] <= g) lo = mid; else hi = mid - 1;
-    }
-    v = ps[lo][g - pre[lo]];
-  }
-  out[i] = v;
+  const int k = tid[i];
+  out[i] = k >= 0 ? ps[k][off[i]] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_gather_multi_sum(qagnn_gather_tabs t, const int* __restrict__ inv, int K, int S, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_gather_multi_sum(qagnn_gather_tabs t, const int* __restrict__ tid, const int* __restrict__ off, int K, int S,
+                                                         float* __restrict__ out) {
   __shared__ const float* ps[QAGNN_GATHER_MAX];
-  __shared__ int pre[QAGNN_GATHER_MAX + 1], len[QAGNN_GATHER_MAX];
-  for (int i = threadIdx.x; i <= t.n; i += blockDim.x) {
-    pre[i] = t.pre[i];
-    if (i < t.n) { ps[i] = t.p[i]; len[i] = t.len[i]; }
-  }
+  for (int i = threadIdx.x; i < t.n; i += blockDim.x) ps[i] = t.p[i];
   __syncthreads();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   float acc = 0.f;
   for (int k = 0; k < K; ++k) {
-    const int g = inv[(int64_t)k * S + s];
-    float v = 0.f;
-    if (g >= 0 && g < pre[t.n]) {
-      int lo = 0, hi = t.n - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (pre[mid] <= g) lo = mid; else hi = mid - 1;
-      }
-      const int off = g - pre[lo];
-      if (ps[lo] != nullptr && off < len[lo]) v = ps[lo][off];
-    }
+    const int g = tid[(int64_t)k * S + s];
+    const float* p = g >= 0 ? ps[g] : nullptr;
+    const float v = p != nullptr ? p[off[(int64_t)k * S + s]] : 0.f;
     acc = k == 0 ? v : acc + v;
   }
   out[s] = acc;
 }
 
-static int gather_tabs_check(const qagnn_gather_tabs* t, const char* who) {
-  QAGNN_REQUIRE(t && t->n > 0 && t->n <= QAGNN_GATHER_MAX && t->pre[0] == 0, QAGNN_EINVAL, "%s: bad tensor table (n=%d)", who, t ? t->n : -1);
-  for (int i = 0; i < t->n; ++i) QAGNN_REQUIRE(t->pre[i + 1] >= t->pre[i], QAGNN_EINVAL, "%s: the prefix table must not decrease", who);
-  return QAGNN_OK;
-}
-
-extern "C" int qagnn_gather_multi_f32(const qagnn_gather_tabs* t, const int32_t* idx, float* out, int32_t total, qagnn_stream_t stream_) {
-  int rc = gather_tabs_check(t, "gather_multi");
-  if (rc != QAGNN_OK) return rc;
-  QAGNN_REQUIRE(idx && out && total > 0, QAGNN_EINVAL, "gather_multi: bad arguments");
+extern "C" int qagnn_gather_multi_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, float* out, int32_t total,
+                                      qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(t && t->n > 0 && t->n <= QAGNN_GATHER_MAX && tid && off && out && total > 0, QAGNN_EINVAL, "gather_multi: bad arguments");
   for (int i = 0; i < t->n; ++i) QAGNN_REQUIRE(t->p[i] != nullptr, QAGNN_EINVAL, "gather_multi: null source %d", i);
-  k_gather_multi<<<cdiv(total, 256), 256, 0, (hipStream_t)stream_>>>(*t, idx, out, total);
+  k_gather_multi<<<cdiv(total, 256), 256, 0, (hipStream_t)stream_>>>(*t, tid, off, out, total);
   QAGNN_LAUNCH_CHECK("k_gather_multi");
   return QAGNN_OK;
 }
 
-extern "C" int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* inv, int32_t K, int32_t S, float* out, qagnn_stream_t stream_) {
-  int rc = gather_tabs_check(t, "gather_multi_sum");
-  if (rc != QAGNN_OK) return rc;
-  QAGNN_REQUIRE(inv && out && K > 0 && S > 0, QAGNN_EINVAL, "gather_multi_sum: bad arguments");
-  k_gather_multi_sum<<<cdiv(S, 256), 256, 0, (hipStream_t)stream_>>>(*t, inv, K, S, out);
+extern "C" int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, int32_t K, int32_t S, float* out,
+                                          qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(t && t->n > 0 && t->n <= QAGNN_GATHER_MAX && tid && off && out && K > 0 && S > 0, QAGNN_EINVAL, "gather_multi_sum: bad arguments");
+  k_gather_multi_sum<<<cdiv(S, 256), 256, 0, (hipStream_t)stream_>>>(*t, tid, off, K, S, out);
   QAGNN_LAUNCH_CHECK("k_gather_multi_sum");
   return QAGNN_OK;
 }

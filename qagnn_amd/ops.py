@@ -82,7 +82,7 @@ class _PlanGatherFn(torch.autograd.Function):
     def forward(ctx, plan, *sources):
         K = plan.kernels_for(sources)
         if K is not None:  # one launch over the tensors where they lie (qagnn_gather_multi_f32)
-            packed = K.gather_multi([t.contiguous() for t in sources], plan.src_starts, plan.idx32)
+            packed = K.gather_multi([t.contiguous() for t in sources], plan.src_tid, plan.src_off)
         else:
             flat = torch.cat([t.reshape(-1) for t in sources] + [plan.zeros[:1]])  # (the appended zero element: the plan's cached zeros, no fill)
             packed = flat.index_select(0, plan.idx)
@@ -98,8 +98,7 @@ class _PlanGatherFn(torch.autograd.Function):
         join_wgrads(next((g for g in grads if g is not None), None))  # the packed operands' gradients may still be in flight
         K = plan.kernels_for(grads)
         if K is not None and any(g is not None for g in grads):  # one launch: every source element sums its packed copies' gradients
-            gsrc = K.gather_multi_sum([None if g is None else g.contiguous() for g in grads], plan.pack_starts, [n for _, n, _ in plan.slices],
-                                      plan.inv32)
+            gsrc = K.gather_multi_sum([None if g is None else g.contiguous() for g in grads], plan.inv_tid, plan.inv_off)
             out, off = [], 0
             for shape in ctx.src_shapes:
                 n = 1
@@ -174,14 +173,21 @@ class GatherPlan:
         for k in range(max(K, 1)):
             take = order[torch.clamp(starts + k, max=order.numel() - 1)]
             self.inv.append(torch.where(counts > k, take, torch.full_like(take, pos)))
-        # the same maps for the one-launch kernels (qagnn_gather_multi{,_sum}_f32): int32 indices, element offsets of the tensors
-        self.idx32 = self.idx.to(torch.int32)
-        self.inv32 = torch.stack(self.inv).to(torch.int32).contiguous()
-        self.src_starts, a = [0], 0
+        # the same maps for the one-launch kernels (qagnn_gather_multi{,_sum}_f32): (tensor, element) per position, -1 = zero
+        def locate(flat_idx, starts, lens):
+            """flat position in a virtual concatenation with slice k at [starts[k], starts[k + 1]) and lens[k] real elements"""
+            st = torch.tensor(starts, dtype=torch.long, device=dev)
+            k = torch.bucketize(flat_idx, st[1:], right=True).clamp_(max=len(lens) - 1)
+            o = flat_idx - st[k]
+            ok = (flat_idx >= 0) & (flat_idx < starts[-1]) & (o < torch.tensor(lens, dtype=torch.long, device=dev)[k])
+            return torch.where(ok, k, torch.full_like(k, -1)).to(torch.int32).contiguous(), torch.where(ok, o, torch.zeros_like(o)).to(torch.int32).contiguous()
+        src_starts, a = [0], 0
         for t in sources:
             a += t.numel()
-            self.src_starts.append(a)
-        self.pack_starts = [a for a, _, _ in self.slices] + [pos]
+            src_starts.append(a)
+        self.src_tid, self.src_off = locate(self.idx, src_starts, [t.numel() for t in sources])
+        inv = torch.stack(self.inv)
+        self.inv_tid, self.inv_off = locate(inv, [a for a, _, _ in self.slices] + [pos], [n for _, n, _ in self.slices])
         self.n_sources, self.fits = len(sources), total < 2 ** 31 - 1 and pos < 2 ** 31 - 1
 
     def kernels_for(self, tensors):

@@ -330,24 +330,23 @@ class EmuKernels:
 
     GATHER_MAX = 160
 
-    def gather_multi(self, sources, starts, idx):
-        flat = torch.cat([t.reshape(-1) for t in sources] + [sources[0].new_zeros(1)])
-        i = idx.long()
-        return flat[torch.where((i < 0) | (i >= starts[-1]), torch.full_like(i, starts[-1]), i)]
+    def gather_multi(self, sources, tid, off):
+        out = sources[0].new_zeros(tid.numel())
+        for k, t in enumerate(sources):
+            m = tid == k
+            out[m] = t.reshape(-1)[off[m].long()]
+        return out
 
-    def gather_multi_sum(self, grads, starts, lens, inv):
+    def gather_multi_sum(self, grads, tid, off):
         ref = next(g for g in grads if g is not None)
-        parts = []
-        for g, a, b, n in zip(grads, starts[:-1], starts[1:], lens):
-            parts.append(g.reshape(-1) if g is not None else ref.new_zeros(n))
-            if b - a != n:
-                parts.append(ref.new_zeros(b - a - n))
-        flat = torch.cat(parts + [ref.new_zeros(1)])
-        i = inv.long()
-        i = torch.where((i < 0) | (i >= starts[-1]), torch.full_like(i, starts[-1]), i)
-        out = flat[i[0]]
-        for k in range(1, i.size(0)):
-            out = out + flat[i[k]]
+        out = None
+        for r in range(tid.size(0)):
+            v = ref.new_zeros(tid.size(1))
+            for k, g in enumerate(grads):
+                if g is not None:
+                    m = tid[r] == k
+                    v[m] = g.reshape(-1)[off[r][m].long()]
+            out = v if out is None else out + v
         return out
 
     def add_row0(self, dK, dZ):
