@@ -586,3 +586,94 @@ def test_gather_plan_one_launch_kernels_equal_the_cat_and_gather_path(monkeypatc
         assert torch.equal(g1[3], torch.zeros_like(g1[3]))
     finally:
         ops.set_kernels(old)
+
+
+@pytest.mark.parametrize('nkt', [1, 2, 3, 7, 10, 20, 25])
+def test_nn2_staggered_ring_schedule(nkt):
+    """The timeline of the staggered 8-wave block of k_gemm_nn2 (csrc/gemm_nn2.hip), played through phase by phase: group g runs one
+    global phase behind group 0 (N_t in phase 2t + g, M_t in phase 2t + 1 + g); it issues its share of B tile t + 1 + g by DMA in its N_t and
+    waits for its own DMAs at the end of its M phases; tile t lives in image t % 3 and is read by group g in its N_t (two fragments ahead)
+    and its M_t.  Checked for every tile: each share is issued after the image's previous tenant was read for the last time, and has been
+    waited for -- with a barrier behind the wait -- before the tile's first read."""
+    issue, waited, reads = {}, {}, {}
+    for g in (0, 1):
+        # prologue (phase -1, both groups together): tile 0, and group 1's share of tile 1; waited for right there
+        issue[(0, g)] = waited[(0, g)] = -1
+        if g == 1 and nkt > 1:
+            issue[(1, 1)] = waited[(1, 1)] = -1
+        for t in range(nkt):
+            n_phase, m_phase = 2 * t + g, 2 * t + 1 + g
+            reads.setdefault(t, []).extend([n_phase, m_phase])
+            tb = t + 1 + g
+            if tb < nkt:
+                issue[(tb, g)] = n_phase       # in N_t
+                waited[(tb, g)] = m_phase      # s_waitcnt vmcnt(0) at the end of M_t, then the barrier that ends that phase
+    for t in range(nkt):
+        for g in (0, 1):
+            assert (t, g) in issue, f'nobody issues group {g}\'s share of tile {t}'
+            assert waited[(t, g)] < min(reads[t]), (t, g, waited[(t, g)], reads[t])            # landed before the first read
+            if t >= 3:
+                assert issue[(t, g)] > max(reads[t - 3]), (t, g, issue[(t, g)], reads[t - 3])  # the image was free
+    # both groups pass the same number of barriers: prologue 1 + (1 extra for group 1) + 2 per k-tile (+ 1 extra for group 0 at the end)
+    assert 1 + 0 + 2 * nkt + 1 == 1 + 1 + 2 * nkt + 0
+
+
+def test_tn_ws_producer_schedule():
+    """k_gemm_tn_ws (csrc/gemm_split.hip): 5 task-waves of a k-tile over 4 producer waves -- wave i always holds task-wave i, the fifth
+    rotates: tile T's is held by the producer with (i - T) % 4 == 0.  Every task-wave of every tile has exactly one owner, an owner loads
+    and stores a tile out of the same register set (even tiles a, odd tiles b), and a set is reloaded only after it was stored."""
+    for T in range(64):
+        owners = {tw: [] for tw in range(5)}
+        for i in range(4):
+            owners[i].append(i)
+            if (i - T) % 4 == 0:
+                owners[4].append(i)
+        assert all(len(v) == 1 for v in owners.values()), (T, owners)
+    # the unrolled loop: at position p of a group of four (compute works on tile t + p) the producers load tile t + p + 2 and store t + p + 1
+    for t in range(0, 40, 4):
+        live = {'a': t, 'b': t + 1}  # which tile each register set holds when the group starts (loaded, not yet stored: b; a was stored)
+        stored = {t}
+        for p in range(4):
+            ld, st = t + p + 2, t + p + 1
+            set_ld, set_st = 'ab'[ld & 1], 'ab'[st & 1]
+            assert live[set_st] == st and set_ld != set_st
+            assert live[set_ld] in stored, 'a register set is overwritten before its tile went to LDS'
+            live[set_ld] = ld
+            stored.add(st)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_xcd_partition_mirror(seed):
+    """Python twin of k_xcd_partition (csrc/graph_prep.hip) on adversarial degree profiles: the eight runs cover every 4-node block once,
+    none exceeds the cap the grids provide for, and where the cap does not bind the heaviest run stays within one block's work of an
+    eighth of the total."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(5, 70000))
+    kind = seed % 3
+    deg = (rng.integers(0, 30, N) if kind == 0 else np.where(np.arange(N) < N // 9, rng.integers(50, 200, N), 0) if kind == 1
+           else np.repeat(rng.integers(1, 12, N // 200 + 1), 200)[:N]) + 1
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    nbk, per = (N + 3) // 4, ((N + 3) // 4 + 7) // 8
+    cap = (per * 5 + 3) // 4
+    work = lambda nd: 4 * int(rowptr[nd]) - 3 * nd  # noqa: E731
+    W, base, prev = work(N), [0], 0
+    for k in range(1, 8):
+        target = (W * k + 7) // 8
+        lo, hi = 0, nbk
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if work(min(4 * mid, N)) >= target:
+                hi = mid
+            else:
+                lo = mid + 1
+        b = max(max(min(lo, prev + cap), nbk - (8 - k) * cap), prev)
+        base.append(b)
+        prev = b
+    base.append(nbk)
+    runs = [base[k + 1] - base[k] for k in range(8)]
+    assert sum(runs) == nbk and all(0 <= r <= cap for r in runs), (runs, cap)
+    loads = [work(min(4 * base[k + 1], N)) - work(min(4 * base[k], N)) for k in range(8)]
+    assert sum(loads) == W
+    if max(runs) < cap:  # the cap did not bind: every run ends within one block of its target
+        blk = max(work(min(4 * (b + 1), N)) - work(min(4 * b, N)) for b in range(nbk))
+        assert max(loads) <= W / 8 + blk, (loads, W / 8, blk)
