@@ -37,6 +37,18 @@ Extra objects on the JSON line:
   cpu_baseline the CPU oracle (reference formulation, torch CPU) on a bounded sample of the headline workload (B = 10 subgraphs =
                the reference's own mini-batch of 2 questions), fwd+bwd; `small_batch` is the GPU on that SAME batch size, so
                `speedup_vs_cpu_baseline_same_batch` compares like with like (the headline `value` is at B = 320).
+  optimizer    the fused multi-tensor RAdam of qagnn_amd.optimization_utils over the ~2.85 M decoder parameters (reference
+               utils/optimization_utils.py:31-97; qagnn.py:278), HIP events around `optimizer.step()`: `optimizer.ms_per_step`; and
+               `optimizer.reference_operating_point`: one optimiser step AS THE REFERENCE RUNS IT (run_qagnn__csqa.sh: bs = 64 questions
+               accumulated over 32 mini-batches of mbs = 2, qagnn.py:249-278) = 32 GraphedStep(accumulate=True) replays + RAdam.
+               Neither is part of `value` (the metric is the decoder's fwd+bwd).
+  configs[1]/edge_lists   the headline step fed the way north_star words the signature: int64 (edge_index [2, E], edge_type [E]) on
+               the device, graph orderings re-derived per batch (qagnn_graph_prep_blocked), eager launches.
+  configs[1]/with_lm      SURVEY 8d: the frozen LM encoder beside the decoder.  A randomly initialised RobertaConfig(hidden 1024, 24
+               layers, 16 heads) on stock PyTorch-ROCm (HF offline, no checkpoint), 320 sequences x 100 tokens (max_seq_len of
+               utils/parser_utils.py:58), timed separately (fp32 and under the reference's --fp16 autocast) and as one
+               LM_QAGNN.forward + loss + backward step with the encoder frozen (qagnn.py:240-247); `decoder_share` says what part
+               of that step the decoder still is.  Excluded from `value`.
   N > 1:       `comm_ms_per_step` (gradient all-reduce + logits all-gather, HIP events on the compute stream around the
                collectives), `rank_ms_per_step` (min / max over ranks of each rank's own time for the median region).
                `--global-batch Q` switches to STRONG scaling: one global batch of Q questions with skewed subgraph sizes, dealt out to
@@ -504,6 +516,143 @@ def secondary_config(name, wl, args, dev, timed):
     return out
 
 
+def optimizer_leg(model, b, wl, args, dev):
+    """Fused RAdam over the decoder's trainable tensors (reference utils/optimization_utils.py:31-97), and the reference's own
+    optimiser step: bs = 64 questions as 32 accumulated mini-batches of 2 questions (qagnn.py:249-278) + RAdam."""
+    from qagnn_amd.optimization_utils import RAdam
+    nc = wl['nc']
+    params = [p for p in model.parameters() if p.requires_grad]
+    step(model, b, nc, 1.0, params)  # leaves .grad on every trainable tensor
+    opt = RAdam(params, lr=1e-3)     # the reference's decoder learning rate (run_qagnn__csqa.sh: dlr 1e-3)
+    for _ in range(6):               # steps 1-5 take the SGD branch of the rectification (N_sma < 5), step 6 onward the Adam branch
+        opt.step()
+    ev = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        opt.step()
+        e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    opt_ms = sorted(a.elapsed_time(c) for a, c in ev)[len(ev) // 2]
+    out = dict(optimizer='RAdam (qagnn_amd.optimization_utils: qagnn_radam_step_f32, one fused multi-tensor launch per step count)',
+               tensors=len(params), parameters=sum(p.numel() for p in params), ms_per_step=round(opt_ms, 4),
+               timed_in='median of 20 optimizer.step() calls, HIP events on the launch stream; not part of `value`')
+    # -- the reference's operating point: 32 mini-batches of 2 questions accumulated, then one optimiser step
+    del opt
+    bs_q, mbs = 64, 2
+    small = to_device(make_batch(wl, mbs, seed=321, n_concept=args.n_concept), dev, True, nc)
+    m2 = build_model(MQ, wl, args.n_concept, p=args.dropout).to(dev)
+    fill_table(m2, args.n_concept)
+    m2.train()
+    p2 = [p for p in m2.parameters() if p.requires_grad]
+    opt2 = RAdam(p2, lr=1e-3)
+    gs = graphed.GraphedStep(m2, nc)
+
+    def opt_step():
+        opt2.zero_grad(set_to_none=True)
+        for _ in range(bs_q // mbs):  # (the same device-resident mini-batch 32 times: the metric is time, the inputs are refilled per replay)
+            gs(small['sent'], small['cids'], small['nt'], small['ns'], small['al'], small['adj'], small['labels'], mbs / bs_q, accumulate=True)
+        opt2.step()
+    for _ in range(2):
+        opt_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 4
+    for _ in range(reps):
+        opt_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out['reference_operating_point'] = dict(
+        what='one optimiser step as the reference runs it: bs = 64 questions = 32 accumulated mini-batches of mbs = 2 questions (10 subgraphs) '
+             'through GraphedStep(accumulate=True), then the fused RAdam step (run_qagnn__csqa.sh:16-17, qagnn.py:249-278); decoder only',
+        ms_per_optimizer_step=round(dt * 1e3, 3), ms_per_mini_batch=round(dt * 1e3 / (bs_q // mbs), 3),
+        value=round(bs_q * nc / dt, 1), unit='QA-subgraphs/s', hip_graph_captures=gs.n_graphs)
+    del m2, gs, opt2, small
+    torch.cuda.empty_cache()
+    return out
+
+
+class StockRobertaEncoder(torch.nn.Module):
+    """The reference's TextEncoder for a RoBERTa model (modeling/modeling_encoder.py:89-143) over a RANDOMLY INITIALISED HF RobertaModel
+    (no checkpoint offline): module(input_ids, token_type_ids, attention_mask) with all hidden states, sent_vecs = pooler(hidden[layer_id])."""
+
+    def __init__(self, hidden=1024, layers=24, heads=16, dev=None):
+        super().__init__()
+        from transformers import RobertaConfig, RobertaModel
+        cfg = RobertaConfig(vocab_size=50265, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=4 * hidden,
+                            max_position_embeddings=514, type_vocab_size=1, output_hidden_states=True)
+        with torch.device(dev if dev is not None else 'cpu'):
+            self.module = RobertaModel(cfg, add_pooling_layer=True)
+        self.sent_dim = hidden
+
+    def forward(self, input_ids, attention_mask, token_type_ids, output_mask, layer_id=-1):
+        outputs = self.module(input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask)
+        all_hidden_states = outputs.hidden_states
+        return self.module.pooler(all_hidden_states[layer_id]), all_hidden_states
+
+
+def with_lm_leg(wl, args, dev, decoder_ms, seq_len=100):
+    """the frozen LM encoder timed beside the decoder (stock PyTorch-ROCm, random init), and one LM_QAGNN step."""
+    nc, n, q = wl['nc'], wl['n'], wl['questions']
+    B = q * nc
+    try:
+        enc = StockRobertaEncoder(dev=dev)
+    except Exception as e:  # noqa: BLE001 -- transformers missing / changed: the decoder line must not depend on it
+        return dict(error=f'{type(e).__name__}: {str(e)[:200]}')
+    for p in enc.parameters():
+        p.requires_grad_(False)  # freeze_net (qagnn.py:240-243): the encoder is frozen for the first `unfreeze_epoch` epochs
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 50000, (q, nc, seq_len), generator=g).to(dev)
+    lens = torch.randint(20, seq_len + 1, (q, nc, 1), generator=g)
+    am = (torch.arange(seq_len).view(1, 1, -1) < lens).long().to(dev)
+    tt, om = torch.zeros_like(ids), (1 - am).bool()
+    host = make_batch(wl, q, seed=1000, n_concept=args.n_concept)
+    b = to_device(host, dev, True, nc)
+    model = MQ.LM_QAGNN(None, 'roberta-large', K_LAYERS, N_NTYPE, wl['n_etype'], args.n_concept, D, wl['concept_in'], 2, 200, 0,
+                        args.dropout, args.dropout, args.dropout, pretrained_concept_emb=None, freeze_ent_emb=True, init_range=0.02, encoder=enc).to(dev)
+    model.train()  # the reference trains the whole LM_QAGNN in train mode (encoder dropout active) whether or not the encoder is frozen
+    params = [p for p in model.decoder.parameters() if p.requires_grad]
+    lm = (ids, am, tt, om)
+    graph_in = (b['cids'].view(q, nc, n), b['nt'].view(q, nc, n), b['ns'].view(q, nc, n, 1), b['al'].view(q, nc))
+
+    def ms_of(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    flat = [x.reshape(B, seq_len) for x in lm]
+    enc32 = ms_of(lambda: enc(*flat), 3)
+    with torch.autocast('cuda', dtype=torch.float16):
+        enc16 = ms_of(lambda: enc(*flat), 5)
+
+    def full_step():
+        for p in params:
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.float16):  # the reference's --fp16 mode (qagnn.py:254-257); the GNN stack stays fp32
+            logits, _ = model(*lm, *graph_in, b['adj'], None)
+            loss = torch.nn.functional.cross_entropy(logits.float(), b['labels'])
+        loss.backward()
+    step16 = ms_of(full_step, 5)
+    n_enc = sum(p.numel() for p in enc.parameters())
+    del model, enc, b
+    torch.cuda.empty_cache()
+    return dict(encoder=f'RobertaConfig(hidden 1024, 24 layers, 16 heads), {n_enc / 1e6:.0f} M parameters, RANDOM init (no checkpoint offline), frozen, '
+                        'train mode, stock PyTorch-ROCm', sequences=B, seq_len=seq_len,
+                encoder_fwd_ms_fp32=round(enc32, 2), encoder_fwd_ms_autocast_fp16=round(enc16, 2),
+                lm_qagnn_step_ms_autocast_fp16=round(step16, 2), decoder_ms_per_step=round(decoder_ms, 3),
+                decoder_share_of_lm_qagnn_step=round(decoder_ms / step16, 4) if step16 > 0 else None,
+                decoder_share_beside_fp32_encoder=round(decoder_ms / (decoder_ms + enc32), 4),
+                what='LM_QAGNN.forward (encoder forward, frozen + QAGNN decoder) + cross-entropy + backward into the decoder, under the reference\'s '
+                     '--fp16 autocast; the encoder is outside `value` (north_star: the LM stays on stock PyTorch-ROCm)',
+                value_with_lm=round(B / (step16 * 1e-3), 1) if step16 > 0 else None, unit='QA-subgraphs/s')
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -757,9 +906,23 @@ def main():
             else:
                 out['cpu_baseline'] = None
             if not args.no_configs:
+                try:
+                    out['optimizer'] = optimizer_leg(model, b, wl, args, dev)
+                except Exception as e:  # noqa: BLE001
+                    out['optimizer'] = dict(error=f'{type(e).__name__}: {str(e)[:300]}')
                 del model, b, run, run_eager, gs
                 torch.cuda.empty_cache()
                 out['configs'] = {name: secondary_config(name, w, args, dev, timed) for name, w in WORKLOADS.items() if name != HEADLINE}
+                if not args.edge_lists:
+                    # the reference protocol on the same line: int64 (edge_index, edge_type), orderings re-derived per batch, eager launches
+                    el_args = argparse.Namespace(**dict(vars(args), edge_lists=True))
+                    out['configs']['configs[1]/edge_lists'] = secondary_config('configs[1]/edge_lists', dict(
+                        wl, n_concept=args.n_concept, what=wl['what'] + '; graph fed as int64 (edge_index [2, E], edge_type [E]) on the device (the '
+                        'reference protocol, modeling_qagnn.py:224-228,244-251), graph orderings derived per batch'), el_args, dev, timed)
+                try:
+                    out['configs']['configs[1]/with_lm'] = with_lm_leg(wl, args, dev, dt / args.steps * 1e3)
+                except Exception as e:  # noqa: BLE001
+                    out['configs']['configs[1]/with_lm'] = dict(error=f'{type(e).__name__}: {str(e)[:300]}')
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -281,12 +281,18 @@ class QAGNN_Message_Passing(nn.Module):
         self.activation = GELU()
         self.dropout = nn.Dropout(dropout)
         self.dropout_rate = dropout
+        # tests only: layer_dropout(l, X) -> X' stands in for the F.dropout of hop l, so that a parity test can replay the KEEP MASKS the
+        # HIP kernels drew (a counter hash, recomputed on the host) instead of torch's generator (tests/helpers.py: install_keep_masks)
+        self.layer_dropout = None
 
     def mp_helper(self, _X, edge_index, edge_type, _node_type, _node_feature_extra):
         for l in range(self.k):  # :45-50
             _X = self.gnn_layers[l](_X, edge_index, edge_type, _node_type, _node_feature_extra)
             _X = self.activation(_X)
-            _X = F.dropout(_X, self.dropout_rate, training=self.training)
+            if self.layer_dropout is not None:
+                _X = self.layer_dropout(l, _X)
+            else:
+                _X = F.dropout(_X, self.dropout_rate, training=self.training)
         return _X
 
     def forward(self, H, A, node_type, node_score, cache_output=False):

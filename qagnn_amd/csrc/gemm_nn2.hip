@@ -859,8 +859,11 @@ static std::vector<PrepackEntry> g_prepack;
 
 const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No) {
   std::lock_guard<std::mutex> lk(g_prepack_mu);
-  for (const PrepackEntry& e : g_prepack)
+  // newest registration first: should an owner ever leave stale entries behind, a live one for the same address wins
+  for (size_t i = g_prepack.size(); i-- > 0;) {
+    const PrepackEntry& e = g_prepack[i];
     if (e.B1n == B1n && e.K1 == K1 && e.No == No && e.ldn1 == ldn1 && e.K2 == K2 && (K2 == 0 || (e.B2n == B2n && e.ldn2 == ldn2))) return e.pk;
+  }
   return nullptr;
 }
 
@@ -887,10 +890,10 @@ extern "C" int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t
 
 extern "C" int qagnn_gemm_nn_prepack_clear(int64_t tag) {
   std::lock_guard<std::mutex> lk(g_prepack_mu);
-  for (size_t i = 0; i < g_prepack.size();) {
-    if (tag == 0 || g_prepack[i].tag == tag) { g_prepack[i] = g_prepack.back(); g_prepack.pop_back(); }
-    else ++i;
-  }
+  size_t keep = 0;  // (stable: the lookup walks the registry newest first)
+  for (size_t i = 0; i < g_prepack.size(); ++i)
+    if (!(tag == 0 || g_prepack[i].tag == tag)) g_prepack[keep++] = g_prepack[i];
+  g_prepack.resize(keep);
   return QAGNN_OK;
 }
 

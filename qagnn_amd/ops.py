@@ -198,8 +198,10 @@ class GatherPlan:
         lim = getattr(K, 'GATHER_MAX', 0)
         if self.n_sources > lim or len(self.slices) > lim:
             return None
-        t0 = next((t for t in tensors if t is not None), None)
-        return K if t0 is not None and t0.dtype == torch.float32 and (t0.is_cuda or K.name != 'hip') else None
+        ts = [t for t in tensors if t is not None]
+        if not ts or any(t.dtype != torch.float32 or t.device != ts[0].device for t in ts):
+            return None  # mixed dtypes / devices (autocast, a half-precision parameter): the cat + index_select path promotes, the kernel cannot
+        return K if (ts[0].is_cuda or K.name != 'hip') else None
 
     def __call__(self, sources, build):
         sig = tuple((tuple(t.shape), str(t.device), t.dtype) for t in sources)
@@ -391,15 +393,29 @@ PREPACK = _os.environ.get('QAGNN_PREPACK', '1') == '1'
 PREPACK_MIN_ROWS = int(_os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))
 
 
+_PREPACK_STATE = None  # weakref.WeakKeyDictionary: owner module -> [registry tag, what must stay alive until the next forward]
+_prepack_tags = [0]
+
+
 def prepack_weights(owner, pairs, rows):
-    """pairs = [(B1n, B2n or None), ...] in their [No, K] layouts, as the products of this forward (and its backward) will pass them."""
+    """pairs = [(B1n, B2n or None), ...] in their [No, K] layouts, as the products of this forward (and its backward) will pass them.
+
+    The per-owner state (registry tag, packed buffer, pinned weights) lives OUTSIDE the module, keyed weakly by the owner object: a
+    copy.deepcopy / pickle of the model carries none of it, a copy registers under a tag of its own on its first forward, and the tag
+    is cleared when its owner is collected (the tag is a process-wide counter -- id() values are recycled, a counter is not)."""
+    global _PREPACK_STATE
     K = kernels()
     if not (PREPACK and rows >= PREPACK_MIN_ROWS and pairs and pairs[0][0].is_cuda and hasattr(K, 'prepack')):
         return
-    owner._qagnn_prepacked = K.prepack(pairs, id(owner))  # (replaces, and thereby releases, what the previous forward registered)
-    if not getattr(owner, '_qagnn_prepack_finalizer', None):
-        import weakref
-        owner._qagnn_prepack_finalizer = weakref.finalize(owner, K.prepack_clear, id(owner))
+    import weakref
+    if _PREPACK_STATE is None:
+        _PREPACK_STATE = weakref.WeakKeyDictionary()
+    st = _PREPACK_STATE.get(owner)
+    if st is None:
+        _prepack_tags[0] += 1
+        st = _PREPACK_STATE[owner] = [(1 << 62) | _prepack_tags[0], None]
+        weakref.finalize(owner, K.prepack_clear, st[0])
+    st[1] = K.prepack(pairs, st[0])  # (replaces, and thereby releases, what the previous forward registered)
 
 
 class GradAcc:
@@ -1025,7 +1041,8 @@ class HeadFn(torch.autograd.Function):
 def head_supported(nh, dv, width, n):
     K = kernels()
     lim = getattr(K, 'HEAD_LIMITS', None)
-    return (HEAD_FUSED and lim is not None and nh <= lim[0] and nh * dv <= lim[1] and width <= lim[2] and width % 4 == 0
+    # (k_head_post_{fwd,bwd} index the GNN output as H_HEADS = 4 groups of width / 4 floats: the head-padded layout of HeadLayout)
+    return (HEAD_FUSED and lim is not None and H_HEADS == 4 and nh <= lim[0] and nh * dv <= lim[1] and width <= lim[2] and width % 4 == 0
             and pool_attention_supported(nh, width, n))
 
 

@@ -266,6 +266,206 @@ def load_golden(name):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Dropout parity: the keep masks of the HIP kernels, replayed on the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+# Every dropout site of the HIP path draws its mask from a counter hash uniform01(seed, element index) (csrc/common.h; numpy twin below)
+# with a seed from ops.next_seed().  A test records the seeds of one forward, recomputes the masks on the host and installs them in the
+# oracle in place of torch's generator-driven dropout: the oracle then computes the SAME function as the train-mode HIP step with
+# p > 0, and logits / gradients can be compared at the usual bars (reference sites: modeling_qagnn.py:45-50, 92-93, 156, 187,
+# utils/layers.py:297, 369).
+def uniform01(seed, idx):
+    """numpy twin of uniform01() in csrc/common.h (splitmix64 finaliser over seed + (idx + 1) * golden ratio)."""
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed % (1 << 64)) + (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def keep_mask(seed, shape, p):
+    """bool tensor `shape`: element i (flat, row-major) is KEPT iff uniform01(seed, i) >= p (the kernels drop on `< p`)."""
+    n = int(np.prod(shape))
+    return torch.from_numpy(uniform01(seed, np.arange(n, dtype=np.uint64)) >= np.float32(p)).view(*shape)
+
+
+class SeedRecorder:
+    """Context manager: records every seed qagnn_amd.ops.next_seed() hands out (in call order)."""
+
+    def __enter__(self):
+        from qagnn_amd import ops
+        self.ops, self.orig, self.seeds = ops, ops.next_seed, []
+
+        def rec():
+            s = self.orig()
+            self.seeds.append(s)
+            return s
+        ops.next_seed = rec
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.next_seed = self.orig
+        return False
+
+
+class MaskDropout(torch.nn.Module):
+    """x -> x * keep / (1 - p) with a fixed keep mask (the dropout of one site of one recorded forward)."""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.keep, self.p = keep, p
+
+    def forward(self, x):
+        return x * self.keep.to(x.dtype).view_as(x) * (1.0 / (1.0 - self.p))
+
+
+def hip_keep_masks(seeds, k, B, n, d, sent_dim, nh, ps):
+    """The keep masks of one recorded QAGNN.forward of the package (fused input stage, fused head: 1 + k + 1 + 3 seeds in call order:
+    dropout_e, the k hops, the stack's output dropout, pooling attention, pooling output, dropout_fc) in the ORACLE's dense layouts.
+    ps = dict(p_emb, p_gnn, p_fc, p_attn, p_pool)."""
+    from qagnn_amd import ops
+    assert len(seeds) == k + 5, f'{len(seeds)} dropout seeds recorded, expected {k + 5} (fused input stage + fused head, every p > 0)'
+    L = ops.HeadLayout(d, 'cpu')
+    N = B * n
+
+    def rows(seed, p):  # a [N, DP] site of the head-padded layout -> the dense [N, d] mask
+        return keep_mask(seed, (N, L.DP), p)[:, L.dense_pos]
+    out = {'e': rows(seeds[0], ps['p_emb']).view(B, n, d),
+           'gnn': [rows(seeds[1 + l], ps['p_gnn']) for l in range(k)],
+           'out': rows(seeds[1 + k], ps['p_gnn']).view(B, n, d)}
+    attn = keep_mask(seeds[2 + k], (B, nh, n), ps['p_attn'])                     # kernel order [b, h, l]
+    out['attn'] = attn.transpose(0, 1).reshape(nh * B, n)                        # the reference's [h * bs + b, l] (utils/layers.py:354-360)
+    out['pool'] = keep_mask(seeds[3 + k], (B, d), ps['p_pool'])                  # [b, h * dv + j]
+    out['fc'] = keep_mask(seeds[4 + k], (B, d + sent_dim + d), ps['p_fc'])       # [graph_vecs | sent_vecs | Z_vecs]
+    return out
+
+
+def install_keep_masks(omodel, masks, ps):
+    """Put fixed-mask dropouts at the six dropout sites of an oracle QAGNN (any dtype)."""
+    omodel.dropout_e = MaskDropout(masks['e'], ps['p_emb'])
+    omodel.gnn.dropout = MaskDropout(masks['out'], ps['p_gnn'])
+    per_layer = [MaskDropout(m, ps['p_gnn']) for m in masks['gnn']]
+    omodel.gnn.layer_dropout = lambda l, x: per_layer[l](x)
+    omodel.pooler.attention.dropout = MaskDropout(masks['attn'], ps['p_attn'])
+    omodel.pooler.dropout = MaskDropout(masks['pool'], ps['p_pool'])
+    omodel.dropout_fc = MaskDropout(masks['fc'], ps['p_fc'])
+    return omodel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ReLU kinks at bench size: the candidate's subgradient choice, replayed on the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+# Every GATConvE.mlp (and the shared edge encoder) is Linear -> BatchNorm -> ReLU -> Linear.  At 320 subgraphs a forward has 64 M
+# BatchNorm outputs per layer stack; a few dozen lie within fp32 rounding of 0, two correct fp32 implementations put a handful of
+# them on different sides, and ONE flipped mask moves every gradient upstream of it by up to 1e-2 of its scale.  Measured on the
+# 256-subgraph OpenBookQA-shaped batch (float64 oracle against the fp32 oracle, same weights): median 5.9e-3 / worst 2.5e-2 of scale with
+# each run's own masks, median 3.6e-4 / worst 1.2e-3 once the float64 run uses the fp32 run's ReLU masks -- the whole "ill-conditioning"
+# is the subgradient choice at the kink, nothing else.  So the bench-size parity test does not widen its bars by yardsticks: it records
+# the BatchNorm outputs the HIP forward fed to its ReLUs (PreActRecorder), and the oracle takes the HIP side's mask on exactly those
+# elements where ITS OWN BatchNorm output is within KINK_ALIGN_TAU of 0 (AlignedReLU).  Everywhere else the two masks must agree -- that
+# is asserted, element by element -- and every gradient is then held to a fixed bar.
+KINK_ALIGN_TAU = 5e-5
+
+
+class PreActRecorder:
+    """Kernel-provider proxy (ops.set_kernels): keeps, in call order, the ReLU inputs relu(h1 * scale + shift) of one forward --
+    the shared edge encoder on the C edge-class rows first, then the k hops -- as dense [rows, d] fp32 CPU tensors.  Sees the composed
+    per-kernel path (the second Linear's gemm_nn carries h1 and the BatchNorm scale / shift as its operand prologue) and the natively
+    sequenced hop / stack (their saved tensors hold h1 and the statistics)."""
+
+    def __init__(self, inner, d):
+        from qagnn_amd import ops
+        self._inner, self.name = inner, inner.name
+        self._pos = ops.HeadLayout(d, 'cpu').dense_pos
+        self.pre = []
+
+    def _keep(self, h1, scale, shift):
+        pre = torch.addcmul(shift, h1, scale)  # the kernels' fmaf(x, scale, shift)
+        self.pre.append(pre.detach().cpu()[:, self._pos].contiguous())
+
+    def __getattr__(self, attr):
+        fn = getattr(self._inner, attr)
+        if attr == 'gemm_nn':
+            def gemm_nn(*a, **kw):
+                if kw.get('a_scale') is not None:
+                    self._keep(a[0], kw['a_scale'], kw['a_shift'])
+                return fn(*a, **kw)
+            return gemm_nn
+        if attr == 'hop_fwd':
+            def hop_fwd(*a, **kw):
+                y, saved = fn(*a, **kw)
+                self._keep(saved[3], saved[5][3], saved[5][4])
+                return y, saved
+            return hop_fwd
+        if attr == 'stack_fwd':
+            def stack_fwd(*a, **kw):
+                y, saved = fn(*a, **kw)
+                if len(saved) == 4 and saved[2].dim() == 4:  # libqagnn_hip: (KMQ, aa, rows [k, 4, N, DP] = aggr | h1 | out | y, stats [k, 5, DP])
+                    rows, stats = saved[2], saved[3]
+                    for l in range(rows.size(0)):
+                        self._keep(rows[l, 1], stats[l, 3], stats[l, 4])
+                else:  # the torch emulation: the composed hops' six saved tensors each, then the hop inputs
+                    for l in range(len(saved) // 7):
+                        sv = saved[6 * l:6 * l + 6]
+                        self._keep(sv[3], sv[5][3], sv[5][4])
+                return y, saved
+            return stack_fwd
+        return fn
+
+
+def edge_class_ids(edge_index, edge_type, node_type_flat, n_etype, n_ntype):
+    """Class of every row of the reference's edge-encoder input (modeling_qagnn.py:419-433: the E edges in the caller's order, then one
+    self loop per node row): etype * T^2 + type(src) * T + type(tgt); self loops R * T^2 + own type (qagnn_amd.modeling_qagnn
+    ._edge_class_features)."""
+    T, R = n_ntype, n_etype
+    nt = node_type_flat.reshape(-1)
+    real = edge_type * T * T + nt[edge_index[0]] * T + nt[edge_index[1]]
+    return torch.cat([real, R * T * T + nt])
+
+
+class AlignedReLU(torch.nn.Module):
+    """relu(x) whose 0/1 mask is the candidate's on the elements with |x| < tau, and which counts where the masks differ elsewhere.
+    `pre`: the candidate's ReLU input, [rows, d] (or [C, d] with `rows_of` = the class of every row)."""
+
+    def __init__(self, pre, tau=KINK_ALIGN_TAU, rows_of=None):
+        super().__init__()
+        self.pre, self.tau, self.rows_of = pre, tau, rows_of
+        self.calls = self.aligned = self.outside = 0
+        self.worst_outside = 0.0
+        self.max_dev = 0.0
+
+    def forward(self, x):
+        xd = x.detach()
+        cand = self.pre if self.rows_of is None else self.pre.index_select(0, self.rows_of)
+        own, theirs = xd > 0, cand.view_as(xd) > 0
+        near = xd.abs() < self.tau
+        differ = own != theirs
+        if self.calls == 0:  # (the shared edge encoder sees the same input on every call)
+            self.aligned = int((differ & near).sum())
+            out = differ & ~near
+            self.outside = int(out.sum())
+            self.worst_outside = float(xd.abs()[out].max()) if self.outside else 0.0
+            self.max_dev = float((xd.double() - cand.view_as(xd).double()).abs().max())
+        self.calls += 1
+        return x * torch.where(near, theirs, own).to(x.dtype)
+
+
+def install_aligned_relus(omodel, pre, edge_rows_of):
+    """pre = PreActRecorder.pre of the candidate's forward (edge encoder first, then the hops) -> the AlignedReLU modules installed in
+    an oracle QAGNN's Linear-BN-ReLU-Linear blocks, same order."""
+    gnn = omodel.gnn
+    assert len(pre) == 1 + len(gnn.gnn_layers), f'{len(pre)} ReLU inputs recorded for {len(gnn.gnn_layers)} hops + the edge encoder'
+    mods = [AlignedReLU(pre[0], rows_of=edge_rows_of)]
+    assert isinstance(gnn.edge_encoder[2], (torch.nn.ReLU, AlignedReLU))
+    gnn.edge_encoder[2] = mods[0]
+    for l, layer in enumerate(gnn.gnn_layers):
+        assert layer.edge_encoder is gnn.edge_encoder and isinstance(layer.mlp[2], (torch.nn.ReLU, AlignedReLU))
+        mods.append(AlignedReLU(pre[1 + l]))
+        layer.mlp[2] = mods[-1]
+    return mods
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # float64 yardstick for gradients
 # ---------------------------------------------------------------------------------------------------------------------
 def build_oracle(case):
@@ -394,8 +594,9 @@ class F64Ref:
     `case`: a GOLDEN_CASES name, or a case dict with `inputs` = (sent_vecs, concept_ids, node_type_ids, node_scores,
     adj_lengths, edge_index, edge_type)."""
 
-    def __init__(self, case, section, inputs=None):
+    def __init__(self, case, section, inputs=None, prepare=None):
         from oracle import qagnn_oracle as O
+        self.prepare = prepare  # callable(oracle model): e.g. install_keep_masks for a dropout-parity run (applied to every model built here)
         self.c = c = GOLDEN_CASES[case] if isinstance(case, str) else case
         self.section = section
         if inputs is None:
@@ -404,6 +605,8 @@ class F64Ref:
         self.mp_in = mp_inputs(c)  # drawn under the fp32 default dtype: the same numbers for every run
         self.state = _KinkState()
         model = build_oracle(c).double()  # weights are drawn in fp32, then widened
+        if prepare is not None:
+            prepare(model)
         if section == 'layergrad':
             layer = model.gnn.gnn_layers[0]
             self.sites = [(layer.edge_encoder, 'edge_encoder.1.bias'), (layer.mlp, 'mlp.1.bias')]
@@ -465,6 +668,8 @@ class F64Ref:
     def oracle32(self):
         """Gradients (and forward outputs) of the fp32 oracle on the same inputs."""
         model = build_oracle(self.c)
+        if self.prepare is not None:
+            self.prepare(model)
         loss, params, extra = self._forward(model, torch.float32)
         names = list(params.keys())
         gs = torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)

@@ -378,6 +378,45 @@ def test_gpu_parity_harness_on_cpu(train):
     assert len(report) > 20 and max(report.values()) < 1e-3
 
 
+def test_dropout_parity_harness_on_cpu():
+    """The mask-replay harness of tests/test_hip_parity.py (dropout 0.2 / 0.1 on the package side, the kernels' keep masks recomputed on
+    the host and installed in the oracle) with the torch emulation of the kernels, whose dropout is the same counter hash."""
+    import test_hip_parity as T
+    case = dict(shape='tiny', nq=3, nc=4, n=37, n_rel=17, std=0.6, train=True, seed=33,
+                cfg=helpers.model_cfg(d=100, k=3, sent_dim=40, n_concept=500, concept_in_dim=32))
+    report = T.oracle_vs_package(case, device='cpu', dropout=T.RUN_SCRIPT_DROPOUT)
+    assert len(report) > 20 and max(report.values()) < 1e-3
+    # and the harness notices a wrong mask: with the seeds of the sites swapped the oracle computes a different function
+    with pytest.raises(AssertionError):
+        orig = helpers.hip_keep_masks
+        try:
+            helpers.hip_keep_masks = lambda seeds, *a, **kw: orig(seeds[::-1], *a, **kw)
+            T.oracle_vs_package(case, device='cpu', dropout=T.RUN_SCRIPT_DROPOUT)
+        finally:
+            helpers.hip_keep_masks = orig
+
+
+@pytest.mark.parametrize('variant', ['default', 'dropout'])
+def test_bench_size_harness_on_cpu(variant, monkeypatch):
+    """The bench-size harness of tests/test_hip_parity.py (the candidate's ReLU masks replayed on the oracle inside the kink band and
+    asserted equal outside it, dropout keep masks replayed, fixed bars) on 2 questions of the CSQA workload with the torch emulation."""
+    import test_hip_parity as T
+    out = T.bench_size_step_vs_oracle(variant, 'configs1_csqa_320', device='cpu', B_override=2)
+    assert len(out['kinks']) == 6 and all(k['outside'] == 0 for k in out['kinks'])
+    assert max(out['rel'].values()) < 1e-3
+    # a candidate whose ReLU input is wrong far from the kink is caught by the mask comparison, not hidden by the alignment
+    orig = helpers.PreActRecorder._keep
+
+    def bad(self, h1, scale, shift):
+        orig(self, h1, scale, shift)
+        if len(self.pre) == 3:
+            self.pre[-1][5, 7] = -self.pre[-1][5, 7].sign() * 0.3
+    monkeypatch.setattr(helpers.PreActRecorder, '_keep', bad)
+    T._BENCH_ORACLE.clear()
+    with pytest.raises(AssertionError, match='OUTSIDE the kink band'):
+        T.bench_size_step_vs_oracle(variant, 'configs1_csqa_320', device='cpu', B_override=2)
+
+
 def test_model_accepts_a_packed_blob_batch():
     """QAGNN.forward / LM_QAGNN.forward with the graph as a PackedGraphBatch of load-time blobs == with (edge_index, edge_type)."""
     from qagnn_amd import data_utils
