@@ -189,6 +189,12 @@ PY
       done
       python scripts/pmc_edge_counters.py $files > gpurun_out/edge_counters.txt 2>&1
       stamp edgepmc ;;
+    profreplay)   # kernel trace of the REPLAYED step (one hipGraph launch per step): busy time and gaps of the step as bench.py times it
+      rm -rf /tmp/profrp; mkdir -p /tmp/profrp gpurun_out/prof
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profrp -o r5 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 1 --no-cpu-baseline --no-pmc --no-configs ) > gpurun_out/profreplay.log 2>&1
+      python scripts/trace_by_shape.py "$(find /tmp/profrp -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape_replay.txt 2>&1
+      tail -n 4 gpurun_out/profreplay.log > /tmp/x && mv /tmp/x gpurun_out/profreplay.log
+      stamp profreplay ;;
     cmd:*)
       c="${arg#cmd:}"
       bash -c "$c" > gpurun_out/cmd.log 2>&1; echo "cmd exit $?" >> gpurun_out/summary.txt; stamp "cmd" ;;

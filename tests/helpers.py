@@ -360,18 +360,25 @@ def install_keep_masks(omodel, masks, ps):
 # them on different sides, and ONE flipped mask moves every gradient upstream of it by up to 1e-2 of its scale.  Measured on the
 # 256-subgraph OpenBookQA-shaped batch (float64 oracle against the fp32 oracle, same weights): median 5.9e-3 / worst 2.5e-2 of scale with
 # each run's own masks, median 3.6e-4 / worst 1.2e-3 once the float64 run uses the fp32 run's ReLU masks -- the whole "ill-conditioning"
-# is the subgradient choice at the kink, nothing else.  So the bench-size parity test does not widen its bars by yardsticks: it records
-# the BatchNorm outputs the HIP forward fed to its ReLUs (PreActRecorder), and the oracle takes the HIP side's mask on exactly those
-# elements where ITS OWN BatchNorm output is within KINK_ALIGN_TAU of 0 (AlignedReLU).  Everywhere else the two masks must agree -- that
-# is asserted, element by element -- and every gradient is then held to a fixed bar.
-KINK_ALIGN_TAU = 5e-5
+# is the subgradient choice at the kink, nothing else.  So the bench-size parity test does not widen its bars by yardsticks.  It records
+# what the HIP forward fed to its ReLUs (PreActRecorder: the BatchNorm output x = h1 * scale + shift of every element) and the oracle's
+# ReLUs (AlignedReLU)
+#   * check the hidden BatchNorm outputs of EVERY node row of every layer against the HIP values: the root-mean-square deviation of a row,
+#     rms_c(x_oracle[r, c] - x_hip[r, c]), must stay below HIDDEN_RTOL of the row's own scale s(r) = rms_c(x_oracle[r, :]) + 1 (1 = the
+#     scale of a BatchNorm output) -- a forward parity statement on all 64 000 rows of all hops, not only on the logits; measured on
+#     MI355X: <= 3.9e-5 at every site of every workload -- and
+#   * take the HIP side's 0/1 mask where the two signs differ AND the oracle's own value lies in the rounding band of the kink,
+#     |x_oracle| <= KINK_BAND * s(r) (measured: every element whose sign differed lay within 9e-5 s(r); 30-120 elements per hop, and
+#     one whole edge class = ~9 000 identical rows of the edge encoder).  A sign difference outside the band is counted and fails the test.
+# Every gradient is then held to a fixed bar.
+HIDDEN_RTOL = 5e-4
+KINK_BAND = 5e-4
 
 
 class PreActRecorder:
-    """Kernel-provider proxy (ops.set_kernels): keeps, in call order, the ReLU inputs relu(h1 * scale + shift) of one forward --
-    the shared edge encoder on the C edge-class rows first, then the k hops -- as dense [rows, d] fp32 CPU tensors.  Sees the composed
-    per-kernel path (the second Linear's gemm_nn carries h1 and the BatchNorm scale / shift as its operand prologue) and the natively
-    sequenced hop / stack (their saved tensors hold h1 and the statistics)."""
+    """Kernel-provider proxy (ops.set_kernels): keeps, in call order, the ReLU inputs of one forward -- the shared edge encoder on the
+    C edge-class rows first, then the k hops -- as dense [rows, d] fp32 CPU tensors `pre` = h1 * scale + shift.  Sees the composed per-kernel path (the second Linear's gemm_nn carries h1 and the BatchNorm scale / shift
+    as its operand prologue) and the natively sequenced hop / stack (their saved tensors hold h1 and the statistics)."""
 
     def __init__(self, inner, d):
         from qagnn_amd import ops
@@ -380,8 +387,7 @@ class PreActRecorder:
         self.pre = []
 
     def _keep(self, h1, scale, shift):
-        pre = torch.addcmul(shift, h1, scale)  # the kernels' fmaf(x, scale, shift)
-        self.pre.append(pre.detach().cpu()[:, self._pos].contiguous())
+        self.pre.append(torch.addcmul(shift, h1, scale).detach().cpu()[:, self._pos].contiguous())
 
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
@@ -424,35 +430,38 @@ def edge_class_ids(edge_index, edge_type, node_type_flat, n_etype, n_ntype):
 
 
 class AlignedReLU(torch.nn.Module):
-    """relu(x) whose 0/1 mask is the candidate's on the elements with |x| < tau, and which counts where the masks differ elsewhere.
-    `pre`: the candidate's ReLU input, [rows, d] (or [C, d] with `rows_of` = the class of every row)."""
+    """relu(x) that checks x against the candidate's ReLU input row by row and takes the candidate's 0/1 mask where the signs differ
+    inside the rounding band of the kink (see above).  `pre`: [rows, d], or [C, d] with `rows_of` = the class of every row."""
 
-    def __init__(self, pre, tau=KINK_ALIGN_TAU, rows_of=None):
+    def __init__(self, pre, rows_of=None):
         super().__init__()
-        self.pre, self.tau, self.rows_of = pre, tau, rows_of
+        self.pre, self.rows_of = pre, rows_of
         self.calls = self.aligned = self.outside = 0
-        self.worst_outside = 0.0
-        self.max_dev = 0.0
+        self.row_dev = self.flip_sigmas = self.flip_of_scale = 0.0
 
     def forward(self, x):
         xd = x.detach()
-        cand = self.pre if self.rows_of is None else self.pre.index_select(0, self.rows_of)
-        own, theirs = xd > 0, cand.view_as(xd) > 0
-        near = xd.abs() < self.tau
+        cand = (self.pre if self.rows_of is None else self.pre.index_select(0, self.rows_of)).view_as(xd).to(xd.dtype)
+        own, theirs = xd > 0, cand > 0
         differ = own != theirs
+        dev = (xd - cand).abs()
+        rdev = dev.pow(2).mean(1, keepdim=True).sqrt()                      # the row's HIP-vs-oracle noise level
+        rscale = xd.pow(2).mean(1, keepdim=True).sqrt() + 1.0             # the row's scale (BatchNorm outputs are O(1) per column)
+        ok = xd.abs() <= KINK_BAND * rscale
         if self.calls == 0:  # (the shared edge encoder sees the same input on every call)
-            self.aligned = int((differ & near).sum())
-            out = differ & ~near
-            self.outside = int(out.sum())
-            self.worst_outside = float(xd.abs()[out].max()) if self.outside else 0.0
-            self.max_dev = float((xd.double() - cand.view_as(xd).double()).abs().max())
+            self.row_dev = float((rdev / rscale).max())
+            self.aligned = int((differ & ok).sum())
+            self.outside = int((differ & ~ok).sum())
+            if bool(differ.any()):
+                self.flip_sigmas = float((dev / (rdev + 1e-30))[differ].max())
+                self.flip_of_scale = float((xd.abs() / rscale)[differ].max())
         self.calls += 1
-        return x * torch.where(near, theirs, own).to(x.dtype)
+        return x * torch.where(differ & ok, theirs, own).to(x.dtype)
 
 
 def install_aligned_relus(omodel, pre, edge_rows_of):
-    """pre = PreActRecorder.pre of the candidate's forward (edge encoder first, then the hops) -> the AlignedReLU modules installed in
-    an oracle QAGNN's Linear-BN-ReLU-Linear blocks, same order."""
+    """pre = PreActRecorder.pre of the candidate's forward (edge encoder first, then the hops) -> the AlignedReLU modules
+    installed in an oracle QAGNN's Linear-BN-ReLU-Linear blocks, same order."""
     gnn = omodel.gnn
     assert len(pre) == 1 + len(gnn.gnn_layers), f'{len(pre)} ReLU inputs recorded for {len(gnn.gnn_layers)} hops + the edge encoder'
     mods = [AlignedReLU(pre[0], rows_of=edge_rows_of)]

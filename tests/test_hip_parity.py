@@ -486,18 +486,21 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
 # size "ill-conditioned" in earlier rounds is the subgradient choice at the ReLU kinks of 64 M train-mode BatchNorm outputs per hop
 # (helpers.py, "ReLU kinks at bench size": the float64 oracle sits a median 5.9e-3 / worst 2.5e-2 of scale from the fp32 oracle with its
 # own masks and 3.6e-4 / 1.2e-3 with the fp32 run's masks).  The oracle therefore takes the HIP forward's ReLU mask on the elements
-# whose BatchNorm output -- in the oracle's OWN forward -- lies within helpers.KINK_ALIGN_TAU of 0; on every other element the two
-# masks must agree (asserted: zero disagreements).  Then: logits within 5e-4 of scale, every gradient tensor within BENCH_SIZE_BAR of
+# whose value in the oracle's OWN forward lies in the rounding band of the kink (helpers.KINK_BAND of the row's scale); on every other element the two
+# masks must agree (asserted: zero disagreements), and every node row's hidden BatchNorm outputs are held to the HIP values (HIDDEN_RTOL).  Then: logits within 5e-4 of scale, every gradient tensor within BENCH_SIZE_BAR of
 # its scale, the median over the tensors within BENCH_SIZE_MEDIAN.  The `dropout` variant is the configuration bench.py times
 # (0.2 / 0.2 / 0.2, pooler 0.1): the keep masks of its ten dropout sites are replayed on the oracle the same way (helpers.hip_keep_masks).
-BENCH_SIZE_BAR, BENCH_SIZE_MEDIAN = 5e-3, 1e-3
+BENCH_SIZE_BAR, BENCH_SIZE_MEDIAN = 3e-3, 3e-4  # measured on MI355X: worst 1.3e-3 / median 7e-5 (320 CSQA subgraphs), 5.2e-4 / 7e-5 (256 OBQA), 5.4e-4 / 2.7e-5 (64 MedQA)
 # ---------------------------------------------------------------------------------------------------------------------------------
 _BENCH_SIZE, _BENCH_ORACLE = {}, {}
 # (workload of BASELINE.json) -> questions, choices, record shape, relations, edge types, input width.  configs[2] at 64 x 4 = 256
 # subgraphs: the full 128 x 4 needs ~50 GB of autograd state on the host; configs[4]/gpu is the MedQA shard as bench.py runs it.
 BENCH_WORKLOADS = {
-    'configs1_csqa_320': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.6),
-    'configs2_obqa_256': dict(nq=64, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.6),
+    # (fill gain 0.2 at the two large batches: with the 0.6 of the small cases every hop amplifies a forward difference ~10x -- measured, the
+    # fp32 oracle then sits a median 4.7e-2 of scale from its own float64 run at 320 subgraphs even with identical ReLU masks, i.e. the case
+    # itself says nothing; at 0.2 the same pair agrees to 3.6e-4 / 1.2e-3 (median / worst, 256 subgraphs))
+    'configs1_csqa_320': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
+    'configs2_obqa_256': dict(nq=64, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
     'configs4_medqa_64': dict(nq=16, nc=4, shape='medqa', n_rel=15, n_etype=34, dim=768, std=0.6),
 }
 
@@ -552,7 +555,7 @@ def _bench_size_oracle(case, pre, dropout, seeds):
     _BENCH_ORACLE.clear()  # one resident result at a time (the gradients are small, but the key space is per variant)
     _BENCH_ORACLE[key] = dict(logits=ologits.detach().clone(), grads={k: p.grad.detach().clone() for k, p in omodel.named_parameters() if p.grad is not None},
                               bufs={k: b.detach().clone() for k, b in omodel.named_buffers()},
-                              kinks=[dict(aligned=m.aligned, outside=m.outside, worst_outside=m.worst_outside, max_dev=m.max_dev) for m in relus])
+                              kinks=[dict(aligned=m.aligned, outside=m.outside, row_dev=m.row_dev, flip_sigmas=m.flip_sigmas, flip_of_scale=m.flip_of_scale) for m in relus])
     return _BENCH_ORACLE[key]
 
 
@@ -590,7 +593,9 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
     ref = _bench_size_oracle(case, rec.pre, dropout, tuple(seeds.seeds))
     # -- the ReLU masks: aligned inside the kink band, identical outside it
     kinks = ref['kinks']
-    assert all(kk['outside'] == 0 for kk in kinks), f'ReLU masks differ OUTSIDE the kink band of {helpers.KINK_ALIGN_TAU}: {kinks}'
+    summary = [{k: (float('%.1e' % v) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kinks]
+    assert all(kk['outside'] == 0 for kk in kinks), f'ReLU signs differ OUTSIDE the rounding band of the kink (|x_oracle| > {helpers.KINK_BAND} of the row\'s scale): {summary}'
+    assert all(kk['row_dev'] <= helpers.HIDDEN_RTOL for kk in kinks), f'hidden BatchNorm outputs of a row differ by more than {helpers.HIDDEN_RTOL} of the row\'s scale: {summary}'
     # forward bar 5e-4 of the logits' scale (1e-4 at the small cases): both sides are fp32, and at N = 64 000 rows x 5 layers of
     # train-mode BatchNorm each is ~1e-4 from exact arithmetic (measured 1.4e-4 between them)
     helpers._close(logits.detach().cpu(), ref['logits'], what=f'{workload} train-mode logits [{variant}]', rtol=5e-4, atol=1e-5)
@@ -609,11 +614,12 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
             fails.append(f'{k}: {rel[k]:.2e} of scale (bar {BENCH_SIZE_BAR:.1e})')
     rs = sorted(rel.values())
     worst = max(rel, key=rel.get)
-    devs = [float('%.1e' % kk['max_dev']) for kk in kinks]
     line = (f'bench-size {workload} train [{variant}] vs fp32 oracle (ReLU kinks aligned): {len(rs)} tensors, worst {rel[worst]:.3e} of scale ({worst}), '
             f'median {rs[len(rs) // 2]:.2e}, 90th percentile {rs[int(len(rs) * 0.9)]:.2e}, {sum(r <= 1e-3 for r in rs)} of {len(rs)} within 1e-3; '
-            f'kink elements aligned per ReLU site (edge encoder, hops 0..{cfg["k"] - 1}): {[kk["aligned"] for kk in kinks]}, mask disagreements outside '
-            f'the band: {[kk["outside"] for kk in kinks]}, max |BN output: HIP - oracle| per site: {devs}')
+            f'per ReLU site (edge encoder, hops 0..{cfg["k"] - 1}): elements whose sign was taken from the HIP run {[kk["aligned"] for kk in kinks]}, unexplained sign '
+            f'differences {[kk["outside"] for kk in kinks]}, largest row deviation rms(x_hip - x_oracle) / (rms(x_oracle) + 1) {[kk["row_dev"] for kk in summary]}, '
+            f'largest deviation of an aligned element in units of its row\'s {[kk["flip_sigmas"] for kk in summary]}, largest |x_oracle| / row scale of an aligned '
+            f'element {[kk["flip_of_scale"] for kk in summary]}')
     if helpers.REPORT:
         with open(helpers.REPORT, 'a') as f:
             f.write(line + '\n')
