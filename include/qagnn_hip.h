@@ -162,6 +162,9 @@ int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32
  * split (19 % of the projection [N, 320] x [320, 624] at N = 64 000).  ws = NULL (or too small, or a small product) = qagnn_gemm_nn_split_f32.
  * Same arithmetic per output element as the unpacked route: bit-identical results. */
 int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2);
+/* Bytes of scratch qagnn_gemm_nn_split_ws_f32 would USE for this very call: 0 when B is a registered (pre-packed) operand, when the product
+ * is not one the packed kernels take, or when it has too few rows to pay for a pack launch -- a caller that allocates per call asks first. */
+int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2);
 /* All B operands of a step's large NN products packed in ONE launch, ahead of the products: `d[i]` names a weight in its [No][K]
  * layout(s) exactly as the product will pass it (B1n / ldn1 / K1, B2n / ldn2 / K2, No); the images go to `out`
  * (>= qagnn_gemm_nn_prepack_bytes(d, n) bytes, 16-byte aligned) and are REGISTERED under `tag` (!= 0, replaces the tag's earlier

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
-           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_nn_prepack_bytes', 'qagnn_gemm_nn_prepack_f32',
+           'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_ws_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_nn_prepack_bytes', 'qagnn_gemm_nn_prepack_f32',
            'qagnn_gemm_nn_prepack_clear', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
@@ -25,7 +25,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 15  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32)
+ABI_VERSION = 16  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -92,6 +92,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_nn_pack_bytes.restype = _i64
     lib.qagnn_gemm_nn_pack_bytes.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_nn_split_ws_f32.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32, _vp, _i64, _vp]
+    lib.qagnn_gemm_nn_ws_bytes.restype = _i64
+    lib.qagnn_gemm_nn_ws_bytes.argtypes = [C.POINTER(qagnn_gemm_nn_args), _vp, _i32, _vp, _i32]
     lib.qagnn_gemm_nn_prepack_bytes.restype = _i64
     lib.qagnn_gemm_nn_prepack_bytes.argtypes = [C.POINTER(qagnn_pack_desc), _i32]
     lib.qagnn_gemm_nn_prepack_f32.argtypes = [C.POINTER(qagnn_pack_desc), _i32, _vp, _i64, _i64, _vp]
@@ -488,10 +490,11 @@ class HipKernels(metaclass=_GuardedMeta):
                 _chk2d(B2n, 'B2n')
                 assert B2n.shape == (No, A2.size(1))
                 n2, ld2 = B2n.data_ptr(), B2n.size(1)
-            if M >= self.PACK_MIN_M:
-                # large products: B is split ONCE into the kernel's LDS image order (scratch from the caching allocator, stream-ordered:
-                # the next product may reuse it), every row tile then streams it by DMA instead of repeating the split
-                ws_bytes = self.lib.qagnn_gemm_nn_pack_bytes(No, K1, A2.size(1) if A2 is not None else 0)
+            # large products whose B is not registered (qagnn_gemm_nn_prepack_f32): B is split ONCE into the kernel's LDS image order
+            # (scratch from the caching allocator, stream-ordered: the next product may reuse it), every row tile then streams it by DMA
+            # instead of repeating the split.  The library says whether this very call would use the scratch (0: pre-packed / not taken)
+            ws_bytes = self.lib.qagnn_gemm_nn_ws_bytes(C.byref(a), B1n.data_ptr(), K1, n2, ld2) if M >= self.PACK_MIN_M else 0
+            if ws_bytes > 0:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A1.device)
                 self._check(self.lib.qagnn_gemm_nn_split_ws_f32(C.byref(a), B1n.data_ptr(), K1, n2, ld2, ws.data_ptr(), ws_bytes, self._stream()),
                             'qagnn_gemm_nn_split_ws_f32')

@@ -1038,7 +1038,11 @@ static int tn_ws_mode() {
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
                      int chunk_rows, hipStream_t stream) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
-  if (tn_ws_mode() >= 1) return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
+  // (the warp-specialised kernel pays for its one block per CU with an uncovered first load and partial-sum store: only chunks of
+  // QAGNN_TN_WS_MIN_TILES k-tiles and more amortise them -- a 10-subgraph batch has 2-tile chunks: 29 us against the 4-wave kernel's ~14)
+  static const int ws_min_tiles = getenv("QAGNN_TN_WS_MIN_TILES") ? atoi(getenv("QAGNN_TN_WS_MIN_TILES")) : 28;
+  if (tn_ws_mode() >= 1 && chunk_rows >= ws_min_tiles * 32)
+    return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
@@ -1072,6 +1076,13 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
 using namespace qagnn;
 
 extern "C" int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2) { return nn2_pack_bytes(No, K1, K2); }
+
+extern "C" int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2) {
+  if (!a || !B1n || !nn2_ok(*a, ldn1, ldn2)) return 0;                                      // not a product of the packed kernels
+  if (nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return 0;                // B is registered: nothing to pack per call
+  const int64_t need = nn2_pack_bytes(a->No, a->K1, a->K2);
+  return nn2_packed_ok(*a, need) ? need : 0;                                                  // (too few rows: the in-kernel split)
+}
 
 extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                                        qagnn_stream_t stream_) {
@@ -1119,6 +1130,8 @@ extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const flo
     if (small_nt > 0 && small_nt < nt) nt = small_nt;
   }
   if (nn2_ok(*a, ldn1, ldn2)) {
+    // few row tiles: every load of the block up front, one global round trip per launch (k_gemm_nn_small)
+    if (const int snt = nn_small_nt(*a)) return launch_nn_small(snt, *a, B1n, ldn1, B2n, ldn2, stream);
     // B pre-packed by the caller (qagnn_gemm_nn_prepack_f32: one launch for all weights of a step)?
     if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return launch_nn2_prepacked(nt, *a, pk, stream);
     if (ws && nn2_packed_ok(*a, ws_bytes)) {

@@ -166,7 +166,10 @@ GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (
                (9000, 208, 0, 208), (8192, 624, 0, 112), (10000, 40, 56, 200),
                # the staggered 8-wave block (>= 10 k-tiles, one 256-row tile per CU or more): ragged last row tile, a column tail, the
                # 8-column-tile block (and one it leaves to the 4-wave blocks: 7 column tiles); the projection above walks three tiles per block (stores of one tile under the loads of the next)
-               (63901, 624, 0, 208), (61003, 320, 0, 200), (60001, 320, 8, 112), (60100, 320, 0, 128)]
+               (63901, 624, 0, 208), (61003, 320, 0, 200), (60001, 320, 8, 112), (60100, 320, 0, 128),
+               # round 5 (k_gemm_nn_small takes every product whose grid is resident at once -- most of the small shapes above): a 64-column
+               # block of it (8 k-tiles), and two shapes just past it that stay with the unpacked k_gemm_nn2
+               (5000, 208, 0, 208), (6000, 208, 112, 624), (4500, 624, 0, 208)]
 
 
 @pytest.mark.gpu
