@@ -299,7 +299,7 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
-        self.PACK_MIN_M = int(os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))  # (the library applies the same threshold)
+        self.PACK_MIN_M = 8192  # (the library applies the same threshold: nn2_packed_ok)
         self._side_streams = {}  # per device: the stream the natively sequenced hops put their weight-gradient products on
 
     # -- helpers -----------------------------------------------------------------------------------------------

@@ -27,8 +27,6 @@ bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes);
 const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No);
 int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream);
 int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream);
-int nn_small_nt(const qagnn_gemm_nn_args& a);  // 0: not a product for k_gemm_nn_small
-int launch_nn_small(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream);
 
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \

@@ -257,14 +257,10 @@ constexpr int TN_RC = 256;  // minimum rows per chunk (and the chunking the work
 constexpr int TN_RC_SMALL = 64;  // ... and for reductions over <= 4096 rows (class tables, C = 612): the k-loop of a chunk is serial
 __host__ __device__ constexpr int tn_min_chunk(int R) { return R <= 4096 ? TN_RC_SMALL : TN_RC; }
 // the bf16-split weight-gradient kernel over <= 4096 rows (10 subgraphs = 2 000 node rows): one 32-row k-tile per chunk puts twice the
-// blocks on the idle chip (2 000 x 208 x 208: 126 instead of 64) and halves each block's serial work.  QAGNN_TN_SMALL_CHUNK=64 is the
-// earlier chunking (A/B switch).  The workspace query sizes for 32-row chunks there.
+// blocks on the idle chip (2 000 x 208 x 208: 126 instead of 64) and halves each block's serial work (A/B against 64-row chunks:
+// profiles/r3_run18_small_batch_ab.txt).  The workspace query sizes for 32-row chunks there.
 constexpr int TN_RC_SPLIT_SMALL = 32;
-static int tn_split_min_chunk(int R) {
-  static const int env = getenv("QAGNN_TN_SMALL_CHUNK") ? atoi(getenv("QAGNN_TN_SMALL_CHUNK")) : 0;
-  if (R > 4096) return TN_RC;
-  return env >= TN_RC_SPLIT_SMALL ? (env + 31) / 32 * 32 : TN_RC_SPLIT_SMALL;
-}
+static int tn_split_min_chunk(int R) { return R > 4096 ? TN_RC : TN_RC_SPLIT_SMALL; }
 
 __host__ __device__ constexpr int pitch16(int w) { return (w % 32 == 16) ? w : w + 16; }  // rows k, k+1 land 16 banks apart
 
@@ -635,22 +631,16 @@ static int num_cus() {
 
 template <int NT>
 static int launch_nn(const qagnn_gemm_nn_args& a, hipStream_t stream) {
-  static const int xcd_env = getenv("QAGNN_NN_XCD") ? atoi(getenv("QAGNN_NN_XCD")) : 1;
-  static const int persist = getenv("QAGNN_NN_PERSIST") ? atoi(getenv("QAGNN_NN_PERSIST")) : 1;
-  static const int per_cu = getenv("QAGNN_NN_BLOCKS_PER_CU") ? atoi(getenv("QAGNN_NN_BLOCKS_PER_CU")) : (QAGNN_NN_OCC > 0 ? QAGNN_NN_OCC : 1);
+  // persistent 8-wave blocks, one per CU (QAGNN_NN_OCC per CU in the micro-benchmark builds), XCD-aware tile order: the forms these
+  // replaced (4-wave two-row-tile blocks, one block per tile, launch-order tiles) were A/B-ed in profiles/r1_run23_nn_xcd_ab.txt, r1_run32_gemm_ab.txt
+  constexpr int per_cu = QAGNN_NN_OCC > 0 ? QAGNN_NN_OCC : 1;
   qagnn_gemm_nn_args b = a;
-  b.xcd_remap = xcd_env;
+  b.xcd_remap = 1;
   const int ntiles = cdiv(a.No, NT * 16) * cdiv(a.M, NN_BM);
-  const int cap = (num_cus() * (per_cu > 0 ? per_cu : 1)) & ~7;  // multiple of 8: block -> XCD mapping survives the tile walk
-  if (persist == 1) {
-    const int grid = ntiles < cap ? ntiles : cap;
-    if (a.a_scale) k_gemm_nn<NT, true, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
-    else k_gemm_nn<NT, false, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
-  } else {
-    const int grid = (persist == 2 && ntiles > cap) ? cap : ntiles;
-    if (a.a_scale) k_gemm_nn<NT, true, 4, 2><<<grid, 256, 0, stream>>>(b, ntiles);
-    else k_gemm_nn<NT, false, 4, 2><<<grid, 256, 0, stream>>>(b, ntiles);
-  }
+  const int cap = (num_cus() * per_cu) & ~7;  // multiple of 8: block -> XCD mapping survives the tile walk
+  const int grid = ntiles < cap ? ntiles : cap;
+  if (a.a_scale) k_gemm_nn<NT, true, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
+  else k_gemm_nn<NT, false, 8, 1><<<grid, 512, 0, stream>>>(b, ntiles);
   QAGNN_LAUNCH_CHECK("k_gemm_nn");
   return QAGNN_OK;
 }
@@ -679,11 +669,7 @@ static int launch_tn(const float* A, int lda, const float* B, int ldb, float* P,
   return QAGNN_OK;
 }
 
-// QAGNN_TN_STRIP=0 falls back to the run-time-shaped k_gemm_tn everywhere (A/B switch)
-static bool tn_strip_enabled() {
-  static const int v = getenv("QAGNN_TN_STRIP") ? atoi(getenv("QAGNN_TN_STRIP")) : 1;
-  return v != 0;
-}
+static bool tn_strip_enabled() { return true; }  // (the run-time-shaped k_gemm_tn serves the widths the strip kernel is not compiled for)
 
 // compile-time strip launch (NT = 13 and 7 / 13 / 16 waves: every weight gradient of the stack at d = 200)
 template <int NWT>
@@ -717,11 +703,8 @@ static int launch_tn_strip(const float* A, int lda, const float* B, int ldb, flo
 // Rows per split-K chunk.  Every chunk costs one Ka x No partial (written, then re-read by k_sum_chunks), so a launch whose
 // chunk already spans several blocks (column blocks x row blocks) takes longer chunks: just enough blocks to fill the CUs
 // once (twice for blocks of <= 8 waves).  Never below TN_RC, which is what qagnn_gemm_tn_workspace_elems() sizes for.
-// QAGNN_TN_CHUNK=<rows> pins it (256 = the fixed chunking of earlier revisions).
 static int pick_tn_chunk_rows(int R, int Ka, int No, int nt) {
-  static const int env = getenv("QAGNN_TN_CHUNK") ? atoi(getenv("QAGNN_TN_CHUNK")) : 0;
   const int lo = tn_min_chunk(R);
-  if (env >= lo) return (env + 15) & ~15;
   const int rb = pick_tn_waves(Ka), nw = rb;
   const int blocks_per_chunk = cdiv(No, nt * 16) * cdiv(Ka, rb * 16);
   const int target = (num_cus() * (nw <= 8 ? 2 : 1)) / blocks_per_chunk;

@@ -115,8 +115,8 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
 
-// ORDER 0: per column tile 12 MFMAs (hipcc interleaves the two row tiles' accumulate chains by itself), then the split work of a B
-// load round as one clump.  ORDER 1: the same instructions pinned as MFMA, 2 VALU, MFMA, 2 VALU, ... (sched_group_barrier).
+// Per column tile 12 MFMAs (hipcc interleaves the two row tiles' accumulate chains by itself), then the split work of a B load round as
+// one clump (ORDER is a vestigial template argument, always 0: the pinned MFMA / 2 VALU interleave it selected measured no faster).
 // PACKED: B arrives pre-split in the kernel's own LDS image order (k_pack_b below: [k-tile of the walk][column tile][piece][lane] x 16 B,
 // zero-filled past K and No), B1n = that buffer, ldn1 = column tiles per k-tile.  A k-tile of B is then NT * 3 contiguous KB that go
 // to LDS by DMA (global_load_lds, 1 KB per wave-instruction): no registers, no split arithmetic, no ds_write for B in the k-loop
@@ -345,14 +345,6 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           _Pragma("unroll") for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(bf[p]));                                   \
         }                                                                                                                \
         if ((STORE) && j >= NT - BR) QAGNN_NN2_STORE_B(j - (NT - BR), NXT)                                               \
-        if constexpr (ORDER == 1) { /* one MFMA, two VALU, ... instead of 12 MFMAs and a clump of 24 split instructions */ \
-          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                                             \
-          _Pragma("unroll") for (int r = 0; r < 12; ++r) {                                                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                           \
-          }                                                                                                              \
-          __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                                                             \
-        }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
       }                                                                                                                  \
       __builtin_amdgcn_s_setprio(0);                                                                                     \
@@ -657,132 +649,6 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
 }
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Small-M products (the host-bound batches: 10 subgraphs = 2 000 node rows = 16 row tiles on 256 CUs).  There a block of
-// k_gemm_nn2 is ALONE on its CU and its time is its serial k-loop: 7-20 k-tiles, each exposing a global-load round trip (13-15 us per
-// launch, ~40 launches per step: profiles/r4_run27_op_census_b10.txt).  This kernel has no k-loop in flight terms: every load of the
-// block is issued up front -- a wave owns ONE 16-row strip, so the raw A fragments of ALL k-tiles fit its registers (8 per k-tile), and
-// the block's B columns for all k-tiles are split into one LDS image -- then one barrier, then nothing but split arithmetic, fragment
-// reads and MFMAs.  One global round trip per launch instead of one per k-tile.  Same arithmetic per output element as k_gemm_nn2
-// (same split, same six products per k-tile); the two K segments are padded to whole k-tiles separately instead of sharing the
-// straddling tile, so a two-segment product groups its k differently: equal to fp32 rounding, bit for bit for one-segment products.
-// Block = 8 waves x 16 rows = 128 rows x NT*16 columns; KT = k-tiles it is compiled for (K1 and K2 each rounded up to 32).
-template <int NT, int KT, bool AFFINE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn_small(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
-                                                                                            int ldn1, const float* __restrict__ B2n, int ldn2) {
-  constexpr int BN = NT * 16, IMG = NT * 3 * 1024;
-  constexpr int TASKS = KT * BN * 8;          // float4 loads of the B panel: (k-tile, column, float4 of the tile)
-  constexpr int BP = (TASKS + 511) / 512;     // per thread
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = a.M, No = a.No, K1 = a.K1, K2 = a.K2;
-  const int nk1 = (K1 + 31) >> 5, nkt = nk1 + ((K2 + 31) >> 5);
-  const int ncb = (No + BN - 1) / BN;
-  const int m0 = ((int)blockIdx.x / ncb) * 128, n0 = ((int)blockIdx.x % ncb) * BN;
-  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A1), 0, M * a.lda1 * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A2), 0, K2 > 0 ? M * a.lda2 * 4 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B1n), 0, No * ldn1 * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B2n), 0, K2 > 0 ? No * ldn2 * 4 : 0, 0x00020000);
-
-  // ---- every load of the block, B first (its registers are free again once the image is written)
-  u32x4s rb[BP];
-#pragma unroll
-  for (int i = 0; i < BP; ++i) {
-    const int task = tid + i * 512;
-    const int t = task / (BN * 8), n = (task / 8) % BN, kq = task & 7;
-    const bool s1 = t < nk1;
-    const int kb = (s1 ? t : t - nk1) * 32 + kq * 4;
-    const bool in = task < TASKS && t < nkt && n0 + n < No && kb < (s1 ? K1 : K2);
-    const uint32_t off = in ? ((uint32_t)(n0 + n) * (uint32_t)(s1 ? ldn1 : ldn2) + (uint32_t)kb) * 4u : OOB;
-    rb[i] = s1 ? bload(rB1, off, 0u) : bload(rB2, off, 0u);
-  }
-  const int ac = lane >> 4;
-  const int row = m0 + w * 16 + (lane & 15);
-  const bool rok = row < M;
-  u32x4s ra[KT][2];
-#pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    const bool s1 = t < nk1;
-    const int kb = (s1 ? t : t - nk1) * 32 + ac * 8;
-    const bool in = rok && t < nkt && kb < (s1 ? K1 : K2);
-    const uint32_t off = in ? ((uint32_t)row * (uint32_t)(s1 ? a.lda1 : a.lda2) + (uint32_t)kb) * 4u : OOB;
-    ra[t][0] = s1 ? bload(rA1, off, 0u) : bload(rA2, off, 0u);
-    ra[t][1] = s1 ? bload(rA1, off, 16u) : bload(rA2, off, 16u);
-  }
-  // ---- B image: [k-tile][column tile][piece][slot] (the slot permutation of k_gemm_nn2: same fragment offsets)
-#pragma unroll
-  for (int i = 0; i < BP; ++i) {
-    const int task = tid + i * 512;
-    const int t = task / (BN * 8), n = (task / 8) % BN, kq = task & 7;
-    if (task < TASKS && t < nkt) {
-      const int bx = n & 15, bc = kq >> 1;
-      store_b4(smem + t * IMG + ((n >> 4) * 3 * 64 + ((bx ^ (2 * bc)) + 16 * bc)) * 16 + (kq & 1) * 8, rb[i]);
-    }
-  }
-  __syncthreads();
-  // ---- split + MFMA: the transposed products (a lane ends up with four consecutive columns of its row: direct stores)
-  const int rd_off = (((lane & 15) ^ (2 * ac)) + 16 * ac) * 16;
-  f32x4s acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = (f32x4s){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    if (t < nkt) {
-      bf16x8 af[3];
-      if constexpr (AFFINE) {  // segment 1 only (BatchNorm + ReLU of the operand); a segment-2 chunk passes through unchanged
-        const bool s1 = t < nk1;
-        const int k = min(t * 32 + ac * 8, ((K1 + 7) & ~7) - 8);
-        float sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool on = s1 && t * 32 + ac * 8 + e < K1;
-          sc[e] = on ? a.a_scale[k + e] : (s1 ? 0.f : 1.f);
-          sh[e] = on ? a.a_shift[k + e] : 0.f;
-        }
-        split_frag<true>(ra[t], af, sc, sh, s1 ? 0.f : -INFINITY);
-      } else {
-        split_frag<false>(ra[t], af, nullptr, nullptr, 0.f);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bf16x8 bf[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(smem + t * IMG + (j * 3 + p) * 1024 + rd_off);
-        f32x4s c = acc[j];
-        QAGNN_NN2_SIX_T(c, af, bf)
-        acc[j] = c;
-      }
-    }
-  }
-  // ---- epilogue, in k_gemm_nn2's order: product + bias + table row + old value
-  const int c4 = 4 * (lane >> 4);
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, M * a.ldc * 4, 0x00020000);
-  const uint32_t crow = rok ? (uint32_t)row * (uint32_t)a.ldc * 4u : OOB;
-  if (a.bias) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] += __builtin_bit_cast(f32x4s, ld4(a.bias + min(n0 + j * 16 + c4, No - 4)));
-  }
-  if (a.rowtab) {
-    const float* const trow = a.rowtab + (int64_t)a.rowidx[rok ? row : 0] * a.ldt;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] += __builtin_bit_cast(f32x4s, ld4(trow + min(n0 + j * 16 + c4, No - 4)));
-  }
-  if (a.accumulate) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 16 + c4;
-      acc[j] += __builtin_bit_cast(f32x4s, bload(rC, rok && col < No ? crow + (uint32_t)col * 4u : OOB, 0u));
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + j * 16 + c4;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, acc[j]), rC, (int)(crow != OOB && col < No ? crow + (uint32_t)col * 4u : OOB), 0, 0);
-  }
-}
-
 #undef QAGNN_NN2_SIX
 #undef QAGNN_NN2_SIX_T
 
@@ -899,24 +765,17 @@ static int walk_tiles(int K1, int K2) {
 
 int64_t nn2_pack_bytes(int No, int K1, int K2);
 
-// QAGNN_NN2: 0 = k_gemm_nn_split everywhere (A/B switch), 1 = k_gemm_nn2 with the in-kernel split of B, 2 = the same with the fine
-// MFMA / VALU interleave pinned, 3 = B packed once per product (k_pack_b) wherever the caller hands over a workspace and
-// the product has at least QAGNN_NN2_PACK_MIN_M rows, the in-kernel split otherwise, 4 (default) = 3 with the staggered 8-wave block
-// wherever a packed product has at least one 256-row tile per CU
-int nn2_mode() {
-  static const int v = getenv("QAGNN_NN2") ? atoi(getenv("QAGNN_NN2")) : 4;
-  return v;
-}
-bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes) {
-  static const int min_m = getenv("QAGNN_NN2_PACK_MIN_M") ? atoi(getenv("QAGNN_NN2_PACK_MIN_M")) : 8192;
-  return nn2_mode() >= 3 && a.M >= min_m && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2);
-}
+// Which form a product takes (the A/B runs of the forms against each other: profiles/r4_run16_nn2_stagger.txt, r4_run28_round4_switches_ab.txt):
+// B packed once per product (k_pack_b) wherever the caller hands over a workspace and the product has at least NN2_PACK_MIN_M rows, the
+// in-kernel split otherwise; the staggered 8-wave block wherever a packed product has at least one 256-row tile per CU.
+constexpr int NN2_PACK_MIN_M = 8192;
+bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes) { return a.M >= NN2_PACK_MIN_M && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2); }
 // Measured at M = 64 000 (tools/nn2_ablate.hip, profiles/r4_run16_nn2_stagger.txt), 4-wave blocks -> staggered block:
 // [208|112] -> 624 141 -> 122 us, 624 -> 208 96..101 -> 79, but 208 -> 208 38 -> 39 and 624 -> 112 (NT = 7) 53 -> 54: with one block per
 // CU nothing runs under a tile's first loads, and the last tiles' stores are a tail at HBM speed, which 10 k-tiles of 13 column tiles
 // amortise and 7 k-tiles or 7 column tiles do not.
 static bool nn2_staggered(int nt, const qagnn_gemm_nn_args& a) {
-  return nn2_mode() >= 4 && nt >= 8 && nn2::walk_tiles(a.K1, a.K2) >= 10 && (int64_t)cdiv(a.No, nt * 16) * cdiv(a.M, 256) * 10 >= nn2::num_cus() * 9;
+  return nt >= 8 && nn2::walk_tiles(a.K1, a.K2) >= 10 && (int64_t)cdiv(a.No, nt * 16) * cdiv(a.M, 256) * 10 >= nn2::num_cus() * 9;
 }
 // the PACKED kernel on an image `p` of B (NJ column tiles per k-tile)
 static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p, int NJ, hipStream_t stream) {
@@ -933,56 +792,10 @@ static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p,
   }
 }
 
-// The all-loads-up-front kernel for products whose whole grid is resident at once and whose B panel fits LDS (see k_gemm_nn_small).
-// QAGNN_NN_SMALL=0 pins k_gemm_nn2 (A/B switch).
-namespace nn2 {
-template <int NT, int KT>
-static int launch_small_i(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
-  const int grid = cdiv(a.No, NT * 16) * cdiv(a.M, 128);
-  const size_t lds = (size_t)KT * NT * 3 * 1024;
-  static bool raised[2][64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  const int af = a.a_scale ? 1 : 0;
-  if (lds > 64 * 1024 && !raised[af][dev & 63]) {
-    hipError_t e = af ? hipFuncSetAttribute((const void*)k_gemm_nn_small<NT, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                      : hipFuncSetAttribute((const void*)k_gemm_nn_small<NT, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("gemm_nn_small: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
-    raised[af][dev & 63] = true;
-  }
-  if (af) k_gemm_nn_small<NT, KT, true><<<grid, 512, lds, stream>>>(a, B1n, ldn1, B2n, ldn2);
-  else k_gemm_nn_small<NT, KT, false><<<grid, 512, lds, stream>>>(a, B1n, ldn1, B2n, ldn2);
-  QAGNN_LAUNCH_CHECK("k_gemm_nn_small");
-  return QAGNN_OK;
-}
-}  // namespace nn2
-
-// -> the column-tile count the small kernel would run with (2 or 4), or 0: not a product for it
-int nn_small_nt(const qagnn_gemm_nn_args& a) {
-  static const int on = getenv("QAGNN_NN_SMALL") ? atoi(getenv("QAGNN_NN_SMALL")) : 1;
-  if (!on || a.colstat_part || a.a_rowidx) return 0;
-  const int kt = ((a.K1 + 31) >> 5) + ((a.K2 + 31) >> 5);
-  if (kt > 20 || (a.a_scale && a.K1 > 256)) return 0;
-  // the whole grid must be resident at once (one 8-wave block per CU: 256 registers per lane), which is what "no load waits behind
-  // another block's" needs: 32-column blocks while they fit, 64-column blocks (<= 12 k-tiles: the B panel must fit LDS) otherwise
-  const int cus = nn2::num_cus(), rt = cdiv(a.M, 128);
-  if (cdiv(a.No, 32) * rt <= cus) return 2;
-  if (kt <= 12 && cdiv(a.No, 64) * rt <= cus) return 4;
-  return 0;
-}
-
-int launch_nn_small(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
-  const int kt = ((a.K1 + 31) >> 5) + ((a.K2 + 31) >> 5);
-  if (nt == 4) return kt <= 8 ? nn2::launch_small_i<4, 8>(a, B1n, ldn1, B2n, ldn2, stream) : nn2::launch_small_i<4, 12>(a, B1n, ldn1, B2n, ldn2, stream);
-  if (kt <= 8) return nn2::launch_small_i<2, 8>(a, B1n, ldn1, B2n, ldn2, stream);
-  if (kt <= 12) return nn2::launch_small_i<2, 12>(a, B1n, ldn1, B2n, ldn2, stream);
-  return nn2::launch_small_i<2, 20>(a, B1n, ldn1, B2n, ldn2, stream);
-}
-
 // what the second-generation kernel takes: no fused row gather, 32-bit operand offsets, segments that are multiples of 8
 bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
   const int64_t lim = (int64_t)0x7FFFFFFF;
-  if (nn2_mode() == 0 || a.a_rowidx) return false;
+  if (a.a_rowidx) return false;
   if (a.K1 % 8 != 0 || a.K2 % 8 != 0) return false;
   if ((int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.M * a.ldc * 4 >= lim) return false;
   if (a.K2 > 0 && ((int64_t)a.M * a.lda2 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim)) return false;
@@ -992,17 +805,13 @@ bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
 }
 
 int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
-  const bool il = nn2_mode() == 2;
-#define QAGNN_NN2_CASE(N) \
-  case N: return il ? nn2::launch_nt<N, 1>(a, B1n, ldn1, B2n, ldn2, stream) : nn2::launch_nt<N, 0>(a, B1n, ldn1, B2n, ldn2, stream);
   switch (nt) {
-    QAGNN_NN2_CASE(13)
-    QAGNN_NN2_CASE(8)
-    QAGNN_NN2_CASE(7)
-    QAGNN_NN2_CASE(4)
-    default: return il ? nn2::launch_nt<2, 1>(a, B1n, ldn1, B2n, ldn2, stream) : nn2::launch_nt<2, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 13: return nn2::launch_nt<13, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 8: return nn2::launch_nt<8, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 7: return nn2::launch_nt<7, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 4: return nn2::launch_nt<4, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    default: return nn2::launch_nt<2, 0>(a, B1n, ldn1, B2n, ldn2, stream);
   }
-#undef QAGNN_NN2_CASE
 }
 
 // bytes of the packed image of B for one product (13 column tiles of slack: the last column block of a k-tile reads its full width)

@@ -349,8 +349,7 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
   const int cap = (split_num_cus() * 2) & ~7;
   const int grid = ntiles < cap ? ntiles : cap;
   const int64_t lim = (int64_t)0x7FFFFFFF;
-  static const int force_flat = getenv("QAGNN_NN_FLAT") ? atoi(getenv("QAGNN_NN_FLAT")) : 0;  // 1 = the 64-bit-pointer loads everywhere (A/B switch)
-  const bool flat = force_flat || a.a_rowidx || (int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.M * a.lda2 * 4 >= lim ||
+  const bool flat = a.a_rowidx || (int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.M * a.lda2 * 4 >= lim ||
                     (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim;
   if constexpr (NT == 13 || NT == 7 || NT == 4 || NT == 2) {
     if (a.colstat_part) {  // (validated by the entry point: bias-only epilogue, no gather, 32-bit offsets)
@@ -634,11 +633,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 //   * one barrier per k-tile.  The roles are taken by arrival order on each SIMD (HW_ID), so that every SIMD holds one wave of each
 //     kind: the matrix pipe sees an MFMA stream, the vector ALU the split arithmetic, at the same time.
 // ------------------------------------------------------------------------------------------------------------
-// QAGNN_TN_XCD=0: the weight-gradient blocks in launch order (A/B switch)
-static bool tn_xcd() {
-  static const int v = getenv("QAGNN_TN_XCD") ? atoi(getenv("QAGNN_TN_XCD")) : 1;
-  return v != 0;
-}
+static bool tn_xcd() { return true; }  // the blocks of one split-K chunk on one XCD (-2..5 % per kernel: profiles/r4_run17_tn_ws.txt)
 constexpr int WTHR = 512;
 // QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
 // do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them
@@ -998,9 +993,10 @@ static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int 
   return QAGNN_OK;
 }
 
-// QAGNN_TN_SPLIT=0 pins the fp32-MFMA weight-gradient kernels of gemm.hip
+// QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels of gemm.hip: the one numerically distinct fallback (the module mirror reads the same
+// variable for the NN products: qagnn_amd/_lib.py)
 static int tn_split_mode() {
-  static const int v = getenv("QAGNN_TN_SPLIT") ? atoi(getenv("QAGNN_TN_SPLIT")) : 1;
+  static const int v = getenv("QAGNN_GEMM_SPLIT") ? atoi(getenv("QAGNN_GEMM_SPLIT")) : 1;
   return v;
 }
 bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affine) {
@@ -1027,21 +1023,16 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
   const int lo32 = (lo + TKR - 1) / TKR * TKR;
   return rows > lo32 ? rows : lo32;
 }
-// QAGNN_TN_WS: 0 = k_gemm_tn_split everywhere, 1 (default) = k_gemm_tn_ws for the two-operand product [X | S]^T dKMQ (36 k-tiles per
-// block: 201 -> 171 us at 64 000 rows), 2 = for every product it takes.  Measured with 8 - 24 k-tiles per block (tools/tn_ablate.hip,
-// profiles/r4_run17_tn_ws.txt): 208 x 624 115 -> 126 us, 208 x 208 43 -> 57, 112 x 624 72 -> 74 -- one block per CU leaves a block's
-// first loads and its partial-sum stores uncovered, which only a long chunk amortises.
-static int tn_ws_mode() {
-  static const int v = getenv("QAGNN_TN_WS") ? atoi(getenv("QAGNN_TN_WS")) : 1;
-  return v;
-}
+// k_gemm_tn_ws serves the two-operand product [X | S]^T dKMQ where its chunks are long (36 k-tiles per block at 64 000 rows: 201 -> 171 us).
+// Measured with 8 - 24 k-tiles per block (tools/tn_ablate.hip, profiles/r4_run17_tn_ws.txt): 208 x 624 115 -> 126 us, 208 x 208 43 -> 57,
+// 112 x 624 72 -> 74 -- one block per CU leaves a block's first loads and its partial-sum stores uncovered, which only a long chunk
+// amortises; at the 2-tile chunks of a 10-subgraph batch it took 29 us against the 4-wave kernel's ~14 (profiles/r5_run5_tn_ws_min_tiles_ab_b10.txt:
+// the step 2.29 -> 2.22 ms)
+constexpr int TN_WS_MIN_TILES = 28;
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
                      int chunk_rows, hipStream_t stream) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
-  // (the warp-specialised kernel pays for its one block per CU with an uncovered first load and partial-sum store: only chunks of
-  // QAGNN_TN_WS_MIN_TILES k-tiles and more amortise them -- a 10-subgraph batch has 2-tile chunks: 29 us against the 4-wave kernel's ~14)
-  static const int ws_min_tiles = getenv("QAGNN_TN_WS_MIN_TILES") ? atoi(getenv("QAGNN_TN_WS_MIN_TILES")) : 28;
-  if (tn_ws_mode() >= 1 && chunk_rows >= ws_min_tiles * 32)
+  if (chunk_rows >= TN_WS_MIN_TILES * 32)
     return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
@@ -1050,16 +1041,6 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
   if (ridx) {
     dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
     return launch_tn_split_i<13, 7, false, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
-  }
-  if (tn_ws_mode() >= 2) {
-    if (tn_split_wide_b(Ka)) {
-      dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
-      return sc ? launch_tn_ws_i<7, 13, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
-                : launch_tn_ws_i<7, 13, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
-    }
-    dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
-    return sc ? launch_tn_ws_i<13, 7, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows)
-              : launch_tn_ws_i<13, 7, false>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows);
   }
   if (tn_split_wide_b(Ka)) {
     dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
@@ -1120,18 +1101,14 @@ extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const flo
   // tile narrows until there are about 1.5 blocks per CU (or it is 32 columns wide).  Measured, rocprofv3 kernel durations
   // (profiles/r3_run5_nn_small_m.txt): 2 000 x 208 x 208 25.3 -> 9.4 us at 32 columns; 12 800 rows 27.3 -> 16.3 us at 64 columns
   // (18.6 at 32); 624 -> 208 at 12 800 rows 63 -> 37 us.  The arithmetic per output element does not depend on the tile shape:
-  // results are bit-identical.  QAGNN_NN_SMALL_NT=13 pins the wide tile (A/B switch).
-  static const int small_nt = getenv("QAGNN_NN_SMALL_NT") ? atoi(getenv("QAGNN_NN_SMALL_NT")) : 0;
-  if (small_nt != 13) {
+  // results are bit-identical.
+  {
     const int row_tiles = cdiv(a->M, SBM), want = split_num_cus() * 3 / 2;
     const int cands[3] = {7, 4, 2};
     for (int ci = 0; ci < 3 && row_tiles * cdiv(a->No, nt * 16) < want; ++ci)
       if (cands[ci] < nt) nt = cands[ci];
-    if (small_nt > 0 && small_nt < nt) nt = small_nt;
   }
   if (nn2_ok(*a, ldn1, ldn2)) {
-    // few row tiles: every load of the block up front, one global round trip per launch (k_gemm_nn_small)
-    if (const int snt = nn_small_nt(*a)) return launch_nn_small(snt, *a, B1n, ldn1, B2n, ldn2, stream);
     // B pre-packed by the caller (qagnn_gemm_nn_prepack_f32: one launch for all weights of a step)?
     if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return launch_nn2_prepacked(nt, *a, pk, stream);
     if (ws && nn2_packed_ok(*a, ws_bytes)) {

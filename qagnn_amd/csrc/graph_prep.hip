@@ -432,8 +432,8 @@ __global__ void k_xcd_partition(const int* __restrict__ rowptr_s, int N, int cap
 using namespace qagnn;
 
 static int xcd_partition(qagnn_graph* g, hipStream_t stream) {
-  static const int balance = getenv("QAGNN_EDGE_XCD_BALANCE") ? atoi(getenv("QAGNN_EDGE_XCD_BALANCE")) : 1;
-  k_xcd_partition<<<1, 64, 0, stream>>>(g->rowptr_s, g->N, edge_xcd_cap(g->N), balance, g->err + 4);
+  // (work-balanced runs; the equal-node-count partition it replaced: profiles/r4_run15_edge_counters.txt, -5.6 % / -3.7 % on the edge stages)
+  k_xcd_partition<<<1, 64, 0, stream>>>(g->rowptr_s, g->N, edge_xcd_cap(g->N), 1, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_xcd_partition");
   return QAGNN_OK;
 }

@@ -27,7 +27,6 @@ The captured work is exactly the eager step's launch sequence (same kernels, sam
 bit-identical to the eager path on the same capacity-laid-out batch (tests/test_graphed.py).
 """
 import math
-import os
 
 import torch
 
@@ -70,8 +69,8 @@ class GraphedStep:
         # weight-gradient products on a stream of their own do NOT pay in a replayed graph: every fork / join is a cross-queue
         # dependency of the graph, and at 10 / 65 / 150 subgraphs the step is 6 % slower / equal / 2 % slower with them
         # (profiles/r3_run13_graph_overlap_ab.txt) -- so the captured step keeps them in the chain.
-        self.overlap = os.environ.get('QAGNN_GRAPH_OVERLAP', '1') == '1'               # graph preparation; off if a capture rejects it
-        self.wgrad_overlap = os.environ.get('QAGNN_GRAPH_WGRAD_OVERLAP', '0') == '1'
+        self.overlap = True            # graph preparation on its side stream inside the capture; switched off if a capture rejects it
+        self.wgrad_overlap = False     # (see above: measured, not taken)
 
     # -- the eager step that gets captured -------------------------------------------------------------------------------------------
     def _step(self, c):

@@ -37,10 +37,10 @@ def set_kernels(k):
 
 H_HEADS = 4  # GATConvE hard-codes head_count=4 (reference modeling_qagnn.py:387)
 
-import os as _os0
 # bias / type-table gradients as rows of weight-gradient products that are computed anyway (type indicators in S's padding, a column
-# of ones in relu(bn(h1))): QAGNN_BYPRODUCT_GRADS=0 goes back to the stand-alone column reductions (A/B switch)
-BYPRODUCT_GRADS = _os0.environ.get('QAGNN_BYPRODUCT_GRADS', '1') == '1'
+# of ones in relu(bn(h1))) wherever the layout has a padding column for them; the stand-alone column reductions remain for layouts
+# without padding (dim_per_head a multiple of 4).  (A/B of round 3: profiles/r3_run9_byproduct_grads_ab.txt)
+BYPRODUCT_GRADS = True
 
 
 def roundup(x, m):
@@ -215,10 +215,8 @@ class GatherPlan:
 import os as _os
 
 _SIDE_STREAMS = {}
-# bias gradients as a by-product of the wgrad GEMM (qagnn_gemm_tn_colsum_f32).  Measured (interleaved A/B, run 21): ON 21 138 /
-# 21 156 vs OFF 21 539 / 21 538 QA-subgraphs/s -- the extra LDS sweep of the B tile inside the k-loop costs the GEMM more than
-# the three separate column-sum passes it replaces.  Default OFF; kept (and tested) for a better in-kernel schedule.
-FUSED_COLSUM = _os.environ.get('QAGNN_FUSED_COLSUM', '0') == '1'
+# (Bias gradients as a by-product of the weight-gradient GEMM's k-loop -- the colsum_groups form of qagnn_gemm_tn_colsum_f32 -- measured
+# slower than the separate column sums, profiles/r1_run21_fused_colsum_ab.txt, and is no longer wired into the operators.)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -249,7 +247,7 @@ class wgrad_scope:
 
     def __enter__(self):
         self.prev = _DEFER[0]
-        _DEFER[0] = WGRAD_OVERLAP and not FUSED_COLSUM
+        _DEFER[0] = WGRAD_OVERLAP
         if not self.prev:
             reset_wgrad_queue()  # a backward that raised after defer_wgrads() must not leak its jobs into this pass
         return self
@@ -387,10 +385,11 @@ def graph_prep_async(adj, node_type, n_etype, n_ntype, block_n):
 # launch right behind the operand-packing gather and registers them with the library, which recognises a registered operand by its
 # pointers.  `owner` (a module) holds the packed buffer and the weights until its next forward replaces them: a registered pointer
 # always names live, unchanged memory.
-GATHER_FUSED = _os.environ.get('QAGNN_GATHER_FUSED', '1') == '1'  # GatherPlan through qagnn_gather_multi{,_sum}_f32 (0 = cat + index_select: A/B switch)
-HEAD_FUSED = _os.environ.get('QAGNN_HEAD_FUSED', '1') == '1'  # the head behind the pooling as two kernels each way (0 = stock torch ops: A/B switch)
-PREPACK = _os.environ.get('QAGNN_PREPACK', '1') == '1'
-PREPACK_MIN_ROWS = int(_os.environ.get('QAGNN_NN2_PACK_MIN_M', '8192'))
+# (module attributes, not environment switches: the A/B runs that set them are recorded in profiles/r4_run28_round4_switches_ab.txt;
+# the tests still flip GATHER_FUSED to compare the one-launch gather with the cat + index_select form it replaces)
+GATHER_FUSED = True     # GatherPlan through qagnn_gather_multi{,_sum}_f32
+HEAD_FUSED = True       # the head behind the pooling as two kernels each way
+PREPACK_MIN_ROWS = 8192  # = the library's threshold for packed B images (csrc/gemm_nn2.hip: nn2_packed_ok)
 
 
 _PREPACK_STATE = None  # weakref.WeakKeyDictionary: owner module -> [registry tag, what must stay alive until the next forward]
@@ -405,7 +404,7 @@ def prepack_weights(owner, pairs, rows):
     is cleared when its owner is collected (the tag is a process-wide counter -- id() values are recycled, a counter is not)."""
     global _PREPACK_STATE
     K = kernels()
-    if not (PREPACK and rows >= PREPACK_MIN_ROWS and pairs and pairs[0][0].is_cuda and hasattr(K, 'prepack')):
+    if not (rows >= PREPACK_MIN_ROWS and pairs and pairs[0][0].is_cuda and hasattr(K, 'prepack')):
         return
     import weakref
     if _PREPACK_STATE is None:
@@ -507,16 +506,12 @@ class LinearNNFn(torch.autograd.Function):
             if A2 is not None and need[3]:
                 dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
             return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
-        cs = joint = None
-        if FUSED_COLSUM and need[1] and (want_tab or want_bias):
-            # the bias / node-type-table gradients are column sums of dC: by-product of the weight-gradient GEMM
-            dB1t, cs = K.gemm_tn(A1, dC, colsum_groups=G if want_tab else 1, b_rowidx=rowidx if want_tab else None)
-        else:
-            joint = K.gemm_tn2(A1, A2, dC) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
-            dB1t = joint[:A1.size(1)] if joint is not None else (K.gemm_tn(A1, dC) if need[1] else None)
-            tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
-            if (want_tab or want_bias) and not tab_from_wgrad:
-                cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
+        cs = None
+        joint = K.gemm_tn2(A1, A2, dC) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
+        dB1t = joint[:A1.size(1)] if joint is not None else (K.gemm_tn(A1, dC) if need[1] else None)
+        tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
+        if (want_tab or want_bias) and not tab_from_wgrad:
+            cs = K.colsum(dC, rowidx if want_tab else None, G if want_tab else 1)
         if joint is not None:
             dB2t = joint[A1.size(1):]
         else:
@@ -805,7 +800,7 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
 _fh = _os.environ.get('QAGNN_FUSED_HOP', 'auto')
 FUSED_HOP = {'1': True, '0': False}.get(_fh, None)  # None = auto
 FUSED_HOP_MAX_ROWS = 32768
-FUSED_STACK = _os.environ.get('QAGNN_FUSED_STACK', '1') == '1'  # where the native hop is taken, take all k hops in one call
+FUSED_STACK = True  # where the native hop is taken, take all k hops in one call (a module attribute: the tests compare the two forms)
 
 
 def use_fused_hop(n_rows):
@@ -1087,10 +1082,7 @@ class ConceptInputFn(torch.autograd.Function):
         n, p, seed = ctx.cfg
         dpre = K.gelu_dropout_bwd(pre, dHp.contiguous(), p, seed)
         dctx = dpre.view(-1, n, dpre.size(1))[:, 0].contiguous()
-        if FUSED_COLSUM:
-            dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx, colsum_groups=1)
-        else:
-            dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx), K.colsum(dpre)
+        dWc_t, cs = K.gemm_tn(emb_w, dpre, a_rowidx=rowidx), K.colsum(dpre)
         dbc = cs[0] - dctx.sum(0)  # the bias only acts on the entity rows (context-node rows were overwritten)
         return None, None, dWc_t, dbc, dctx, None, None, None, None
 

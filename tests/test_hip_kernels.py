@@ -167,9 +167,8 @@ GEMM_SHAPES = [(1000, 208, 0, 208), (777, 208, 208, 624), (4100, 624, 0, 208), (
                # the staggered 8-wave block (>= 10 k-tiles, one 256-row tile per CU or more): ragged last row tile, a column tail, the
                # 8-column-tile block (and one it leaves to the 4-wave blocks: 7 column tiles); the projection above walks three tiles per block (stores of one tile under the loads of the next)
                (63901, 624, 0, 208), (61003, 320, 0, 200), (60001, 320, 8, 112), (60100, 320, 0, 128),
-               # round 5 (k_gemm_nn_small takes every product whose grid is resident at once -- most of the small shapes above): a 64-column
-               # block of it (8 k-tiles), and two shapes just past it that stay with the unpacked k_gemm_nn2
-               (5000, 208, 0, 208), (6000, 208, 112, 624), (4500, 624, 0, 208)]
+               # round 5: two more shapes of the unpacked k_gemm_nn2 (4 000 .. 8 191 rows)
+               (6000, 208, 112, 624), (4500, 624, 0, 208)]
 
 
 @pytest.mark.gpu
@@ -258,15 +257,14 @@ def test_gemm_tn_two_operands(R, Ka1, Ka2, No):
     assert torch.equal(buf[:Ka1 + Ka2].cpu(), got) and bool((buf[Ka1 + Ka2] == 7.0).all())
 
 
-# The GEMM kernel families that an environment switch selects once per process (the library reads it at its first call), each through
-# the SAME tests above in an interpreter of its own: QAGNN_TN_WS=2 the warp-specialised weight-gradient kernel (k_gemm_tn_ws) for every
-# product it takes (by default only the two-operand product runs on it), QAGNN_TN_WS=0 k_gemm_tn_split everywhere, QAGNN_NN2=3 the
-# 4-wave packed blocks where the staggered 8-wave block would run, QAGNN_NN2=1 the in-kernel split of B.
+# The one kernel family an environment switch still selects (read once per process by the library): QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA
+# kernels of gemm.hip -- the numerically distinct fallback -- for the weight-gradient products too (k_gemm_tn_strip / k_gemm_tn); the NN side
+# of it is the split=False half of test_gemm_nn above.  The SAME tests, in an interpreter of their own.  (The forms of the bf16-split
+# kernels that earlier rounds kept selectable -- QAGNN_NN2 = 0..3, QAGNN_TN_WS = 0 / 2, ... -- are retired: their A/B records are in
+# profiles/r4_run28_round4_switches_ab.txt, r4_run16_nn2_stagger.txt, r4_run17_tn_ws.txt.)
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('env,sel', [('QAGNN_TN_WS=2', 'test_gemm_tn'), ('QAGNN_TN_WS=0', 'test_gemm_tn'),
-                                     ('QAGNN_NN2=3', 'test_gemm_nn and (64000 or 63901 or 61003 or 60100)'),
-                                     ('QAGNN_NN2=1', 'test_gemm_nn and (64000 or 9000 or 8192 or 10000)')])
+@pytest.mark.parametrize('env,sel', [('QAGNN_GEMM_SPLIT=0', 'test_gemm_tn')])
 def test_gemm_kernel_families(env, sel):
     import subprocess
     import sys

@@ -658,14 +658,12 @@ def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# The non-default GEMM families through the module-level parity tests (they are selected by environment variables that the library
-# reads once per process, so each variant runs in its own interpreter): QAGNN_GEMM_SPLIT=0 / QAGNN_TN_SPLIT=0 pin the fp32-MFMA
-# kernels, QAGNN_WGRAD_POISON=1 starts deferred weight gradients as NaN, QAGNN_NN2=0 pins the first-generation split NN kernel
-# (k_gemm_nn_split), QAGNN_NN2=2 the pinned MFMA / VALU interleave of k_gemm_nn2.
+# The non-default kernel family through the module-level parity tests (selected by an environment variable that the library reads once
+# per process, so it runs in its own interpreter): QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels (NN and weight-gradient products);
+# QAGNN_WGRAD_POISON=1 starts deferred weight gradients as NaN.
 # ---------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('env', ['QAGNN_GEMM_SPLIT=0', 'QAGNN_TN_SPLIT=0', 'QAGNN_GEMM_SPLIT=0 QAGNN_TN_SPLIT=0', 'QAGNN_WGRAD_POISON=1',
-                                 'QAGNN_NN2=0', 'QAGNN_NN2=2'])
+@pytest.mark.parametrize('env', ['QAGNN_GEMM_SPLIT=0', 'QAGNN_WGRAD_POISON=1'])
 def test_module_parity_under_the_non_default_kernel_families(env):
     import os
     import subprocess
