@@ -225,9 +225,12 @@ TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'ge
 class Comm:
     """What a step does across ranks: the flat-bucket gradient all-reduce and the logits gather, bracketed by HIP events."""
 
-    def __init__(self, params, world, assignment=None, n_global=None):
+    def __init__(self, params, world, assignment=None, n_global=None, model=None, overlap=False):
         self.world, self.assignment = world, assignment
-        self.bucket = parallel.GradBucket(params) if world > 1 else None
+        # --comm-overlap: two buckets, the stack's 2.15 M parameters reduced from a hook under the tail of the backward
+        # (parallel.SplitGradBuckets; eager steps only -- a replayed hipGraph runs no autograd hooks and reduces both behind the replay)
+        self.split = parallel.SplitGradBuckets(model, model.gnn) if (world > 1 and overlap and model is not None) else None
+        self.bucket = parallel.GradBucket(params) if (world > 1 and self.split is None) else None
         self.n_global = n_global
         self.events = []
 
@@ -236,7 +239,10 @@ class Comm:
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self.bucket.allreduce()  # RCCL all-reduce(sum) of ~2.85 M fp32 through one persistent flat bucket (parallel.GradBucket)
+        if self.split is not None:
+            self.split.finish()
+        else:
+            self.bucket.allreduce()  # RCCL all-reduce(sum) of ~2.85 M fp32 through one persistent flat bucket (parallel.GradBucket)
         if self.assignment is None:
             parallel.allgather_logits(logits, equal_shards=True)  # per-batch logits of all ranks, for accuracy / reporting
         else:  # balanced shards differ in size: variable-size gather, then back to question order
@@ -671,6 +677,8 @@ def main():
     ap.add_argument('--graphs', default=os.environ.get('QAGNN_BENCH_GRAPHS', 'auto'), choices=['auto', '0', '1'],
                     help='1: every step is ONE hipGraph replay (qagnn_amd.graphed.GraphedStep; needs the blob input form); 0: eager launches; '
                          'auto (default): replay where the step is host-bound (fewer than ops.FUSED_HOP_MAX_ROWS node rows)')
+    ap.add_argument('--comm-overlap', action='store_true', help='N > 1: gradient all-reduce in two buckets, the first issued from an autograd '
+                    'hook under the tail of the backward (parallel.SplitGradBuckets); default: one bucket behind the backward')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic)')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -740,7 +748,7 @@ def main():
     fill_table(model, args.n_concept)
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    comm = Comm(params, world, assignment=assignment)
+    comm = Comm(params, world, assignment=assignment, model=model, overlap=args.comm_overlap)
     timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops},
                          useful={'gemm_nn': _nn_useful, 'gemm_tn': _tn_useful, 'gemm_tn2': _tn2_useful})
     ops.set_kernels(timed)
@@ -893,7 +901,8 @@ def main():
         if world > 1:
             out['comm_ms_per_step'] = round(comm_ms, 4)
             out['comm_fraction_of_step'] = round(comm_ms / (dt / args.steps * 1e3), 4)
-            out['comm_is'] = 'RCCL all-reduce(sum) of the flat 11.4 MB gradient bucket + logits all-gather, HIP events on the compute stream (rank 0)'
+            out['comm_is'] = ('RCCL all-reduce(sum) of the flat 11.4 MB gradient bucket + logits all-gather, HIP events on the compute stream (rank 0)'
+                              + ('; --comm-overlap: the stack\'s bucket is issued from a hook inside the backward, the events bracket what is left behind it' if args.comm_overlap else ''))
             out['rank_ms_per_step'] = {'min': round(dt_min / args.steps * 1e3, 3), 'max': round(dt / args.steps * 1e3, 3)}
             if balance is not None:
                 out['balance'] = balance

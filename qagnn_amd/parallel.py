@@ -99,6 +99,58 @@ class GradBucket:
         return self.flat.numel()
 
 
+class SplitGradBuckets:
+    """The gradient all-reduce in TWO flat buckets, the first one issued under the tail of the backward.
+
+    Almost all decoder gradients leave autograd in ONE node, the backward of the stack's operand-packing gather, which runs behind the
+    first hop's backward -- but the step is not over then: the input stage's backward (GELU / dropout, the cpt_transform weight
+    gradient over the gathered entity rows, svec2nvec) still follows, ~0.25 ms at 320 subgraphs.  `early` = the parameters of
+    `early_module` (decoder.gnn: ~2.15 M of the 2.85 M); a post-accumulate-grad hook counts their gradients in and, at the last one,
+    packs the bucket and issues its all-reduce asynchronously (RCCL runs it on its own stream behind the kernels enqueued so far), so
+    the transfer overlaps what is left of the backward.  `finish()` -- called where GradBucket.allreduce() would be -- reduces the
+    small `late` bucket, waits for the early one and copies both back into the existing p.grad tensors.
+
+    A step that produces no autograd callbacks (a replayed hipGraph) or misses a gradient simply reduces both buckets in finish():
+    the result is the same as GradBucket's in every case (tests/test_parallel_gloo.py)."""
+
+    def __init__(self, model, early_module, group=None):
+        early_ids = {id(p) for p in early_module.parameters() if p.requires_grad}
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.early = GradBucket([p for p in params if id(p) in early_ids])
+        late = [p for p in params if id(p) not in early_ids]
+        self.late = GradBucket(late) if late else None
+        self.group = group
+        self._seen, self._work, self._packed = 0, None, None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early.params]
+
+    def _on_grad(self, _p):
+        self._seen += 1
+        if self._seen == len(self.early.params) and self._work is None:
+            b = self.early
+            self._packed = [(v, p.grad) for v, p in zip(b.views, b.params)]
+            torch._foreach_copy_([v for v, _ in self._packed], [g for _, g in self._packed])
+            self._work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """-> number of elements reduced.  Both buckets are reduced when this returns (on the current stream for RCCL)."""
+        n = 0
+        if self.late is not None:
+            n += self.late.allreduce(self.group)
+        if self._work is not None:
+            self._work.wait()
+            torch._foreach_copy_([g for _, g in self._packed], [v for v, _ in self._packed])
+            n += self.early.flat.numel()
+        else:  # no hook fired for every early gradient (hipGraph replay, a frozen tensor): the plain path
+            n += self.early.allreduce(self.group)
+        self._seen, self._work, self._packed = 0, None, None
+        return n
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def sync_batchnorm_running_stats(model, group=None):
     """Average the BatchNorm running statistics over the ranks, in place (optional, at epoch end or before a
     checkpoint is written).

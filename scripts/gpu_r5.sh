@@ -143,6 +143,7 @@ PY
     dp2)   # two ranks time-slicing the one GPU over gloo: exercises the N > 1 code paths of bench.py (comm events, strong scaling)
       QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 2>&1 | tail -n 3 > gpurun_out/bench_dp2_weak.log
       QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --global-batch 32 2>&1 | tail -n 3 > gpurun_out/bench_dp2_strong.log
+      QAGNN_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --graphs 0 --comm-overlap 2>&1 | tail -n 3 > gpurun_out/bench_dp2_weak_comm_overlap.log
       stamp dp2 ;;
     pmc)   # fabric traffic of the edge kernels (FETCH_SIZE / WRITE_SIZE in separate passes) -> gpurun_out/pmc_edge_fwd.json
       for ctr in FETCH_SIZE WRITE_SIZE; do

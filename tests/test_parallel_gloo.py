@@ -90,6 +90,28 @@ def _worker(rank, world, port, q):
     params2 = [p for p in model2.parameters() if p.requires_grad]
     parallel.GradBucket(params2).allreduce()
     z2 = parallel.scatter_logits_by_assignment(parallel.allgather_logits(logits2), parts)
+    # ---- the same reduction in two buckets, the first issued from a hook under the tail of the backward (parallel.SplitGradBuckets):
+    #      bit-identical gradients to the one-bucket path above; a second step re-arms the hooks; a step whose gradients arrive without
+    #      autograd callbacks (what a hipGraph replay looks like) falls back to reducing both buckets in finish() ----
+    model3 = _build()
+    split = parallel.SplitGradBuckets(model3, model3.gnn)
+    for _ in range(2):
+        for p in model3.parameters():
+            p.grad = None
+        _run_question_list(model3, inp, parts[rank], CASE['nq'])
+        assert split._work is not None, 'the early all-reduce was not issued from the backward'
+        n3 = split.finish()
+    assert n3 == sum(p.numel() for p in params2)
+    g2 = {k: p.grad for k, p in model2.named_parameters() if p.grad is not None}
+    g3 = {k: p.grad for k, p in model3.named_parameters() if p.grad is not None}
+    assert set(g2) == set(g3) and all(torch.equal(g2[k], g3[k]) for k in g2), [k for k in g2 if not torch.equal(g2[k], g3[k])][:5]
+    saved = {k: p.grad.clone() for k, p in model3.named_parameters() if p.grad is not None}
+    with torch.no_grad():  # "replay": the gradients are simply there, no hook ran
+        for k, p in model3.named_parameters():
+            if p.grad is not None:
+                p.grad = saved[k] / world
+    assert split.finish() == n3 and all(torch.allclose(p.grad, saved[k] * 1.0) for k, p in model3.named_parameters() if p.grad is not None)
+    split.close()
     # ---- BatchNorm running statistics: per-shard after a training forward (different on the two ranks), averaged by
     #      sync_batchnorm_running_stats(); the edge encoder's BatchNorm is one module shared by all layers and must be reduced once ----
     names = [k for k, _ in model2.named_buffers() if k.endswith('running_mean') or k.endswith('running_var')]
