@@ -80,9 +80,6 @@ typedef struct qagnn_graph {
                                   [err[4 + k], err[5 + k]), an eighth of the batch's edge work each (csrc/graph_prep.hip) */
   int32_t block_n;             /* 0, or the node-block size the graph was checked against (subgraph = n consecutive rows) */
   int32_t n_groups;            /* position groups of the class order */
-  int32_t* lone_tiles;         /* [ceil(ceil(N/32)/32)] bit t: every node row of [32 t, 32 t + 32) has the self loop as its ONLY edge, both ways
-                                  (PAD rows, isolated nodes).  Such a row's K and Q projections are never read and its dK = dQ = 0
-                                  (qagnn_edge_attn_bwd_f32 writes exact zeros): qagnn_gemm_tn2_skip_f32 skips those k-tiles */
 } qagnn_graph;
 
 #define QAGNN_CLS_CHUNK 64
@@ -192,13 +189,6 @@ int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, 
 /* C [Ka1 + Ka2, No] = [A1 | A2]^T B (rows [0, Ka1) from A1, the rest from A2): the two weight gradients of a product with two A operands
  * (modeling_qagnn.py:464-466 on [x ; extra]: dWx^T = X^T dK|dM|dQ, dWs^T = S^T dK|dM|dQ) in ONE split-K launch and one chunk sum where
  * the bf16-split kernel takes the shapes, two qagnn_gemm_tn_f32 calls otherwise.  workspace: qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No). */
-/* qagnn_gemm_tn2_f32 with a promise about B: bit t of b_zero_tiles (may be NULL) says that rows [32 t, 32 t + 32) of B are EXACTLY zero in the
- * 208-column blocks whose bits are set in zero_colblocks (bit j = columns [208 j, 208 j + 208)).  A hop's dK | dM | dQ has that shape for node
- * rows whose only edge is their self loop (qagnn_graph.lone_tiles, zero_colblocks = 5): the long-chunk kernel walks only the k-tiles that can
- * contribute.  Skipping exact zeros changes no output bit; a kernel that does not implement the skip ignores the promise. */
-int qagnn_gemm_tn2_skip_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
-                            float* C, int32_t ldc, int32_t R, int32_t No, const int32_t* b_zero_tiles, uint32_t zero_colblocks, float* workspace,
-                            qagnn_stream_t stream);
 int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
                        float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream);
 /* Same, and additionally  bsum[g][no] = sum_r [grp(r) == g] B[r][no]  (groups in 1..4; b_rowidx NULL = one group): the

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('QAGNN_LIB') or os.path.join(_HERE, 'libqagnn_hip.so')
 EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems', 'qagnn_graph_prep', 'qagnn_graph_prep_blocked',
            'qagnn_graph_from_blobs', 'qagnn_radam_step_f32', 'qagnn_node_prep_f32', 'qagnn_seed_epoch_advance', 'qagnn_seed_epoch_set',
            'qagnn_gemm_nn_f32', 'qagnn_gemm_nn_split_f32', 'qagnn_gemm_nn_pack_bytes', 'qagnn_gemm_nn_ws_bytes', 'qagnn_gemm_nn_split_ws_f32', 'qagnn_gemm_nn_prepack_bytes', 'qagnn_gemm_nn_prepack_f32',
-           'qagnn_gemm_nn_prepack_clear', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_skip_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
+           'qagnn_gemm_nn_prepack_clear', 'qagnn_gemm_tn_workspace_elems', 'qagnn_gemm_tn_f32', 'qagnn_gemm_tn2_f32', 'qagnn_gemm_tn_colsum_f32',
            'qagnn_colreduce_workspace_elems', 'qagnn_colreduce_f32', 'qagnn_bn_finalize_f32', 'qagnn_bn_stats_finalize_f32', 'qagnn_bn_relu_bwd_f32',
            'qagnn_gelu_dropout_fwd_f32', 'qagnn_gelu_dropout_bwd_f32', 'qagnn_sin_basis_f32',
            'qagnn_bn_relu_bwd_colsum_f32',
@@ -35,7 +35,7 @@ class qagnn_graph(C.Structure):
                 [(n, _vp) for n in ('rowptr_s', 'tgt_s', 'src_s', 'cls_s', 'eid_s', 'rowptr_t', 'src_t', 'tgt_t', 'cls_t', 'pos_t',
                                     'cls_count', 'src_c', 'tgt_c', 'pos_c', 'chunk_cls', 'chunk_beg',
                                     'chunk_len', 'n_chunks', 'chunkptr')] +
-                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32), ('lone_tiles', _vp)])
+                [('max_chunks', _i32), ('err', _vp), ('block_n', _i32), ('n_groups', _i32)])
 
 
 GATHER_MAX = 160
@@ -102,7 +102,6 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
     lib.qagnn_gemm_tn2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]
-    lib.qagnn_gemm_tn2_skip_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, C.c_uint32, _vp, _vp]
     lib.qagnn_gemm_tn_colsum_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
@@ -241,11 +240,6 @@ class HipGraph:
     @property
     def eid_s(self):
         return self.array('eid_s', self.Ep)
-
-    @property
-    def lone_tiles(self):
-        """int32 words of the bitmask over 32-row tiles: bit t = every node row of tile t has only its self loop (qagnn_graph.lone_tiles)."""
-        return self.array('lone_tiles', -(-(-(-self.N // 32)) // 32))
 
 
 def _device_of(args, kwargs):
@@ -532,10 +526,8 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(rc, 'qagnn_gemm_tn_colsum_f32')
         return (out, bsum) if colsum_groups else out
 
-    def gemm_tn2(self, A1, A2, B, out=None, zero_tiles=None):
-        """[A1 | A2]^T B -> [Ka1 + Ka2, No]: two weight gradients that share their B operand, one launch (qagnn_gemm_tn2_f32).
-        zero_tiles = (int32 bitmask over 32-row tiles, column-block mask): a promise that those rows of B are exactly zero in the 208-column
-        blocks named by the mask (qagnn_gemm_tn2_skip_f32; HipGraph.lone_tiles for a hop's dK | dM | dQ)."""
+    def gemm_tn2(self, A1, A2, B, out=None):
+        """[A1 | A2]^T B -> [Ka1 + Ka2, No]: two weight gradients that share their B operand, one launch (qagnn_gemm_tn2_f32)."""
         _chk2d(A1, 'A1'), _chk2d(A2, 'A2'), _chk2d(B, 'B')
         Ka1, Ka2 = A1.size(1), A2.size(1)
         R, No = B.shape
@@ -546,11 +538,9 @@ class HipKernels(metaclass=_GuardedMeta):
             _chk2d(out, 'out')
             assert out.shape == (Ka1 + Ka2, No)
         ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
-        zt, zm = (zero_tiles[0], int(zero_tiles[1])) if zero_tiles is not None else (None, 0)
-        assert zt is None or (zt.dtype == torch.int32 and zt.is_contiguous() and zt.numel() * 1024 >= R)
-        rc = self.lib.qagnn_gemm_tn2_skip_f32(A1.data_ptr(), Ka1, Ka1, A2.data_ptr(), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No,
-                                              _ptr(zt), zm, ws.data_ptr(), self._stream())
-        self._check(rc, 'qagnn_gemm_tn2_skip_f32')
+        rc = self.lib.qagnn_gemm_tn2_f32(A1.data_ptr(), Ka1, Ka1, A2.data_ptr(), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No,
+                                         ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_gemm_tn2_f32')
         return out
 
     # -- reductions / elementwise ----------------------------------------------------------------------------------

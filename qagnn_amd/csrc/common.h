@@ -17,7 +17,7 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
                     const int64_t* a_rowidx, int chunk_rows, hipStream_t stream);
 int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo);
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream, const unsigned* b_zero_tiles = nullptr, unsigned zero_colblocks = 0);
+                     int chunk_rows, hipStream_t stream);
 
 // NN products, second kernel generation (gemm_nn2.hip): A fragments straight from global memory, B double-buffered in LDS
 bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2);

@@ -805,17 +805,6 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
 // split-K launch and ONE chunk sum where the bf16-split kernel takes the shapes; otherwise two qagnn_gemm_tn_f32 calls.
 extern "C" int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
                                   int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream_) {
-  return qagnn_gemm_tn2_skip_f32(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, C, ldc, R, No, nullptr, 0, workspace, stream_);
-}
-
-// The same with a promise about B: bit t of b_zero_tiles says that rows [32 t, 32 t + 32) of B are EXACTLY zero in the 208-column blocks
-// whose bits are set in zero_colblocks (bit j = columns [208 j, 208 j + 208)).  The gradient dK | dM | dQ of a hop has that shape: node rows
-// whose only edge is their self loop (every PAD row: 40 % of the rows of a CommonsenseQA batch) get dK = dQ = 0 from the edge backward
-// (qagnn_graph.lone_tiles, zero_colblocks = 0b101).  The long-chunk kernel then walks only the k-tiles that can contribute -- skipping
-// exact zeros changes no output bit; kernels that do not implement the skip ignore the promise.
-extern "C" int qagnn_gemm_tn2_skip_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
-                                       int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const int32_t* b_zero_tiles,
-                                       uint32_t zero_colblocks, float* workspace, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(A1 && A2 && B && C && workspace, QAGNN_EINVAL, "gemm_tn2: null pointer");
   QAGNN_REQUIRE(R > 0 && Ka1 > 0 && Ka2 > 0 && No > 0 && Ka1 % 4 == 0 && Ka2 % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
@@ -831,8 +820,7 @@ extern "C" int qagnn_gemm_tn2_skip_f32(const float* A1, int32_t lda1, int32_t Ka
   }
   const int crows = tn_split2_chunk_rows(R, Ka1, Ka2, No, tn_split_min_chunk(R));
   const int nchunks = cdiv(R, crows), Ka = Ka1 + Ka2;
-  int rc = launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream,
-                            reinterpret_cast<const unsigned*>(b_zero_tiles), zero_colblocks);
+  int rc = launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream);
   if (rc != QAGNN_OK) return rc;
   const int64_t tot = (int64_t)Ka * No;
   k_sum_chunks4<<<cdiv(tot / 4, 64), SC_G * 64, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, 0);

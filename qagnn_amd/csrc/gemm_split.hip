@@ -635,7 +635,6 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 // ------------------------------------------------------------------------------------------------------------
 static bool tn_xcd() { return true; }  // the blocks of one split-K chunk on one XCD (-2..5 % per kernel: profiles/r4_run17_tn_ws.txt)
 constexpr int WTHR = 512;
-constexpr int TN_WS_LIST = 512;  // ints of the k-tile walk list in LDS (count + tiles + 8 past the end): chunks of up to 503 k-tiles
 // QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
 // do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them
 #ifndef QAGNN_TNW_ABL
@@ -664,8 +663,7 @@ __device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int im
 template <int KT, int NT, bool AFFINE>
 __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_ws(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
-    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const float* __restrict__ A2, int lda2, int Ka2,
-    const unsigned* __restrict__ b_zero_tiles, unsigned zero_colblocks) {
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const float* __restrict__ A2, int lda2, int Ka2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tw[];
   constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
   constexpr int IMG_EL = 3 * (A_EL + B_EL), IMG_B = IMG_EL * 2;  // one k-tile's image: [A: piece][column][32 rows + pad] | [B: ...]
@@ -698,30 +696,13 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
   const int n0 = bx * BC, m0 = by * AC;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
-  const int ntile_all = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
-  // The k-tiles this block walks: all of its chunk's, or -- b_zero_tiles: bit t promises that rows [32 t, 32 t + 32) of B are exactly zero in
-  // the BC-column blocks named by zero_colblocks (dK | dQ of node rows whose only edge is their self loop: qagnn_graph.lone_tiles) -- the
-  // ones that can contribute.  A list in LDS (tile t of the walk -> tile of the chunk), continued past the chunk's end like the plain walk
-  // (rows past R read zeros, rows of the next chunk land in an image nobody reads); skipping exact zeros changes no output bit.
-  int* const tlist = reinterpret_cast<int*>(smem_tw + 2 * IMG_B + 64);  // [TN_WS_LIST]: count | tiles
+  const int ntile = (r_end - r_beg + TKR - 1) / TKR;  // chunk_rows is a multiple of TKR: only the last chunk has a ragged tile, past R
 
   // roles: the first wave to arrive on a SIMD computes, the second produces; should the hardware ever place the waves otherwise
   // (not 4 + 4), waves 0-3 compute and 4-7 produce -- correct either way, only the overlap is lost
   int* const ctl = reinterpret_cast<int*>(smem_tw + 2 * IMG_B);
   if (tid < 8) ctl[tid] = 0;
-  if (tid == 64) {  // (one lane of a wave that is not the role arbiter's)
-    const bool skip = b_zero_tiles != nullptr && ((zero_colblocks >> bx) & 1u) != 0 && ntile_all + 8 < TN_WS_LIST;
-    const int t0 = r_beg / TKR;
-    int cnt = 0;
-    for (int i = 0; i < ntile_all && cnt + 9 < TN_WS_LIST; ++i) {
-      const int t = t0 + i;
-      if (!(skip && ((b_zero_tiles[t >> 5] >> (t & 31)) & 1u))) tlist[1 + cnt++] = i;
-    }
-    for (int j = 0; j < 8; ++j) tlist[1 + cnt + j] = ntile_all + j;
-    tlist[0] = cnt;
-  }
   __syncthreads();
-  const int ntile = ntile_all + 8 < TN_WS_LIST ? tlist[0] : ntile_all;
   int role, idx;
   {
     const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;  // HW_ID[5:4] = SIMD_ID
@@ -750,7 +731,6 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     // vmcnt(0) in front of every split -- i.e. for the loads it had just issued for the tile after (3.1 us per k-tile instead of 1.2).
     // Loads and stores run past the chunk's last tile unconditionally (rows past R read zeros, rows of the next chunk land in an
     // image nobody reads).
-    const bool listed = ntile_all + 8 < TN_WS_LIST;
     auto produce = [&](auto IDXC) {
       constexpr int IDX = decltype(IDXC)::value;
       const int g = lane & 3;
@@ -795,8 +775,7 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       // the rows of tile T of task slot K -> the registers RR (a task-wave that straddles the end of A asks both operands and ORs)
 #define QAGNN_TNW_LOAD1(T, K, RR)                                                                          \
       {                                                                                                    \
-        const uint32_t tt_ = (uint32_t)__builtin_amdgcn_readfirstlane(listed ? tlist[1 + (T)] : (T));    \
-        const uint32_t a_ = voA[K] + tt_ * (TKR * ldA4), b_ = voB[K] + tt_ * (TKR * ldB4);                 \
+        const uint32_t a_ = voA[K] + (uint32_t)(T) * (TKR * ldA4), b_ = voB[K] + (uint32_t)(T) * (TKR * ldB4); \
         if constexpr (HAS_A[K] && HAS_B[K]) {                                                              \
           _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                  \
             const u32x4s x_ = __builtin_bit_cast(u32x4s, bload4(rsA, a_ + (uint32_t)i * ldA4)) |           \
@@ -980,9 +959,8 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
 template <int KT, int NT, bool AFFINE>
 static int launch_tn_ws_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
-                          const float* sc, const float* sh, int chunk_rows, const float* A2 = nullptr, int lda2 = 0, int Ka2 = 0,
-                          const unsigned* b_zero_tiles = nullptr, unsigned zero_colblocks = 0) {
-  constexpr size_t lds = (size_t)2 * 3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t) + 64 + TN_WS_LIST * sizeof(int);
+                          const float* sc, const float* sh, int chunk_rows, const float* A2 = nullptr, int lda2 = 0, int Ka2 = 0) {
+  constexpr size_t lds = (size_t)2 * 3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t) + 64;
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -991,8 +969,7 @@ static int launch_tn_ws_i(dim3 grid, hipStream_t stream, const float* A, int lda
     if (e != hipSuccess) { set_error("gemm_tn_ws: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, A2, lda2, Ka2,
-                                                            b_zero_tiles, zero_colblocks);
+  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, A2, lda2, Ka2);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_ws");
   return QAGNN_OK;
 }
@@ -1053,11 +1030,10 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
 // the step 2.29 -> 2.22 ms)
 constexpr int TN_WS_MIN_TILES = 28;
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream, const unsigned* b_zero_tiles, unsigned zero_colblocks) {
+                     int chunk_rows, hipStream_t stream) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
   if (chunk_rows >= TN_WS_MIN_TILES * 32)
-    return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2, b_zero_tiles,
-                                        zero_colblocks);  // (the 4-wave kernel below ignores the promise: it is only a licence to skip)
+    return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,

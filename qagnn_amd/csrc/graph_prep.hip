@@ -427,24 +427,6 @@ __global__ void k_xcd_partition(const int* __restrict__ rowptr_s, int N, int cap
   }
 }
 
-// bit t of `out`: all node rows of the 32-row tile t have out-degree 1 and in-degree 1 (self loops are counted: the self loop is their only
-// edge).  One lane per tile, one ballot per 64 tiles.
-__global__ void k_lone_tiles(const int* __restrict__ rowptr_s, const int* __restrict__ rowptr_t, int N, int* __restrict__ out) {
-  const int t = blockIdx.x * 64 + threadIdx.x, nt = (N + 31) >> 5;
-  bool lone = false;
-  if (t < nt) {
-    lone = true;
-    const int r1 = min(N, 32 * t + 32);
-    for (int r = 32 * t; r < r1; ++r) lone = lone && rowptr_s[r + 1] - rowptr_s[r] == 1 && rowptr_t[r + 1] - rowptr_t[r] == 1;
-  }
-  const unsigned long long m = __ballot(lone);
-  if (threadIdx.x == 0) {
-    const int w0 = blockIdx.x * 2, nw = (nt + 31) >> 5;
-    if (w0 < nw) out[w0] = (int)(unsigned)(m & 0xFFFFFFFFull);
-    if (w0 + 1 < nw) out[w0 + 1] = (int)(unsigned)(m >> 32);
-  }
-}
-
 }  // namespace qagnn
 
 using namespace qagnn;
@@ -453,8 +435,6 @@ static int xcd_partition(qagnn_graph* g, hipStream_t stream) {
   // (work-balanced runs; the equal-node-count partition it replaced: profiles/r4_run15_edge_counters.txt, -5.6 % / -3.7 % on the edge stages)
   k_xcd_partition<<<1, 64, 0, stream>>>(g->rowptr_s, g->N, edge_xcd_cap(g->N), 1, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_xcd_partition");
-  k_lone_tiles<<<cdiv(cdiv(g->N, 32), 64), 64, 0, stream>>>(g->rowptr_s, g->rowptr_t, g->N, g->lone_tiles);
-  QAGNN_LAUNCH_CHECK("k_lone_tiles");
   return QAGNN_OK;
 }
 
@@ -484,7 +464,6 @@ static carved carve(qagnn_graph* g, int32_t* storage, int N, int E, int R, int T
   g->cls_count = take(C);
   g->chunk_cls = take(maxch); g->chunk_beg = take(maxch); g->chunk_len = take(maxch);
   g->n_chunks = take(4); g->err = take(16);  // err[4 .. 12]: the XCD partition of the node blocks (k_xcd_partition)
-  g->lone_tiles = take(cdiv(cdiv(N, 32), 32));
   // ---- scratch; the zero-initialised region comes first (cls_count, which sits just before it, must be zero too) ----
   cv.cnt_s = take(N); cv.cnt_t = take(N);
   cv.es = take(Ep); cv.et = take(Ep); cv.ec = take(Ep);
@@ -531,7 +510,6 @@ extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, in
   tot += up4(C);              // cls_count
   tot += 3 * up4(maxch);      // chunk tables
   tot += up4(4) + up4(16);    // n_chunks, err (+ the XCD partition)
-  tot += up4(cdiv(cdiv(N, 32), 32));  // lone_tiles
   tot += 2 * up4(N);          // cnt_s, cnt_t
   tot += 6 * up4(Ep);         // es et ec tmp_s tmp_t srcpos
   tot += up4(nblk * C);       // per-block class histograms

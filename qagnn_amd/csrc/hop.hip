@@ -255,10 +255,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   // projection: weight gradients, node-type-table gradient, data gradients
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
   if (SP > 0 && h->dWs_t == h->dWx_t + (int64_t)DP * 3 * DP) {  // the two gradients are one [DP + SP, 3 DP] matrix: one launch
-    // (dK = dQ = 0 on the node rows whose only edge is their self loop: the k-tiles that lie wholly inside such rows are skipped for the K
-    // and Q column blocks -- which are the kernel's 208-column blocks 0 and 2 when DP = 208)
-    HOP_TRY(qagnn_gemm_tn2_skip_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, h->g->lone_tiles, DP == 208 ? 5u : 0u, tnws,
-                                    wstream));
+    HOP_TRY(qagnn_gemm_tn2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, tnws, wstream));
   } else {
     HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
     if (SP > 0)

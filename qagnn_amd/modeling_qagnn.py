@@ -305,8 +305,7 @@ class GATConvE(nn.Module):
                                    (Wx_t, Wx, Ws_t, Ws, TT, ekem, W1t, W1p, b1, gam, bet, W2t, W2p, b2, rm_p, rv_p),
                                    self.training or not bn.track_running_stats, bn.eps, p_drop if self.training else 0.0, apply_act,
                                    running, acc=acc, tab_col=cols)
-            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc, tabcol=tab_col,
-                                dc_zero=ops.lone_tiles_of(graph, Wx_t.size(1)))
+            KMQ = ops.linear_nn(Xp, Wx_t, Wx, S, Ws_t, Ws, rowtab=TT, rowidx=ntype, acc=acc, tabcol=tab_col)
             mlp_ops = packed[8:]
         aggr, a = ops.edge_attention(KMQ, ekem, graph, L.HP, 1.0 / math.sqrt(self.dim_per_head))
         bn = self.mlp[1]

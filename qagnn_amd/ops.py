@@ -449,9 +449,8 @@ class LinearNNFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol=-1, dc_zero=None):
+    def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol=-1):
         K = kernels()
-        ctx.dc_zero = dc_zero  # (bitmask over 32-row tiles, column-block mask): rows of dC that WILL be zero in those blocks (see gemm_tn2)
         C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx, B1n=B1, B2n=B2)
         ctx.save_for_backward(A1, B1, A2, B2, rowidx, B1t, B2t)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
@@ -478,7 +477,7 @@ class LinearNNFn(torch.autograd.Function):
                 # both weight gradients share dC: ONE split-K launch and one chunk sum into one [K1 + K2, No] buffer (qagnn_gemm_tn2_f32)
                 joint = _wg_empty(dC, (A1.size(1) + A2.size(1), dC.size(1)))
                 dB1t, dB2t = joint[:A1.size(1)], joint[A1.size(1):]
-                jobs.append(lambda: K.gemm_tn2(A1, A2, dC, out=joint, zero_tiles=ctx.dc_zero))
+                jobs.append(lambda: K.gemm_tn2(A1, A2, dC, out=joint))
             else:
                 if need[1]:
                     dB1t = _wg_empty(dC, (A1.size(1), dC.size(1)))
@@ -506,9 +505,9 @@ class LinearNNFn(torch.autograd.Function):
                     dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t))
             if A2 is not None and need[3]:
                 dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
-            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None, None
+            return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
         cs = None
-        joint = K.gemm_tn2(A1, A2, dC, zero_tiles=ctx.dc_zero) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
+        joint = K.gemm_tn2(A1, A2, dC) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
         dB1t = joint[:A1.size(1)] if joint is not None else (K.gemm_tn(A1, dC) if need[1] else None)
         tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
         if (want_tab or want_bias) and not tab_from_wgrad:
@@ -535,11 +534,11 @@ class LinearNNFn(torch.autograd.Function):
         dA2 = None
         if A2 is not None and need[3]:
             dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
-        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None, None
+        return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
 
 
-def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None, acc=None, tabcol=-1, dc_zero=None):
-    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol, dc_zero)
+def linear_nn(A1, B1t, B1, A2=None, B2t=None, B2=None, bias=None, rowtab=None, rowidx=None, acc=None, tabcol=-1):
+    return LinearNNFn.apply(A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol)
 
 
 def type_indicators(S, ntype, col0, T):
@@ -809,14 +808,6 @@ def use_fused_hop(n_rows):
 HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta', 'W2t', 'W2', 'b2', 'run_mean_p', 'run_var_p')
 
 
-def lone_tiles_of(graph, width):
-    """The promise a hop's dK | dM | dQ [N, width] comes with: node rows whose only edge is their self loop get dK = dQ = 0 from the edge
-    backward, so the 32-row tiles that lie wholly inside such rows are zero in the K and Q column blocks -- blocks 0 and 2 of the
-    weight-gradient kernel when a block is DP = 208 columns wide (mask 0b101); None where the graph or the layout does not provide it."""
-    lt = getattr(graph, 'lone_tiles', None)
-    return (lt, 5) if (lt is not None and width == 624) else None
-
-
 def hop_fwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, running, cols=-1):
     Wx_t, Wx, Ws_t, Ws, TT, EkEm, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean_p, run_var_p = prm
     ones_col = cols[1] if isinstance(cols, tuple) else -1
@@ -857,7 +848,7 @@ def hop_bwd_composed(K, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p
     daggr = K.gemm_nn(dh1, W1, B1n=W1t)
     dKMQ, dEkEm = K.edge_attn_bwd(graph, KMQ, EkEm, HP, qscale, aa[0], aa[1], daggr)
     if S is not None:  # one launch for both (qagnn_gemm_tn2_f32), like qagnn_hop_bwd_f32 when its two outputs are adjacent
-        joint = K.gemm_tn2(X, S, dKMQ, zero_tiles=lone_tiles_of(graph, dKMQ.size(1)))
+        joint = K.gemm_tn2(X, S, dKMQ)
         dWx_t, dWs_t = joint[:X.size(1)], joint[X.size(1):]
     else:
         dWx_t, dWs_t = K.gemm_tn(X, dKMQ), None

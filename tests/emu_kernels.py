@@ -31,13 +31,6 @@ class EmuGraph:
         self.eid_s = eid_s.int()
         self.rowptr_s = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(es, minlength=N).cumsum(0)]).int()
         self.rowptr_t = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.bincount(et, minlength=N).cumsum(0)]).int()
-        # qagnn_graph.lone_tiles: bit t = every node row of the 32-row tile t has the self loop as its only edge, both ways
-        lone = (torch.bincount(es, minlength=N) == 1) & (torch.bincount(et, minlength=N) == 1)
-        nt = (N + 31) // 32
-        tile_lone = torch.nn.functional.pad(lone, (0, nt * 32 - N), value=True).view(nt, 32).all(1)
-        bits = torch.nn.functional.pad(tile_lone.long(), (0, (nt + 31) // 32 * 32 - nt)).view(-1, 32)
-        w = (bits << torch.arange(32)).sum(1)
-        self.lone_tiles = torch.where(w >= 2 ** 31, w - 2 ** 32, w).int()
         self.tgt_s, self.src_s, self.cls_s = et[eid_s].int(), es[eid_s].int(), ec[eid_s].int()
         srcpos = torch.empty_like(eid_s)
         srcpos[eid_s] = torch.arange(self.Ep, device=dev)
@@ -219,17 +212,8 @@ class EmuKernels:
             return C, self.colsum(B, b_rowidx, colsum_groups)
         return C
 
-    def gemm_tn2(self, A1, A2, B, out=None, zero_tiles=None):
+    def gemm_tn2(self, A1, A2, B, out=None):
         _chk(A1, A2, B, out)
-        if zero_tiles is not None:  # the caller's promise (qagnn_gemm_tn2_skip_f32) is CHECKED here: those rows of B must be exactly zero
-            words, mask = zero_tiles
-            R = B.size(0)
-            t = torch.arange((R + 31) // 32)
-            lone = ((words.long()[t // 32] >> (t % 32)) & 1).bool()
-            rows = lone.repeat_interleave(32)[:R]
-            for j in range(B.size(1) // 208):
-                if (mask >> j) & 1:
-                    assert bool((B[rows, 208 * j:208 * (j + 1)] == 0).all()), f'zero_tiles promises zeros in column block {j} that are not there'
         C = torch.cat([A1, A2], 1).t() @ B
         return C if out is None else out.copy_(C)
 

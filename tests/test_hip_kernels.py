@@ -99,7 +99,6 @@ def test_graph_prep_bit_exact(name):
     for arr in ('chunk_cls', 'chunk_beg', 'chunk_len'):
         assert torch.equal(g.array(arr, nch).cpu(), getattr(e, arr)), f'{arr} differs'
     assert int(g.array('err', 1).item()) == 0
-    assert torch.equal(g.lone_tiles.cpu(), e.lone_tiles), 'lone_tiles differs'  # 32-row tiles whose rows all have only their self loop
 
 
 @pytest.mark.gpu
@@ -256,26 +255,6 @@ def test_gemm_tn_two_operands(R, Ka1, Ka2, No):
     buf = torch.full((Ka1 + Ka2 + 1, No), 7.0).cuda()
     K.gemm_tn2(A1.cuda(), A2.cuda(), B.cuda(), out=buf[:Ka1 + Ka2])
     assert torch.equal(buf[:Ka1 + Ka2].cpu(), got) and bool((buf[Ka1 + Ka2] == 7.0).all())
-    if No == 624:
-        # qagnn_gemm_tn2_skip_f32: 32-row tiles of B that are exactly zero in column blocks 0 and 2 (a hop's dK | dQ on self-loop-only
-        # rows) may be skipped there -- the result must not change by a bit, with runs of tiles at the chunk boundaries, a ragged last
-        # tile, and a whole chunk of zero tiles
-        nt = (R + 31) // 32
-        tz = torch.rand(nt, generator=g) < 0.4
-        tz[:40] = True
-        tz[nt - 3:] = True
-        rows = tz.repeat_interleave(32)[:R]
-        Bz = B.clone()
-        Bz[rows, :208] = 0
-        Bz[rows, 416:] = 0
-        bits = torch.nn.functional.pad(tz.long(), (0, (nt + 31) // 32 * 32 - nt)).view(-1, 32)
-        w = (bits << torch.arange(32)).sum(1)
-        words = torch.where(w >= 2 ** 31, w - 2 ** 32, w).int().cuda()
-        plain = K.gemm_tn2(A1.cuda(), A2.cuda(), Bz.cuda())
-        skip = K.gemm_tn2(A1.cuda(), A2.cuda(), Bz.cuda(), zero_tiles=(words, 5))
-        assert torch.equal(plain, skip)
-        refz = A.double().t() @ Bz.double()
-        assert bool(((skip.cpu().double() - refz).abs() <= bound).all())
 
 
 # The one kernel family an environment switch still selects (read once per process by the library): QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA
@@ -480,11 +459,6 @@ def test_edge_attention_forward_backward(name, HP):
     # softmax rows: sum over each source segment of a == 1 (size-independent property)
     seg = torch.zeros(e.N, 4, dtype=torch.float64).index_add_(0, e.src_s.long(), a.cpu().double())
     assert (seg - 1).abs().max().item() < 1e-5
-    # the promise qagnn_gemm_tn2_skip_f32 is given for this gradient (qagnn_graph.lone_tiles): a node row whose only edge is its self loop
-    # gets dK = dQ = 0 EXACTLY (softmax of one score has gradient a (ga - a ga) = 0), whatever K, Q, G hold
-    lone = (torch.bincount(e.es, minlength=e.N) == 1) & (torch.bincount(e.et, minlength=e.N) == 1)
-    dk = dKMQ.cpu()
-    assert (dk[lone][:, :DP] == 0).all() and (dk[lone][:, 2 * DP:] == 0).all()
 
 
 @pytest.mark.gpu
