@@ -92,6 +92,47 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(nq, nc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('prep_overlap', [True, False])
+@pytest.mark.parametrize('nq,p', [(36, 0.0), (64, 0.0), (64, 0.2)])
+def test_replays_and_eager_steps_alternate_on_one_model(nq, p, prep_overlap, monkeypatch):
+    """bench.py's `--graphs auto` times eager steps, then replays, then runs whichever won -- on ONE model; a training script may do
+    the same (an eager evaluation between replayed training steps).  Eager steps before the capture, replays, eager steps, replays:
+    every replay must still equal the eager step bit for bit and leave clean validation words, with the graph preparation captured on
+    its side stream and on the main stream (`ops.PREP_OVERLAP` off: what GraphedStep falls back to when a capture rejects the fork,
+    and what the two-ranks-on-one-GPU rig of bench.py runs)."""
+    ops.set_kernels(None)
+    from qagnn_amd import _lib
+    monkeypatch.setattr(ops, 'PREP_OVERLAP', prep_overlap)
+    _lib.ERR_WATCH.poll(block=True)
+    nc, n = 5, 200
+    b = _batch(nq, nc, n, 13)
+    cap = graphed.edge_capacity(b['packed'].E)
+    m_ref, m = _model(p), _model(p)
+    want = _eager(m_ref, b, nc, e_cap=cap)
+    step = graphed.GraphedStep(m, nc)
+
+    def replay(tag):
+        logits, loss = step(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['packed'], b['labels'])
+        got = (logits.detach().clone(), loss.detach().clone(), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}, want[3])
+        if p == 0.0:
+            _same(got, want, tag)  # (train-mode results do not depend on the running statistics, which the interleaved steps keep moving)
+        else:  # (dropout: every replay draws its own masks -- finite results and clean validation words are what can be asked)
+            assert torch.isfinite(got[0]).all() and all(torch.isfinite(g).all() for g in got[2].values()), tag
+
+    for _ in range(3):
+        _eager(m, b, nc)
+    for i in range(3):
+        replay(f'replay {i} behind the first eager steps')
+    for _ in range(2):
+        _eager(m, b, nc)
+    for i in range(2):
+        replay(f'replay {i} behind the second eager steps')
+    torch.cuda.synchronize()
+    _lib.ERR_WATCH.poll(block=True)  # raises if a replay left a validation word behind
+    assert step.n_graphs == 1
+
+
+@pytest.mark.gpu
 def test_capacity_layout_changes_nothing():
     ops.set_kernels(None)
     b = _batch(2, 5, 200, 7)
