@@ -1,5 +1,4 @@
-"""Severity of the spurious validation words (graph preparation captured on the main stream, eager steps between replays): do the
-replayed RESULTS change?  p = 0: every replay of the same batch must give the same loss and gradients."""
+"""Who owns the memory of the captured preparation's validation words?  (caching-allocator snapshot around the failing sequence)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,29 +8,39 @@ from qagnn_amd._lib import ERR_WATCH
 dev = torch.device('cuda', 0)
 wl = bench.WORKLOADS[bench.HEADLINE]
 b = bench.to_device(bench.make_batch(wl, 64, seed=1000, n_concept=100000), dev, True, wl['nc'])
-model = bench.build_model(MQ, wl, 100000, p=float(os.environ.get('PROBE_P', '0'))).to(dev).train()
+model = bench.build_model(MQ, wl, 100000, p=0.2).to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
 gs = graphed.GraphedStep(model, wl['nc'])
 
 
-def replay(tag):
-    logits, loss = gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], 1.0)
-    torch.cuda.synchronize()
+def owner(tag):
     c = next(iter(gs._captured.values()))
-    gsum = sum(float(p.grad.double().abs().sum()) for p in params)
-    print(tag, 'loss %.9f' % float(loss), 'sum|grad| %.9e' % gsum, 'device words', [w[0].tolist() for w in c.watched], flush=True)
-    ERR_WATCH.pending = []
+    f = c.watched[0][0]
+    ptr = f.data_ptr()
+    for seg in torch.cuda.memory_snapshot():
+        if seg['address'] <= ptr < seg['address'] + seg['total_size']:
+            a = seg['address']
+            for blk in seg['blocks']:
+                if a <= ptr < a + blk['size']:
+                    print(tag, 'segment pool', seg.get('segment_pool_id'), 'stream', seg.get('stream'), 'seg size', seg['total_size'], 'block', hex(a), blk['size'], blk['state'], 'flags at +', ptr - a, flush=True)
+                a += blk['size']
+    print(tag, 'storage ptr', hex(f.untyped_storage().data_ptr()), 'device words', f.tolist(), flush=True)
 
 
 for _ in range(3):
     bench.step(model, b, wl['nc'], 1.0, params)
-for i in range(3):
-    replay(f'replay {i}')
-for _ in range(2):
-    bench.step(model, b, wl['nc'], 1.0, params)
-torch.cuda.synchronize()
-ERR_WATCH.pending = []
-for i in range(2):
-    replay(f'replay {i} behind eager steps')
-lg, _ = model(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'])
-print('eager loss %.9f' % float(torch.nn.functional.cross_entropy(lg.view(-1, wl['nc']), b['labels'])))
+for _ in range(3):
+    gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], 1.0)
+owner('after capture + 3 replays')
+import qagnn_amd._lib as L
+orig = L.HipKernels.graph_from_blobs
+def spy(self, packed, node_type):
+    G = orig(self, packed, node_type)
+    print('   eager graph storage', hex(G.storage.data_ptr()), G.storage.numel() * 4, 'capturing', torch.cuda.is_current_stream_capturing(), flush=True)
+    return G
+L.HipKernels.graph_from_blobs = spy
+bench.step(model, b, wl['nc'], 1.0, params)
+bench.step(model, b, wl['nc'], 1.0, params)
+L.HipKernels.graph_from_blobs = orig
+gs(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['adj'], b['labels'], 1.0)
+owner('after eager, eager, replay')
