@@ -40,14 +40,16 @@ def test_qagnn_matches_reference(case):
     B = c['nq'] * c['nc']
     model = build(case).cuda()
     sv, cids, nt, ns, al, ei, et = cu(*golden_inputs(case, fix))
-    logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
     assert ops.kernels().name == 'hip'
     helpers.check_plain(fix, 'logits', logits, **FWD)
     helpers.check_plain(fix, 'pool_attn', pool_attn, **FWD)
     w = torch.linspace(0.5, 1.5, B, device='cuda').view(B, 1)
     (logits * w).sum().backward()
     ref = helpers.F64Ref(case, 'grad')
-    ref.check_all({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, what=case + ' grad::', min_checked=20)
+    ref.check_all({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, what=case + ' grad::', min_checked=20,
+                  **helpers.kink_args(rec, c['cfg'], ei, et, nt))
     for bname, b in model.named_buffers():
         helpers.check_plain(fix, 'buf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -62,13 +64,14 @@ def test_message_passing_stack_matches_reference(case):
     H, ns, x, extra = helpers.mp_inputs(case)
     ns = ns * (torch.arange(n) < al.unsqueeze(1)).float().unsqueeze(2)
     Hg = H.cuda().requires_grad_(True)
-    out = model.gnn(Hg, (ei.cuda(), et.cuda()), nt.cuda(), ns.cuda())
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        out = model.gnn(Hg, (ei.cuda(), et.cuda()), nt.cuda(), ns.cuda())
     helpers.check_stored(fix, 'mp_out', out, **FWD)
     wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out).cuda()
     (out * wg).sum().backward()
     grads = {k: p.grad for k, p in model.gnn.named_parameters() if p.grad is not None}
     grads['::mp_dH'] = Hg.grad
-    helpers.F64Ref(case, 'mpgrad').check_all(grads, what=case + ' mpgrad::', min_checked=20)
+    helpers.F64Ref(case, 'mpgrad').check_all(grads, what=case + ' mpgrad::', min_checked=20, **helpers.kink_args(rec, c['cfg'], ei, et, nt))
     for bname, b in model.gnn.named_buffers():
         helpers.check_plain(fix, 'mpbuf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -82,7 +85,8 @@ def test_single_gatconve_layer_matches_reference(case):
     H, ns, x, extra = helpers.mp_inputs(case)
     layer = model.gnn.gnn_layers[0]
     xg = x.cuda().requires_grad_(True)
-    out, (ei_loops, alpha) = layer(xg, ei.cuda(), et.cuda(), nt.view(-1).cuda(), extra.cuda(), return_attention_weights=True)
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        out, (ei_loops, alpha) = layer(xg, ei.cuda(), et.cuda(), nt.view(-1).cuda(), extra.cuda(), return_attention_weights=True)
     assert ei_loops.size(1) == ei.size(1) + x.size(0)
     helpers.check_stored(fix, 'layer_out', out, **FWD)
     helpers.check_stored(fix, 'layer_alpha', alpha, rtol=1e-4, atol=1e-7)
@@ -90,7 +94,7 @@ def test_single_gatconve_layer_matches_reference(case):
     (out * wl).sum().backward()
     grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
     grads['::layer_dx'] = xg.grad
-    helpers.F64Ref(case, 'layergrad').check_all(grads, what=case + ' layergrad::', min_checked=10)
+    helpers.F64Ref(case, 'layergrad').check_all(grads, what=case + ' layergrad::', min_checked=10, **helpers.kink_args(rec, c['cfg'], ei, et, nt))
 
 
 DEVICE = 'cuda'  # the CPU self-check of these tests (tests/test_host_logic_emu.py) swaps in 'cpu' + the torch emulation
@@ -134,7 +138,7 @@ def oracle_vs_package(case_dict, device=None, dropout=None):
     B, n = case_dict['nq'] * case_dict['nc'], case_dict['n']
     model = _package_model(case_dict, device, dropout)
     dargs = [a.to(device) for a in args]
-    with helpers.SeedRecorder() as rec:
+    with helpers.SeedRecorder() as rec, helpers.recorded_forward(cfg['concept_dim']) as relu_in:
         logits, attn = model(*dargs[:5], (dargs[5], dargs[6]))
     (logits * torch.linspace(0.5, 1.5, B, device=logits.device).view(B, 1)).sum().backward()
     prepare = None
@@ -153,7 +157,7 @@ def oracle_vs_package(case_dict, device=None, dropout=None):
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(grads) == {k for k in ref.g0 if not k.startswith('::')}
     tag = ' dropout' if dropout is not None else ''
-    return ref.check_all(grads, what=f"{case_dict['shape']} B={B}{tag} grad::", min_checked=20)
+    return ref.check_all(grads, what=f"{case_dict['shape']} B={B}{tag} grad::", min_checked=20, **helpers.kink_args(relu_in, cfg, args[5], args[6], args[2]))
 
 
 @pytest.mark.parametrize('train', [True, False])

@@ -65,13 +65,15 @@ def test_qagnn_matches_reference(case):
     B = c['nq'] * c['nc']
     model = build(case)
     sv, cids, nt, ns, al, ei, et = golden_inputs(case, fix)
-    logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        logits, pool_attn = model(sv, cids, nt, ns, al, (ei, et))
     helpers.check_plain(fix, 'logits', logits, **FWD)
     helpers.check_plain(fix, 'pool_attn', pool_attn, **FWD)
     w = torch.linspace(0.5, 1.5, B).view(B, 1)
     (logits * w).sum().backward()
     ref = helpers.F64Ref(case, 'grad')
-    ref.check_all({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, what=case + ' grad::', min_checked=20)
+    ref.check_all({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, what=case + ' grad::', min_checked=20,
+                  **helpers.kink_args(rec, c['cfg'], ei, et, nt))
     for bname, b in model.named_buffers():
         helpers.check_plain(fix, 'buf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -86,13 +88,14 @@ def test_message_passing_stack_matches_reference(case):
     H, ns, x, extra = helpers.mp_inputs(case)
     ns = ns * (torch.arange(n) < al.unsqueeze(1)).float().unsqueeze(2)
     Hg = H.clone().requires_grad_(True)
-    out = model.gnn(Hg, (ei, et), nt, ns)
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        out = model.gnn(Hg, (ei, et), nt, ns)
     helpers.check_stored(fix, 'mp_out', out, **FWD)
     wg = torch.cos(torch.arange(out.numel(), dtype=torch.float32) * 0.37).view_as(out)
     (out * wg).sum().backward()
     grads = {k: p.grad for k, p in model.gnn.named_parameters() if p.grad is not None}
     grads['::mp_dH'] = Hg.grad
-    helpers.F64Ref(case, 'mpgrad').check_all(grads, what=case + ' mpgrad::', min_checked=20)
+    helpers.F64Ref(case, 'mpgrad').check_all(grads, what=case + ' mpgrad::', min_checked=20, **helpers.kink_args(rec, c['cfg'], ei, et, nt))
     for bname, b in model.gnn.named_buffers():
         helpers.check_plain(fix, 'mpbuf::' + bname, b, rtol=1e-4, atol=1e-6)
 
@@ -106,7 +109,8 @@ def test_single_gatconve_layer_matches_reference(case):
     H, ns, x, extra = helpers.mp_inputs(case)
     layer = model.gnn.gnn_layers[0]
     xg = x.clone().requires_grad_(True)
-    out, (ei_loops, alpha) = layer(xg, ei, et, nt.view(-1), extra, return_attention_weights=True)
+    with helpers.recorded_forward(c['cfg']['concept_dim']) as rec:
+        out, (ei_loops, alpha) = layer(xg, ei, et, nt.view(-1), extra, return_attention_weights=True)
     assert ei_loops.size(1) == ei.size(1) + x.size(0)
     helpers.check_stored(fix, 'layer_out', out, **FWD)
     helpers.check_stored(fix, 'layer_alpha', alpha, rtol=1e-4, atol=1e-7)
@@ -114,7 +118,7 @@ def test_single_gatconve_layer_matches_reference(case):
     (out * wl).sum().backward()
     grads = {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
     grads['::layer_dx'] = xg.grad
-    helpers.F64Ref(case, 'layergrad').check_all(grads, what=case + ' layergrad::', min_checked=10)
+    helpers.F64Ref(case, 'layergrad').check_all(grads, what=case + ' layergrad::', min_checked=10, **helpers.kink_args(rec, c['cfg'], ei, et, nt))
 
 
 @pytest.mark.parametrize('case', ['config1_train', 'small_eval', 'medqa_b8'])
