@@ -899,8 +899,8 @@ def main():
                               'launches_per_step': ins['gemm_launches'],
                               'timed_in': f'{GEMM_STEPS} extra steps after the timed regions (HIP events around every launch)',
                               'note': 'fp32-equivalent FLOPs.  The NN products run as six bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per '
-                                      'product = one fp32 rounding) unless QAGNN_GEMM_SPLIT=0, the weight-gradient (TN) products the same way with the '
-                                      'tiles transposed into LDS unless QAGNN_TN_SPLIT=0'},
+                                      'product = one fp32 rounding), the weight-gradient (TN) products the same way with the tiles transposed '
+                                      'into LDS; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels for both'},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
                                       'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms, 3)},
         }

@@ -616,9 +616,8 @@ __global__ __launch_bounds__(SC_G * 64) void k_sum_chunks4(const float* __restri
   }
 }
 
-// NN launch shapes (QAGNN_NN_PERSIST): 1 (default) = 8-wave blocks walking the tiles persistently, QAGNN_NN_BLOCKS_PER_CU
-// (default: the build's QAGNN_NN_OCC = 2) blocks per CU; 0 = one 128-row tile per 4-wave block, grid = tiles; 2 = the
-// 4-wave block, persistent.  Measured at M = 64000 (profiles/r1_gemm_micro.txt): 1 is 10-18 % faster than 0.
+// NN launch shape: 8-wave blocks walking the tiles persistently, QAGNN_NN_OCC (= 2) blocks per CU.  Measured at M = 64000
+// (profiles/r1_gemm_micro.txt): 10-18 % faster than one 128-row tile per 4-wave block; the other forms were removed in round 5.
 static int num_cus() {
   static int n = [] {
     int dev = 0, v = 0;

@@ -56,27 +56,6 @@ for arg in "$@"; do
       python scripts/trace_by_shape.py "$(find /tmp/profno -name '*kernel_trace.csv' | head -n 1)" > gpurun_out/prof/by_shape_no_overlap.txt 2>&1
       tail -n 4 gpurun_out/profno.log > /tmp/x && mv /tmp/x gpurun_out/profno.log
       stamp profno ;;
-    nnmicro)   # small-M NN GEMMs under rocprofv3 (kernel durations; the Python launch loop itself is host-bound), per column-tile width
-      for nt in 0 7 4 2; do
-        rm -rf /tmp/nnm; mkdir -p /tmp/nnm
-        ( cd /tmp && QAGNN_NN_SMALL_NT=$nt timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nnm -o m -- python "$REPO/tools/nn_micro.py" --small ) > /tmp/nnm.log 2>&1
-        echo "== QAGNN_NN_SMALL_NT=$nt" >> gpurun_out/nn_micro.txt
-        python scripts/nn_micro_trace.py "$(find /tmp/nnm -name '*kernel_trace.csv' | head -n 1)" >> gpurun_out/nn_micro.txt 2>&1
-      done; stamp nnmicro ;;
-    nnabl)   # NN split GEMM at M = 64 000 with the operand-split arithmetic ablated (B only / A and B): what pre-split operands could buy
-      for lib in "" tools/bin/libqagnn_hip_nobsplit.so tools/bin/libqagnn_hip_nosplit.so; do
-        rm -rf /tmp/nna; mkdir -p /tmp/nna
-        ( cd /tmp && QAGNN_LIB=${lib:+$REPO/$lib} timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nna -o m -- python "$REPO/tools/nn_micro.py" ) > /tmp/nna.log 2>&1
-        echo "== library: ${lib:-qagnn_amd/libqagnn_hip.so (shipped)}" >> gpurun_out/nn_ablate.txt
-        python scripts/nn_micro_trace.py "$(find /tmp/nna -name '*kernel_trace.csv' | head -n 1)" --big >> gpurun_out/nn_ablate.txt 2>&1
-      done; stamp nnabl ;;
-    nnvar)   # build variants of the NN split GEMM at M = 64 000 (tools/bin/libqagnn_hip_<name>.so, names in NNVAR)
-      for lib in "" $NNVAR; do
-        rm -rf /tmp/nna; mkdir -p /tmp/nna
-        ( cd /tmp && QAGNN_LIB=${lib:+$REPO/tools/bin/libqagnn_hip_$lib.so} timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nna -o m -- python "$REPO/tools/nn_micro.py" ) > /tmp/nna.log 2>&1
-        echo "== library: ${lib:-shipped}" >> gpurun_out/nn_variants.txt
-        python scripts/nn_micro_trace.py "$(find /tmp/nna -name '*kernel_trace.csv' | head -n 1)" --big >> gpurun_out/nn_variants.txt 2>&1
-      done; stamp nnvar ;;
     prof10)
       rm -rf /tmp/prof10; mkdir -p /tmp/prof10 gpurun_out/prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof10 -o r3 -- python "$REPO/bench.py" --steps 10 --warmup 3 --repeats 1 --graphs 0 --questions 2 --no-cpu-baseline --no-pmc --no-configs ) 2>&1 | tail -n 8 > gpurun_out/prof10.log
@@ -110,13 +89,6 @@ PY
         echo "$var=$v (2 questions)" >> gpurun_out/ab10_$var.txt
         env $var=$v timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>/dev/null | tail -n 1 | cut -c1-200 >> gpurun_out/ab10_$var.txt
       done; stamp "ab10:$var" ;;
-    probe10)   # which side streams the captured step really has, and what the capture said (stderr kept)
-      for e in "X=1" "QAGNN_WGRAD_OVERLAP=0" "X=1" "QAGNN_WGRAD_OVERLAP=0"; do
-        echo "== $e" >> gpurun_out/probe10.txt
-        env $e timeout 300 python bench.py --steps 40 --warmup 8 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2> /tmp/probe10.err | tail -n 1 > /tmp/probe10.json
-        python -c "import json; d = json.load(open('/tmp/probe10.json')); print(d['ms_per_step'], d['hip_graph'])" >> gpurun_out/probe10.txt 2>&1
-        grep -i "warn\|error\|GraphedStep" /tmp/probe10.err | cut -c1-400 | head -n 6 >> gpurun_out/probe10.txt
-      done; stamp probe10 ;;
     ablib:*)   # ablib:<name>  -- the shipped library vs tools/bin/libqagnn_hip_<name>.so, whole step, interleaved
       name="${arg#ablib:}"
       for lib in "" "$name" "" "$name"; do
@@ -153,31 +125,10 @@ PY
       done
       python scripts/pmc_edge_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -n 1)" "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -n 1)" 64000 208 > gpurun_out/pmc_edge_fwd.json 2> gpurun_out/pmc_edge_traffic.err
       stamp pmc ;;
-    sqpmc)   # SQ counters of the NN split GEMMs at M = 64 000 (tools/nn_micro.py), two passes of <= 8 counters
-      i=0
-      for ctrs in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
-                  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC"; do
-        i=$((i+1)); rm -rf /tmp/sqp$i; mkdir -p /tmp/sqp$i
-        ( cd /tmp && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/sqp$i -o p -- python "$REPO/tools/nn_micro.py" ) > gpurun_out/sqpmc$i.log 2>&1
-        tail -n 3 gpurun_out/sqpmc$i.log > /tmp/x && mv /tmp/x gpurun_out/sqpmc$i.log
-        python scripts/pmc_sq_by_kernel.py "$(find /tmp/sqp$i -name '*counter_collection.csv' | head -n 1)" 2>&1 | grep "nn_split\|nn2\|pack_b\|Traceback\|Error" | head -n 20 >> gpurun_out/sqpmc.txt
-      done; stamp sqpmc ;;
     census)   # kernel launches of one step by forward region (backward attributed through autograd sequence numbers)
       timeout 300 python tools/op_census.py 2>&1 | cut -c1-230 | grep -v "Warning\|warn" | head -n 700 > gpurun_out/op_census.txt; stamp census ;;
     hostprof)
       timeout 300 python -m cProfile -s tottime bench.py --steps 40 --warmup 5 --repeats 1 --questions 2 --no-cpu-baseline --no-pmc --no-configs 2>&1 | head -n 70 > gpurun_out/hostprof_b10.txt; stamp hostprof ;;
-    nn2micro)   # the NN products at M = 64 000 under the three settings of QAGNN_NN2 (0 = k_gemm_nn_split, 1 = k_gemm_nn2, 2 = pinned interleave)
-      for v in 0 1 2 0 1 2; do
-        echo "== QAGNN_NN2=$v" >> gpurun_out/nn2_micro.txt
-        QAGNN_NN2=$v timeout 300 python tools/nn_micro.py 2>&1 | grep -v "^==" >> gpurun_out/nn2_micro.txt
-      done; stamp nn2micro ;;
-    nn2small)
-      for v in 0 1; do
-        echo "== QAGNN_NN2=$v" >> gpurun_out/nn2_micro_small.txt
-        rm -rf /tmp/nnm; mkdir -p /tmp/nnm
-        ( cd /tmp && QAGNN_NN2=$v timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/nnm -o m -- python "$REPO/tools/nn_micro.py" --small ) > /tmp/nnm.log 2>&1
-        python scripts/nn_micro_trace.py "$(find /tmp/nnm -name '*kernel_trace.csv' | head -n 1)" >> gpurun_out/nn2_micro_small.txt 2>&1
-      done; stamp nn2small ;;
     edgepmc)   # what bounds the edge kernels: TA / TD busy, L1 and L2 hit rates, issue stalls (three passes; --pmc with --kernel-trace only)
       i=0; files=""
       for ctrs in "GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max TD_TD_BUSY_sum TCC_HIT_sum TCC_MISS_sum" \

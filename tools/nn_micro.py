@@ -11,7 +11,7 @@ K = ops.kernels()
 g = torch.Generator().manual_seed(0)
 SMALL = '--small' in sys.argv   # the row counts of the host-bound configurations: 5 / 10 / 64 subgraphs
 for M in ((500, 2000, 12800) if SMALL else (64000,)):
-  print(f'== M = {M} rows, QAGNN_NN_SMALL_NT = {os.environ.get("QAGNN_NN_SMALL_NT", "0")}')
+  print(f'== M = {M} rows, QAGNN_GEMM_SPLIT = {os.environ.get("QAGNN_GEMM_SPLIT", "1")}')
   ALL = (('mlp 208->208', 208, 0, 208, 208), ('proj [208|112]->624', 208, 112, 624, 208), ('dX 624->208', 624, 0, 208, 624),
          ('640->208', 640, 0, 208, 640), ('1024->208', 1024, 0, 208, 1024), ('416->208', 416, 0, 208, 416),
          ('dS 624->112', 624, 0, 112, 624), ('[dX|dS] 624->320', 624, 0, 320, 624))

@@ -1,4 +1,4 @@
-"""Time qagnn_gemm_tn_f32 on the weight-gradient shapes of a B = 320 step (run once per QAGNN_TN_SPLIT setting)."""
+"""Time qagnn_gemm_tn_f32 on the weight-gradient shapes of a B = 320 step (run once per QAGNN_GEMM_SPLIT setting)."""
 import os
 import sys
 
@@ -32,5 +32,5 @@ for R, Ka, No, aff in ((64000, 208, 208, False), (64000, 208, 208, True), (64000
     Ae = torch.relu(A * kw['a_scale'] + kw['a_shift']) if aff else A
     ref = Ae.double().t() @ B.double()
     err = ((out.double() - ref).abs() / (Ae.abs().double().t() @ B.abs().double()).clamp_min(1e-30)).max().item()
-    print(f'TN_SPLIT={os.environ.get("QAGNN_TN_SPLIT", "1")} R={R} Ka={Ka} No={No} affine={aff}: {us:8.1f} us  '
+    print(f'GEMM_SPLIT={os.environ.get("QAGNN_GEMM_SPLIT", "1")} R={R} Ka={Ka} No={No} affine={aff}: {us:8.1f} us  '
           f'{2.0 * R * Ka * No / us / 1e6:7.1f} TFLOP/s  max err / sum|a||b| = {err:.2e}')
