@@ -711,11 +711,10 @@ def main():
         # collective after a step (profiles/r2_run50_mg_probe.txt); with one queue per process the rig behaves (12.6 ms per step)
         ops.WGRAD_OVERLAP = False
         ops.PREP_OVERLAP = False
-        # ... and eager launches only: with the graph preparation captured on the MAIN stream, replays that follow eager steps of the same
-        # model back to back (no synchronisation in between: exactly what `--graphs auto` does when it times both forms) have left
-        # garbage in the preparation's validation words on the 320-subgraph model -- a race that a synchronisation between the phases
-        # hides and the default configuration (preparation on its side stream) has never shown (open issue;
-        # scripts/r5_replay_flag_probe.py).  The rig measures the N > 1 code paths, not launch overhead.
+        # ... and eager launches: two processes replaying 400-kernel hipGraphs on one time-sliced GPU between gloo's host-side waits take
+        # 1-5 s per step (profiles/r5_run31_bench_dp2_weak_replay_shared_gpu.json; eager: 21-24 ms).  The rig measures the N > 1 code paths
+        # of this file, not launch overhead.  (Until round 5's visit 30 the rig also tripped over the memset-node fault of fork-free
+        # captured steps -- DESIGN.md section 6; csrc/graph_prep.hip zeroes with a kernel of its own since.)
         args.graphs = '0'
     if world > 1:
         import torch.distributed as dist

@@ -438,6 +438,25 @@ static int xcd_partition(qagnn_graph* g, hipStream_t stream) {
   return QAGNN_OK;
 }
 
+// Zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel of this library, NOT hipMemsetAsync.  Measured (round 5, visits 27-28,
+// profiles/r5_run28_memset_node_fault.txt): ROCm 7.2 replays a captured hipMemsetAsync node of a LINEAR hipGraph (no forked stream:
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) with its 16-byte fill pattern read from a kernel-argument slot that later eager launches
+// of the same process recycle -- the replay then "zeroes" the range with the head of somebody's argument block.  A kernel has no such
+// side buffer.
+__global__ void k_zero16(int4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = make_int4(0, 0, 0, 0);
+}
+static hipError_t zero_range(void* p, size_t bytes, hipStream_t stream) {
+#ifdef QAGNN_PREP_MEMSET_NODE  // the faulty form, only to reproduce the fault (tools/build_micro.sh -> scripts/r5_memset_node_fault.sh)
+  return hipMemsetAsync(p, 0, bytes, stream);
+#endif
+  const int64_t n16 = (int64_t)(bytes / 16);
+  int blocks = (int)((n16 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (n16 > 0) k_zero16<<<blocks, 256, 0, stream>>>((int4*)p, n16);
+  return hipGetLastError();
+}
+
 // carve `storage` into the arrays of *g plus scratch (layout shared by qagnn_graph_prep_blocked and qagnn_graph_from_blobs)
 struct carved {
   int32_t *eid_t, *gc_cnt, *gcptr, *nch, *cnt_s, *cnt_t, *es, *et, *ec, *tmp_s, *tmp_t, *srcpos, *hist;
@@ -539,8 +558,8 @@ extern "C" int qagnn_graph_prep_blocked(qagnn_graph* g, int32_t* storage, const 
   int32_t *srcpos = cv.srcpos, *eid_t = cv.eid_t, *hist = cv.hist, *gc_cnt = cv.gc_cnt, *gcptr = cv.gcptr, *nch = cv.nch;
   const int nblk = cv.nblk, gb = cv.gb, NG = cv.NG, pairs = cv.pairs;
 
-  hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)es - (char*)g->cls_count), stream);
-  if (he != hipSuccess) { set_error("graph_prep: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  hipError_t he = zero_range(g->cls_count, (size_t)((char*)es - (char*)g->cls_count), stream);
+  if (he != hipSuccess) { set_error("graph_prep: k_zero16 failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   const int TB = 256;
   k_decode_count<<<cdiv(Ep, TB), TB, 0, stream>>>(edge_index, edge_type, node_type, N, E, R, T, es, et, ec, cnt_s, cnt_t,
                                                    g->err, block_n);
@@ -572,8 +591,8 @@ extern "C" int qagnn_graph_from_blobs(qagnn_graph* g, int32_t* storage, const in
   QAGNN_REQUIRE(Ep64 < (1ll << 30), QAGNN_EUNSUPPORTED, "graph_from_blobs: E+N=%lld too large", (long long)Ep64);
   QAGNN_REQUIRE(C64 <= 8192, QAGNN_EUNSUPPORTED, "graph_from_blobs: %lld edge classes > 8192", (long long)C64);
   carved cv = carve(g, storage, (int)N64, E, R, T, n);
-  hipError_t he = hipMemsetAsync(g->cls_count, 0, (size_t)((char*)cv.es - (char*)g->cls_count), stream);
-  if (he != hipSuccess) { set_error("graph_from_blobs: memset failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
+  hipError_t he = zero_range(g->cls_count, (size_t)((char*)cv.es - (char*)g->cls_count), stream);
+  if (he != hipSuccess) { set_error("graph_from_blobs: k_zero16 failed: %s", hipGetErrorString(he)); return QAGNN_EHIP; }
   k_blob_assemble<<<B, 256, (size_t)(2 * (n + 1)) * sizeof(int), stream>>>(blobs, blob_off, edge_off, node_type, n, B, R, T, g->rowptr_s,
                                                                            g->tgt_s, g->src_s, g->cls_s, g->eid_s, g->rowptr_t, g->src_t, g->tgt_t,
                                                                            g->cls_t, g->pos_t, g->err);

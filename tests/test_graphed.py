@@ -133,6 +133,51 @@ def test_replays_and_eager_steps_alternate_on_one_model(nq, p, prep_overlap, mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('prep_overlap', [True, False])
+@pytest.mark.parametrize('nq', [2, 64])
+def test_replays_enqueued_back_to_back_equal_the_eager_step(nq, prep_overlap, monkeypatch):
+    """The host runs ahead of the device here, as in a training loop and in bench.py: groups of three calls enqueued back to back behind a
+    synchronisation (the eager launches of call i + 1 -- the refill of the static inputs -- go out while replay i is pending), then 12
+    calls with no synchronisation at all.  The test above compares after every replay, i.e. never lets the host run ahead.
+
+    Regression test of round 5's memset-node fault (csrc/graph_prep.hip, k_zero16): ROCm 7.2 replays the captured
+    hipMemsetAsync node of a fork-free hipGraph with a fill pattern read from a kernel-argument slot that eager launches recycle, and
+    the first call sequence that shows it is "synchronise, three calls".  With the library built -DQAGNN_PREP_MEMSET_NODE the
+    `prep_overlap = False` cases fail in the first group (scripts/r5_memset_node_fault.sh, profiles/r5_run31_memset_node_fault.txt)."""
+    ops.set_kernels(None)
+    from qagnn_amd import _lib
+    monkeypatch.setattr(ops, 'PREP_OVERLAP', prep_overlap)
+    _lib.ERR_WATCH.poll(block=True)
+    nc, n = 5, 200
+    b = _batch(nq, nc, n, 13)
+    cap = graphed.edge_capacity(b['packed'].E)
+    m_ref, m = _model(0.0), _model(0.0)
+    want = _eager(m_ref, b, nc, e_cap=cap)
+    step = graphed.GraphedStep(m, nc)
+    call = lambda: step(b['sent'], b['cids'], b['nt'], b['ns'], b['al'], b['packed'], b['labels'])  # noqa: E731
+
+    def check(tag, logits, loss):
+        torch.cuda.synchronize()
+        got = (logits, loss, {k: q.grad for k, q in m.named_parameters() if q.grad is not None}, want[3])
+        _same(got, want, tag)
+        for flags, _, _ in next(iter(step._captured.values())).watched:
+            assert flags.tolist() == [0, 0, 0, 0], f'{tag}: validation words {flags.tolist()}'
+
+    check('the capturing call', *call())
+    for r in range(8):
+        for _ in range(3):
+            out = call()  # (a validation word left by the previous replay raises here)
+        check(f'group {r}: three calls behind a synchronisation', *out)
+    for i in range(12):
+        if i == 6:
+            _eager(m, b, nc)  # eager launches of the same model in between (clones on the device: no synchronisation)
+        out = call()
+    check('12 calls with no synchronisation', *out)
+    _lib.ERR_WATCH.poll(block=True)
+    assert step.n_graphs == 1
+
+
+@pytest.mark.gpu
 def test_capacity_layout_changes_nothing():
     ops.set_kernels(None)
     b = _batch(2, 5, 200, 7)
