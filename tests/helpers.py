@@ -387,7 +387,12 @@ class PreActRecorder:
         self.pre = []
 
     def _keep(self, h1, scale, shift):
-        self.pre.append(torch.addcmul(shift, h1, scale).detach().cpu()[:, self._pos].contiguous())
+        # the kernels take relu(fmaf(h1, scale, shift)): ONE rounding of the exact value.  In float64 the product of two fp32 numbers is
+        # exact and the sum keeps its sign, so this has the kernel's sign (and zero-ness) element for element -- an fp32 addcmul that
+        # the compiler does not contract rounds twice and flips the sign of a cancelling element now and then (seen: one element of
+        # sapbert_b4 under QAGNN_GEMM_SPLIT=0, visit 32).
+        pre = torch.addcmul(shift.detach().double(), h1.detach().double(), scale.detach().double()).float()
+        self.pre.append(pre.cpu()[:, self._pos].contiguous())
 
     def __getattr__(self, attr):
         fn = getattr(self._inner, attr)
