@@ -180,8 +180,8 @@ __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __res
 // per 128-row tile t and column c: x0 = the tile's first value, S1 = sum (x - x0), S2 = sum (x - x0)^2), combined by the pairwise
 // update of Chan, Golub & LeVeque -- every tile is shifted by one of its own values, so nothing cancels -- plus the whole
 // bookkeeping of k_bn_finalize, in one launch and ONE pass over the partials.  A block owns 16 columns; its 1024 threads are
-// 16 columns x 64 partitions (partition q merges tiles q, q + 64, ... in order), the 64 partition results are merged in partition
-// order by the column's first thread: a fixed order, whatever the timing.
+// 16 columns x 64 partitions (partition q merges tiles q, q + 64, ... in order), the 64 partition results are merged in a fixed binary
+// tree: a fixed order, whatever the timing.
 constexpr int ST_TILE = 128;  // = SBM of gemm_split.hip
 constexpr int BF_COLS = 16, BF_PARTS = 64;
 struct Moments { float n, mean, m2; };
@@ -202,15 +202,34 @@ __global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const 
   const int c = blockIdx.x * BF_COLS + cl;
   Moments a = {0.f, 0.f, 0.f};
   if (c < Cc)
-    for (int t = q; t < nt; t += BF_PARTS) {
-      const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
-      const float x0 = part[((int64_t)t * 3 + 0) * Cc + c], S1 = part[((int64_t)t * 3 + 1) * Cc + c], S2 = part[((int64_t)t * 3 + 2) * Cc + c];
-      merge(a, n_t, x0 + S1 / n_t, S2 - S1 * S1 / n_t);
+    for (int t0 = q; t0 < nt; t0 += 4 * BF_PARTS) {  // four tiles' partials in flight together (the kernel is load latency: 500 tiles = 8 per thread)
+      float x0[4], S1[4], S2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t t = min(t0 + u * BF_PARTS, nt - 1);  // clamped: unconditional loads
+        x0[u] = part[(t * 3 + 0) * Cc + c]; S1[u] = part[(t * 3 + 1) * Cc + c]; S2[u] = part[(t * 3 + 2) * Cc + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * BF_PARTS;
+        if (t < nt) {
+          const float n_t = (float)min(ST_TILE, R - t * ST_TILE);
+          merge(a, n_t, x0[u] + S1[u] / n_t, S2[u] - S1[u] * S1[u] / n_t);
+        }
+      }
     }
   sn[q][cl] = a.n; sm[q][cl] = a.mean; s2[q][cl] = a.m2;
   __syncthreads();
+  // the 64 partitions meet in a fixed binary tree (6 levels; partition q absorbs q + stride): the column's first thread ends with all of them
+#pragma unroll
+  for (int stride = 1; stride < BF_PARTS; stride *= 2) {
+    if ((q & (2 * stride - 1)) == 0 && c < Cc) {
+      merge(a, sn[q + stride][cl], sm[q + stride][cl], s2[q + stride][cl]);
+      sn[q][cl] = a.n; sm[q][cl] = a.mean; s2[q][cl] = a.m2;
+    }
+    __syncthreads();
+  }
   if (q == 0 && c < Cc) {
-    for (int k = 1; k < BF_PARTS; ++k) merge(a, sn[k][cl], sm[k][cl], s2[k][cl]);
     const float mean = a.mean, var = fmaxf(a.m2 / (float)R, 0.f);  // biased, as BatchNorm normalises with
     const float is = rsqrtf(var + eps), sc = gamma[c] * is;
     stats[c] = mean;
