@@ -427,6 +427,15 @@ __global__ void k_xcd_partition(const int* __restrict__ rowptr_s, int N, int cap
   }
 }
 
+// Zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel of this library, NOT hipMemsetAsync.  Measured (round 5, visits 27-28,
+// profiles/r5_run28_race_variants.txt, r5_run31_memset_node_fault.txt): ROCm 7.2 replays a captured hipMemsetAsync node of a LINEAR hipGraph (no forked stream:
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) with its 16-byte fill pattern read from a kernel-argument slot that later eager launches
+// of the same process recycle -- the replay then "zeroes" the range with the head of somebody's argument block.  A kernel has no such
+// side buffer.
+__global__ void k_zero16(int4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = make_int4(0, 0, 0, 0);
+}
+
 }  // namespace qagnn
 
 using namespace qagnn;
@@ -438,14 +447,6 @@ static int xcd_partition(qagnn_graph* g, hipStream_t stream) {
   return QAGNN_OK;
 }
 
-// Zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel of this library, NOT hipMemsetAsync.  Measured (round 5, visits 27-28,
-// profiles/r5_run28_memset_node_fault.txt): ROCm 7.2 replays a captured hipMemsetAsync node of a LINEAR hipGraph (no forked stream:
-// DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) with its 16-byte fill pattern read from a kernel-argument slot that later eager launches
-// of the same process recycle -- the replay then "zeroes" the range with the head of somebody's argument block.  A kernel has no such
-// side buffer.
-__global__ void k_zero16(int4* __restrict__ p, int64_t n16) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = make_int4(0, 0, 0, 0);
-}
 static hipError_t zero_range(void* p, size_t bytes, hipStream_t stream) {
 #ifdef QAGNN_PREP_MEMSET_NODE  // the faulty form, only to reproduce the fault (tools/build_micro.sh -> scripts/r5_memset_node_fault.sh)
   return hipMemsetAsync(p, 0, bytes, stream);
