@@ -163,12 +163,9 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
     const float* const Bw = smem + A_F + (lane >> 4) * PB + (lane & 15);
     auto ktile = [&](auto curc, int kt) {  // cur = kt & 1 names both the LDS buffer of tile kt and the A register set of tile kt+2
       constexpr int cur = decltype(curc)::value;
-#ifndef QAGNN_ABLATE_NOGLOAD
       gloadB(min(kt + 1, nkt - 1));               // past the last tile: a redundant reload, never consumed
       gloadA(min(kt + 2, nkt - 1), raS[cur]);
       __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to the LDS store
-#endif
-#ifndef QAGNN_ABLATE_NOMMA
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         float av[RT];
@@ -181,7 +178,6 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
           for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv, acc[i][j], 0, 0, 0);
         }
       }
-#endif
       lstore(ic<cur ^ 1>{}, min(kt + 1, nkt - 1), raS[cur ^ 1]);  // after the MFMAs: the loads had one k-tile (B) / two (A) to land
       __syncthreads();
     };
@@ -197,15 +193,6 @@ __global__ __launch_bounds__(WAVES * 64) QAGNN_NN_ATTR void k_gemm_nn(qagnn_gemm
       ktile(ic<0>{}, kt);
       if (kt + 1 < nkt) ktile(ic<1>{}, kt + 1);
     }
-#ifdef QAGNN_ABLATE_NOEPI
-    {  // keep the accumulators live with one dword store per lane, skip the real epilogue
-      float keep = 0.f;
-      for (int i = 0; i < RT; ++i)
-        for (int j = 0; j < NT; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (m0 + (tid >> 1) < a.M) a.C[(int64_t)(m0 + (tid >> 1)) * a.ldc + n0 + (tid & 1)] = keep;
-      continue;
-    }
-#endif
 
     // epilogue.  The MFMA layout gives a lane ONE column of 4 rows per accumulator; storing that directly is 104 dword
     // stores per lane in 64-byte row fragments (store-issue bound).  Instead each wave transposes SLAB_ROWS rows at a
@@ -369,29 +356,15 @@ __global__ __launch_bounds__(1024) void k_gemm_tn(const float* __restrict__ A, i
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nkt;
-#ifndef QAGNN_ABLATE_NOGLOAD
     if (more) gload(kt + 1);
-#endif
-#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 0);
     mma(cur, 1);
-#endif
     if (do_cs) colsum_tile(cur);
-#ifndef QAGNN_ABLATE_NOMMA
     mma(cur, 2);
     mma(cur, 3);
-#endif
     if (more) lstore(cur ^ 1);  // as late as possible: the global loads get the whole tile's MFMA time to land
     __syncthreads();
   }
-#ifdef QAGNN_ABLATE_NOEPI
-  {
-    float keep = 0.f;
-    for (int j = 0; j < NT; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
-    if (keep == 123.456f) P[tid] = keep;
-    return;
-  }
-#endif
   if (do_cs && n0 + tid < No) {
     float* pc = Pcs + (int64_t)chunk * groups * No + n0 + tid;
     pc[0] = cs0;
@@ -499,10 +472,7 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
   auto ktile = [&](auto curc, int kt) {
     constexpr int cur = decltype(curc)::value;
     const bool more = kt + 1 < nkt;
-#ifndef QAGNN_ABLATE_NOGLOAD
     if (more) gload(kt + 1);
-#endif
-#ifndef QAGNN_ABLATE_NOMMA
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const float av = a_frag[cur * TBUF_F + kk * 4 * PA];
@@ -513,7 +483,6 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[j], 0, 0, 0);
     }
     sched_ktile_pipeline<NT>();
-#endif
     if (do_cs) {  // rows in tile order = row order: the summation order is fixed
       const float* Bs = smem + cur * TBUF_F + TA_F + tid;
 #pragma unroll
@@ -539,14 +508,6 @@ __global__ __launch_bounds__(NWT * 64) void k_gemm_tn_strip(const float* __restr
     ktile(ic<0>{}, kt);
     if (kt + 1 < nkt) ktile(ic<1>{}, kt + 1);
   }
-#ifdef QAGNN_ABLATE_NOEPI
-  {
-    float keep = 0.f;
-    for (int j = 0; j < NT; ++j) keep += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
-    if (keep == 123.456f) P[tid] = keep;
-    return;
-  }
-#endif
   if (do_cs && n0 + tid < No) {
     float* pc = Pcs + (int64_t)chunk * groups * No + n0 + tid;
     pc[0] = cs[0];
