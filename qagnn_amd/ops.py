@@ -232,7 +232,7 @@ _SIDE_STREAMS = {}
 #   * only operators created inside `wgrad_scope()` defer, and the stack guarantees that every weight operand there comes
 #     straight out of GatherPlan, so nothing on the main stream reads a deferred gradient before the join;
 #   * a gradient consumed inside the graph is either computed on the main stream (the grouped column reduction over dC when
-#     QAGNN_BYPRODUCT_GRADS=0) or -- the default -- handed out as a VIEW of a deferred weight-gradient product (the node-type-table
+#     `BYPRODUCT_GRADS` is off) or -- the default -- handed out as a VIEW of a deferred weight-gradient product (the node-type-table
 #     gradient = rows [tab_col, tab_col + T) of S^T dC, LinearNNFn.tabcol) whose ONE consumer, SplitColsFn.backward, joins the side
 #     stream before it reads; hop() refuses the combination "table gradient as a by-product" + "tables computed inside the hop"
 #     (torch.addmm would read the view without a join);
