@@ -54,6 +54,8 @@ namespace nn2 {
 #endif
 
 constexpr int BK = 32;
+// bit 7 (128): the three-product form's time ceiling -- two operand pieces (fp16 split arithmetic), three MFMAs, two B images
+constexpr int ABL_NP = (QAGNN_NN2_ABL & 128) ? 2 : 3;
 constexpr uint32_t OOB = 0x80000000u;  // beyond any operand this kernel is launched on: the buffer load answers with zeros
 
 __device__ __forceinline__ u32x4s bload(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
@@ -73,6 +75,24 @@ __device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return _
 // 8 consecutive k of one row (two 16-byte loads) -> the three bf16x8 fragments
 template <bool AFFINE>
 __device__ __forceinline__ void split_frag(const u32x4s (&r)[2], bf16x8 (&f)[3], const float* __restrict__ sc, const float* __restrict__ sh, float lo) {
+  if constexpr (QAGNN_NN2_ABL & 128) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float x = __builtin_bit_cast(float, r[e >> 2][e & 3]), y = __builtin_bit_cast(float, r[(e + 1) >> 2][(e + 1) & 3]);
+      if constexpr (AFFINE) { x = fmaxf(fmaf(x, sc[e], sh[e]), lo); y = fmaxf(fmaf(y, sc[e + 1], sh[e + 1]), lo); }
+      x *= lo == 0.f ? 64.f : 128.f; y *= lo == 0.f ? 64.f : 128.f;
+      const h2v hi = {(_Float16)x, (_Float16)y};
+      const h2v lw = {(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
+      ph[e >> 1] = __builtin_bit_cast(uint32_t, hi);
+      pl[e >> 1] = __builtin_bit_cast(uint32_t, lw);
+    }
+    f[0] = __builtin_bit_cast(bf16x8, (u32x4s){ph[0], ph[1], ph[2], ph[3]});
+    f[1] = __builtin_bit_cast(bf16x8, (u32x4s){pl[0], pl[1], pl[2], pl[3]});
+    f[2] = f[1];
+    return;
+  }
   uint32_t h1[8], h2[8], h3[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -101,16 +121,18 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
 }
 
 #define QAGNN_NN2_SIX_T(C, AF, BF)                                        \
+  if constexpr (ABL_NP == 3) {                                            \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[2], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[2], AF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[1], C, 0, 0, 0); } \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[0], C, 0, 0, 0);
 #define QAGNN_NN2_SIX(C, AF, BF)                                          \
+  if constexpr (ABL_NP == 3) {                                            \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const unsigned char* src_ = pk + ((int64_t)(IT) * ldn1 + n0 / 16) * 3072 + lane * 16;                              \
       _Pragma("unroll") for (int b = 0; b < (NT * 3 + WV - 1) / WV; ++b) {                                               \
         const int blk_ = w + b * WV;                                                                                     \
-        if (blk_ < NT * 3)                                                                                               \
+        if (blk_ < NT * 3 && (ABL_NP == 3 || blk_ % 3 != 2))                                                             \
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + blk_ * 1024),         \
                                            (__attribute__((address_space(3))) void*)((BUF) + blk_ * 1024), 16, 0, 0);    \
       }                                                                                                                  \
@@ -327,12 +349,12 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     {                                                                                                                    \
       __builtin_amdgcn_s_setprio(1);                                                                                     \
       bf16x8 bfa[3], bfb[3];                                                                                             \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) bfa[p] = *reinterpret_cast<const bf16x8*>((CUR) + p * 1024 + rd_off); \
+      _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p) bfa[p] = *reinterpret_cast<const bf16x8*>((CUR) + p * 1024 + rd_off); \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                   \
         bf16x8(&bf)[3] = (j & 1) ? bfb : bfa;                                                                            \
         bf16x8(&bn)[3] = (j & 1) ? bfa : bfb;                                                                            \
         if (j + 1 < NT && !(QAGNN_NN2_ABL & 16)) {                                                                       \
-          _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                  \
+          _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p)                                                             \
               bn[p] = *reinterpret_cast<const bf16x8*>((CUR) + ((j + 1) * 3 + p) * 1024 + rd_off);                       \
         }                                                                                                                \
         if constexpr (!(QAGNN_NN2_ABL & 32)) {                                                                           \
@@ -357,11 +379,11 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // barriers: the compiler must not add its vmcnt(0), the loads issued in N land under M.
 #define QAGNN_NN2_FRAG(DST, ADDR, J)                                                                                     \
     {                                                                                                                    \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                      \
+      _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p)                                                                 \
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"(((J) * 3 + p) * 1024));           \
     }
     // the fragments of column tile j are the oldest reads in flight; behind them: tiles j + 1 and j + 2 (LDS returns in order)
-#define QAGNN_NN2_FRAG_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]))
+#define QAGNN_NN2_FRAG_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * ABL_NP / 3))
 #define QAGNN_NN2_MFMA_TILE3(ADDR)                                                                                       \
     {                                                                                                                    \
       __builtin_amdgcn_s_setprio(1);                                                                                     \

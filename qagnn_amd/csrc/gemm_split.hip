@@ -390,9 +390,31 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
 // registers across the column loop); the tiles of the KT%4 leftover strips are dealt out one by one (tile q -> wave q % 4).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TKR = 32, TCP = 40, TTHR = 256;
+// QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
+// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them,
+// bit 5 the three-product form's time ceiling (two pieces by fp16 split arithmetic, three MFMAs, two images), both TN kernels
+#ifndef QAGNN_TNW_ABL
+#define QAGNN_TNW_ABL 0
+#endif
+constexpr int TN_NP = (QAGNN_TNW_ABL & 32) ? 2 : 3;
 
 // 8 rows of one column -> three 16-byte chunks
 __device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_elems, const float (&x)[8]) {
+  if constexpr (TN_NP == 2) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const float a = x[e] * 64.f, b = x[e + 1] * 64.f;
+      const h2v hi = {(_Float16)a, (_Float16)b};
+      const h2v lw = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
+      ph[e >> 1] = __builtin_bit_cast(uint32_t, hi);
+      pl[e >> 1] = __builtin_bit_cast(uint32_t, lw);
+    }
+    *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    *reinterpret_cast<uint4*>(dst + img_elems) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+    return;
+  }
   uint32_t h1[8], h2[8], h3[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) split3(x[i], h1[i], h2[i], h3[i]);
@@ -546,9 +568,10 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
   const int rd_off = (lane & 15) * TCP + (((lane >> 4) ^ ((((lane & 15) >> 2) ^ ((lane & 15) >> 3)) & 1)) << 3);
 #define QAGNN_SIX(C, AF, BF)                                              \
+  if constexpr (TN_NP == 3) {                                             \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
@@ -566,12 +589,12 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (w + 4 * i) * 16 * TCP + rd_off);
+      for (int p = 0; p < TN_NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (w + 4 * i) * 16 * TCP + rd_off);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       bf16x8 bf[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + j * 16 * TCP + rd_off);
+      for (int p = 0; p < TN_NP; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + j * 16 * TCP + rd_off);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {  // small terms first
         f32x4s c = acc[i][j];
@@ -586,7 +609,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         const int ir = q / NT, jr = q % NT;
         bf16x8 ar[3], br[3];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < TN_NP; ++p) {
           ar[p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (4 * MT + ir) * 16 * TCP + rd_off);
           br[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + jr * 16 * TCP + rd_off);
         }
@@ -635,12 +658,6 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 // ------------------------------------------------------------------------------------------------------------
 static bool tn_xcd() { return true; }  // the blocks of one split-K chunk on one XCD (-2..5 % per kernel: profiles/r4_run17_tn_ws.txt)
 constexpr int WTHR = 512;
-// QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
-// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them
-#ifndef QAGNN_TNW_ABL
-#define QAGNN_TNW_ABL 0
-#endif
-
 // store_task with a per-lane floor (AFF: relu for the lanes of A, -inf = pass-through for the lanes of B)
 template <bool AFF>
 __device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh, float lo) {
@@ -862,15 +879,16 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 #define QAGNN_TNW_FRAG(DST, ADDR, OFF, PIECE)                                                                            \
   {                                                                                                                      \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                        \
+    _Pragma("unroll") for (int p = 0; p < TN_NP; ++p)                                                                    \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"((OFF) + p * (PIECE)));              \
   }
-#define QAGNN_TNW_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]))
+#define QAGNN_TNW_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * TN_NP / 3))
 #define QAGNN_TNW_SIX(C, AF, BF)                                          \
   if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[1]), "v"(AF[2]), "v"(BF[0]), "v"(BF[1]), "v"(BF[2])); } else { \
+  if constexpr (TN_NP == 3) {                                             \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); \
+  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
   C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0); }

@@ -64,7 +64,6 @@ int main() {
     float* P;
     CK(hipMalloc(&P, (size_t)nchunk * (sh.Ka1 + sh.Ka2) * sh.No * 4));
     for (int ws = 0; ws < 2; ++ws) {
-      setenv("QAGNN_TN_WS", ws ? "1" : "0", 1);
       auto run = [&] {
         if (sh.Ka2) {
           if (ws) { dim3 grid((sh.No + 207) / 208, (sh.Ka1 + 111) / 112 + (sh.Ka2 + 111) / 112, nchunk);
