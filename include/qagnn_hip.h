@@ -147,6 +147,13 @@ typedef struct qagnn_gemm_nn_args {
                                         per 128-row tile t and output column c, over the tile's rows of C:  x0 = C[first row][c],
                                         S1 = sum (C - x0),  S2 = sum (C - x0)^2 -- BatchNorm batch statistics as a by-product of the
                                         GEMM that produces the BatchNorm input (qagnn_bn_stats_finalize_f32 combines the tiles) */
+  const uint32_t* a_amax1;           /* NULL, or a device word holding the BIT PATTERN of (an upper bound within 2^8 of) max |A1| -- after the
+                                        a_scale / a_shift prologue where there is one -- and likewise a_amax2 for A2 (ignored when K2 = 0).
+                                        qagnn_gemm_nn_split*_f32 only: with both known, a large product takes the THREE-MFMA form (scaled
+                                        two-piece fp16 split, csrc/gemm_nn2.hip; ~2^-21 per product instead of 2^-23).  A word that
+                                        understates the maximum by 2x or more makes the result inf / nan (never silently wrong): the
+                                        producers of this library fill it exactly (qagnn_absmax_f32 and the *_amax arguments) */
+  const uint32_t* a_amax2;
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 /* The same product on the bf16 matrix cores by EXACT operand splitting (csrc/gemm_split.hip): every fp32 operand is the exact sum
@@ -161,7 +168,7 @@ int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32
  * bf16 images in the order the kernel's LDS wants them, and every row tile then streams it into LDS by DMA instead of repeating the
  * split (19 % of the projection [N, 320] x [320, 624] at N = 64 000).  ws = NULL (or too small, or a small product) = qagnn_gemm_nn_split_f32.
  * Same arithmetic per output element as the unpacked route: bit-identical results. */
-int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2);
+int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2); /* (sized for either arithmetic form) */
 /* Bytes of scratch qagnn_gemm_nn_split_ws_f32 would USE for this very call: 0 when B is a registered (pre-packed) operand, when the product
  * is not one the packed kernels take, or when it has too few rows to pay for a pack launch -- a caller that allocates per call asks first. */
 int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2);
@@ -173,12 +180,20 @@ int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, in
  * same tag (the module mirror packs behind its operand-packing gather every forward and holds both tensors).  Entries that the
  * packed kernels do not take (K not a multiple of 8, ...) are skipped silently: their products pack per call as before.  Host-side
  * registry, mutex-protected; clear(0) empties it. */
-typedef struct qagnn_pack_desc { const float* B1n; int32_t ldn1; int32_t K1; const float* B2n; int32_t ldn2; int32_t K2; int32_t No; } qagnn_pack_desc;
+typedef struct qagnn_pack_desc { const float* B1n; int32_t ldn1; int32_t K1; const float* B2n; int32_t ldn2; int32_t K2; int32_t No;
+                                 int32_t pieces; /* 0 / 3: the three bf16 images; 2: the two scaled fp16 images of the three-MFMA form (taken by
+                                                    products that come with a_amax1 / a_amax2) */ } qagnn_pack_desc;
 int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n);
 int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, void* out, int64_t out_bytes, int64_t tag, qagnn_stream_t stream);
 int qagnn_gemm_nn_prepack_clear(int64_t tag);
 int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                                void* ws, int64_t ws_bytes, qagnn_stream_t stream);
+
+/* max |x| over n floats (n % 4 == 0, x 16-byte aligned), merged into *slot by an integer atomic max on the bit pattern -- order-independent, hence
+ * deterministic; the caller zeroes the word first (qagnn_zero_words).  The operand maxima of the three-MFMA GEMM form (a_amax1 / a_amax2 above,
+ * qagnn_gemm_tn_h2_f32 below) for tensors whose producer does not leave one.  NaNs are skipped; an inf gives 0x7F800000 (scale 1). */
+int qagnn_absmax_f32(const float* x, int64_t n, uint32_t* slot, qagnn_stream_t stream);
+int qagnn_zero_words(uint32_t* p, int64_t n, qagnn_stream_t stream);
 
 /* workspace floats needed by qagnn_gemm_tn_f32 for (R, Ka, No) (includes room for the optional column sums of B) */
 int64_t qagnn_gemm_tn_workspace_elems(int32_t R, int32_t Ka, int32_t No);
@@ -191,6 +206,12 @@ int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, int32_t ldb, 
  * the bf16-split kernel takes the shapes, two qagnn_gemm_tn_f32 calls otherwise.  workspace: qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No). */
 int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
                        float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream);
+/* C [Ka1 + Ka2, No] = [A1 | A2]^T B as qagnn_gemm_tn_f32 (Ka2 = 0) / qagnn_gemm_tn2_f32, in the three-MFMA form: every operand comes with the bit
+ * pattern of its max |.| (amax_a1 covers A1 AFTER the a_scale / a_shift prologue).  Falls back to the six-MFMA kernels (same results to fp32
+ * round-off, amax ignored) for shapes the split kernels do not take.  workspace: qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No). */
+int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
+                         float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift, const uint32_t* amax_a1,
+                         const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace, qagnn_stream_t stream);
 /* Same, and additionally  bsum[g][no] = sum_r [grp(r) == g] B[r][no]  (groups in 1..4; b_rowidx NULL = one group): the
  * bias gradient (and the node-type-table gradient) of a Linear falls out of the weight-gradient GEMM's B tiles for free
  * instead of costing separate passes over dC. */
@@ -377,7 +398,8 @@ typedef struct qagnn_hop_args {
   float* dbn;                      /* [2, DP]: d beta, d gamma */
   float* dW2t; float* db2;         /* [DP, DP], [DP] */
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
-  int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split) */
+  int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split);
+                                      2: the same, and the three-MFMA form wherever `amax` (below) makes it possible */
   int32_t ones_col;                /* see qagnn_bn_finalize_f32: >= 0 makes db2 = row ones_col of dW2t (no column reduction of d out); a caller
                                       that passes db2 = dW2t + ones_col * DP (and, for tab_col, dTT = dWs_t + tab_col * 3 DP) gets no copy */
   int32_t tab_col;                 /* >= 0: columns [tab_col, tab_col + T) of S hold the node-type indicators (1 at tab_col + ntype[r], S's
@@ -391,7 +413,15 @@ typedef struct qagnn_hop_args {
                                       bit-identical either way (same launches).  Capture-safe: the fork makes the side stream part
                                       of a capture in progress on `stream`, the join closes the branch.  In a stack call the field of
                                       the LAST hop is the one that is read */
+  uint32_t* amax;                  /* NULL, or QAGNN_HOP_AMAX_WORDS device words that belong to this hop and that the caller keeps, untouched, from
+                                      the forward call to the backward call (the library zeroes them at the start of the forward).  With
+                                      gemm_split == 2 and batch statistics, the hop's large products then run in the three-MFMA form
+                                      (csrc/gemm_nn2.hip): the words hold the bit patterns of max |X|, max |S|, max |aggr|, the bound of
+                                      relu(bn(h1)), max |y|, and (backward) max |d out|, max |d h1|, max |d K|M|Q|, each left behind by the
+                                      kernel that produces the tensor (X, S of the first hop: one reduction pass each).  In a stack call
+                                      whose hops are chained (hops[l + 1].X == hops[l].y, one shared S) the words of X and S are shared too */
 } qagnn_hop_args;
+#define QAGNN_HOP_AMAX_WORDS 16
 int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);
 int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP,
                                       int32_t cls_part_rows /* g->max_chunks + QAGNN_CLS_SLICES * g->C */);

@@ -22,10 +22,10 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32', 'qagnn_gather_multi_f32', 'qagnn_gather_multi_sum_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
-           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32']
+           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 16  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes)
+ABI_VERSION = 17  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -46,7 +46,7 @@ class qagnn_gather_tabs(C.Structure):
 
 
 class qagnn_pack_desc(C.Structure):
-    _fields_ = [('B1n', _vp), ('ldn1', _i32), ('K1', _i32), ('B2n', _vp), ('ldn2', _i32), ('K2', _i32), ('No', _i32)]
+    _fields_ = [('B1n', _vp), ('ldn1', _i32), ('K1', _i32), ('B2n', _vp), ('ldn2', _i32), ('K2', _i32), ('No', _i32), ('pieces', _i32)]
 
 
 class qagnn_gemm_nn_args(C.Structure):
@@ -54,7 +54,8 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('A2', _vp), ('lda2', _i32), ('K2', _i32), ('B2', _vp), ('ldb2', _i32),
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
-                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32), ('colstat_part', _vp)]
+                ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32), ('colstat_part', _vp),
+                ('a_amax1', _vp), ('a_amax2', _vp)]
 
 
 class qagnn_hop_args(C.Structure):
@@ -68,7 +69,10 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32), ('side_stream', _vp)])
+                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32), ('side_stream', _vp), ('amax', _vp)])
+
+
+HOP_AMAX_WORDS = 16  # QAGNN_HOP_AMAX_WORDS
 
 
 def load_library(path=LIB_PATH):
@@ -102,6 +106,9 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_workspace_elems.argtypes = [_i32, _i32, _i32]
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
     lib.qagnn_gemm_tn2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]
+    lib.qagnn_gemm_tn_h2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_absmax_f32.argtypes = [_vp, _i64, _vp, _vp]
+    lib.qagnn_zero_words.argtypes = [_vp, _i64, _vp]
     lib.qagnn_gemm_tn_colsum_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
@@ -298,7 +305,9 @@ class HipKernels(metaclass=_GuardedMeta):
             raise RuntimeError('libqagnn_hip.so ABI version mismatch')
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
-        self.gemm_split = os.environ.get('QAGNN_GEMM_SPLIT', '1') == '1'
+        # 2 (default): additionally the THREE-MFMA form (scaled two-piece fp16 split, csrc/gemm_nn2.hip) wherever the operand maxima are
+        # known -- inside the natively sequenced hops; 1 pins the exact 3 x bf16 split everywhere
+        self.gemm_split = {'0': 0, '1': 1}.get(os.environ.get('QAGNN_GEMM_SPLIT', '2'), 2)
         self.PACK_MIN_M = 8192  # (the library applies the same threshold: nn2_packed_ok)
         self._side_streams = {}  # per device: the stream the natively sequenced hops put their weight-gradient products on
 
@@ -420,7 +429,9 @@ class HipKernels(metaclass=_GuardedMeta):
         pairs = [(B1n, B2n or None), ...], each weight in its [No, K] layout exactly as gemm_nn() will receive it.  Returns what must
         stay alive (and unchanged) until the tag is cleared or packed again: the packed buffer and the weights themselves."""
         descs = (qagnn_pack_desc * len(pairs))()
-        for d, (b1, b2) in zip(descs, pairs):
+        for d, pr in zip(descs, pairs):
+            b1, b2 = pr[0], pr[1]
+            d.pieces = pr[2] if len(pr) > 2 else 3  # (b1, b2, 2): the two scaled fp16 images of the three-MFMA form
             _chk2d(b1, 'B1n')
             d.B1n, d.ldn1, d.K1, d.No = b1.data_ptr(), b1.size(1), b1.size(1), b1.size(0)
             if b2 is not None:
@@ -433,13 +444,13 @@ class HipKernels(metaclass=_GuardedMeta):
                     'qagnn_gemm_nn_prepack_f32')
         # (detached aliases: they pin the storage, not the autograd graph that produced the weights -- a kept-alive graph of the previous
         # iteration makes its AccumulateGrad nodes run on THEIR stream during a later hipGraph capture, which breaks the capture)
-        return out, [t.detach() for pr in pairs for t in pr if t is not None]
+        return out, [t.detach() for pr in pairs for t in pr[:2] if t is not None]
 
     def prepack_clear(self, tag=0):
         self.lib.qagnn_gemm_nn_prepack_clear(int(tag))
 
     def gemm_nn(self, A1, B1, A2=None, B2=None, bias=None, rowtab=None, rowidx=None, a_scale=None, a_shift=None,
-                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None, colstats=False):
+                out=None, accumulate=False, a_rowidx=None, B1n=None, B2n=None, colstats=False, a_amax1=None, a_amax2=None):
         """B1n / B2n: the same weights as B1 / B2 in their [No, K] layout (optional); with them the product runs on the bf16 matrix
         cores by exact operand splitting (see gemm_split.hip), else on the fp32-input MFMAs.
         colstats=True (only where colstats_supported()): returns (C, part) with part [ceil(M/128), 3, No] = per 128-row tile x0 | S1 | S2
@@ -473,6 +484,9 @@ class HipKernels(metaclass=_GuardedMeta):
             assert a_scale.numel() == K1 and a_shift.numel() == K1 and a_scale.is_contiguous() and a_shift.is_contiguous()
             a.a_scale, a.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
         a.accumulate = 1 if accumulate else 0
+        if a_amax1 is not None and self.gemm_split == 2:  # int32 [1] device words: absmax() of A1 / A2 -> the three-MFMA form
+            assert a_amax1.dtype == torch.int32 and a_amax1.is_cuda and (A2 is None or a_amax2 is not None)
+            a.a_amax1, a.a_amax2 = a_amax1.data_ptr(), _ptr(a_amax2)
         if a_rowidx is not None:
             assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
             a.a_rowidx = a_rowidx.data_ptr()
@@ -525,6 +539,28 @@ class HipKernels(metaclass=_GuardedMeta):
                                                colsum_groups, ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_gemm_tn_colsum_f32')
         return (out, bsum) if colsum_groups else out
+
+    def absmax(self, x, out=None):
+        """int32 [1]: the bit pattern of max |x| (qagnn_absmax_f32 into a zeroed word) -- the operand maximum of the three-MFMA GEMM form"""
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.numel() % 4 == 0
+        if out is None:
+            out = torch.empty(4, dtype=torch.int32, device=x.device)
+            self._check(self.lib.qagnn_zero_words(out.data_ptr(), 4, self._stream()), 'qagnn_zero_words')
+        self._check(self.lib.qagnn_absmax_f32(x.data_ptr(), x.numel(), out.data_ptr(), self._stream()), 'qagnn_absmax_f32')
+        return out
+
+    def gemm_tn_h2(self, A1, B, amax_a1, amax_b, A2=None, amax_a2=None, a_scale=None, a_shift=None, out=None):
+        """[A1 | A2]^T B in the three-MFMA form (qagnn_gemm_tn_h2_f32); amax_*: absmax() words (amax_a1 AFTER the scale / shift prologue)"""
+        _chk2d(A1, 'A1'), _chk2d(B, 'B')
+        Ka1, Ka2 = A1.size(1), (A2.size(1) if A2 is not None else 0)
+        R, No = B.shape
+        if out is None:
+            out = torch.empty((Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
+        ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
+        rc = self.lib.qagnn_gemm_tn_h2_f32(A1.data_ptr(), Ka1, Ka1, _ptr(A2), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No, _ptr(a_scale),
+                                           _ptr(a_shift), amax_a1.data_ptr(), _ptr(amax_a2), amax_b.data_ptr(), ws.data_ptr(), self._stream())
+        self._check(rc, 'qagnn_gemm_tn_h2_f32')
+        return out
 
     def gemm_tn2(self, A1, A2, B, out=None):
         """[A1 | A2]^T B -> [Ka1 + Ka2, No]: two weight gradients that share their B operand, one launch (qagnn_gemm_tn2_f32)."""
@@ -812,7 +848,7 @@ class HipKernels(metaclass=_GuardedMeta):
         h.batch_stats, h.eps = (1 if batch_stats else 0), float(eps)
         h.run_mean_p, h.run_var_p = run_mean_p.data_ptr(), run_var_p.data_ptr()
         h.apply_act, h.p_drop, h.seed = (1 if apply_act else 0), float(p), int(seed)
-        h.gemm_split = 1 if self.gemm_split else 0
+        h.gemm_split = int(self.gemm_split)
         tc, oc = tab_col if isinstance(tab_col, tuple) else (tab_col, -1)  # (type-indicator column of S, ones column of relu(bn(h1)))
         h.tab_col = int(tc) if S is not None else -1
         h.ones_col = int(oc)
@@ -827,6 +863,8 @@ class HipKernels(metaclass=_GuardedMeta):
         aa = torch.empty((2, graph.Ep, 4), dtype=torch.float32, device=dev)
         rows = torch.empty((4 if apply_act else 3, N, DP), dtype=torch.float32, device=dev)  # aggr, h1, out (, y)
         stats = torch.empty((5, DP), dtype=torch.float32, device=dev)
+        amax = torch.empty(HOP_AMAX_WORDS, dtype=torch.int32, device=dev)  # operand maxima of the three-MFMA form (zeroed by the library)
+        h.amax = amax.data_ptr()
         ws = torch.empty(self.lib.qagnn_hop_fwd_workspace_elems(N, graph.Ep, DP), dtype=torch.float32, device=dev)
         h.KMQ, h.a, h.alpha, h.stats = KMQ.data_ptr(), aa[0].data_ptr(), aa[1].data_ptr(), stats.data_ptr()
         h.aggr, h.h1, h.out = rows[0].data_ptr(), rows[1].data_ptr(), rows[2].data_ptr()
@@ -839,13 +877,14 @@ class HipKernels(metaclass=_GuardedMeta):
             h.d, h.momentum = rm.numel(), float(mom)
         h.ws, h.ws_elems = ws.data_ptr(), ws.numel()
         self._check(self.lib.qagnn_hop_fwd_f32(C.byref(h), self._stream()), 'qagnn_hop_fwd_f32')
-        return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats)
+        return rows[3 if apply_act else 2], (KMQ, aa, rows[0], rows[1], rows[2], stats, amax)
 
     def hop_bwd(self, graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, saved, dy, need_dX, need_dS,
                 dX_acc=None, dS_acc=None, tab_col=-1, overlap=True):
         """-> (dX, dS, dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2); overlap: the weight-gradient products on a side stream"""
         h = self._hop_struct(graph, HP, qscale, X, S, ntype, prm, batch_stats, eps, p, seed, apply_act, tab_col, side=overlap)
-        KMQ, aa, aggr, h1, out, stats = saved
+        KMQ, aa, aggr, h1, out, stats = saved[:6]
+        h.amax = saved[6].data_ptr() if len(saved) > 6 else None
         N, DP, dev, SP, T = graph.N, 4 * HP, X.device, h.SP, h.T
         _chk2d(dy, 'dy')
         h.KMQ, h.a, h.alpha, h.stats = KMQ.data_ptr(), aa[0].data_ptr(), aa[1].data_ptr(), stats.data_ptr()
@@ -892,6 +931,8 @@ class HipKernels(metaclass=_GuardedMeta):
         aa = torch.empty((k, 2, graph.Ep, 4), dtype=torch.float32, device=dev)
         rows = torch.empty((k, 4, N, DP), dtype=torch.float32, device=dev)  # per hop: aggr, h1, out, y
         stats = torch.empty((k, 5, DP), dtype=torch.float32, device=dev)
+        amax = torch.empty((k, HOP_AMAX_WORDS), dtype=torch.int32, device=dev)  # one array: the library zeroes it with one launch
+        p_amax = amax.data_ptr()
         ws = torch.empty(self.lib.qagnn_hop_fwd_workspace_elems(N, graph.Ep, DP), dtype=torch.float32, device=dev)
         hops = (qagnn_hop_args * k)()
         x = X
@@ -902,6 +943,7 @@ class HipKernels(metaclass=_GuardedMeta):
             h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out, h.y = (p_rows + (4 * l + i) * row_b for i in range(4))
+            h.amax = p_amax + l * HOP_AMAX_WORDS * 4
             if runnings[l] is not None:
                 rm, rv, nbt, pos, mom, _unb = runnings[l]
                 assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
@@ -911,14 +953,15 @@ class HipKernels(metaclass=_GuardedMeta):
             hops[l] = h
             x = rows[l, 3]
         self._check(self.lib.qagnn_stack_fwd_f32(hops, k, self._stream()), 'qagnn_stack_fwd_f32')
-        return rows[k - 1, 3], (KMQ, aa, rows, stats)
+        return rows[k - 1, 3], (KMQ, aa, rows, stats, amax)
 
     def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1,
                   overlap=True):
         """-> (dX, dS, [per layer: (dWx_t, dWs_t, dTT, dEkEm, dW1t, db1, dgamma, dbeta, dW2t, db2)]); dX_acc: an existing running total of
         the stack input's gradient (the output GEMM's share), added to in place."""
         k = len(prms)
-        KMQ, aa, rows, stats = saved
+        KMQ, aa, rows, stats = saved[:4]
+        p_amax = saved[4].data_ptr() if len(saved) > 4 else None
         N, DP, dev = graph.N, 4 * HP, X.device
         SP = S.size(1) if S is not None else 0
         T = prms[0][4].size(0)
@@ -946,7 +989,8 @@ class HipKernels(metaclass=_GuardedMeta):
             h.KMQ, h.stats = p_kmq + l * 3 * row_b, p_stats + l * 5 * DP * 4
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out = (p_rows + (4 * l + i) * row_b for i in range(3))
-            h.y = h.out
+            h.y = p_rows + (4 * l + 3) * row_b  # (what the forward wrote: the chain hops[l + 1].X == hops[l].y is what shares the amax words)
+            h.amax = p_amax + l * HOP_AMAX_WORDS * 4 if p_amax else None
             h.dy = dy.data_ptr() if l == k - 1 else p_dxs + l * row_b
             base = p_flat + l * per * 4
             h.dWx_t, pdWs_t, h.dTT, h.dEkEm, h.dW1t, h.db1, h.dbn, h.dW2t, h.db2 = (base + o * 4 for o in offs[:9])

@@ -13,20 +13,39 @@ void set_error(const char* fmt, ...);
 // weight-gradient products on the bf16 matrix cores (gemm_split.hip), used by qagnn_gemm_tn_f32's dispatch in gemm.hip
 bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affine);
 int tn_split_chunk_rows(int R, int Ka, int No, int lo);
+// amax (both launchers): nullptr, or {max|A1|, max|A2|, max|B|} device words -> the three-MFMA form (gemm_nn2.hip, header)
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    const int64_t* a_rowidx, int chunk_rows, hipStream_t stream);
+                    const int64_t* a_rowidx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr);
 int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo);
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream);
+                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr);
 
 // NN products, second kernel generation (gemm_nn2.hip): A fragments straight from global memory, B double-buffered in LDS
 bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2);
 int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream);
-int64_t nn2_pack_bytes(int No, int K1, int K2);
-bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes);
-const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No);
-int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream);
-int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream);
+// np: the arithmetic form of a packed image -- 3 = exact 3 x bf16 split, 2 = scaled two-piece fp16 split (gemm_nn2.hip, header)
+int64_t nn2_pack_bytes(int No, int K1, int K2, int np = 3);
+bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes, int np = 3);
+bool nn2_h2_ok(const qagnn_gemm_nn_args& a);
+const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No, int np = 3);
+int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream, int np = 3);
+int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream, int np = 3);
+
+// producers that can leave max |output| behind for the three-MFMA GEMM form (elementwise.hip; amax = nullptr: plain launch)
+int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, hipStream_t stream);
+int launch_bn_relu_bwd_colsum(const float* dR, const float* Hh, float* dH, int ld, int R, int Cc, const float* mean, const float* invstd,
+                              const float* scale, const float* shift, const float* gamma, const float* sum_dy, const float* sum_dy_hhat,
+                              float inv_rows, const float* roww, float* colsum, float* workspace, uint32_t* amax, hipStream_t stream);
+int launch_bn_stats_finalize(const float* part, int n_tiles, int R, int Cc, const float* gamma, const float* beta, float eps, float* stats,
+                             float* run_mean, float* run_var, int64_t* nbt, int d, float momentum, float unbias, int ones_col, uint32_t* amax_bound,
+                             hipStream_t stream);
+
+int launch_edge_attn_fwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
+                         float* score, float* a, float* alpha, float* aggr, int32_t lda, float* amax_part /* [N] or nullptr */, hipStream_t stream);
+int launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
+                         const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ, float* dEkEm, float* ga, float* rs,
+                         float* cls_part, float* amax_part /* [3 N] or nullptr */, hipStream_t stream);
+int launch_amax_reduce(const float* part, int64_t n, uint32_t* slot, hipStream_t stream);  // max of n non-negative floats -> *slot (elementwise.hip)
 
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \
@@ -128,6 +147,58 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+// ---- the two-piece fp16 GEMM form (NP = 2; gemm_nn2.hip, header): power-of-two operand scales from the bit pattern of max |x| (0 for an all-zero operand; inf / nan: scale 1, the result
+// is inf / nan as it would be in fp32).  field = biased exponent of the scale that maps [2^e, 2^(e+1)) onto [2^14, 2^15), clamped so
+// that its inverse 254 - field is a normal number too.
+__host__ __device__ __forceinline__ uint32_t h2_scale_field(uint32_t amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xFFu);
+  if (e == 0xFF) return 127u;
+  int f = 268 - e;  // 2^(14 - (e - 127)) = 2^(f - 127)
+  f = f < 1 ? 1 : (f > 253 ? 253 : f);
+  return (uint32_t)f;
+}
+__device__ __forceinline__ float h2_field_to_scale(uint32_t f) { return __builtin_bit_cast(float, f << 23); }
+// 1 / (s_a s_b) as a float: exponent fields add; clamped into the normal range (a product that leaves it would have left fp32 too)
+__device__ __forceinline__ float h2_inv_scale(uint32_t fa, uint32_t fb) {
+  int f = (254 - (int)fa) + (254 - (int)fb) - 127;
+  f = f < 1 ? 1 : (f > 254 ? 254 : f);
+  return __builtin_bit_cast(float, (uint32_t)f << 23);
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two numbers -> (hi, lo) pairs packed as fp16x2 dwords; the subtraction is exact (hi is x s rounded to 11 bits)
+__device__ __forceinline__ void split2(float x, float y, float s, uint32_t& hi, uint32_t& lo) {
+  const float xs = x * s, ys = y * s;
+  const f16x2 h = {(_Float16)xs, (_Float16)ys};
+  const f16x2 l = {(_Float16)(xs - (float)h[0]), (_Float16)(ys - (float)h[1])};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// the partial products of one tile pair, small terms first; a, b: raw 16-byte fragments [piece] of the A and the B operand.  SWAP: the
+// MFMA is issued with its operands exchanged (the transposed output tile: gemm_nn2.hip's direct-store epilogue) -- same products, same
+// order, so both orientations give the same bits
+#define QAGNN_BF(V) __builtin_bit_cast(bf16x8, V)
+#define QAGNN_HF(V) __builtin_bit_cast(f16x8, V)
+template <int NP, bool SWAP = false>
+__device__ __forceinline__ f32x4s mfma_pieces(const u32x4s* __restrict__ a, const u32x4s* __restrict__ b, f32x4s c) {
+#define QAGNN_MF3(I, J) c = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(QAGNN_BF(b[J]), QAGNN_BF(a[I]), c, 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(QAGNN_BF(a[I]), QAGNN_BF(b[J]), c, 0, 0, 0);
+#define QAGNN_MF2(I, J) c = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(QAGNN_HF(b[J]), QAGNN_HF(a[I]), c, 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(QAGNN_HF(a[I]), QAGNN_HF(b[J]), c, 0, 0, 0);
+  if constexpr (NP == 3) {
+    QAGNN_MF3(2, 0) QAGNN_MF3(0, 2) QAGNN_MF3(1, 1) QAGNN_MF3(1, 0) QAGNN_MF3(0, 1) QAGNN_MF3(0, 0)
+  } else {
+    QAGNN_MF2(1, 0) QAGNN_MF2(0, 1) QAGNN_MF2(0, 0)
+  }
+#undef QAGNN_MF3
+#undef QAGNN_MF2
+  return c;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -135,5 +206,35 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 fma4(float s, float4 a, float4 acc) {
   return make_float4(fmaf(s, a.x, acc.x), fmaf(s, a.y, acc.y), fmaf(s, a.z, acc.z), fmaf(s, a.w, acc.w));
 }
+
+// Operand maxima for the three-MFMA GEMM form (gemm_nn2.hip).  Agent-scope atomics are executed at the memory side on this chip (the
+// eight L2s are not coherent with each other): ~4 ns EACH and serialised per address -- one atomic per wave of a 13 000-block elementwise
+// launch (52 000 of them) doubled the whole training step (round 6, visit 2).  So: at most ~1 000 atomics per launch (fat blocks, one
+// atomic per BLOCK), and the one-wave-per-node edge kernels store per-node maxima with plain stores that a 64-block kernel reduces.
+// The wave reduction stays in the DPP network: rows by row_ror, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+// leave the total in LANE 63 (no LDS round trip).  All 64 lanes must be active; m >= 0.
+__device__ __forceinline__ float wave_amax_lane63(float m) {
+  m = row16_max(m);
+  int b = __builtin_bit_cast(int, m);
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x142, 0xA, 0xF, false)));
+  b = __builtin_bit_cast(int, m);
+  m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x143, 0xC, 0xF, false)));
+  return m;
+}
+// max over the block's waves (<= 16), merged into *amax by ONE integer atomic max on the bit pattern (order-independent, hence
+// deterministic).  Every thread of the block must call it (it holds a barrier); red: >= 16 floats of LDS.
+__device__ __forceinline__ void block_amax_merge(float m, uint32_t* __restrict__ amax, float* __restrict__ red) {
+  m = wave_amax_lane63(m);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 63) red[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    if (t > 0.f) __hip_atomic_fetch_max(amax, __builtin_bit_cast(uint32_t, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ float absmax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 
 }  // namespace qagnn

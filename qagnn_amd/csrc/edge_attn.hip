@@ -221,12 +221,19 @@ __global__ __launch_bounds__(256) void k_edge_scores(const int* __restrict__ row
   }
 }
 
+// the wave's maximum |.| of the row it wrote -> part[node] (a plain store; k_amax_reduce folds the N entries: common.h says why)
+__device__ __forceinline__ void node_amax(float m, float* __restrict__ part, int node) {
+  m = wave_amax_lane63(m);
+  if ((threadIdx.x & 63) == 63) part[node] = m;
+}
+
 // forward 2/2: weighted sum of messages, one wave per TARGET node (gathers M[src] and Em[cls]; no atomics)
 __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
                                                         const int* __restrict__ cls_t, const int* __restrict__ pos_t,
                                                         const float* __restrict__ KMQ, int ldk, const float* __restrict__ EkEm,
                                                         int lde, int HP, const float* __restrict__ alpha,
-                                                        float* __restrict__ aggr, int lda, int N, int C, const int* __restrict__ xcd_base) {
+                                                        float* __restrict__ aggr, int lda, int N, int C, const int* __restrict__ xcd_base,
+                                                        float* __restrict__ amax_part) {
   __shared__ float4 slab[4][SLAB_ROWS];
   const int t = wave_node(xcd_base);
   if (t >= N) return;
@@ -241,7 +248,9 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
     const int pv = __builtin_amdgcn_readfirstlane(pos_t[beg]);
     const float4 m1 = buf_ld4(rK, vm, (uint32_t)sv * pk), em1 = buf_ld4(rE, vm, (uint32_t)cv * pe);
     const float al = alpha[(int64_t)pv * 4 + L.g];
-    if (L.act) st4(aggr + (int64_t)t * lda + L.off, fma4(al, add4(m1, em1), zero4()));
+    const float4 o1 = fma4(al, add4(m1, em1), zero4());
+    if (L.act) st4(aggr + (int64_t)t * lda + L.off, o1);
+    if (amax_part) node_amax(L.act ? absmax4(o1) : 0.f, amax_part, t);  // (the operand maximum of the GEMMs that read aggr: common.h)
     return;
   }
   slab_init(slab[L.w], L.lane);
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(256) void k_edge_aggregate(const int* __restrict__ 
     }
   }
   if (L.act) st4(aggr + (int64_t)t * lda + L.off, acc);
+  if (amax_part) node_amax(L.act ? absmax4(acc) : 0.f, amax_part, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
                                                        const float* __restrict__ a, const float* __restrict__ alpha,
                                                        const float* __restrict__ G, int ldg, float* __restrict__ dKMQ,
                                                        float* __restrict__ ga, float* __restrict__ rs, int N, int C,
-                                                       const int* __restrict__ xcd_base) {
+                                                       const int* __restrict__ xcd_base, float* __restrict__ amax_part) {
   __shared__ float4 slab[3][4][SLAB_ROWS];  // a | alpha | ga of the current chunk
   const int s = wave_node(xcd_base);
   if (s >= N) return;
@@ -294,6 +304,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
     // src pass 2 reproduces from ga = 0, rs = 0 without reading a row (and then leaves dQ[s] = 0, gs = 0 behind)
     const float4 g1 = buf_ld4(rG, L.voff, (uint32_t)s * pg);
     if (L.act) st4(dKMQ + (int64_t)s * ldk + DP + L.off, g1);
+    if (amax_part) node_amax(L.act ? absmax4(g1) : 0.f, amax_part, s);
     if (L.lane == 0) {
       st4(ga + (int64_t)beg * 4, zero4());
       st4(rs + (int64_t)s * 4, zero4());
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src1(const int* __restrict__ r
     if (L.lane < cnt) st4(ga + (int64_t)lc * 4, gv);
   }
   if (L.act) st4(dKMQ + (int64_t)s * ldk + DP + L.off, dM);
+  if (amax_part) node_amax(L.act ? absmax4(dM) : 0.f, amax_part, s);
   if (L.j == 0) rs[(int64_t)s * 4 + L.g] = r;
 }
 
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
                                                        const float* __restrict__ EkEm, int lde, int HP, float qscale,
                                                        const float* __restrict__ a, float* __restrict__ dKMQ,
                                                        float* __restrict__ ga, const float* __restrict__ rs, int N, int C,
-                                                       const int* __restrict__ xcd_base) {
+                                                       const int* __restrict__ xcd_base, float* __restrict__ amax_part) {
   __shared__ float4 slab[4][SLAB_ROWS];
   const int s = wave_node(xcd_base);
   if (s >= N) return;
@@ -353,6 +365,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
   const int beg = __builtin_amdgcn_readfirstlane(rowptr_s[s]), end = __builtin_amdgcn_readfirstlane(rowptr_s[s + 1]);
   if (end - beg == 1) {  // the self loop alone: gs = 0 (src pass 1 left ga = 0 there), so dQ[s] = 0
     if (L.act) st4(dKMQ + (int64_t)s * ldk + 2 * DP + L.off, zero4());
+    if (amax_part && L.lane == 63) amax_part[s] = 0.f;
     return;
   }
   const float4 r4 = ld4(rs + (int64_t)s * 4);  // the node's 4 head values, same address in every lane
@@ -384,12 +397,13 @@ __global__ __launch_bounds__(256) void k_edge_bwd_src2(const int* __restrict__ r
     }
   }
   if (L.act) st4(dKMQ + (int64_t)s * ldk + 2 * DP + L.off, dQ);
+  if (amax_part) node_amax(L.act ? absmax4(dQ) : 0.f, amax_part, s);
 }
 
 __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ rowptr_t, const int* __restrict__ src_t,
                                                       const int* __restrict__ pos_t, const float* __restrict__ KMQ, int ldk,
                                                       int HP, const float* __restrict__ gsb, float* __restrict__ dKMQ, int N,
-                                                      const int* __restrict__ xcd_base) {
+                                                      const int* __restrict__ xcd_base, float* __restrict__ amax_part) {
   __shared__ float4 slab[4][SLAB_ROWS];
   const int t = wave_node(xcd_base);
   if (t >= N) return;
@@ -402,7 +416,9 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
     const int sv = __builtin_amdgcn_readfirstlane(src_t[beg]), pv = __builtin_amdgcn_readfirstlane(pos_t[beg]);
     const float4 q1 = buf_ld4(rK, vq, (uint32_t)sv * pk);
     const float gs1 = gsb[(int64_t)pv * 4 + L.g];
-    if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, fma4(gs1, q1, zero4()));
+    const float4 k1 = fma4(gs1, q1, zero4());
+    if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, k1);
+    if (amax_part) node_amax(L.act ? absmax4(k1) : 0.f, amax_part, t);
     return;
   }
   slab_init(slab[L.w], L.lane);
@@ -421,6 +437,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_tgt(const int* __restrict__ ro
     }
   }
   if (L.act) st4(dKMQ + (int64_t)t * ldk + L.off, dK);
+  if (amax_part) node_amax(L.act ? absmax4(dK) : 0.f, amax_part, t);
 }
 
 // one wave per class chunk (<= QAGNN_CLS_CHUNK edges of one class inside one position group), walked 64 edges at a time
@@ -539,9 +556,10 @@ static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const f
 
 using namespace qagnn;
 
-static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP,
-                                 float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
-                                 hipStream_t stream) {
+namespace qagnn {
+// amax_part != nullptr: [N] floats, max |aggr row| per node (k_edge_aggregate; launch_amax_reduce folds them into the word)
+int launch_edge_attn_fwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
+                         float* score, float* a, float* alpha, float* aggr, int32_t lda, float* amax_part, hipStream_t stream) {
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
@@ -549,21 +567,28 @@ static int edge_attn_fwd_generic(const qagnn_graph* g, const float* KMQ, int32_t
   const int nb = 8 * edge_xcd_cap(g->N);  // (8 runs of at most edge_xcd_cap blocks: see k_xcd_partition)
   k_edge_scores<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, g->N, g->C, g->err + 4);
   QAGNN_LAUNCH_CHECK("k_edge_scores");
-  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C, g->err + 4);
+  k_edge_aggregate<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->cls_t, g->pos_t, KMQ, ldk, EkEm, lde, HP, alpha, aggr, lda, g->N, g->C, g->err + 4, amax_part);
   QAGNN_LAUNCH_CHECK("k_edge_aggregate");
   return QAGNN_OK;
 }
+}  // namespace qagnn
 
 extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
                                        int32_t HP, float qscale, float* score, float* a, float* alpha, float* aggr, int32_t lda,
                                        qagnn_stream_t stream_) {
-  return edge_attn_fwd_generic(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, (hipStream_t)stream_);
+  return launch_edge_attn_fwd(g, KMQ, ldk, EkEm, lde, HP, qscale, score, a, alpha, aggr, lda, nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
                                        int32_t HP, float qscale, const float* a, const float* alpha, const float* G, int32_t ldg,
                                        float* dKMQ, float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return launch_edge_attn_bwd(g, KMQ, ldk, EkEm, lde, HP, qscale, a, alpha, G, ldg, dKMQ, dEkEm, ga, rs, cls_part, nullptr, (hipStream_t)stream_);
+}
+
+// amax_part != nullptr: [3 N] floats, max |d M row|, |d Q row|, |d K row| per node (the three node-side kernels)
+int qagnn::launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
+                                const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ, float* dEkEm, float* ga, float* rs,
+                                float* cls_part, float* amax_part, hipStream_t stream) {
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_bwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(a && alpha && G && dKMQ && dEkEm && ga && rs && cls_part, QAGNN_EINVAL, "edge_attn_bwd: null pointer");
@@ -573,11 +598,11 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
   const int DP2 = 8 * HP;
   QAGNN_REQUIRE(DP2 / 4 <= 1024, QAGNN_EUNSUPPORTED, "edge_attn_bwd: HP too large");
   const int nb = 8 * edge_xcd_cap(g->N);  // (8 runs of at most edge_xcd_cap blocks: see k_xcd_partition)
-  k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N, g->C, g->err + 4);
+  k_edge_bwd_src1<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, a, alpha, G, ldg, dKMQ, ga, rs, g->N, g->C, g->err + 4, amax_part);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_src1");
-  k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N, g->C, g->err + 4);
+  k_edge_bwd_src2<<<nb, 256, 0, stream>>>(g->rowptr_s, g->tgt_s, g->cls_s, KMQ, ldk, EkEm, lde, HP, qscale, a, dKMQ, ga, rs, g->N, g->C, g->err + 4, amax_part ? amax_part + g->N : nullptr);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_src2");
-  k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N, g->err + 4);
+  k_edge_bwd_tgt<<<nb, 256, 0, stream>>>(g->rowptr_t, g->src_t, g->pos_t, KMQ, ldk, HP, ga, dKMQ, g->N, g->err + 4, amax_part ? amax_part + 2 * (int64_t)g->N : nullptr);
   QAGNN_LAUNCH_CHECK("k_edge_bwd_tgt");
   k_edge_bwd_cls<<<cdiv(g->max_chunks, 4), 256, 0, stream>>>(g->n_chunks, g->chunk_beg, g->chunk_len, g->src_c, g->tgt_c, g->pos_c,
                                                              KMQ, ldk, HP, alpha, ga, G, ldg, cls_part, g->N);

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const 
                                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                         float eps, float* __restrict__ stats, float* __restrict__ run_mean,
                                                                         float* __restrict__ run_var, int64_t* __restrict__ nbt, int d,
-                                                                        float momentum, float unbias, int ones_col) {
+                                                                        float momentum, float unbias, int ones_col,
+                                                                        uint32_t* __restrict__ amax_bound) {
   __shared__ float sn[BF_PARTS][BF_COLS], sm[BF_PARTS][BF_COLS], s2[BF_PARTS][BF_COLS];
   const int cl = threadIdx.x & (BF_COLS - 1), q = threadIdx.x / BF_COLS;
   const int c = blockIdx.x * BF_COLS + cl;
@@ -237,6 +238,14 @@ __global__ __launch_bounds__(BF_COLS * BF_PARTS) void k_bn_stats_finalize(const 
     stats[2 * Cc + c] = is;
     stats[3 * Cc + c] = c == ones_col ? 0.f : sc;                     // (see k_bn_finalize: the column of ones)
     stats[4 * Cc + c] = c == ones_col ? 1.f : beta[c] - mean * sc;
+    // amax_bound: an upper bound of max |relu(bn(h1))| without a pass over h1 (the operand maximum the three-MFMA GEMM form asks for,
+    // gemm_nn2.hip): (x - mean)^2 <= sum_r (x_r - mean)^2 = R var, so |x - mean| invstd <= sqrt(R var / (var + eps)) <= sqrt(R) and
+    // |bn(x)| <= |gamma| sqrt(R) + |beta|; 1 % on top for the rounding of the fp32 statistics.  It overstates the true maximum by
+    // sqrt(R) / (the largest |z| of the batch) ~ 2^6 at 64 000 rows: inside the form's 2^19 window.
+    if (amax_bound) {
+      const float bnd = c == ones_col ? 1.f : 1.01f * (fabsf(gamma[c]) * sqrtf((float)R) + fabsf(beta[c]));
+      atomicMax(amax_bound, __builtin_bit_cast(uint32_t, bnd));
+    }
     if (run_mean) {  // head-padded column c = h * HP + j is dense feature h * dh + j when j < dh (4 heads: ops.HeadLayout)
       const int HP = Cc >> 2, dh = d >> 2, h = c / HP, j = c - h * HP;
       if (j < dh) {
@@ -260,16 +269,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float t = tanhf(u);
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
 }
+// AMAX: the launch also merges max |out| into *amax.  Such a launch is a grid of at most GD_AMAX_BLOCKS fat blocks walking the tensor
+// with a grid stride (one atomic per block: common.h says why), four float4 per thread in flight.
+constexpr int GD_AMAX_BLOCKS = 2048;
 template <bool BWD>
-__global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
-                               float p, uint64_t seed, const unsigned long long* __restrict__ epoch) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  if (p > 0.f) seed = epoch_seed(seed, epoch);
-  const float4 x = ld4(X + i * 4);
-  float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (BWD) g = ld4(dY + i * 4);
-  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+__device__ __forceinline__ float4 gelu_dropout_val(float4 x, float4 g, int64_t i, float p, uint64_t seed, float inv) {
   float4 o;
 #define ONE(f, k)                                                                  \
   {                                                                                \
@@ -278,7 +282,61 @@ __global__ void k_gelu_dropout(const float* __restrict__ X, const float* __restr
   }
   ONE(x, 0) ONE(y, 1) ONE(z, 2) ONE(w, 3)
 #undef ONE
-  st4(out + i * 4, o);
+  return o;
+}
+template <bool BWD>
+__device__ __forceinline__ float4 gelu_dropout_one(const float* __restrict__ X, const float* __restrict__ dY, int64_t i, float p, uint64_t seed, float inv) {
+  return gelu_dropout_val<BWD>(ld4(X + i * 4), BWD ? ld4(dY + i * 4) : make_float4(1.f, 1.f, 1.f, 1.f), i, p, seed, inv);
+}
+template <bool BWD, bool AMAX = false>
+__global__ __launch_bounds__(256) void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
+                                                      float p, uint64_t seed, const unsigned long long* __restrict__ epoch,
+                                                      uint32_t* __restrict__ amax = nullptr) {
+  if (p > 0.f) seed = epoch_seed(seed, epoch);
+  const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  if constexpr (!AMAX) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    st4(out + i * 4, gelu_dropout_one<BWD>(X, dY, i, p, seed, inv));
+  } else {
+    __shared__ float red[16];
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+      float4 x[4], g[4];  // four float4 per thread in flight (a fat block is a latency chain otherwise: 20.6 -> 28.7 us with one)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * stride < n4 ? i0 + u * stride : i0;
+        x[u] = ld4(X + i * 4);
+        g[u] = BWD ? ld4(dY + i * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < n4) {
+          const float4 o = gelu_dropout_val<BWD>(x[u], g[u], i, p, seed, inv);
+          st4(out + i * 4, o);
+          m = fmaxf(m, absmax4(o));
+        }
+      }
+    }
+    block_amax_merge(m, amax, red);
+  }
+}
+
+// max |x| of a tensor whose producer leaves none (qagnn_absmax_f32); N1: n counts single floats (k_amax_reduce: the edge kernels' per-node maxima)
+template <bool N1>
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ slot) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if constexpr (N1) m = fmaxf(m, fabsf(x[i]));
+    else m = fmaxf(m, absmax4(ld4(x + i * 4)));
+  }
+  block_amax_merge(m, slot, red);
+}
+__global__ void k_zero_words(uint32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
 
 // ---- BatchNorm + ReLU backward that also leaves the column sums of what it writes -------------------------------------------
@@ -293,7 +351,8 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ gamma,
                                                             const float* __restrict__ k1v, const float* __restrict__ k2v, float inv_rows,
-                                                            const float* __restrict__ roww, float* __restrict__ part) {
+                                                            const float* __restrict__ roww, float* __restrict__ part,
+                                                            uint32_t* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 256 + lane * 4;
@@ -301,6 +360,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
   constexpr int CR_ROWS = 4 * CR_WR;
   const int r0 = blockIdx.y * CR_ROWS + w * CR_WR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float am = 0.f;  // max |dH| of this thread's elements (amax != nullptr: merged per wave below)
   if (act) {
     const float4 mu = ld4(mean + col), is = ld4(invstd + col), sc = ld4(scale + col), sh = ld4(shift + col);
     const float4 ga = ld4(gamma + col), k1 = ld4(k1v + col), k2 = ld4(k2v + col);
@@ -333,6 +393,7 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
         asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
         st4(dH + (int64_t)r * ld + col, o);
         acc = add4(acc, o);
+        am = fmaxf(am, absmax4(o));
       }
     }
   }
@@ -341,6 +402,10 @@ __global__ __launch_bounds__(256) void k_bn_relu_bwd_colsum(const float* __restr
   const int c = threadIdx.x;
   if (blockIdx.x * 256 + c < Cc)
     part[(int64_t)blockIdx.y * Cc + blockIdx.x * 256 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (amax) {  // (kernel argument: uniform; idle lanes carry 0.  One atomic per block -- 500 at 64 000 rows)
+    __shared__ float ared[16];
+    block_amax_merge(am, amax, ared);
+  }
 }
 
 // ---- the dropout seed epoch (see common.h) --------------------------------------------------------------------
@@ -438,6 +503,18 @@ extern "C" int qagnn_bn_finalize_f32(const float* mean, const float* var, const 
   return QAGNN_OK;
 }
 
+namespace qagnn {
+// (validated by the entry point / by hop.hip's own argument checks)
+int launch_bn_stats_finalize(const float* part, int n_tiles, int R, int Cc, const float* gamma, const float* beta, float eps, float* stats,
+                             float* run_mean, float* run_var, int64_t* nbt, int d, float momentum, float unbias, int ones_col, uint32_t* amax_bound,
+                             hipStream_t stream) {
+  k_bn_stats_finalize<<<cdiv(Cc, BF_COLS), BF_COLS * BF_PARTS, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var, nbt, d,
+                                                                            momentum, unbias, ones_col, amax_bound);
+  QAGNN_LAUNCH_CHECK("k_bn_stats_finalize");
+  return QAGNN_OK;
+}
+}  // namespace qagnn
+
 extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, int32_t R, int32_t Cc, const float* gamma, const float* beta,
                                            float eps, float* stats, float* run_mean, float* run_var, int64_t* num_batches_tracked,
                                            const int64_t* dense_pos, int32_t d, float momentum, float unbias, int32_t ones_col,
@@ -447,10 +524,8 @@ extern "C" int qagnn_bn_stats_finalize_f32(const float* part, int32_t n_tiles, i
                 "bn_stats_finalize: bad arguments (R=%d needs %d tiles of %d rows, got %d)", R, cdiv(R, ST_TILE), ST_TILE, n_tiles);
   QAGNN_REQUIRE(!run_mean || (run_var && d > 0 && d % 4 == 0 && Cc % 4 == 0 && d <= Cc), QAGNN_EINVAL, "bn_stats_finalize: running-stat arguments");
   (void)dense_pos;  // the head-padded layout is implied by (Cc, d); kept in the signature for symmetry with qagnn_bn_finalize_f32
-  k_bn_stats_finalize<<<cdiv(Cc, BF_COLS), BF_COLS * BF_PARTS, 0, stream>>>(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var,
-                                                              num_batches_tracked, d, momentum, unbias, ones_col);
-  QAGNN_LAUNCH_CHECK("k_bn_stats_finalize");
-  return QAGNN_OK;
+  return launch_bn_stats_finalize(part, n_tiles, R, Cc, gamma, beta, eps, stats, run_mean, run_var, num_batches_tracked, d, momentum, unbias, ones_col,
+                                  nullptr, stream);
 }
 
 // ---- weight packing without the concatenations (qagnn_amd.ops.GatherPlan) ------------------------------------------------------
@@ -504,13 +579,27 @@ extern "C" int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int3
   return QAGNN_OK;
 }
 
+namespace qagnn {
+// dY == nullptr: forward.  amax != nullptr: the launch also merges max |out| into that word (k_gelu_dropout, AMAX)
+int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, hipStream_t stream) {
+  const int grid = cdiv(n / 4, 256), fat = grid < GD_AMAX_BLOCKS ? grid : GD_AMAX_BLOCKS;
+  if (dY) {
+    if (amax) k_gelu_dropout<true, true><<<fat, 256, 0, stream>>>(X, dY, out, n / 4, p, seed, seed_epoch_ptr(), amax);
+    else k_gelu_dropout<true><<<grid, 256, 0, stream>>>(X, dY, out, n / 4, p, seed, seed_epoch_ptr());
+  } else {
+    if (amax) k_gelu_dropout<false, true><<<fat, 256, 0, stream>>>(X, nullptr, out, n / 4, p, seed, seed_epoch_ptr(), amax);
+    else k_gelu_dropout<false><<<grid, 256, 0, stream>>>(X, nullptr, out, n / 4, p, seed, seed_epoch_ptr());
+  }
+  QAGNN_LAUNCH_CHECK("k_gelu_dropout");
+  return QAGNN_OK;
+}
+}  // namespace qagnn
+
 extern "C" int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(X && Y && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(Y), QAGNN_EINVAL, "gelu_dropout_fwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_fwd: p=%f", p);
-  k_gelu_dropout<false><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, nullptr, Y, n / 4, p, seed, seed_epoch_ptr());
-  QAGNN_LAUNCH_CHECK("k_gelu_dropout_fwd");
-  return QAGNN_OK;
+  return launch_gelu_dropout(X, nullptr, Y, n, p, seed, nullptr, stream);
 }
 
 extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed,
@@ -519,8 +608,30 @@ extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float
   QAGNN_REQUIRE(X && dY && dX && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX), QAGNN_EINVAL,
                 "gelu_dropout_bwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd: p=%f", p);
-  k_gelu_dropout<true><<<cdiv(n / 4, 256), 256, 0, stream>>>(X, dY, dX, n / 4, p, seed, seed_epoch_ptr());
-  QAGNN_LAUNCH_CHECK("k_gelu_dropout_bwd");
+  return launch_gelu_dropout(X, dY, dX, n, p, seed, nullptr, stream);
+}
+
+extern "C" int qagnn_absmax_f32(const float* x, int64_t n, uint32_t* slot, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(x && slot && n > 0 && n % 4 == 0 && aligned16(x), QAGNN_EINVAL, "absmax: bad arguments");
+  const int64_t n4 = n / 4;
+  const int grid = (int)(n4 / 256 + 1 < 1024 ? n4 / 256 + 1 : 1024);
+  k_absmax<false><<<grid, 256, 0, (hipStream_t)stream_>>>(x, n4, slot);
+  QAGNN_LAUNCH_CHECK("k_absmax");
+  return QAGNN_OK;
+}
+
+// the per-node maxima of an edge kernel (non-negative floats) -> the word: 64 blocks, one atomic each
+int qagnn::launch_amax_reduce(const float* part, int64_t n, uint32_t* slot, hipStream_t stream) {
+  const int grid = (int)(n / 1024 + 1 < 64 ? n / 1024 + 1 : 64);
+  k_absmax<true><<<grid, 256, 0, stream>>>(part, n, slot);
+  QAGNN_LAUNCH_CHECK("k_amax_reduce");
+  return QAGNN_OK;
+}
+
+extern "C" int qagnn_zero_words(uint32_t* p, int64_t n, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(p && n > 0, QAGNN_EINVAL, "zero_words: bad arguments");
+  k_zero_words<<<(int)(n / 256 + 1 < 256 ? n / 256 + 1 : 256), 256, 0, (hipStream_t)stream_>>>(p, n);
+  QAGNN_LAUNCH_CHECK("k_zero_words");
   return QAGNN_OK;
 }
 
@@ -551,6 +662,25 @@ extern "C" int qagnn_sin_basis_f32(const float* score, const float* js, float* o
 }
 
 // qagnn_bn_relu_bwd_f32 that also returns colsum[c] = sum_r dH[r][c] (the bias gradient of the Linear in front of the BatchNorm)
+namespace qagnn {
+// amax != nullptr: the launch also merges max |dH| into that word
+int launch_bn_relu_bwd_colsum(const float* dR, const float* Hh, float* dH, int ld, int R, int Cc, const float* mean, const float* invstd,
+                              const float* scale, const float* shift, const float* gamma, const float* sum_dy, const float* sum_dy_hhat,
+                              float inv_rows, const float* roww, float* colsum, float* workspace, uint32_t* amax, hipStream_t stream) {
+  dim3 grid(cdiv(Cc, 256), cdiv(R, 4 * cr_wr(R)));
+  if (cr_wr(R) == CR_WR_SMALL)
+    k_bn_relu_bwd_colsum<CR_WR_SMALL><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
+                                                                inv_rows, roww, workspace, amax);
+  else
+    k_bn_relu_bwd_colsum<CR_WR_BIG><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
+                                                              inv_rows, roww, workspace, amax);
+  QAGNN_LAUNCH_CHECK("k_bn_relu_bwd_colsum");
+  k_colreduce_final<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(workspace, colsum, grid.y, Cc, 1.0f);
+  QAGNN_LAUNCH_CHECK("k_colreduce_final");
+  return QAGNN_OK;
+}
+}  // namespace qagnn
+
 extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, float* dH, int32_t ld, int32_t R, int32_t Cc, const float* mean,
                                             const float* invstd, const float* scale, const float* shift, const float* gamma,
                                             const float* sum_dy, const float* sum_dy_hhat, float inv_rows, const float* roww, float* colsum,
@@ -559,17 +689,8 @@ extern "C" int qagnn_bn_relu_bwd_colsum_f32(const float* dR, const float* Hh, fl
   QAGNN_REQUIRE(dR && Hh && dH && mean && invstd && scale && shift && gamma && sum_dy && sum_dy_hhat && colsum && workspace, QAGNN_EINVAL,
                 "bn_relu_bwd_colsum: null pointer");
   QAGNN_REQUIRE(R > 0 && Cc > 0 && Cc % 4 == 0 && ld % 4 == 0, QAGNN_EINVAL, "bn_relu_bwd_colsum: bad sizes");
-  dim3 grid(cdiv(Cc, 256), cdiv(R, 4 * cr_wr(R)));
-  if (cr_wr(R) == CR_WR_SMALL)
-    k_bn_relu_bwd_colsum<CR_WR_SMALL><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
-                                                                inv_rows, roww, workspace);
-  else
-    k_bn_relu_bwd_colsum<CR_WR_BIG><<<grid, 256, 0, stream>>>(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat,
-                                                              inv_rows, roww, workspace);
-  QAGNN_LAUNCH_CHECK("k_bn_relu_bwd_colsum");
-  k_colreduce_final<<<cdiv(Cc, 64), 64 * CF_Q, 0, stream>>>(workspace, colsum, grid.y, Cc, 1.0f);
-  QAGNN_LAUNCH_CHECK("k_colreduce_final");
-  return QAGNN_OK;
+  return launch_bn_relu_bwd_colsum(dR, Hh, dH, ld, R, Cc, mean, invstd, scale, shift, gamma, sum_dy, sum_dy_hhat, inv_rows, roww, colsum, workspace,
+                                   nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

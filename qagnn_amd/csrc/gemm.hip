@@ -794,3 +794,36 @@ extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, in
   return qagnn_gemm_tn_colsum_f32(A, lda, B, ldb, C, ldc, R, Ka, No, a_scale, a_shift, a_rowidx, accumulate, nullptr, nullptr, 0,
                                   workspace, stream_);
 }
+
+// The weight-gradient products in the three-MFMA form (scaled two-piece fp16 split: gemm_nn2.hip's header, gemm_split.hip's NP = 2 kernels).
+// Same chunking, same ordered chunk sum as the six-MFMA route; shapes the split kernels do not take fall back to it (amax unused).
+extern "C" int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
+                                    int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift,
+                                    const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace,
+                                    qagnn_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool two = A2 != nullptr && Ka2 > 0;
+  QAGNN_REQUIRE(A1 && B && C && workspace, QAGNN_EINVAL, "gemm_tn_h2: null pointer");
+  QAGNN_REQUIRE(!two || !a_scale, QAGNN_EINVAL, "gemm_tn_h2: the two-operand product has no BatchNorm prologue");
+  const bool have = amax_a1 && amax_b && (!two || amax_a2);
+  const bool ok = have && ldc % 4 == 0 && aligned16(C) && tn_split_ok(R, Ka1, No, lda1, ldb, false, a_scale != nullptr) &&
+                  (!two || tn_split_ok(R, Ka2, No, lda2, ldb, false, false));
+  if (!ok) {
+    if (two) return qagnn_gemm_tn2_f32(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, C, ldc, R, No, workspace, stream_);
+    return qagnn_gemm_tn_f32(A1, lda1, B, ldb, C, ldc, R, Ka1, No, a_scale, a_shift, nullptr, 0, workspace, stream_);
+  }
+  QAGNN_REQUIRE(R > 0 && Ka1 % 4 == 0 && No % 4 == 0 && (!two || Ka2 % 4 == 0), QAGNN_EINVAL, "gemm_tn_h2: bad sizes");
+  QAGNN_REQUIRE(lda1 % 4 == 0 && ldb % 4 == 0 && aligned16(A1) && aligned16(B) && (!two || (lda2 % 4 == 0 && aligned16(A2))), QAGNN_EINVAL,
+                "gemm_tn_h2: operands must be 16-byte aligned with pitches multiple of 4");
+  QAGNN_REQUIRE(!a_scale || (a_shift && aligned16(a_scale) && aligned16(a_shift)), QAGNN_EINVAL, "gemm_tn_h2: a_scale/a_shift must both be given");
+  const uint32_t* am[3] = {amax_a1, amax_a2, amax_b};
+  const int Ka = Ka1 + (two ? Ka2 : 0);
+  const int crows = two ? tn_split2_chunk_rows(R, Ka1, Ka2, No, tn_split_min_chunk(R)) : tn_split_chunk_rows(R, Ka1, No, tn_split_min_chunk(R));
+  const int nchunks = cdiv(R, crows);
+  int rc = two ? launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream, am)
+               : launch_tn_split(A1, lda1, B, ldb, workspace, R, Ka1, No, a_scale, a_shift, nullptr, crows, stream, am);
+  if (rc != QAGNN_OK) return rc;
+  k_sum_chunks4<<<cdiv((int64_t)Ka * No / 4, 64), SC_G * 64, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, 0);
+  QAGNN_LAUNCH_CHECK("k_sum_chunks");
+  return QAGNN_OK;
+}

@@ -32,6 +32,16 @@
 //   WV = 8 (PACKED, >= 10 k-tiles, >= 8 column tiles, >= one 256-row tile per CU): the staggered block, see the comment at the kernel.
 //   PACKED: B arrives pre-split in the kernel's LDS image order (k_pack_b / k_pack_b_multi: once per product, or once per training step
 //     for all weights through the registry of qagnn_gemm_nn_prepack_f32) and goes to LDS by DMA.
+// NP (round 6): the arithmetic form.  NP = 3 is the exact 3 x bf16 split above (six MFMAs per product).  NP = 2 is the error-corrected
+// TWO-piece fp16 split (Ootomo & Yokota 2022): x s = hi + lo, hi = fp16(x s), lo = fp16(x s - hi), 22 significant bits, and
+// a b = [a_lo b_hi + a_hi b_lo + a_hi b_hi] / (s_a s_b) with the three products accumulated in fp32 -- THREE v_mfma_f32_16x16x32_f16 per
+// tile pair, dropped term a_lo b_lo <= 2^-22 |a b|, i.e. a relative error of ~2^-21 per product where the bf16 form has 2^-23; both are below
+// the sqrt(K) 2^-24 accumulation noise of any fp32 dot product at K >= 208.  fp16 has 5 exponent bits, so each operand carries an exact
+// power-of-two scale s that puts its largest magnitude into [2^14, 2^15): A's comes from the caller (qagnn_gemm_nn_args.a_amax1 / a_amax2: device
+// words holding the bit pattern of max |A|, produced by the kernel that wrote A; one common scale for [A1 | A2]), B's is computed per
+// column tile by the packer and travels behind the image.  Elements below 2^-24 of the tensor's maximum lose relative (never absolute)
+// accuracy: the error of every output is <= 2^-21 sum_k |a_k| |b_k| + 2^-38 K max|A| max|B_col|.  PACKED, WV = 4 only; a product whose A
+// has no known maximum takes the NP = 3 kernels.
 // Epilogues: PACKED without column statistics stores straight from the accumulators (the MFMAs are issued with their operands swapped,
 // so that a lane holds four consecutive columns of a row); the others go through 16-row LDS slabs as in k_gemm_nn_split (whole-row
 // 16-byte stores; bias / row table / accumulate / BatchNorm column statistics).
@@ -41,9 +51,6 @@
 
 namespace qagnn {
 
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 namespace nn2 {
 
@@ -54,8 +61,6 @@ namespace nn2 {
 #endif
 
 constexpr int BK = 32;
-// bit 7 (128): the three-product form's time ceiling -- two operand pieces (fp16 split arithmetic), three MFMAs, two B images
-constexpr int ABL_NP = (QAGNN_NN2_ABL & 128) ? 2 : 3;
 constexpr uint32_t OOB = 0x80000000u;  // beyond any operand this kernel is launched on: the buffer load answers with zeros
 
 __device__ __forceinline__ u32x4s bload(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
@@ -72,27 +77,28 @@ __device__ __forceinline__ void split3(uint32_t u, uint32_t& h1, uint32_t& h2, u
 }
 __device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+template <bool AFFINE>
+__device__ __forceinline__ void split_frag2(const u32x4s (&r)[2], u32x4s (&f)[2], const float* __restrict__ sc, const float* __restrict__ sh, float lo,
+                                            float s) {
+  uint32_t ph[4], pl[4];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    // (through scalars: __builtin_bit_cast applied to a vector ELEMENT reads the vector's first four bytes whatever the index -- hipcc 7.2)
+    const uint32_t ux = r[e >> 2][e & 3], uy = r[(e + 1) >> 2][(e + 1) & 3];
+    float x = __builtin_bit_cast(float, ux), y = __builtin_bit_cast(float, uy);
+    if constexpr (AFFINE) {
+      x = fmaxf(fmaf(x, sc[e], sh[e]), lo);
+      y = fmaxf(fmaf(y, sc[e + 1], sh[e + 1]), lo);
+    }
+    split2(x, y, s, ph[e >> 1], pl[e >> 1]);
+  }
+  f[0] = (u32x4s){ph[0], ph[1], ph[2], ph[3]};
+  f[1] = (u32x4s){pl[0], pl[1], pl[2], pl[3]};
+}
+
 // 8 consecutive k of one row (two 16-byte loads) -> the three bf16x8 fragments
 template <bool AFFINE>
-__device__ __forceinline__ void split_frag(const u32x4s (&r)[2], bf16x8 (&f)[3], const float* __restrict__ sc, const float* __restrict__ sh, float lo) {
-  if constexpr (QAGNN_NN2_ABL & 128) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-    uint32_t ph[4], pl[4];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      float x = __builtin_bit_cast(float, r[e >> 2][e & 3]), y = __builtin_bit_cast(float, r[(e + 1) >> 2][(e + 1) & 3]);
-      if constexpr (AFFINE) { x = fmaxf(fmaf(x, sc[e], sh[e]), lo); y = fmaxf(fmaf(y, sc[e + 1], sh[e + 1]), lo); }
-      x *= lo == 0.f ? 64.f : 128.f; y *= lo == 0.f ? 64.f : 128.f;
-      const h2v hi = {(_Float16)x, (_Float16)y};
-      const h2v lw = {(_Float16)(x - (float)hi[0]), (_Float16)(y - (float)hi[1])};
-      ph[e >> 1] = __builtin_bit_cast(uint32_t, hi);
-      pl[e >> 1] = __builtin_bit_cast(uint32_t, lw);
-    }
-    f[0] = __builtin_bit_cast(bf16x8, (u32x4s){ph[0], ph[1], ph[2], ph[3]});
-    f[1] = __builtin_bit_cast(bf16x8, (u32x4s){pl[0], pl[1], pl[2], pl[3]});
-    f[2] = f[1];
-    return;
-  }
+__device__ __forceinline__ void split_frag(const u32x4s (&r)[2], u32x4s (&f)[3], const float* __restrict__ sc, const float* __restrict__ sh, float lo) {
   uint32_t h1[8], h2[8], h3[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -103,9 +109,9 @@ __device__ __forceinline__ void split_frag(const u32x4s (&r)[2], bf16x8 (&f)[3],
   const u32x4s p1 = {pack_hi(h1[0], h1[1]), pack_hi(h1[2], h1[3]), pack_hi(h1[4], h1[5]), pack_hi(h1[6], h1[7])};
   const u32x4s p2 = {pack_hi(h2[0], h2[1]), pack_hi(h2[2], h2[3]), pack_hi(h2[4], h2[5]), pack_hi(h2[6], h2[7])};
   const u32x4s p3 = {pack_hi(h3[0], h3[1]), pack_hi(h3[2], h3[3]), pack_hi(h3[4], h3[5]), pack_hi(h3[6], h3[7])};
-  f[0] = __builtin_bit_cast(bf16x8, p1);
-  f[1] = __builtin_bit_cast(bf16x8, p2);
-  f[2] = __builtin_bit_cast(bf16x8, p3);
+  f[0] = p1;
+  f[1] = p2;
+  f[2] = p3;
 }
 
 // one float4 of a weight row (4 consecutive k) -> 8 bytes per piece at `dst` (+ 1024 per piece)
@@ -120,22 +126,8 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
   *reinterpret_cast<uint2*>(dst + 2048) = make_uint2(pack_hi(a3, b3), pack_hi(c3, d3));
 }
 
-#define QAGNN_NN2_SIX_T(C, AF, BF)                                        \
-  if constexpr (ABL_NP == 3) {                                            \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[2], AF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[1], C, 0, 0, 0); } \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[1], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[1], AF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[0], AF[0], C, 0, 0, 0);
-#define QAGNN_NN2_SIX(C, AF, BF)                                          \
-  if constexpr (ABL_NP == 3) {                                            \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
+#define QAGNN_NN2_SIX_T(C, AF, BF) C = mfma_pieces<NP, true>(AF, BF, C);
+#define QAGNN_NN2_SIX(C, AF, BF) C = mfma_pieces<NP>(AF, BF, C);
 
 // Per column tile 12 MFMAs (hipcc interleaves the two row tiles' accumulate chains by itself), then the split work of a B load round as
 // one clump (ORDER is a vestigial template argument, always 0: the pinned MFMA / 2 VALU interleave it selected measured no faster).
@@ -158,35 +150,37 @@ __device__ __forceinline__ void store_b4(unsigned char* __restrict__ dst, u32x4s
 // at the end of M_(t-1); group 1 would be too late there and issues in ITS N_(t-2) (phase 2t - 3; the image's previous tenant, tile t - 3,
 // was last read in phase 2t - 4).  The loop's back edge sits right after the barrier that ends M: every load issued in the previous N has
 // had a whole M phase to land, so nothing is in flight across it.
-template <int NT, bool STATS, int WV>
+template <int NT, bool STATS, int WV, int NP = 3>
 constexpr int nn2_lds_bytes(int aff_bytes) {
-  const int ring = (WV == 8 ? 3 : 2) * NT * 3 * 1024 + aff_bytes;
+  const int ring = (WV == 8 ? 3 : 2) * NT * NP * 1024 + aff_bytes;
   const int epi = WV * 16 * (NT * 16 + 4) * 4 + (STATS ? WV * 2 * NT * 16 * 4 : 0);
   return ring > epi ? ring : epi;
 }
 
-template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED, int WV = 4>
+template <int NT, bool AFFINE, bool STATS, int NP, bool PACKED, int WV = 4>
 __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_nn2(qagnn_gemm_nn_args a, const float* __restrict__ B1n,
                                                                                           int ldn1, const float* __restrict__ B2n, int ldn2,
                                                                                           int ntiles) {
   static_assert(WV == 4 || (WV == 8 && PACKED), "the staggered block takes B by DMA only");
+  static_assert(NP == 3 || (NP == 2 && PACKED && WV == 4), "the two-piece form: packed B, 4-wave blocks");
   static_assert(!(AFFINE && STATS), "no product needs both");
   constexpr bool STAG = WV == 8;
+  constexpr bool DIRECT = PACKED && !STATS;  // (see below)
   // DIRECT: the MFMAs are issued with their operands swapped (the transposed 16 x 16 tile: lane (x, c) then holds FOUR CONSECUTIVE
   // COLUMNS 4c .. 4c + 3 of row x), so the epilogue stores its accumulators straight from the registers -- 16 rows x 64 bytes per
   // instruction, column tiles j and j + 1 completing each other's 128-byte lines -- without the LDS transpose and its four barriers.
   // That leaves LDS free at the end of a tile: the first loads of the NEXT tile are issued in front of the stores, and the stores
   // (address-predicated buffer stores, a fixed 2 NT per wave, so that s_waitcnt vmcnt(2 NT) means "everything older has landed") drain
-  // under the next tile's k-loop.  With one block per CU nothing else would run under either.
-  constexpr bool DIRECT = PACKED && !STATS;  // (the 4-wave packed blocks store the same way, without the early loads)
+  // under the next tile's k-loop.  With one block per CU nothing else would run under either.  (The 4-wave packed blocks store the same
+  // way, without the early loads.)
   constexpr int THR = WV * 64, BM = WV * 32;
   constexpr int BN = NT * 16;
-  constexpr int IMG = NT * 3 * 1024;   // bytes of one B image set: [column tile][piece][64 slots x 16 B]
+  constexpr int IMG = NT * NP * 1024;  // bytes of one B image set: [column tile][piece][64 slots x 16 B]
   constexpr int RING_B = (STAG ? 3 : 2) * IMG;
   constexpr int BR = (NT + 1) / 2;     // load rounds of the B tile: 32 weight rows (output columns) x 8 float4 per round
   constexpr int PS = BN + 4, SLAB_ROWS = 16;
   constexpr int SLAB_B = WV * SLAB_ROWS * PS * 4;
-  static_assert(SLAB_B + (STATS ? WV * 2 * BN * 4 : 0) <= (AFFINE ? RING_B : nn2_lds_bytes<NT, STATS, WV>(0)), "the epilogue reuses the k-loop's LDS");
+  static_assert(DIRECT || SLAB_B + (STATS ? WV * 2 * BN * 4 : 0) <= (AFFINE ? RING_B : nn2_lds_bytes<NT, STATS, WV, NP>(0)), "the epilogue reuses the k-loop's LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const aff = reinterpret_cast<float*>(smem + RING_B);  // AFFINE: scale[KA] | shift[KA], KA = K1 rounded up to 32, zero-filled
 
@@ -218,6 +212,16 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
 
+  // NP == 2: the operands' power-of-two scales (see the header).  A: one common scale from max(max|A1|, max|A2|); B: per column tile,
+  // written behind the image (and its 13 tiles of slack) by the packer
+  uint32_t fa = 127u;
+  float sa = 1.f;
+  if constexpr (NP == 2) {
+    uint32_t mb = a.a_amax1[0];
+    if (K2 > 0 && a.a_amax2) mb = max(mb, a.a_amax2[0]);
+    fa = __builtin_amdgcn_readfirstlane(h2_scale_field(mb));
+    sa = h2_field_to_scale(fa);
+  }
   const int ac = lane >> 4;                 // this lane's k chunk (8 k) of a tile, A side
   const int nl = tid >> 3, kq = tid & 7;    // B loader: weight row of a round, float4 index inside the k-tile
   // LDS byte offset of the loader's (row, float4) inside a round's two column tiles, and of the fragment reads (see the header)
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const uint32_t bbase2 = (uint32_t)(n0 + nl) * (uint32_t)ldn2 * 4u + (uint32_t)kq * 16u;
 
     u32x4s rb[PACKED ? 1 : BR];
-    bf16x8 af[2][3];
+    u32x4s af[2][NP];
 
     // loads of a tile that lies in one segment (steady state); `it` past the last tile: everything out of range, zeros
 #define QAGNN_NN2_GLOAD(IT)                                                                                              \
@@ -307,10 +311,10 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // PACKED: the NT * 3 KB of k-tile IT -> the image BUF by DMA, the 1-KB blocks dealt out over the waves
 #define QAGNN_NN2_GLDS(IT, BUF)                                                                                          \
     {                                                                                                                    \
-      const unsigned char* src_ = pk + ((int64_t)(IT) * ldn1 + n0 / 16) * 3072 + lane * 16;                              \
-      _Pragma("unroll") for (int b = 0; b < (NT * 3 + WV - 1) / WV; ++b) {                                               \
+      const unsigned char* src_ = pk + ((int64_t)(IT) * ldn1 + n0 / 16) * (NP * 1024) + lane * 16;                       \
+      _Pragma("unroll") for (int b = 0; b < (NT * NP + WV - 1) / WV; ++b) {                                              \
         const int blk_ = w + b * WV;                                                                                     \
-        if (blk_ < NT * 3 && (ABL_NP == 3 || blk_ % 3 != 2))                                                             \
+        if (blk_ < NT * NP)                                                                                              \
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + blk_ * 1024),         \
                                            (__attribute__((address_space(3))) void*)((BUF) + blk_ * 1024), 16, 0, 0);    \
       }                                                                                                                  \
@@ -337,9 +341,15 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const float sh[8] = {s1_ ? h0.x : 0.f, s1_ ? h0.y : 0.f, s1_ ? h0.z : 0.f, s1_ ? h0.w : 0.f,                     \
                              s1_ ? h1.x : 0.f, s1_ ? h1.y : 0.f, s1_ ? h1.z : 0.f, s1_ ? h1.w : 0.f};                    \
         const float lo = s1_ ? 0.f : -INFINITY;                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) split_frag<true>(ra[i], af[i], sc, sh, lo);                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+          if constexpr (NP == 2) split_frag2<true>(ra[i], af[i], sc, sh, lo, sa);                                        \
+          else split_frag<true>(ra[i], af[i], sc, sh, lo);                                                               \
+        }                                                                                                                \
       } else {                                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) split_frag<false>(ra[i], af[i], nullptr, nullptr, 0.f);            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
+          if constexpr (NP == 2) split_frag2<false>(ra[i], af[i], nullptr, nullptr, 0.f, sa);                            \
+          else split_frag<false>(ra[i], af[i], nullptr, nullptr, 0.f);                                                   \
+        }                                                                                                                \
       }                                                                                                                  \
     }
     // the MFMAs of one k-tile out of the image CUR; STORE: the next tile's B rows (loaded at the top of this iteration) go to the
@@ -348,14 +358,14 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #define QAGNN_NN2_MFMA_TILE(CUR, NXT, STORE)                                                                             \
     {                                                                                                                    \
       __builtin_amdgcn_s_setprio(1);                                                                                     \
-      bf16x8 bfa[3], bfb[3];                                                                                             \
-      _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p) bfa[p] = *reinterpret_cast<const bf16x8*>((CUR) + p * 1024 + rd_off); \
+      u32x4s bfa[NP], bfb[NP];                                                                                           \
+      _Pragma("unroll") for (int p = 0; p < NP; ++p) bfa[p] = *reinterpret_cast<const u32x4s*>((CUR) + p * 1024 + rd_off); \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                   \
-        bf16x8(&bf)[3] = (j & 1) ? bfb : bfa;                                                                            \
-        bf16x8(&bn)[3] = (j & 1) ? bfa : bfb;                                                                            \
+        u32x4s(&bf)[NP] = (j & 1) ? bfb : bfa;                                                                           \
+        u32x4s(&bn)[NP] = (j & 1) ? bfa : bfb;                                                                           \
         if (j + 1 < NT && !(QAGNN_NN2_ABL & 16)) {                                                                       \
-          _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p)                                                             \
-              bn[p] = *reinterpret_cast<const bf16x8*>((CUR) + ((j + 1) * 3 + p) * 1024 + rd_off);                       \
+          _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                                 \
+              bn[p] = *reinterpret_cast<const u32x4s*>((CUR) + ((j + 1) * NP + p) * 1024 + rd_off);                      \
         }                                                                                                                \
         if constexpr (!(QAGNN_NN2_ABL & 32)) {                                                                           \
           _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             acc[i][j] = c;                                                                                               \
           }                                                                                                              \
         } else {                                                                                                         \
-          _Pragma("unroll") for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(bf[p]));                                   \
+          _Pragma("unroll") for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(bf[p]));                                  \
         }                                                                                                                \
         if ((STORE) && j >= NT - BR) QAGNN_NN2_STORE_B(j - (NT - BR), NXT)                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -379,16 +389,16 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // barriers: the compiler must not add its vmcnt(0), the loads issued in N land under M.
 #define QAGNN_NN2_FRAG(DST, ADDR, J)                                                                                     \
     {                                                                                                                    \
-      _Pragma("unroll") for (int p = 0; p < ABL_NP; ++p)                                                                 \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                      \
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"(((J) * 3 + p) * 1024));           \
     }
     // the fragments of column tile j are the oldest reads in flight; behind them: tiles j + 1 and j + 2 (LDS returns in order)
-#define QAGNN_NN2_FRAG_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * ABL_NP / 3))
+#define QAGNN_NN2_FRAG_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]))
 #define QAGNN_NN2_MFMA_TILE3(ADDR)                                                                                       \
     {                                                                                                                    \
       __builtin_amdgcn_s_setprio(1);                                                                                     \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                                   \
-        bf16x8(&bf)[3] = bfr[j % 3];                                                                                     \
+        u32x4s(&bf)[3] = bfr[j % 3];                                                                                     \
         if (j + 2 < NT) {                                                                                                \
           QAGNN_NN2_FRAG(bfr[(j + 2) % 3], ADDR, j + 2)                                                                  \
           QAGNN_NN2_FRAG_WAIT(bf, 6);                                                                                    \
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         QAGNN_NN2_BAR_VM            // tile 0 (and group 1's share of tile 1) has landed
       }
       if (g == 1) QAGNN_NN2_BAR     // group 1 runs one phase behind from here on
-      bf16x8 bfr[3][3];
+      u32x4s bfr[3][3];
       const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (uint32_t)rd_off;
       for (int it = 0; it < nkt; ++it) {
         const uint32_t cur = lds0 + (uint32_t)((it % 3) * IMG);
@@ -516,6 +526,15 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       unsigned char* const cur = smem + ((nkt - 1) & 1) * IMG;
       QAGNN_NN2_MFMA_TILE(cur, cur, false)
     }
+    }
+    if constexpr (NP == 2) {  // undo the operand scales: one exact power of two per column tile
+      const uint32_t* const bfield = reinterpret_cast<const uint32_t*>(pk + ((int64_t)nkt * ldn1 + 13) * (NP * 1024)) + n0 / 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float inv = h2_inv_scale(fa, bfield[j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] *= inv;
+      }
     }
     if constexpr (DIRECT) {
       // ---- STAG: the next tile's first loads (every wave is past its last fragment read: the ring is free); then this tile's stores
@@ -683,25 +702,25 @@ static int num_cus() {
   return n;
 }
 
-template <int NT, bool AFFINE, bool STATS, int ORDER, bool PACKED, int WV>
+template <int NT, bool AFFINE, bool STATS, int NP, bool PACKED, int WV>
 static int launch_i(const qagnn_gemm_nn_args& b, const float* B1n, int ldn1, const float* B2n, int ldn2, int grid, int ntiles, hipStream_t stream) {
-  const size_t lds = nn2_lds_bytes<NT, STATS, WV>(AFFINE ? 2 * ((b.K1 + 31) & ~31) * 4 : 0);
-  constexpr int lds_max = nn2_lds_bytes<NT, STATS, WV>(AFFINE ? 2 * 256 * 4 : 0);  // (nn2_ok: K1 <= 256 with a scale / shift)
+  const size_t lds = nn2_lds_bytes<NT, STATS, WV, NP>(AFFINE ? 2 * ((b.K1 + 31) & ~31) * 4 : 0);
+  constexpr int lds_max = nn2_lds_bytes<NT, STATS, WV, NP>(AFFINE ? 2 * 256 * 4 : 0);  // (nn2_ok: K1 <= 256 with a scale / shift)
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (lds_max > 64 * 1024 && !raised[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn2<NT, AFFINE, STATS, NP, PACKED, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e != hipSuccess) { set_error("gemm_nn2: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_nn2<NT, AFFINE, STATS, ORDER, PACKED, WV><<<grid, WV * 64, lds, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
+  k_gemm_nn2<NT, AFFINE, STATS, NP, PACKED, WV><<<grid, WV * 64, lds, stream>>>(b, B1n, ldn1, B2n, ldn2, ntiles);
   QAGNN_LAUNCH_CHECK("k_gemm_nn2");
   return QAGNN_OK;
 }
 
 // PACKED: B1n = the packed buffer, ldn1 = its column tiles per k-tile.  WV = 8: the staggered 256-row block, one per CU.
-template <int NT, int ORDER, bool PACKED = false, int WV = 4>
+template <int NT, int NP, bool PACKED = false, int WV = 4>
 static int launch_nt(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
   qagnn_gemm_nn_args b = a;
   b.xcd_remap = 1;
@@ -709,19 +728,42 @@ static int launch_nt(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, co
   const int cap = (num_cus() * (WV == 8 ? 1 : 2)) & ~7;
   const int grid = ntiles < cap ? ntiles : cap;
   if constexpr (NT == 13 || NT == 7 || NT == 4 || NT == 2) {
-    if (a.colstat_part) return launch_i<NT, false, true, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+    if (a.colstat_part) return launch_i<NT, false, true, NP, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
   }
-  if (a.a_scale) return launch_i<NT, true, false, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
-  return launch_i<NT, false, false, ORDER, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  if (a.a_scale) return launch_i<NT, true, false, NP, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
+  return launch_i<NT, false, false, NP, PACKED, WV>(b, B1n, ldn1, B2n, ldn2, grid, ntiles, stream);
 }
 
 // B [No][K1] | [No][K2] (k contiguous) -> the packed image of PACKED kernels: block ((it * NJ + j) * 3 + p) of 1 KB holds, for lane
 // l = (x = l & 15, c = l >> 4), at slot (x ^ 2c) + 16c, the piece-p halves of B[k = position(it, 8 c .. 8 c + 7)][n = 16 j + x]; `it` walks the k-tiles in the
-// kernel's order (the straddling tile first).  One wave per block of three pieces; zeros past K and past No.
+// kernel's order (the straddling tile first).  One wave per block of NP pieces; zeros past K and past No.
+// NP == 2: blocks of 2 KB (hi | lo fp16 pieces of B s_j), s_j = the power of two that puts the largest magnitude of column tile j -- over
+// ALL of its k, both segments -- into [2^14, 2^15); every wave of a column tile derives it again from the weights (they are L2-resident and
+// tiny), the wave of k-tile 0 leaves its exponent field at word j behind the image and its 13 tiles of slack (k_gemm_nn2's epilogue).
+template <int NP>
 __device__ __forceinline__ void pack_b_wave(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2, int No,
-                                            int NJ, int it, int j, unsigned char* __restrict__ out) {
+                                            int NJ, int nkt, int it, int j, unsigned char* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   if (j >= NJ) return;
+  float sb = 1.f;
+  if constexpr (NP == 2) {
+    const int nn = j * 16 + (lane & 15);
+    float m = 0.f;
+    if (nn < No) {
+      for (int k = (lane >> 4) * 4; k < K1; k += 16) {
+        const float4 v = ld4(B1n + (int64_t)nn * ldn1 + k);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+      for (int k = (lane >> 4) * 4; k < K2; k += 16) {
+        const float4 v = ld4(B2n + (int64_t)nn * ldn2 + k);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+    // (fmaxf drops a NaN operand: a NaN weight is not seen by the scale, and reaches the output through its own products)
+    const uint32_t fb = h2_scale_field(__builtin_bit_cast(uint32_t, wave_max(m)));
+    sb = h2_field_to_scale(fb);
+    if (it == 0 && lane == 0) reinterpret_cast<uint32_t*>(out + ((int64_t)nkt * NJ + 13) * (NP * 1024))[j] = fb;
+  }
   const int r1 = K2 > 0 ? (K1 & 31) : 0;
   const int mixi = r1 != 0 ? 1 : 0;
   const int n1 = mixi ? (K1 >> 5) : ((K1 + 31) >> 5);
@@ -747,31 +789,35 @@ __device__ __forceinline__ void pack_b_wave(const float* __restrict__ B1n, int l
     r[0] = *reinterpret_cast<const u32x4s*>(src);
     r[1] = *reinterpret_cast<const u32x4s*>(src + 4);
   }
-  bf16x8 f[3];
-  split_frag<false>(r, f, nullptr, nullptr, 0.f);
+  u32x4s f[NP];
+  if constexpr (NP == 2) split_frag2<false>(r, f, nullptr, nullptr, 0.f, sb);
+  else split_frag<false>(r, f, nullptr, nullptr, 0.f);
   // (the slot permutation of the in-kernel loader, so that both kinds of image are read with the same fragment offsets)
-  unsigned char* dst = out + ((int64_t)it * NJ + j) * 3072 + (((lane & 15) ^ (2 * (lane >> 4))) + 16 * (lane >> 4)) * 16;
+  unsigned char* dst = out + ((int64_t)it * NJ + j) * (NP * 1024) + (((lane & 15) ^ (2 * (lane >> 4))) + 16 * (lane >> 4)) * 16;
 #pragma unroll
-  for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(dst + p * 1024) = f[p];
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4s*>(dst + p * 1024) = f[p];
 }
 
+template <int NP>
 __global__ __launch_bounds__(256) void k_pack_b(const float* __restrict__ B1n, int ldn1, int K1, const float* __restrict__ B2n, int ldn2, int K2,
                                                int No, int NJ, int nkt, unsigned char* __restrict__ out) {
-  pack_b_wave(B1n, ldn1, K1, B2n, ldn2, K2, No, NJ, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), out);
+  pack_b_wave<NP>(B1n, ldn1, K1, B2n, ldn2, K2, No, NJ, nkt, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), out);
 }
 
 // The same for up to PACK_MAX weights in ONE launch (qagnn_gemm_nn_prepack_f32: all B operands of a training step's large NN products,
 // packed right behind the operand-packing gather; 39 pack launches per step of the 320-subgraph batch become one).  The descriptors
 // travel as kernel arguments (3.4 KB): nothing to upload, and a captured graph replays them as they are.
 constexpr int PACK_MAX = 60;
-struct PackOne { const float* B1n; const float* B2n; long long out_off; int ldn1, K1, ldn2, K2, No, NJ, jb, blk0; };  // jb = ceil(NJ / 4)
+struct PackOne { const float* B1n; const float* B2n; long long out_off; int ldn1, K1, ldn2, K2, No, NJ, jb, blk0, np, nkt; };  // jb = ceil(NJ / 4)
 struct PackArgs { int n; int nblk; PackOne d[PACK_MAX]; };
 __global__ __launch_bounds__(256) void k_pack_b_multi(PackArgs a, unsigned char* __restrict__ out) {
   int i = 0;
   while (i + 1 < a.n && (int)blockIdx.x >= a.d[i + 1].blk0) ++i;  // wave-uniform walk over <= 60 entries
   const PackOne& d = a.d[i];
   const int lb = (int)blockIdx.x - d.blk0;
-  pack_b_wave(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, lb / d.jb, (lb % d.jb) * 4 + (threadIdx.x >> 6), out + d.out_off);
+  const int it = lb / d.jb, j = (lb % d.jb) * 4 + (threadIdx.x >> 6);
+  if (d.np == 2) pack_b_wave<2>(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, d.nkt, it, j, out + d.out_off);
+  else pack_b_wave<3>(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, d.nkt, it, j, out + d.out_off);
 }
 
 static int walk_tiles(int K1, int K2) {
@@ -785,13 +831,11 @@ static int walk_tiles(int K1, int K2) {
 
 }  // namespace nn2
 
-int64_t nn2_pack_bytes(int No, int K1, int K2);
-
 // Which form a product takes (the A/B runs of the forms against each other: profiles/r4_run16_nn2_stagger.txt, r4_run28_round4_switches_ab.txt):
 // B packed once per product (k_pack_b) wherever the caller hands over a workspace and the product has at least NN2_PACK_MIN_M rows, the
 // in-kernel split otherwise; the staggered 8-wave block wherever a packed product has at least one 256-row tile per CU.
 constexpr int NN2_PACK_MIN_M = 8192;
-bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes) { return a.M >= NN2_PACK_MIN_M && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2); }
+bool nn2_packed_ok(const qagnn_gemm_nn_args& a, int64_t ws_bytes, int np) { return a.M >= NN2_PACK_MIN_M && ws_bytes >= nn2_pack_bytes(a.No, a.K1, a.K2, np); }
 // Measured at M = 64 000 (tools/nn2_ablate.hip, profiles/r4_run16_nn2_stagger.txt), 4-wave blocks -> staggered block:
 // [208|112] -> 624 141 -> 122 us, 624 -> 208 96..101 -> 79, but 208 -> 208 38 -> 39 and 624 -> 112 (NT = 7) 53 -> 54: with one block per
 // CU nothing runs under a tile's first loads, and the last tiles' stores are a tail at HBM speed, which 10 k-tiles of 13 column tiles
@@ -800,17 +844,26 @@ static bool nn2_staggered(int nt, const qagnn_gemm_nn_args& a) {
   return nt >= 8 && nn2::walk_tiles(a.K1, a.K2) >= 10 && (int64_t)cdiv(a.No, nt * 16) * cdiv(a.M, 256) * 10 >= nn2::num_cus() * 9;
 }
 // the PACKED kernel on an image `p` of B (NJ column tiles per k-tile)
-static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p, int NJ, hipStream_t stream) {
+static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p, int NJ, hipStream_t stream, int np = 3) {
+  if (np == 2) {  // the two-piece fp16 form: 4-wave blocks at every shape (tools/nn2_ablate.hip, profiles/r6_run1_three_product_ablation.txt)
+    switch (nt) {
+      case 13: return nn2::launch_nt<13, 2, true>(a, p, NJ, nullptr, 0, stream);
+      case 8: return nn2::launch_nt<8, 2, true>(a, p, NJ, nullptr, 0, stream);
+      case 7: return nn2::launch_nt<7, 2, true>(a, p, NJ, nullptr, 0, stream);
+      case 4: return nn2::launch_nt<4, 2, true>(a, p, NJ, nullptr, 0, stream);
+      default: return nn2::launch_nt<2, 2, true>(a, p, NJ, nullptr, 0, stream);
+    }
+  }
   if (nn2_staggered(nt, a)) {
-    if (nt == 13) return nn2::launch_nt<13, 0, true, 8>(a, p, NJ, nullptr, 0, stream);
-    return nn2::launch_nt<8, 0, true, 8>(a, p, NJ, nullptr, 0, stream);
+    if (nt == 13) return nn2::launch_nt<13, 3, true, 8>(a, p, NJ, nullptr, 0, stream);
+    return nn2::launch_nt<8, 3, true, 8>(a, p, NJ, nullptr, 0, stream);
   }
   switch (nt) {
-    case 13: return nn2::launch_nt<13, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 8: return nn2::launch_nt<8, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 7: return nn2::launch_nt<7, 0, true>(a, p, NJ, nullptr, 0, stream);
-    case 4: return nn2::launch_nt<4, 0, true>(a, p, NJ, nullptr, 0, stream);
-    default: return nn2::launch_nt<2, 0, true>(a, p, NJ, nullptr, 0, stream);
+    case 13: return nn2::launch_nt<13, 3, true>(a, p, NJ, nullptr, 0, stream);
+    case 8: return nn2::launch_nt<8, 3, true>(a, p, NJ, nullptr, 0, stream);
+    case 7: return nn2::launch_nt<7, 3, true>(a, p, NJ, nullptr, 0, stream);
+    case 4: return nn2::launch_nt<4, 3, true>(a, p, NJ, nullptr, 0, stream);
+    default: return nn2::launch_nt<2, 3, true>(a, p, NJ, nullptr, 0, stream);
   }
 }
 
@@ -828,23 +881,30 @@ bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
 
 int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, hipStream_t stream) {
   switch (nt) {
-    case 13: return nn2::launch_nt<13, 0>(a, B1n, ldn1, B2n, ldn2, stream);
-    case 8: return nn2::launch_nt<8, 0>(a, B1n, ldn1, B2n, ldn2, stream);
-    case 7: return nn2::launch_nt<7, 0>(a, B1n, ldn1, B2n, ldn2, stream);
-    case 4: return nn2::launch_nt<4, 0>(a, B1n, ldn1, B2n, ldn2, stream);
-    default: return nn2::launch_nt<2, 0>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 13: return nn2::launch_nt<13, 3>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 8: return nn2::launch_nt<8, 3>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 7: return nn2::launch_nt<7, 3>(a, B1n, ldn1, B2n, ldn2, stream);
+    case 4: return nn2::launch_nt<4, 3>(a, B1n, ldn1, B2n, ldn2, stream);
+    default: return nn2::launch_nt<2, 3>(a, B1n, ldn1, B2n, ldn2, stream);
   }
 }
 
-// bytes of the packed image of B for one product (13 column tiles of slack: the last column block of a k-tile reads its full width)
-int64_t nn2_pack_bytes(int No, int K1, int K2) { return ((int64_t)nn2::walk_tiles(K1, K2) * cdiv(No, 16) + 13) * 3072; }
+// bytes of the packed image of B for one product (13 column tiles of slack: the last column block of a k-tile reads its full width);
+// np == 2: + one exponent word per column tile (13 more of slack for the same reason), rounded up to 16 bytes
+int64_t nn2_pack_bytes(int No, int K1, int K2, int np) {
+  const int64_t img = ((int64_t)nn2::walk_tiles(K1, K2) * cdiv(No, 16) + 13) * (np * 1024);
+  return np == 2 ? img + (((int64_t)cdiv(No, 16) + 13) * 4 + 15) / 16 * 16 : img;
+}
+// (h2_ok: what the two-piece form additionally asks of a product -- a known maximum of A and a finite-size image)
+bool nn2_h2_ok(const qagnn_gemm_nn_args& a) { return a.a_amax1 != nullptr && (a.K2 == 0 || a.a_amax2 != nullptr) && a.M >= NN2_PACK_MIN_M; }
 
 // pack B into `ws` (>= nn2_pack_bytes), then the PACKED kernel: two launches
-int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream) {
+int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream, int np) {
   const int NJ = cdiv(a.No, 16), nkt = nn2::walk_tiles(a.K1, a.K2);
-  nn2::k_pack_b<<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
+  if (np == 2) nn2::k_pack_b<2><<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
+  else nn2::k_pack_b<3><<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
   QAGNN_LAUNCH_CHECK("k_pack_b");
-  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(ws), NJ, stream);
+  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(ws), NJ, stream, np);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -856,16 +916,16 @@ int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int
 #include <mutex>
 #include <vector>
 namespace qagnn {
-struct PrepackEntry { long long tag; const float* B1n; const float* B2n; int ldn1, K1, ldn2, K2, No; const void* pk; };
+struct PrepackEntry { long long tag; const float* B1n; const float* B2n; int ldn1, K1, ldn2, K2, No, np; const void* pk; };
 static std::mutex g_prepack_mu;
 static std::vector<PrepackEntry> g_prepack;
 
-const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No) {
+const void* nn2_prepack_lookup(const float* B1n, int ldn1, int K1, const float* B2n, int ldn2, int K2, int No, int np) {
   std::lock_guard<std::mutex> lk(g_prepack_mu);
   // newest registration first: should an owner ever leave stale entries behind, a live one for the same address wins
   for (size_t i = g_prepack.size(); i-- > 0;) {
     const PrepackEntry& e = g_prepack[i];
-    if (e.B1n == B1n && e.K1 == K1 && e.No == No && e.ldn1 == ldn1 && e.K2 == K2 && (K2 == 0 || (e.B2n == B2n && e.ldn2 == ldn2))) return e.pk;
+    if (e.np == np && e.B1n == B1n && e.K1 == K1 && e.No == No && e.ldn1 == ldn1 && e.K2 == K2 && (K2 == 0 || (e.B2n == B2n && e.ldn2 == ldn2))) return e.pk;
   }
   return nullptr;
 }
@@ -877,8 +937,8 @@ static bool prepack_takes(const qagnn_pack_desc& d) {
   return true;
 }
 
-int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream) {
-  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(pk), cdiv(a.No, 16), stream);
+int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hipStream_t stream, int np) {
+  return launch_nn2_image(nt, a, reinterpret_cast<const float*>(pk), cdiv(a.No, 16), stream, np);
 }
 }  // namespace qagnn
 
@@ -887,7 +947,7 @@ using namespace qagnn;
 extern "C" int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n) {
   int64_t tot = 0;
   for (int i = 0; i < n; ++i)
-    if (prepack_takes(d[i])) tot += nn2_pack_bytes(d[i].No, d[i].K1, d[i].K2);
+    if (prepack_takes(d[i])) tot += nn2_pack_bytes(d[i].No, d[i].K1, d[i].K2, d[i].pieces == 2 ? 2 : 3);
   return tot;
 }
 
@@ -919,9 +979,11 @@ extern "C" int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, vo
       o.jb = cdiv(o.NJ, 4);
       o.blk0 = pa.nblk;
       o.out_off = off;
-      pa.nblk += o.jb * nn2::walk_tiles(o.K1, o.K2);
-      fresh.push_back(PrepackEntry{(long long)tag, o.B1n, o.B2n, o.ldn1, o.K1, o.ldn2, o.K2, o.No, static_cast<const unsigned char*>(out) + off});
-      off += nn2_pack_bytes(o.No, o.K1, o.K2);
+      o.np = d[i].pieces == 2 ? 2 : 3;
+      o.nkt = nn2::walk_tiles(o.K1, o.K2);
+      pa.nblk += o.jb * o.nkt;
+      fresh.push_back(PrepackEntry{(long long)tag, o.B1n, o.B2n, o.ldn1, o.K1, o.ldn2, o.K2, o.No, o.np, static_cast<const unsigned char*>(out) + off});
+      off += nn2_pack_bytes(o.No, o.K1, o.K2, o.np);
     }
     if (pa.n > 0) {
       nn2::k_pack_b_multi<<<pa.nblk, 256, 0, (hipStream_t)stream_>>>(pa, static_cast<unsigned char*>(out));

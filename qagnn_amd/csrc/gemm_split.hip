@@ -25,9 +25,6 @@
 
 namespace qagnn {
 
-typedef float f32x4s __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 // 16-byte load through a buffer descriptor: per-lane byte offset + wave-uniform byte offset; out of range reads return zeros
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff = 0) {
@@ -390,27 +387,14 @@ static int launch_split(const qagnn_gemm_nn_args& a, const float* B1n, int ldn1,
 // registers across the column loop); the tiles of the KT%4 leftover strips are dealt out one by one (tile q -> wave q % 4).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TKR = 32, TCP = 40, TTHR = 256;
-// QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
-// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them,
-// bit 5 the three-product form's time ceiling (two pieces by fp16 split arithmetic, three MFMAs, two images), both TN kernels
-#ifndef QAGNN_TNW_ABL
-#define QAGNN_TNW_ABL 0
-#endif
-constexpr int TN_NP = (QAGNN_TNW_ABL & 32) ? 2 : 3;
 
-// 8 rows of one column -> three 16-byte chunks
-__device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_elems, const float (&x)[8]) {
-  if constexpr (TN_NP == 2) {
-    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+// 8 rows of one column -> NP 16-byte chunks (NP == 2: the scaled fp16 pieces of x s, common.h / gemm_nn2.hip's header)
+template <int NP>
+__device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_elems, const float (&x)[8], float s) {
+  if constexpr (NP == 2) {
     uint32_t ph[4], pl[4];
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      const float a = x[e] * 64.f, b = x[e + 1] * 64.f;
-      const h2v hi = {(_Float16)a, (_Float16)b};
-      const h2v lw = {(_Float16)(a - (float)hi[0]), (_Float16)(b - (float)hi[1])};
-      ph[e >> 1] = __builtin_bit_cast(uint32_t, hi);
-      pl[e >> 1] = __builtin_bit_cast(uint32_t, lw);
-    }
+    for (int e = 0; e < 8; e += 2) split2(x[e], x[e + 1], s, ph[e >> 1], pl[e >> 1]);
     *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
     *reinterpret_cast<uint4*>(dst + img_elems) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     return;
@@ -424,8 +408,8 @@ __device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_e
 }
 
 // a task's 8 x 4 numbers -> LDS (4 columns); AFF: relu(x * sc + sh) per column first
-template <bool AFF>
-__device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh) {
+template <bool AFF, int NP>
+__device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh, float s) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float x[8];
@@ -438,17 +422,19 @@ __device__ __forceinline__ void store_task(uint16_t* __restrict__ img, int img_e
       }
       x[i] = v;
     }
-    store_col8(img + off + j * TCP, img_elems, x);
+    store_col8<NP>(img + off + j * TCP, img_elems, x, s);
   }
 }
 
 // GATHER: row r of A is A[a_rowidx[r]] (negative = zero row): the frozen entity table under cpt_transform's weight gradient.  The
 // table can exceed 2 GB, so these rows come through 64-bit flat loads; their indices are fetched one tile ahead, behind the stores.
-template <int KT, int NT, bool AFFINE, bool GATHER>
+// NP == 2: the three-MFMA form; amax[0..2] = the words holding max |A|, max |A2|, max |B| (bit patterns)
+struct TnAmax { const uint32_t* a; const uint32_t* a2; const uint32_t* b; };
+template <int KT, int NT, bool AFFINE, bool GATHER, int NP = 3>
 __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_split(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
     const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const int64_t* __restrict__ a_rowidx,
-    const float* __restrict__ A2, int lda2, int Ka2) {
+    const float* __restrict__ A2, int lda2, int Ka2, TnAmax amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tn[];
   constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
   constexpr int MT = KT / 4, REM = KT % 4, RS = (REM * NT + 3) / 4;  // full strips per wave; leftover strips, shared tile by tile
@@ -457,8 +443,9 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   constexpr int MAJ_TW = A_MAJOR ? A_TW : B_TW, MIN_TW = A_MAJOR ? B_TW : A_TW;
   constexpr int MAJ_C = A_MAJOR ? AC : BC, MIN_C = A_MAJOR ? BC : AC, MAJ_EL = A_MAJOR ? A_EL : B_EL, MIN_EL = A_MAJOR ? B_EL : A_EL;
   static_assert(MAJ_TW <= 4 && MIN_TW <= 4, "task-waves per operand");
+  static_assert(NP == 3 || !GATHER, "the gathered table goes through the exact split");
   uint16_t* const As = reinterpret_cast<uint16_t*>(smem_tn);
-  uint16_t* const Bs = As + 3 * A_EL;
+  uint16_t* const Bs = As + NP * A_EL;
   uint16_t* const Maj = A_MAJOR ? As : Bs;
   uint16_t* const Min = A_MAJOR ? Bs : As;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,9 +464,18 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     by = (v / (int)gridDim.x) % (int)gridDim.y;
     chunk = v / (int)(gridDim.x * gridDim.y);
   }
+  bool second = false;
   if (A2 != nullptr) {
     const int n1 = (Ka + AC - 1) / AC;
-    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
+    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; second = true; }
+  }
+  uint32_t fa = 127u, fb = 127u;
+  float sa = 1.f, sb = 1.f;
+  if constexpr (NP == 2) {
+    fa = __builtin_amdgcn_readfirstlane(h2_scale_field(second ? amax.a2[0] : amax.a[0]));
+    fb = __builtin_amdgcn_readfirstlane(h2_scale_field(amax.b[0]));
+    sa = h2_field_to_scale(fa);
+    sb = h2_field_to_scale(fb);
   }
   const int n0 = bx * BC, m0 = by * AC;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
@@ -549,7 +545,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     }
   };
   auto lstore = [&](int t) {
-    if (maj_act) store_task<AFFINE && A_MAJOR>(Maj, MAJ_EL, maj_off, rj, scj, shj);
+    if (maj_act) store_task<AFFINE && A_MAJOR, NP>(Maj, MAJ_EL, maj_off, rj, scj, shj, A_MAJOR ? sa : sb);
     const int mk = (w - t) & 3;
     if (mk < MIN_TW) {
       const int c4 = mk * 16 + (lane >> 2);
@@ -561,20 +557,13 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
           sc = ld4(a_scale + cc);
           sh = ld4(a_shift + cc);
         }
-        store_task<AFFINE && !A_MAJOR>(Min, MIN_EL, off, rn, sc, sh);
+        store_task<AFFINE && !A_MAJOR, NP>(Min, MIN_EL, off, rn, sc, sh, A_MAJOR ? sb : sa);
       }
     }
   };
 
   const int rd_off = (lane & 15) * TCP + (((lane >> 4) ^ ((((lane & 15) >> 2) ^ ((lane & 15) >> 3)) & 1)) << 3);
-#define QAGNN_SIX(C, AF, BF)                                              \
-  if constexpr (TN_NP == 3) {                                             \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0);
+#define QAGNN_SIX(C, AF, BF) C = mfma_pieces<NP>(AF, BF, C);
 
   gidx(0);
   gload(0);
@@ -585,16 +574,16 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     __syncthreads();
     gload(t + 1);  // in flight under the MFMAs; past the last tile: rows of the next chunk (or zeros), never stored
     __builtin_amdgcn_s_setprio(1);  // (as in k_gemm_nn_split: the MFMA phase goes first)
-    bf16x8 af[MT > 0 ? MT : 1][3];
+    u32x4s af[MT > 0 ? MT : 1][NP];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < TN_NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (w + 4 * i) * 16 * TCP + rd_off);
+      for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const u32x4s*>(As + p * A_EL + (w + 4 * i) * 16 * TCP + rd_off);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bf16x8 bf[3];
+      u32x4s bf[NP];
 #pragma unroll
-      for (int p = 0; p < TN_NP; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + j * 16 * TCP + rd_off);
+      for (int p = 0; p < NP; ++p) bf[p] = *reinterpret_cast<const u32x4s*>(Bs + p * B_EL + j * 16 * TCP + rd_off);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {  // small terms first
         f32x4s c = acc[i][j];
@@ -607,11 +596,11 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       const int q = w + 4 * s;  // wave-uniform
       if (q < REM * NT) {
         const int ir = q / NT, jr = q % NT;
-        bf16x8 ar[3], br[3];
+        u32x4s ar[NP], br[NP];
 #pragma unroll
-        for (int p = 0; p < TN_NP; ++p) {
-          ar[p] = *reinterpret_cast<const bf16x8*>(As + p * A_EL + (4 * MT + ir) * 16 * TCP + rd_off);
-          br[p] = *reinterpret_cast<const bf16x8*>(Bs + p * B_EL + jr * 16 * TCP + rd_off);
+        for (int p = 0; p < NP; ++p) {
+          ar[p] = *reinterpret_cast<const u32x4s*>(As + p * A_EL + (4 * MT + ir) * 16 * TCP + rd_off);
+          br[p] = *reinterpret_cast<const u32x4s*>(Bs + p * B_EL + jr * 16 * TCP + rd_off);
         }
         f32x4s c = accr[s];
         QAGNN_SIX(c, ar, br)
@@ -623,11 +612,12 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #undef QAGNN_SIX
 
   float* const Pc = P + (int64_t)chunk * ka_total * No;
+  const float inv = NP == 2 ? h2_inv_scale(fa, fb) : 1.f;  // (NP == 2: the operand scales come out again, exactly)
   auto put = [&](int strip, int j, const f32x4s& c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + strip * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
-      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = c[r];
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP == 2 ? c[r] * inv : c[r];
     }
   };
 #pragma unroll
@@ -658,9 +648,16 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 // ------------------------------------------------------------------------------------------------------------
 static bool tn_xcd() { return true; }  // the blocks of one split-K chunk on one XCD (-2..5 % per kernel: profiles/r4_run17_tn_ws.txt)
 constexpr int WTHR = 512;
+// QAGNN_TNW_ABL (tools/tn_ablate.hip only; numerically wrong, timing only): bit 0 the producers do not split / store, bit 1 the producers
+// do not load, bit 2 the compute waves issue no MFMAs, bit 3 no fragment reads either, bit 4 the producers wait for their loads and drop them
+#ifndef QAGNN_TNW_ABL
+#define QAGNN_TNW_ABL 0
+#endif
+
 // store_task with a per-lane floor (AFF: relu for the lanes of A, -inf = pass-through for the lanes of B)
-template <bool AFF>
-__device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh, float lo) {
+template <bool AFF, int NP>
+__device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int img_elems, int off, const float4 (&r)[8], float4 sc, float4 sh, float lo,
+                                              float s) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float x[8];
@@ -673,17 +670,18 @@ __device__ __forceinline__ void store_task_lo(uint16_t* __restrict__ img, int im
       }
       x[i] = v;
     }
-    store_col8(img + off + j * TCP, img_elems, x);
+    store_col8<NP>(img + off + j * TCP, img_elems, x, s);
   }
 }
 
-template <int KT, int NT, bool AFFINE>
+template <int KT, int NT, bool AFFINE, int NP = 3>
 __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tn_ws(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ P, int R, int Ka, int No,
-    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const float* __restrict__ A2, int lda2, int Ka2) {
+    const float* __restrict__ a_scale, const float* __restrict__ a_shift, int chunk_rows, const float* __restrict__ A2, int lda2, int Ka2,
+    TnAmax amax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_tw[];
   constexpr int AC = KT * 16, BC = NT * 16, A_EL = AC * TCP, B_EL = BC * TCP;
-  constexpr int IMG_EL = 3 * (A_EL + B_EL), IMG_B = IMG_EL * 2;  // one k-tile's image: [A: piece][column][32 rows + pad] | [B: ...]
+  constexpr int IMG_EL = NP * (A_EL + B_EL), IMG_B = IMG_EL * 2;  // one k-tile's image: [A: piece][column][32 rows + pad] | [B: ...]
   constexpr bool MAJ_A = KT >= NT;                                // the operand whose strips a compute wave keeps in registers
   constexpr int MAJT = MAJ_A ? KT : NT, MINT = MAJ_A ? NT : KT;
   constexpr int MT = MAJT / 4, REM = MAJT % 4, RS = (REM * MINT + 3) / 4;
@@ -707,9 +705,18 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     by = (v / (int)gridDim.x) % (int)gridDim.y;
     chunk = v / (int)(gridDim.x * gridDim.y);
   }
+  bool second = false;
   if (A2 != nullptr) {
     const int n1 = (Ka + AC - 1) / AC;
-    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; }
+    if (by >= n1) { by -= n1; row_shift = Ka; A = A2; lda = lda2; Ka = Ka2; second = true; }
+  }
+  uint32_t fa = 127u, fb = 127u;
+  float sa = 1.f, sb = 1.f;
+  if constexpr (NP == 2) {
+    fa = __builtin_amdgcn_readfirstlane(h2_scale_field(second ? amax.a2[0] : amax.a[0]));
+    fb = __builtin_amdgcn_readfirstlane(h2_scale_field(amax.b[0]));
+    sa = h2_field_to_scale(fa);
+    sb = h2_field_to_scale(fb);
   }
   const int n0 = bx * BC, m0 = by * AC;
   const int r_beg = chunk * chunk_rows, r_end = min(R, r_beg + chunk_rows);
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
       uint32_t voA[2], voB[2];
       int off[2], iel[2];
       float4 sc[2], sh[2];
-      float lo[2];
+      float lo[2], ssc[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int c4u = TW[k] * 16 + (lane >> 2);
@@ -771,7 +778,8 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         voA[k] = act && isA && m0 + c4 * 4 < Ka ? (uint32_t)(r_beg + g * 8) * ldA4 + (uint32_t)(m0 + c4 * 4) * 4u : OOB;
         voB[k] = act && !isA && n0 + c4 * 4 < No ? (uint32_t)(r_beg + g * 8) * ldB4 + (uint32_t)(n0 + c4 * 4) * 4u : OOB;
         iel[k] = isA ? A_EL : B_EL;
-        off[k] = act ? (isA ? 0 : 3 * A_EL) + c4 * 4 * TCP + ((g ^ ((c4 ^ (c4 >> 1)) & 1)) << 3) : -1;
+        off[k] = act ? (isA ? 0 : NP * A_EL) + c4 * 4 * TCP + ((g ^ ((c4 ^ (c4 >> 1)) & 1)) << 3) : -1;
+        ssc[k] = isA ? sa : sb;
         sc[k] = make_float4(1.f, 1.f, 1.f, 1.f);
         sh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         lo[k] = -INFINITY;
@@ -819,9 +827,9 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         }                                                                                                  \
       } else if constexpr (!(QAGNN_TNW_ABL & 1)) {                                                         \
         uint16_t* const img_ = reinterpret_cast<uint16_t*>(smem_tw) + ((TP)&1) * IMG_EL;                   \
-        if (off[0] >= 0) store_task_lo<AFFINE>(img_, iel[0], off[0], R1, sc[0], sh[0], lo[0]);             \
+        if (off[0] >= 0) store_task_lo<AFFINE, NP>(img_, iel[0], off[0], R1, sc[0], sh[0], lo[0], ssc[0]); \
         if constexpr (NTW > 4 && ((IDX - (TP)) & 3) == 0) {                                                \
-          if (off[1] >= 0) store_task_lo<AFFINE>(img_, iel[1], off[1], R2, sc[1], sh[1], lo[1]);           \
+          if (off[1] >= 0) store_task_lo<AFFINE, NP>(img_, iel[1], off[1], R2, sc[1], sh[1], lo[1], ssc[1]); \
         }                                                                                                  \
       }
       QAGNN_TNW_LOAD(0, 0, r1a, r2a)
@@ -867,31 +875,34 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
   const int rd_off = (lane & 15) * TCP + (((lane >> 4) ^ ((((lane & 15) >> 2) ^ ((lane & 15) >> 3)) & 1)) << 3);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_tw + (uint32_t)rd_off * 2u;
-  const uint32_t maj0 = lds0 + (MAJ_A ? 0u : (uint32_t)(3 * A_EL * 2)) + (uint32_t)(ci * STRIP_B);  // this wave's first strip
-  const uint32_t min0 = lds0 + (MAJ_A ? (uint32_t)(3 * A_EL * 2) : 0u);
+  const uint32_t maj0 = lds0 + (MAJ_A ? 0u : (uint32_t)(NP * A_EL * 2)) + (uint32_t)(ci * STRIP_B);  // this wave's first strip
+  const uint32_t min0 = lds0 + (MAJ_A ? (uint32_t)(NP * A_EL * 2) : 0u);
   // the leftover strips' tiles, dealt out one by one: tile q = ci + 4 s -> (strip 4 MT + q / MINT, minor tile q % MINT)
   uint32_t rem_maj[RS > 0 ? RS : 1], rem_min[RS > 0 ? RS : 1];
 #pragma unroll
   for (int s_ = 0; s_ < RS; ++s_) {
     const int q = ci + 4 * s_;
-    rem_maj[s_] = lds0 + (MAJ_A ? 0u : (uint32_t)(3 * A_EL * 2)) + (uint32_t)((4 * MT + q / MINT) * STRIP_B);
+    rem_maj[s_] = lds0 + (MAJ_A ? 0u : (uint32_t)(NP * A_EL * 2)) + (uint32_t)((4 * MT + q / MINT) * STRIP_B);
     rem_min[s_] = min0 + (uint32_t)((q % MINT) * STRIP_B);
   }
 #define QAGNN_TNW_FRAG(DST, ADDR, OFF, PIECE)                                                                            \
   {                                                                                                                      \
-    _Pragma("unroll") for (int p = 0; p < TN_NP; ++p)                                                                    \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p)                                                                       \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[p]) : "v"(ADDR), "i"((OFF) + p * (PIECE)));              \
   }
-#define QAGNN_TNW_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * TN_NP / 3))
+  // N: the number of FRAGMENT SETS (NP reads each) that may stay in flight behind F
+#define QAGNN_TNW_WAIT(F, N)                                                                                             \
+  {                                                                                                                      \
+    if constexpr (NP == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * 3));    \
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(F[0]), "+v"(F[1]) : "i"((N) * 2));                                  \
+  }
+#define QAGNN_TNW_TOUCH(F)                                                               \
+  {                                                                                      \
+    if constexpr (NP == 3) asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]));        \
+    else asm volatile("" : "+v"(F[0]), "+v"(F[1]));                                      \
+  }
 #define QAGNN_TNW_SIX(C, AF, BF)                                          \
-  if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[1]), "v"(AF[2]), "v"(BF[0]), "v"(BF[1]), "v"(BF[2])); } else { \
-  if constexpr (TN_NP == 3) {                                             \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[2], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[2], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[1], C, 0, 0, 0); } \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[1], BF[0], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[1], C, 0, 0, 0); \
-  C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[0], BF[0], C, 0, 0, 0); }
+  if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[1]), "v"(BF[0]), "v"(BF[1])); } else { C = mfma_pieces<NP>(AF, BF, C); }
 
   QAGNN_TNW_BAR  // image 0 is complete
   for (int t = 0; t < ntile4; ++t) {
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     }
     const uint32_t cur = (uint32_t)((t & 1) * IMG_B);
     const uint32_t amaj = maj0 + cur, amin = min0 + cur;
-    bf16x8 mf[MT][3], nf[3][3];
+    u32x4s mf[MT][NP], nf[3][NP];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s_ = 0; s_ < MT; ++s_) QAGNN_TNW_FRAG(mf[s_], amaj, s_ * 4 * STRIP_B, MAJ_PIECE)
@@ -913,18 +924,18 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     if constexpr (MINT > 1) QAGNN_TNW_FRAG(nf[1], amin, STRIP_B, MIN_PIECE)
 #pragma unroll
     for (int n = 0; n < MINT; ++n) {
-      bf16x8(&bfn)[3] = nf[n % 3];
+      u32x4s(&bfn)[NP] = nf[n % 3];
       if (n + 2 < MINT) {
         QAGNN_TNW_FRAG(nf[(n + 2) % 3], amin, (n + 2) * STRIP_B, MIN_PIECE)
-        QAGNN_TNW_WAIT(bfn, 6);
+        QAGNN_TNW_WAIT(bfn, 2);
       } else if (n + 1 < MINT) {
-        QAGNN_TNW_WAIT(bfn, 3);
+        QAGNN_TNW_WAIT(bfn, 1);
       } else {
         QAGNN_TNW_WAIT(bfn, 0);
       }
       if (n == 0) {  // (the strips' fragments are older than every minor fragment: landed with the first wait)
 #pragma unroll
-        for (int s_ = 0; s_ < MT; ++s_) asm volatile("" : "+v"(mf[s_][0]), "+v"(mf[s_][1]), "+v"(mf[s_][2]));
+        for (int s_ = 0; s_ < MT; ++s_) QAGNN_TNW_TOUCH(mf[s_])
       }
 #pragma unroll
       for (int s_ = 0; s_ < MT; ++s_) {  // small terms first
@@ -937,11 +948,11 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #pragma unroll
     for (int s_ = 0; s_ < RS; ++s_) {
       if (ci + 4 * s_ < REM * MINT) {  // wave-uniform
-        bf16x8 ar[3], br[3];
+        u32x4s ar[NP], br[NP];
         QAGNN_TNW_FRAG(ar, rem_maj[s_] + cur, 0, MAJ_PIECE)
         QAGNN_TNW_FRAG(br, rem_min[s_] + cur, 0, MIN_PIECE)
         QAGNN_TNW_WAIT(ar, 0);
-        asm volatile("" : "+v"(br[0]), "+v"(br[1]), "+v"(br[2]));
+        QAGNN_TNW_TOUCH(br)
         f32x4s c = accr[s_];
         if constexpr (MAJ_A) { QAGNN_TNW_SIX(c, ar, br) } else { QAGNN_TNW_SIX(c, br, ar) }
         accr[s_] = c;
@@ -952,16 +963,18 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 #undef QAGNN_TNW_FRAG
 #undef QAGNN_TNW_WAIT
+#undef QAGNN_TNW_TOUCH
 #undef QAGNN_TNW_SIX
 #undef QAGNN_TNW_BAR
 
   float* const Pc = P + (int64_t)chunk * ka_total * No;
+  const float inv = NP == 2 ? h2_inv_scale(fa, fb) : 1.f;
   auto put = [&](int maj_strip, int min_tile, const f32x4s& c) {
     const int rstrip = MAJ_A ? maj_strip : min_tile, ctile = MAJ_A ? min_tile : maj_strip;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + rstrip * 16 + (lane >> 4) * 4 + r, col = n0 + ctile * 16 + (lane & 15);
-      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = c[r];
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP == 2 ? c[r] * inv : c[r];
     }
   };
 #pragma unroll
@@ -975,38 +988,39 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
 }
 
-template <int KT, int NT, bool AFFINE>
+template <int KT, int NT, bool AFFINE, int NP = 3>
 static int launch_tn_ws_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
-                          const float* sc, const float* sh, int chunk_rows, const float* A2 = nullptr, int lda2 = 0, int Ka2 = 0) {
-  constexpr size_t lds = (size_t)2 * 3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t) + 64;
+                          const float* sc, const float* sh, int chunk_rows, const float* A2 = nullptr, int lda2 = 0, int Ka2 = 0,
+                          TnAmax amax = TnAmax{nullptr, nullptr, nullptr}) {
+  constexpr size_t lds = (size_t)2 * NP * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t) + 64;
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (!raised[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_ws<KT, NT, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_ws<KT, NT, AFFINE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("gemm_tn_ws: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_ws<KT, NT, AFFINE><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, A2, lda2, Ka2);
+  k_gemm_tn_ws<KT, NT, AFFINE, NP><<<grid, WTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, A2, lda2, Ka2, amax);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_ws");
   return QAGNN_OK;
 }
 
-template <int KT, int NT, bool AFFINE, bool GATHER = false>
+template <int KT, int NT, bool AFFINE, bool GATHER = false, int NP = 3>
 static int launch_tn_split_i(dim3 grid, hipStream_t stream, const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No,
                              const float* sc, const float* sh, int chunk_rows, const int64_t* ridx = nullptr, const float* A2 = nullptr,
-                             int lda2 = 0, int Ka2 = 0) {
-  constexpr size_t lds = (size_t)3 * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t);
+                             int lda2 = 0, int Ka2 = 0, TnAmax amax = TnAmax{nullptr, nullptr, nullptr}) {
+  constexpr size_t lds = (size_t)NP * (KT * 16 + NT * 16) * TCP * sizeof(uint16_t);
   static bool raised[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (lds > 64 * 1024 && !raised[dev & 63]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KT, NT, AFFINE, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_tn_split<KT, NT, AFFINE, GATHER, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("gemm_tn_split: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return QAGNN_EHIP; }
     raised[dev & 63] = true;
   }
-  k_gemm_tn_split<KT, NT, AFFINE, GATHER><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, ridx, A2,
-                                                                       lda2, Ka2);
+  k_gemm_tn_split<KT, NT, AFFINE, GATHER, NP><<<grid, TTHR, lds, stream>>>(A, lda, B, ldb, P, R, Ka, No, sc, sh, tn_xcd() ? chunk_rows : -chunk_rows, ridx,
+                                                                           A2, lda2, Ka2, amax);
   QAGNN_LAUNCH_CHECK("k_gemm_tn_split");
   return QAGNN_OK;
 }
@@ -1048,14 +1062,31 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
 // the step 2.29 -> 2.22 ms)
 constexpr int TN_WS_MIN_TILES = 28;
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream) {
+                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
+  if (amax) {  // the three-MFMA form (amax = {max|A1|, max|A2|, max|B|})
+    const TnAmax am{amax[0], amax[1], amax[2]};
+    if (chunk_rows >= TN_WS_MIN_TILES * 32)
+      return launch_tn_ws_i<7, 13, false, 2>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2, am);
+    return launch_tn_split_i<7, 13, false, false, 2>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2, am);
+  }
   if (chunk_rows >= TN_WS_MIN_TILES * 32)
     return launch_tn_ws_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2);
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    const int64_t* ridx, int chunk_rows, hipStream_t stream) {
+                    const int64_t* ridx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax) {
+  if (amax && !ridx) {  // the three-MFMA form (amax = {max|A|, -, max|B|})
+    const TnAmax am{amax[0], nullptr, amax[2]};
+    if (tn_split_wide_b(Ka)) {
+      dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
+      return sc ? launch_tn_split_i<7, 13, true, false, 2>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am)
+                : launch_tn_split_i<7, 13, false, false, 2>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am);
+    }
+    dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
+    return sc ? launch_tn_split_i<13, 7, true, false, 2>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am)
+              : launch_tn_split_i<13, 7, false, false, 2>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am);
+  }
   if (ridx) {
     dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
     return launch_tn_split_i<13, 7, false, true>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, ridx);
@@ -1074,13 +1105,14 @@ int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, 
 
 using namespace qagnn;
 
-extern "C" int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2) { return nn2_pack_bytes(No, K1, K2); }
+extern "C" int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2) { return nn2_pack_bytes(No, K1, K2, 3) + 256; }  // (>= the two-piece image + its scale words)
 
 extern "C" int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2) {
   if (!a || !B1n || !nn2_ok(*a, ldn1, ldn2)) return 0;                                      // not a product of the packed kernels
-  if (nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return 0;                // B is registered: nothing to pack per call
-  const int64_t need = nn2_pack_bytes(a->No, a->K1, a->K2);
-  return nn2_packed_ok(*a, need) ? need : 0;                                                  // (too few rows: the in-kernel split)
+  if (nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, nn2_h2_ok(*a) ? 2 : 3)) return 0;  // B is registered: nothing to pack per call
+  const int np = nn2_h2_ok(*a) ? 2 : 3;
+  const int64_t need = nn2_pack_bytes(a->No, a->K1, a->K2, np);
+  return nn2_packed_ok(*a, need, np) ? need : 0;                                              // (too few rows: the in-kernel split)
 }
 
 extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
@@ -1127,6 +1159,11 @@ extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const flo
       if (cands[ci] < nt) nt = cands[ci];
   }
   if (nn2_ok(*a, ldn1, ldn2)) {
+    // The three-MFMA form where the operand maxima are known (a_amax1 / a_amax2) and B's two-piece image exists or can be made
+    if (nn2_h2_ok(*a)) {
+      if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, 2)) return launch_nn2_prepacked(nt, *a, pk, stream, 2);
+      if (ws && aligned16(ws) && nn2_packed_ok(*a, ws_bytes, 2)) return launch_nn2_packed(nt, *a, B1n, ldn1, B2n, ldn2, ws, stream, 2);
+    }
     // B pre-packed by the caller (qagnn_gemm_nn_prepack_f32: one launch for all weights of a step)?
     if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return launch_nn2_prepacked(nt, *a, pk, stream);
     if (ws && nn2_packed_ok(*a, ws_bytes)) {

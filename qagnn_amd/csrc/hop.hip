@@ -47,6 +47,32 @@ static int check_hop(const qagnn_hop_args* h, const char* who) {
   return QAGNN_OK;
 }
 
+// ---- the three-MFMA GEMM form inside a hop (qagnn_hop_args.amax, gemm_split == 2; arithmetic: gemm_nn2.hip's header) -------------
+// Word layout of a hop's amax block; X and S may live in another hop's block (a chained stack: the previous hop's y IS this hop's X)
+enum { AM_X = 0, AM_S = 1, AM_AGGR = 2, AM_H1 = 3, AM_Y = 4, AM_DOUT = 5, AM_DH1 = 6, AM_DKMQ = 7 };
+struct HopAmax {
+  bool on;          // this hop runs the form
+  uint32_t* x;      // max |X|   (written by the previous hop's GELU / dropout, or by a reduction pass at the start of the call)
+  uint32_t* s;      // max |S|
+  uint32_t* y;      // where this hop's GELU / dropout leaves max |y|
+  uint32_t* own;    // the hop's own block
+};
+// The form needs batch statistics (the bound of relu(bn(h1)) comes from them) and pays from NN2_PACK_MIN_M rows on (packed B images)
+static bool hop_h2(const qagnn_hop_args* h) { return h->gemm_split == 2 && h->amax != nullptr && h->batch_stats && h->N >= 8192; }
+static HopAmax hop_amax_single(const qagnn_hop_args* h) {
+  HopAmax m{hop_h2(h), nullptr, nullptr, nullptr, h->amax};
+  if (m.on) { m.x = h->amax + AM_X; m.s = h->amax + AM_S; m.y = h->amax + AM_Y; }
+  return m;
+}
+// hop l of a stack: X / S words shared along the chain where the tensors are
+static HopAmax hop_amax_stack(const qagnn_hop_args* hops, int k, int l) {
+  HopAmax m = hop_amax_single(&hops[l]);
+  if (!m.on) return m;
+  if (l > 0 && hop_h2(&hops[l - 1]) && hops[l].X == hops[l - 1].y && hops[l - 1].apply_act) m.x = hops[l - 1].amax + AM_Y;
+  if (l > 0 && hop_h2(&hops[0]) && hops[l].S == hops[0].S && hops[l].SP == hops[0].SP) m.s = hops[0].amax + AM_S;
+  return m;
+}
+
 }  // namespace qagnn
 
 using namespace qagnn;
@@ -62,7 +88,8 @@ using namespace qagnn;
 static int64_t hop_pack_elems(int DP) { return up4((qagnn_gemm_nn_pack_bytes(3 * DP, DP, DP) + 3) / 4); }
 
 extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP) {
-  return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP)) + hop_pack_elems(DP);
+  return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP)) + hop_pack_elems(DP) +
+         up4((int64_t)N);  // (+ the edge forward's per-node maxima: qagnn_hop_args.amax)
 }
 
 // NN product through the kernel family the caller asked for (qagnn_hop_args.gemm_split): the bf16-split kernel takes B in its
@@ -73,7 +100,8 @@ static int hop_nn(const qagnn_hop_args* h, const qagnn_gemm_nn_args* a, const fl
   return qagnn_gemm_nn_f32(a, stream);
 }
 
-extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+// x_ready / s_ready: the words of X / S already hold this call's maxima (an earlier hop of the stack produced them)
+static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready, bool s_ready, qagnn_stream_t stream) {
   HOP_TRY(check_hop(h, "hop_fwd"));
   const int N = h->N, DP = h->DP, SP = h->SP, Ep = h->g->Ep;
   Carver w{h->ws, h->ws + h->ws_elems};
@@ -81,30 +109,41 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   float* crws = w.take(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
   const int64_t pk_elems = hop_pack_elems(DP);
   float* pkws = w.take(pk_elems);
+  float* ampart = w.take(N);
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_fwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   float* mean = h->stats, *var = h->stats + DP, *invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
 
+  if (am.on) {  // operand maxima nobody left behind: one reduction pass each
+    if (!x_ready) HOP_TRY(qagnn_absmax_f32(h->X, (int64_t)N * DP, am.x, stream));
+    if (SP > 0 && !s_ready) HOP_TRY(qagnn_absmax_f32(h->S, (int64_t)N * SP, am.s, stream));
+  }
   // K | M | Q = [X | S] [Wx ; Ws] + TT[node type]      (project-then-gather: linear_key/msg/query on N node rows, :464-466)
   qagnn_gemm_nn_args ga = {};
   ga.A1 = h->X; ga.lda1 = DP; ga.K1 = DP; ga.B1 = h->Wx_t; ga.ldb1 = 3 * DP;
   if (SP > 0) { ga.A2 = h->S; ga.lda2 = SP; ga.K2 = SP; ga.B2 = h->Ws_t; ga.ldb2 = 3 * DP; }
   ga.C = h->KMQ; ga.ldc = 3 * DP; ga.M = N; ga.No = 3 * DP;
   ga.rowtab = h->TT; ga.ldt = 3 * DP; ga.rowidx = h->ntype;
+  if (am.on) { ga.a_amax1 = am.x; ga.a_amax2 = SP > 0 ? am.s : nullptr; }
   HOP_TRY(hop_nn(h, &ga, h->Wx, DP, SP > 0 ? h->Ws : nullptr, SP, pkws, pk_elems, stream));
   // attention + aggregation (:442, 455-484)
-  HOP_TRY(qagnn_edge_attn_fwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP, stream));
+  HOP_TRY(launch_edge_attn_fwd(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP,
+                               am.on ? ampart : nullptr, (hipStream_t)stream));
+  if (am.on) HOP_TRY(launch_amax_reduce(ampart, N, am.own + AM_AGGR, (hipStream_t)stream));
   // mlp: Linear -> BatchNorm1d -> ReLU -> Linear (:443, 408); BN + ReLU are folded into the second GEMM's operand load
   qagnn_gemm_nn_args g1 = {};
   g1.A1 = h->aggr; g1.lda1 = DP; g1.K1 = DP; g1.B1 = h->W1t; g1.ldb1 = DP; g1.C = h->h1; g1.ldc = DP; g1.M = N; g1.No = DP; g1.bias = h->b1;
   // batch statistics as a by-product of this GEMM's epilogue where the split kernel can provide them (same rule as ops.GatMlpFn)
   const bool fused_stats = h->batch_stats && h->gemm_split && DP > 192 && DP <= 208;
   if (fused_stats) g1.colstat_part = crws;
+  if (am.on) g1.a_amax1 = am.own + AM_AGGR;
   HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, pkws, pk_elems, stream));
   const double Rd = (double)N;
   const float unbias = (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0));
+  const bool h1_bound = am.on && fused_stats;  // (the bound of relu(bn(h1)) rides on the statistics launch)
   if (fused_stats) {
-    HOP_TRY(qagnn_bn_stats_finalize_f32(crws, cdiv(N, 128), N, DP, h->gamma, h->beta, h->eps, h->stats, h->run_mean, h->run_var,
-                                        h->num_batches_tracked, h->dense_pos, h->d, h->momentum, unbias, h->ones_col, stream));
+    QAGNN_REQUIRE(!h->run_mean || (h->run_var && h->d > 0 && h->d % 4 == 0 && h->d <= DP), QAGNN_EINVAL, "hop_fwd: running-stat arguments");
+    HOP_TRY(launch_bn_stats_finalize(crws, cdiv(N, 128), N, DP, h->gamma, h->beta, h->eps, h->stats, h->run_mean, h->run_var, h->num_batches_tracked,
+                                     h->d, h->momentum, unbias, h->ones_col, h1_bound ? am.own + AM_H1 : nullptr, (hipStream_t)stream));
   } else {
     const float* mean_u = mean;
     const float* var_u = var;
@@ -124,10 +163,20 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
   g2.a_scale = scale; g2.a_shift = shift;
+  if (h1_bound) g2.a_amax1 = am.own + AM_H1;
   HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, pkws, pk_elems, stream));
-  if (h->apply_act)  // X' = dropout(GELU(out))  (:48-49)
-    HOP_TRY(qagnn_gelu_dropout_fwd_f32(h->out, h->y, (int64_t)N * DP, h->p_drop, h->seed, stream));
+  if (h->apply_act) {  // X' = dropout(GELU(out))  (:48-49)
+    QAGNN_REQUIRE(h->p_drop >= 0.f && h->p_drop < 1.f, QAGNN_EINVAL, "hop_fwd: p=%f", h->p_drop);
+    HOP_TRY(launch_gelu_dropout(h->out, nullptr, h->y, (int64_t)N * DP, h->p_drop, h->seed, am.on ? am.y : nullptr, (hipStream_t)stream));
+  }
   return QAGNN_OK;
+}
+
+extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream) {
+  QAGNN_REQUIRE(h, QAGNN_EINVAL, "hop_fwd: null argument block");
+  const HopAmax am = hop_amax_single(h);
+  if (am.on) HOP_TRY(qagnn_zero_words(h->amax, QAGNN_HOP_AMAX_WORDS, stream));
+  return hop_fwd_one(h, am, false, false, stream);
 }
 
 extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t cls_part_rows) {
@@ -135,7 +184,8 @@ extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t 
   if (SP > 0) tn = max64(tn, qagnn_gemm_tn_workspace_elems(N, DP + SP, 3 * DP));
   // two sets of the buffers the weight-gradient stream reads (d out, d h1, d K|M|Q) + what the main stream keeps to itself
   return 2 * (2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP)) + up4((int64_t)N * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
-         up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4)) + hop_pack_elems(DP);
+         up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4)) + hop_pack_elems(DP) +
+         up4((int64_t)3 * N);  // (+ the edge backward's per-node maxima)
 }
 
 namespace qagnn {
@@ -187,7 +237,7 @@ static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
 // side stream they leave the chain (fork after each of their operands is complete, join at the end of the stack).  What they read
 // from the workspace (d out, d h1, d K|M|Q) lives in buffer set `set`; the caller alternates sets from hop to hop and makes the
 // main stream wait for `*done` before it reuses one, so the side stream may lag the main stream by a whole hop.
-static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_t* done) {
+static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss, int set, hipEvent_t* done) {
   HOP_TRY(check_hop(h, "hop_bwd"));
   QAGNN_REQUIRE(h->dy && h->dWx_t && h->dTT && h->dEkEm && h->dW1t && h->db1 && h->dbn && h->dW2t && h->db2, QAGNN_EINVAL,
                 "hop_bwd: null gradient pointer");
@@ -213,6 +263,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));  // column-reduction partials: main stream only
   const int64_t pk_elems = hop_pack_elems(DP);
   float* pkws = w.take(pk_elems);  // packed B images of the data-gradient products: main stream only
+  float* ampart = w.take((int64_t)3 * N);
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
   const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
@@ -221,15 +272,21 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
 
   // GELU + dropout backward
   const float* dout = h->dy;
+  // (the three-MFMA form in the backward needs every maximum the forward left: the same condition, and h1's bound)
+  const bool h2 = am.on && DP > 192 && DP <= 208;
+  uint32_t* const w_dout = h2 ? am.own + AM_DOUT : nullptr, *const w_dh1 = h2 ? am.own + AM_DH1 : nullptr, *const w_dkmq = h2 ? am.own + AM_DKMQ : nullptr;
   if (h->apply_act) {
-    HOP_TRY(qagnn_gelu_dropout_bwd_f32(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, stream));
+    HOP_TRY(launch_gelu_dropout(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, w_dout, (hipStream_t)stream));
     dout = bufA;
+  } else if (h2) {
+    HOP_TRY(qagnn_absmax_f32(dout, (int64_t)N * DP, w_dout, stream));
   }
   if (h->ones_col < 0)
     HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
-  HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, wstream));
+  if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->h1, DP, DP, nullptr, 0, 0, dout, DP, h->dW2t, DP, N, DP, scale, shift, am.own + AM_H1, nullptr, w_dout, tnws, wstream));
+  else HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, wstream));
   // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient (no copy when the caller's db2 IS
   // that row)
   if (h->ones_col >= 0 && h->db2 != h->dW2t + (int64_t)h->ones_col * DP) {
@@ -238,24 +295,33 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
   }
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
+  gr.a_amax1 = w_dout;
   HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, pkws, pk_elems, stream));
   // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
-  HOP_TRY(qagnn_bn_relu_bwd_colsum_f32(bufB, h->h1, bufC, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
-                                       h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, h->db1, crws, stream));
+  HOP_TRY(launch_bn_relu_bwd_colsum(bufB, h->h1, bufC, DP, N, DP, mean, invstd, scale, shift, h->gamma, h->dbn, h->dbn + DP,
+                                    h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, h->db1, crws, w_dh1, (hipStream_t)stream));
   // first Linear (db1 = colsum(d h1) came out of the pass above)
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
-  HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufC, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
+  if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->aggr, DP, DP, nullptr, 0, 0, bufC, DP, h->dW1t, DP, N, DP, nullptr, nullptr, am.own + AM_AGGR, nullptr, w_dh1, tnws, wstream));
+  else HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufC, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   qagnn_gemm_nn_args gg = {};
   gg.A1 = bufC; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
+  gg.a_amax1 = w_dh1;
   HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, pkws, pk_elems, stream));
   // attention backward
-  HOP_TRY(qagnn_edge_attn_bwd_f32(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs,
-                                  cls_part, stream));
+  HOP_TRY(launch_edge_attn_bwd(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs, cls_part,
+                               h2 ? ampart : nullptr, (hipStream_t)stream));
+  if (h2) HOP_TRY(launch_amax_reduce(ampart, (int64_t)3 * N, w_dkmq, (hipStream_t)stream));
   // projection: weight gradients, node-type-table gradient, data gradients
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
   if (SP > 0 && h->dWs_t == h->dWx_t + (int64_t)DP * 3 * DP) {  // the two gradients are one [DP + SP, 3 DP] matrix: one launch
-    HOP_TRY(qagnn_gemm_tn2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, tnws, wstream));
+    if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, am.s, w_dkmq, tnws, wstream));
+    else HOP_TRY(qagnn_gemm_tn2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, tnws, wstream));
+  } else if (h2) {
+    HOP_TRY(qagnn_gemm_tn_h2_f32(h->X, DP, DP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, nullptr, w_dkmq, tnws, wstream));
+    if (SP > 0)
+      HOP_TRY(qagnn_gemm_tn_h2_f32(h->S, SP, SP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.s, nullptr, w_dkmq, tnws, wstream));
   } else {
     HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
     if (SP > 0)
@@ -282,12 +348,14 @@ static int hop_bwd_one(const qagnn_hop_args* h, SideSync* ss, int set, hipEvent_
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
     gx.accumulate = h->accumulate_dX;
+    gx.a_amax1 = w_dkmq;
     HOP_TRY(hop_nn(h, &gx, h->Wx_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   if (SP > 0 && h->dS) {
     qagnn_gemm_nn_args gs = {};
     gs.A1 = dKMQ; gs.lda1 = 3 * DP; gs.K1 = 3 * DP; gs.B1 = h->Ws; gs.ldb1 = SP; gs.C = h->dS; gs.ldc = SP; gs.M = N; gs.No = SP;
     gs.accumulate = h->accumulate_dS;
+    gs.a_amax1 = w_dkmq;
     HOP_TRY(hop_nn(h, &gs, h->Ws_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   return QAGNN_OK;
@@ -305,7 +373,7 @@ static int stack_bwd_impl(const qagnn_hop_args* hops, int k, hipStream_t main) {
       hipError_t he = hipStreamWaitEvent(ss.main, done[set], 0);
       if (he != hipSuccess) { set_error("stack_bwd: hipStreamWaitEvent failed: %s", hipGetErrorString(he)); rc = QAGNN_EHIP; break; }
     }
-    rc = hop_bwd_one(&hops[l], &ss, set, &done[set]);
+    rc = hop_bwd_one(&hops[l], hop_amax_stack(hops, k, l), &ss, set, &done[set]);
   }
   // join even after an error: whatever was forked must not outlive the call (a capture would be left with an unjoined branch)
   if (ss.side) {
@@ -330,7 +398,18 @@ extern "C" int qagnn_hop_bwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
 // as k calls of qagnn_hop_fwd_f32 / qagnn_hop_bwd_f32 -- one FFI crossing and one autograd node instead of k for host-bound batches.
 extern "C" int qagnn_stack_fwd_f32(const qagnn_hop_args* hops, int32_t k, qagnn_stream_t stream) {
   QAGNN_REQUIRE(hops && k > 0, QAGNN_EINVAL, "stack_fwd: no hops");
-  for (int l = 0; l < k; ++l) HOP_TRY(qagnn_hop_fwd_f32(&hops[l], stream));
+  // the hops' amax blocks start at zero: one launch when they are one array (the module mirror's are), one per hop otherwise
+  bool any = false, one_array = true;
+  for (int l = 0; l < k; ++l) {
+    any = any || hop_h2(&hops[l]);
+    one_array = one_array && hops[l].amax != nullptr && hops[l].amax == hops[0].amax + (int64_t)l * QAGNN_HOP_AMAX_WORDS;
+  }
+  if (any && one_array) HOP_TRY(qagnn_zero_words(hops[0].amax, (int64_t)k * QAGNN_HOP_AMAX_WORDS, stream));
+  for (int l = 0; l < k; ++l) {
+    const HopAmax am = hop_amax_stack(hops, k, l);
+    if (am.on && !one_array) HOP_TRY(qagnn_zero_words(hops[l].amax, QAGNN_HOP_AMAX_WORDS, stream));
+    HOP_TRY(hop_fwd_one(&hops[l], am, am.on && am.x != hops[l].amax + AM_X, am.on && am.s != hops[l].amax + AM_S, stream));
+  }
   return QAGNN_OK;
 }
 

@@ -444,9 +444,16 @@ class QAGNN_Message_Passing(nn.Module):
         # the weight operands of this forward's (and its backward's) large NN products, split into the kernels' bf16 images with ONE
         # launch (ops.prepack_weights): per hop the projection [Wx | Ws], its two data-gradient products, and both ways of the mlp's two
         # Linears; the output layer [Vh | Vx] and the score embedding
+        # (pieces: the natively sequenced stack in train mode runs its products in the three-MFMA form, whose B images are the two scaled
+        # fp16 pieces -- csrc/gemm_nn2.hip; everything else takes the three bf16 images)
+        Kp = ops.kernels()
+        stack_native = self.k > 0 and ops.use_fused_hop(bs * n) and hasattr(Kp, 'stack_fwd') and ops.FUSED_STACK
+        bn0 = self.gnn_layers[0].mlp[1] if self.k > 0 else None
+        pieces = 2 if (stack_native and getattr(Kp, 'gemm_split', 1) == 2 and (self.training or not bn0.track_running_stats)) else 3
         pairs = []
         for pk in per_layer:
-            pairs += [(pk[1], pk[3]), (pk[0], None), (pk[2], None), (pk[9], None), (pk[8], None), (pk[14], None), (pk[13], None)]
+            pairs += [(pk[1], pk[3], pieces), (pk[0], None, pieces), (pk[2], None, pieces), (pk[9], None, pieces), (pk[8], None, pieces),
+                      (pk[14], None, pieces), (pk[13], None, pieces)]
         pairs += [(Vh, Vx), (Vh_t, None), (Vx_t, None), (Wes, None)]
         ops.prepack_weights(self, pairs, bs * n)
         # Every weight operand below comes straight out of pack_all (GatherPlan), whose backward is the only reader of its

@@ -796,15 +796,18 @@ def gat_mlp(aggr, W1t, W1, b1, gamma, beta, W2t, W2, b2, run_mean, run_var, batc
 #     1434 / 1689 vs 1317 / 1373 QA-subgraphs/s;
 #   * GPU-bound batches (320 subgraphs, N = 64 000 rows): the composed path 26 098 / 26 113 vs 25 481 / 25 429, because only it
 #     can run the weight-gradient GEMMs of one operator under the edge backward of the next (QAGNN_WGRAD_OVERLAP above).
-# "auto" therefore takes the native hop below FUSED_HOP_MAX_ROWS node rows, where a step is bounded by the host.
+# Rounds 1-5: "auto" took the native hop below 32 768 node rows, where a step is bounded by the host.  Round 6: the natively sequenced stack
+# at EVERY size -- it is where the operand maxima of the three-MFMA GEMM form travel from the kernel that produces a tensor to the product
+# that reads it (qagnn_hop_args.amax), and the weight-gradient overlap that favoured the composed path is worth 0.5 % since the kernels
+# fill the chip on their own (DESIGN.md, round 5 visits 8-9; the native stack forks its weight gradients onto a side stream itself).
 _fh = _os.environ.get('QAGNN_FUSED_HOP', 'auto')
 FUSED_HOP = {'1': True, '0': False}.get(_fh, None)  # None = auto
-FUSED_HOP_MAX_ROWS = 32768
+FUSED_HOP_MAX_ROWS = None  # (auto: no row limit)
 FUSED_STACK = True  # where the native hop is taken, take all k hops in one call (a module attribute: the tests compare the two forms)
 
 
 def use_fused_hop(n_rows):
-    return FUSED_HOP if FUSED_HOP is not None else n_rows < FUSED_HOP_MAX_ROWS
+    return FUSED_HOP if FUSED_HOP is not None else (FUSED_HOP_MAX_ROWS is None or n_rows < FUSED_HOP_MAX_ROWS)
 HOP_PARAMS = ('Wx_t', 'Wx', 'Ws_t', 'Ws', 'TT', 'EkEm', 'W1t', 'W1', 'b1', 'gamma', 'beta', 'W2t', 'W2', 'b2', 'run_mean_p', 'run_var_p')
 
 

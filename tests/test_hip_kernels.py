@@ -569,13 +569,14 @@ def test_head_post_forward_backward(B, n, NH, DP, dv, Ds, d, p1, p2):
 @pytest.mark.parametrize('name,HP,mode', [('csqa_b10', 52, 'train'), ('csqa_b10', 52, 'eval'), ('small_train', 8, 'train'),
                                           ('rand_hub', 52, 'train_noact'), ('medqa_b8', 52, 'train_noS'), ('big', 52, 'train'),
                                           ('big_pad', 52, 'train')])
-def test_fused_hop_equals_composed_path(name, HP, mode):
+def test_fused_hop_equals_composed_path(name, HP, mode, monkeypatch):
     """qagnn_hop_{fwd,bwd}_f32 (csrc/hop.hip) sequences the library's own launchers: every forward buffer, every gradient and
     the BatchNorm running buffers must be BIT-identical to composing the per-kernel entry points from Python
     (ops.hop_*_composed, the definition of the hop that the host-logic tests hold against the oracle)."""
     from qagnn_amd import ops
     (ei, et, nt, R, T), _, _, _, qs = edge_inputs(name, HP, 5)
     K = hip()
+    monkeypatch.setattr(K, 'gemm_split', 1)  # (the three-MFMA form lives in the native hop only: test_native_hop_in_the_three_mfma_form)
     dev = 'cuda'
     g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
     gen = torch.Generator().manual_seed(77)
@@ -888,3 +889,173 @@ def test_prepacked_weights_are_found_by_pointer_and_change_no_bit():
     del keep
     got = K.gemm_nn(want[0][0], ws[0][0], want[0][1], ws[0][1], B1n=ws[0][2], B2n=ws[0][3])
     assert torch.equal(got, want[0][2])
+
+
+# ---- round 6: the three-MFMA GEMM form (scaled two-piece fp16 split; csrc/gemm_nn2.hip header) ------------------------------------------
+# Worst case per product: both operands are represented to 2^-22 (hi = fp16(x s), lo = fp16(x s - hi)) and the dropped lo x lo term is
+# 2^-22 |a b|: 3 * 2^-22 = 6 eps32 per term, plus the fp32 accumulation any kernel has -- held to 12 eps32 * sum |a| |b| (the exact
+# 3 x bf16 form: 8), plus the absolute floor 2^-38 K max|A| max|B column| of elements that fall below the fp16 subnormals of their scale.
+H2_SHAPES = [(64000, 208, 112, 624), (20000, 208, 0, 208), (9000, 624, 0, 208), (8192, 624, 0, 112), (10000, 40, 56, 200), (63901, 320, 0, 200)]
+
+
+def _ranged(g, rows, cols, kind):
+    """operands whose magnitudes stress the scaling: gradients (1e-7), large activations (1e5), rows spread over six decades"""
+    x = torch.randn(rows, cols, generator=g)
+    if kind == 'tiny':
+        return x * 1e-7
+    if kind == 'huge':
+        return x * 1e5
+    if kind == 'spread':
+        return x * torch.pow(10.0, -6 * torch.rand(rows, 1, generator=g))
+    return x
+
+
+@pytest.mark.gpu
+def test_absmax_is_exact():
+    K = hip()
+    g = torch.Generator().manual_seed(5)
+    for n, kind in ((64000 * 208, 'plain'), (4096, 'tiny'), (12, 'huge')):
+        x = _ranged(g, 1, n, kind).reshape(-1)
+        x[n // 3] = float('nan')  # skipped
+        w = K.absmax(x.cuda())
+        want = x[~torch.isnan(x)].abs().max()
+        assert w[0].item() == want.view(torch.int32).item()
+    assert K.absmax(torch.zeros(64).cuda())[0].item() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K1,K2,No', H2_SHAPES)
+@pytest.mark.parametrize('variant', ['plain', 'bias_tab', 'affine', 'accumulate', 'stats'])
+@pytest.mark.parametrize('kind', ['plain', 'tiny', 'huge', 'spread'])
+def test_gemm_nn_three_mfma_form(M, K1, K2, No, variant, kind):
+    if variant == 'stats' and not (K2 == 0 and 192 < No <= 208):
+        pytest.skip('column statistics: 193..208 output columns, one segment')
+    if variant == 'affine' and K1 > 256:
+        pytest.skip('the scale / shift vectors live in LDS: K1 <= 256')
+    if kind != 'plain' and variant in ('bias_tab', 'accumulate'):
+        pytest.skip('epilogue variants once')
+    g = torch.Generator().manual_seed(M + K1 + No)
+    A1, B1 = _ranged(g, M, K1, kind), torch.randn(K1, No, generator=g) * torch.pow(10.0, -3 * torch.rand(1, No, generator=g))
+    A2 = _ranged(g, M, K2, 'plain' if kind == 'spread' else kind) if K2 else None
+    B2 = torch.randn(K2, No, generator=g) if K2 else None
+    kw = {}
+    if variant == 'bias_tab':
+        kw = dict(bias=torch.randn(No, generator=g), rowtab=torch.randn(4, No, generator=g), rowidx=torch.randint(0, 4, (M,), generator=g))
+    if variant == 'affine':
+        kw = dict(a_scale=torch.randn(K1, generator=g), a_shift=torch.randn(K1, generator=g) * A1.abs().mean())
+    if variant == 'stats':
+        kw = dict(bias=torch.randn(No, generator=g) * A1.abs().mean())
+    out0 = torch.randn(M, No, generator=g) if variant == 'accumulate' else None
+    K = hip()
+    assert K.gemm_split == 2
+    cu = lambda t: None if t is None else t.cuda()  # noqa: E731
+    A1e = torch.relu(A1 * kw['a_scale'] + kw['a_shift']) if variant == 'affine' else A1
+    am1, am2 = K.absmax(cu(A1e.contiguous())), (K.absmax(cu(A2)) if K2 else None)
+    got = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), out=cu(out0), accumulate=out0 is not None, B1n=cu(B1.t().contiguous()),
+                    B2n=cu(B2.t().contiguous()) if K2 else None, a_amax1=am1, a_amax2=am2, colstats=variant == 'stats',
+                    **{k: cu(v) for k, v in kw.items()})
+    part = None
+    if variant == 'stats':
+        got, part = got
+    got = got.cpu()
+    d = lambda t: None if t is None else (t.double() if t.is_floating_point() else t)  # noqa: E731
+    ref = EMU.gemm_nn(d(A1), d(B1), d(A2), d(B2), **{k: d(v) for k, v in kw.items()})
+    if out0 is not None:
+        ref = ref + out0.double()
+    amax = max(A1e.abs().max().item(), A2.abs().max().item() if K2 else 0.0)
+    bcol = B1.abs().max(0).values.double() if not K2 else torch.maximum(B1.abs().max(0).values, B2.abs().max(0).values).double()
+    bound = 12 * EPS * (A1e.abs().double() @ B1.abs().double()) + 2.0 ** -38 * (K1 + K2) * amax * bcol + 4 * EPS * ref.abs() + 1e-30
+    if K2:
+        bound = bound + 12 * EPS * (A2.abs().double() @ B2.abs().double())
+    err = (got.double() - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+    # ... and it is not the six-MFMA kernel that answered: the two forms differ in the last bits
+    if kind == 'plain' and variant == 'plain':
+        six = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), B1n=cu(B1.t().contiguous()), B2n=cu(B2.t().contiguous()) if K2 else None).cpu()
+        assert not torch.equal(six, got)
+        assert ((six.double() - ref).abs() <= bound).all()
+    if part is not None:  # the statistics by-product describes the scaled-back values it was computed from
+        stats = K.bn_stats_finalize(part, M, torch.ones(No).cuda(), torch.zeros(No).cuda(), 1e-5, None, -1).cpu()
+        assert (stats[0].double() - got.double().mean(0)).abs().max().item() <= 1e-5 * got.abs().max().item()
+        assert (stats[1].double() - got.double().var(0, unbiased=False)).abs().max().item() <= 1e-4 * got.double().var(0).max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Ka1,Ka2,No', [(64000, 208, 112, 624), (64000, 208, 0, 208), (20000, 208, 0, 624), (5000, 112, 0, 624), (2049, 208, 0, 208),
+                                          (12800, 208, 208, 208), (700, 32, 0, 96)])
+@pytest.mark.parametrize('kind', ['plain', 'tiny', 'spread', 'affine'])
+def test_gemm_tn_three_mfma_form(R, Ka1, Ka2, No, kind):
+    """qagnn_gemm_tn_h2_f32: [A1 | A2]^T B with every operand's maximum handed over; shapes the split kernels decline fall back to the
+    six-MFMA route (same bound)."""
+    if kind == 'affine' and Ka2:
+        pytest.skip('no prologue on the two-operand product')
+    g = torch.Generator().manual_seed(R + Ka1 + Ka2 + No)
+    k0 = 'plain' if kind == 'affine' else kind
+    A1, B = _ranged(g, R, Ka1, k0), _ranged(g, R, No, 'tiny' if kind == 'tiny' else 'plain')
+    A2 = _ranged(g, R, Ka2, 'plain') if Ka2 else None
+    kw = dict(a_scale=torch.randn(Ka1, generator=g), a_shift=torch.randn(Ka1, generator=g)) if kind == 'affine' else {}
+    A1e = torch.relu(A1 * kw['a_scale'] + kw['a_shift']) if kind == 'affine' else A1
+    K = hip()
+    cu = lambda t: None if t is None else t.cuda()  # noqa: E731
+    got = K.gemm_tn_h2(cu(A1), cu(B), K.absmax(cu(A1e.contiguous())), K.absmax(cu(B)), A2=cu(A2), amax_a2=K.absmax(cu(A2)) if Ka2 else None,
+                       **{k: cu(v) for k, v in kw.items()}).cpu()
+    A = A1e if not Ka2 else torch.cat([A1e, A2], 1)
+    ref = A.double().t() @ B.double()
+    arow = torch.cat([torch.full((Ka1,), A1e.abs().max().item()), torch.full((Ka2,), A2.abs().max().item() if Ka2 else 0.0)]).double()
+    bound = 16 * EPS * (A.abs().double().t() @ B.abs().double()) + 2.0 ** -38 * R * arow[:, None] * B.abs().max().item() + 1e-30
+    err = (got.double() - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['big', 'big_pad'])
+def test_native_hop_in_the_three_mfma_form(name, monkeypatch):
+    """The natively sequenced hop with gemm_split = 2 (every large product in the three-MFMA form, the operand maxima travelling from the
+    producing kernels) against the same hop with the exact 3 x bf16 products: every forward buffer and every gradient within fp32
+    round-off of each other, none bit-identical (the form did run), everything finite; the amax words hold the true maxima."""
+    (ei, et, nt, R, T), _, _, _, qs = edge_inputs(name, 52, 5)
+    K = hip()
+    HP, dev = 52, 'cuda'
+    g = K.graph_prep(ei.cuda(), et.cuda(), nt.cuda(), R, T)
+    gen = torch.Generator().manual_seed(78)
+    N, DP, C, SP, dh = nt.numel(), 208, R * T * T + T, 112, 50
+    assert N >= 8192
+    rnd = lambda *shape, s=0.3: (torch.randn(*shape, generator=gen) * s).to(dev)  # noqa: E731
+    Wx_t, Ws_t, W1t, W2t = rnd(DP, 3 * DP, s=0.1), rnd(SP, 3 * DP, s=0.1), rnd(DP, DP, s=0.1), rnd(DP, DP, s=0.1)
+    prm = (Wx_t, Wx_t.t().contiguous(), Ws_t, Ws_t.t().contiguous(), rnd(T, 3 * DP), rnd(C, 2 * DP),
+           W1t, W1t.t().contiguous(), rnd(DP), 1 + rnd(DP), 9 + rnd(DP), W2t, W2t.t().contiguous(), rnd(DP), rnd(DP), 0.5 + rnd(DP).abs())
+    # (beta = 9 +- 1: every BatchNorm output is positive, the ReLU is the identity -- the two runs cannot differ by a subgradient choice at a
+    # kink, only by round-off; the kinks are the business of the module tests, which align them)
+    X, S, dy = rnd(N, DP, s=1.0), rnd(N, SP, s=1.0), rnd(N, DP, s=1e-6)  # (a gradient-sized dy: 1e-6)
+    args = (g, HP, qs, X, S, nt.cuda(), prm, True, 1e-5, 0.2, 4321, True)
+    res = {}
+    for mode in (2, 1):
+        monkeypatch.setattr(K, 'gemm_split', mode)
+        y, saved = K.hop_fwd(*args, None)
+        grads = K.hop_bwd(*args, saved, dy, True, True)
+        torch.cuda.synchronize()
+        res[mode] = ([y] + list(saved[:6]), grads, saved[6])
+    names = ['y', 'KMQ', 'a|alpha', 'aggr', 'h1', 'out', 'stats', 'dX', 'dS', 'dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dgamma', 'dbeta', 'dW2t', 'db2']
+    differ = 0
+    for nm, a, b in zip(names, res[2][0] + list(res[2][1]), res[1][0] + list(res[1][1])):
+        assert torch.isfinite(a).all(), nm
+        scale = b.abs().max().item() + 1e-30
+        err = (a - b).abs()
+        tol = 2e-4 if nm.startswith('d') else 2e-5
+        if nm == 'db1':  # colsum(d h1) is zero by construction under batch statistics (BatchNorm's backward removes the mean): round-off
+            scale = res[1][1][6].abs().max().item()  # of sums of 64 000 terms; held against the size of dW1t, which sums the same rows
+        assert err.max().item() <= tol * scale, f'{nm}: {err.max().item():.3e} of scale {scale:.3e}'
+        differ += int(not torch.equal(a, b))
+    assert differ >= 12, differ
+    # the words of the forward: X, S, aggr exact; h1's an upper bound within 2^8; y exact
+    w = res[2][2].cpu()
+    f = res[2][0]
+    bits = lambda t: t.abs().max().cpu().view(torch.int32).item()  # noqa: E731
+    assert w[0].item() == bits(X) and w[1].item() == bits(S) and w[2].item() == bits(f[3]) and w[4].item() == bits(f[0])
+    st = f[6].cpu()
+    h1n = torch.relu(f[4].cpu() * st[3] + st[4]).abs().max()
+    bound = w[3:4].view(torch.float32).item()
+    assert h1n.item() <= bound <= 256 * h1n.item(), (h1n.item(), bound)
+    assert w[5].item() != 0 and w[6].item() != 0 and w[7].item() != 0

@@ -635,30 +635,33 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize('variant,workload', [('default', 'configs1_csqa_320'), ('poison', 'configs1_csqa_320'), ('blobs', 'configs1_csqa_320'),
-                                              ('native', 'configs1_csqa_320'), ('dropout', 'configs1_csqa_320'), ('blobs', 'configs2_obqa_256'),
-                                              ('blobs', 'configs4_medqa_64')])
+@pytest.mark.parametrize('variant,workload', [('default', 'configs1_csqa_320'), ('composed', 'configs1_csqa_320'), ('poison', 'configs1_csqa_320'),
+                                              ('blobs', 'configs1_csqa_320'), ('exact', 'configs1_csqa_320'), ('dropout', 'configs1_csqa_320'),
+                                              ('blobs', 'configs2_obqa_256'), ('blobs', 'configs4_medqa_64')])
 def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch):
-    """default: int64 edge lists; poison: deferred weight gradients start as NaN (a reader that runs before the side-stream join
-    would carry the NaN into a gradient); blobs: the graph arrives as load-time blobs, as in bench.py's default mode; native: the
-    natively sequenced stack (qagnn_stack_{fwd,bwd}_f32, what the host-bound batches take) at this size, where its weight-gradient
-    stream (qagnn_hop_args.side_stream) really lags the data-gradient chain by a hop -- the two buffer sets earn their keep here;
-    dropout: blobs + the run scripts' dropout rates, i.e. exactly the step bench.py times, keep masks replayed on the oracle."""
+    """default: int64 edge lists through the natively sequenced stack (qagnn_stack_{fwd,bwd}_f32; round 6: the path every batch size takes),
+    whose large products run in the three-MFMA form and whose weight-gradient stream (qagnn_hop_args.side_stream) lags the data-gradient
+    chain by a hop at this size; composed: the per-kernel path (ops.FUSED_HOP = False: LinearNNFn / EdgeAttnFn / GatMlpFn, exact 3 x bf16
+    products) with the weight-gradient GEMMs deferred onto a side stream; poison: the same with deferred weight gradients starting as NaN (a
+    reader that runs before the side-stream join would carry the NaN into a gradient); blobs: the graph arrives as load-time blobs, as in
+    bench.py's default mode; exact: the native stack with gemm_split = 1 (the exact 3 x bf16 products of rounds 2-5: the same bars hold for
+    both arithmetic forms); dropout: blobs + the run scripts' dropout rates, i.e. exactly the step bench.py times, keep masks replayed on
+    the oracle."""
     wl = BENCH_WORKLOADS[workload]
     nq, nc, n = wl['nq'], wl['nc'], 200
-    big = nq * nc * n >= 32768  # the composed path + weight-gradient side stream (the MedQA shard takes the native stack: host-bound size)
+    composed = variant in ('composed', 'poison')
     if variant == 'poison':
         monkeypatch.setattr(ops, 'WGRAD_POISON', True)
-    if variant == 'native':
-        monkeypatch.setattr(ops, 'FUSED_HOP', True)
-        assert ops.FUSED_STACK and ops.use_fused_hop(nq * nc * n)
-    elif big:
-        assert not ops.use_fused_hop(nq * nc * n), 'this test is about the composed path + weight-gradient overlap'
-    assert ops.WGRAD_OVERLAP
+    if composed:
+        monkeypatch.setattr(ops, 'FUSED_HOP', False)
+    if variant == 'exact':
+        monkeypatch.setattr(ops.kernels(), 'gemm_split', 1)
+    assert ops.FUSED_STACK and ops.use_fused_hop(nq * nc * n) == (not composed)
+    assert ops.WGRAD_OVERLAP and (variant == 'exact' or ops.kernels().gemm_split == 2)
     deferred0 = ops._WgradQueue.n_deferred
     bench_size_step_vs_oracle(variant, workload)
-    if variant != 'native' and big:
-        assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the path bench.py times'
+    if composed:
+        assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the composed path + overlap'
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
