@@ -304,6 +304,11 @@ int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* tid, c
                                qagnn_stream_t stream);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
+/* qagnn_gelu_dropout_fwd_f32 that also merges max |Y| into *amax (bit pattern, integer atomic max; the caller zeroed the word): the operand
+ * maximum of the three-MFMA GEMM form for a consumer of Y (qagnn_hop_args.x_amax / s_amax, qagnn_gemm_nn_args.a_amax1) without a pass over Y */
+int64_t qagnn_gelu_dropout_amax_scratch_elems(int64_t n);
+int qagnn_gelu_dropout_fwd_amax_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, uint32_t* amax,
+                                    float* scratch /* qagnn_gelu_dropout_amax_scratch_elems(n) floats */, qagnn_stream_t stream);
 /* qagnn_bn_relu_bwd_f32 with the column sums of its OUTPUT as a by-product (the bias gradient of the Linear in front of the
  * BatchNorm): one pass instead of an elementwise pass + a column-reduction pass; sums bit-identical to qagnn_colreduce_f32
  * mode 0 on the output.  workspace: qagnn_colreduce_workspace_elems(R, Cc, 1) floats.  (The same fusion for the GELU + dropout
@@ -420,6 +425,10 @@ typedef struct qagnn_hop_args {
                                       relu(bn(h1)), max |y|, and (backward) max |d out|, max |d h1|, max |d K|M|Q|, each left behind by the
                                       kernel that produces the tensor (X, S of the first hop: one reduction pass each).  In a stack call
                                       whose hops are chained (hops[l + 1].X == hops[l].y, one shared S) the words of X and S are shared too */
+  const uint32_t* x_amax;          /* NULL, or a word that already holds max |X| (bit pattern; e.g. left by qagnn_gelu_dropout_fwd_amax_f32 when it
+                                      produced X): the hop then skips its own reduction pass over X.  Likewise s_amax for S.  Read-only, read
+                                      again by the backward call */
+  const uint32_t* s_amax;
 } qagnn_hop_args;
 #define QAGNN_HOP_AMAX_WORDS 16
 int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP);

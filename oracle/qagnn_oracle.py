@@ -140,7 +140,8 @@ class MultiheadAttPoolLayer(nn.Module):
 
 
 class CustomizedEmbedding(nn.Module):
-    """utils/layers.py:571-607 (use_contextualized=False branch, the one QAGNN uses)."""
+    """utils/layers.py:571-607 (constructed with use_contextualized=False, as QAGNN does; forward takes both inputs: table ids, or
+    `emb_data` -- contextualised embeddings, :596-603; pinned by tests/golden/embdata.npz)."""
 
     def __init__(self, concept_num, concept_in_dim, concept_out_dim, use_contextualized=False,
                  pretrained_concept_emb=None, freeze_ent_emb=True, scale=1.0, init_range=0.02):
@@ -160,7 +161,13 @@ class CustomizedEmbedding(nn.Module):
             self.activation = GELU()
 
     def forward(self, index, contextualized_emb=None):
-        assert contextualized_emb is None
+        if contextualized_emb is not None:  # utils/layers.py:596-603: transform every contextualised row, then gather along dim 1
+            assert index.size(0) == contextualized_emb.size(0)
+            if hasattr(self, 'cpt_transform'):
+                contextualized_emb = self.activation(self.cpt_transform(contextualized_emb * self.scale))
+            else:
+                contextualized_emb = contextualized_emb * self.scale
+            return contextualized_emb.gather(1, index.unsqueeze(-1).expand(-1, -1, contextualized_emb.size(-1)))
         if hasattr(self, 'cpt_transform'):
             return self.activation(self.cpt_transform(self.emb(index) * self.scale))
         return self.emb(index) * self.scale

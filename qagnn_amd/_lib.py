@@ -22,7 +22,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32', 'qagnn_gather_multi_f32', 'qagnn_gather_multi_sum_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
-           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32']
+           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32', 'qagnn_gelu_dropout_fwd_amax_f32', 'qagnn_gelu_dropout_amax_scratch_elems']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
 ABI_VERSION = 17  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32)
@@ -69,7 +69,7 @@ class qagnn_hop_args(C.Structure):
                 [(n, _vp) for n in ('KMQ', 'a', 'alpha', 'aggr', 'h1', 'out', 'y', 'stats', 'dy', 'dX', 'dS')] +
                 [('accumulate_dS', _i32), ('accumulate_dX', _i32)] +
                 [(n, _vp) for n in ('dWx_t', 'dWs_t', 'dTT', 'dEkEm', 'dW1t', 'db1', 'dbn', 'dW2t', 'db2', 'ws')] +
-                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32), ('side_stream', _vp), ('amax', _vp)])
+                [('ws_elems', _i64), ('gemm_split', _i32), ('ones_col', _i32), ('tab_col', _i32), ('side_stream', _vp), ('amax', _vp), ('x_amax', _vp), ('s_amax', _vp)])
 
 
 HOP_AMAX_WORDS = 16  # QAGNN_HOP_AMAX_WORDS
@@ -119,6 +119,9 @@ def load_library(path=LIB_PATH):
     lib.qagnn_bn_relu_bwd_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
+    lib.qagnn_gelu_dropout_fwd_amax_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp, _vp, _vp]
+    lib.qagnn_gelu_dropout_amax_scratch_elems.restype = _i64
+    lib.qagnn_gelu_dropout_amax_scratch_elems.argtypes = [_i64]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
     lib.qagnn_bn_relu_bwd_colsum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]
     lib.qagnn_pool_attn_fwd_f32.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u64, _vp, _vp, _vp, _vp]
@@ -755,9 +758,17 @@ class HipKernels(metaclass=_GuardedMeta):
         self._check(self.lib.qagnn_add_row0_f32(dK.data_ptr(), n * Cc, dZ.data_ptr(), B, Cc, self._stream()), 'qagnn_add_row0_f32')
         return dK
 
-    def gelu_dropout_fwd(self, X, p, seed):
+    def gelu_dropout_fwd(self, X, p, seed, amax=False):
+        """amax=True: -> (Y, word) with word = int32 [4], [0] = the bit pattern of max |Y| (qagnn_gelu_dropout_fwd_amax_f32)"""
         assert X.is_contiguous() and X.dtype == torch.float32
         Y = torch.empty_like(X)
+        if amax:
+            word = torch.empty(4, dtype=torch.int32, device=X.device)
+            self._check(self.lib.qagnn_zero_words(word.data_ptr(), 4, self._stream()), 'qagnn_zero_words')
+            scratch = torch.empty(self.lib.qagnn_gelu_dropout_amax_scratch_elems(X.numel()), dtype=torch.float32, device=X.device)
+            self._check(self.lib.qagnn_gelu_dropout_fwd_amax_f32(X.data_ptr(), Y.data_ptr(), X.numel(), float(p), int(seed), word.data_ptr(),
+                                                                 scratch.data_ptr(), self._stream()), 'qagnn_gelu_dropout_fwd_amax_f32')
+            return Y, word
         self._check(self.lib.qagnn_gelu_dropout_fwd_f32(X.data_ptr(), Y.data_ptr(), X.numel(), float(p), int(seed),
                                                         self._stream()), 'qagnn_gelu_dropout_fwd_f32')
         return Y
@@ -923,7 +934,7 @@ class HipKernels(metaclass=_GuardedMeta):
                 dW1t.view(DP, DP), db1, dbn[DP:], dbn[:DP], dW2t.view(DP, DP), db2)
 
     # -- the whole k-hop stack per call (csrc/hop.hip: qagnn_stack_{fwd,bwd}_f32) -------------------------------------------------------
-    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, cols=-1):
+    def stack_fwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, cols=-1, x_amax=None, s_amax=None):
         """k hops with GELU + dropout after each; prms / seeds / runnings: per-layer lists.  -> (y [N, DP], saved)."""
         k = len(prms)
         N, DP, dev = graph.N, 4 * HP, X.device
@@ -944,6 +955,10 @@ class HipKernels(metaclass=_GuardedMeta):
             h.a, h.alpha = p_aa + (2 * l) * graph.Ep * 16, p_aa + (2 * l + 1) * graph.Ep * 16
             h.aggr, h.h1, h.out, h.y = (p_rows + (4 * l + i) * row_b for i in range(4))
             h.amax = p_amax + l * HOP_AMAX_WORDS * 4
+            if l == 0 and x_amax is not None:  # max |X| from X's producer (ops.amax_lookup): no reduction pass over the stack input
+                h.x_amax = x_amax.data_ptr()
+            if s_amax is not None:
+                h.s_amax = s_amax.data_ptr()
             if runnings[l] is not None:
                 rm, rv, nbt, pos, mom, _unb = runnings[l]
                 assert rm.is_contiguous() and rv.is_contiguous() and pos.dtype == torch.long and (nbt is None or nbt.dtype == torch.long)
@@ -953,7 +968,8 @@ class HipKernels(metaclass=_GuardedMeta):
             hops[l] = h
             x = rows[l, 3]
         self._check(self.lib.qagnn_stack_fwd_f32(hops, k, self._stream()), 'qagnn_stack_fwd_f32')
-        return rows[k - 1, 3], (KMQ, aa, rows, stats, amax)
+        ext = torch.empty(0, dtype=torch.int32, device=dev)
+        return rows[k - 1, 3], (KMQ, aa, rows, stats, amax, x_amax if x_amax is not None else ext, s_amax if s_amax is not None else ext)
 
     def stack_bwd(self, graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, saved, dy, need_dX, need_dS, dX_acc=None, tab_col=-1,
                   overlap=True):
@@ -962,6 +978,7 @@ class HipKernels(metaclass=_GuardedMeta):
         k = len(prms)
         KMQ, aa, rows, stats = saved[:4]
         p_amax = saved[4].data_ptr() if len(saved) > 4 else None
+        x_amax, s_amax = (saved[5], saved[6]) if len(saved) > 6 else (None, None)
         N, DP, dev = graph.N, 4 * HP, X.device
         SP = S.size(1) if S is not None else 0
         T = prms[0][4].size(0)
@@ -991,6 +1008,10 @@ class HipKernels(metaclass=_GuardedMeta):
             h.aggr, h.h1, h.out = (p_rows + (4 * l + i) * row_b for i in range(3))
             h.y = p_rows + (4 * l + 3) * row_b  # (what the forward wrote: the chain hops[l + 1].X == hops[l].y is what shares the amax words)
             h.amax = p_amax + l * HOP_AMAX_WORDS * 4 if p_amax else None
+            if l == 0 and x_amax is not None and x_amax.numel():
+                h.x_amax = x_amax.data_ptr()
+            if s_amax is not None and s_amax.numel():
+                h.s_amax = s_amax.data_ptr()
             h.dy = dy.data_ptr() if l == k - 1 else p_dxs + l * row_b
             base = p_flat + l * per * 4
             h.dWx_t, pdWs_t, h.dTT, h.dEkEm, h.dW1t, h.db1, h.dbn, h.dW2t, h.db2 = (base + o * 4 for o in offs[:9])

@@ -32,7 +32,9 @@ int launch_nn2_prepacked(int nt, const qagnn_gemm_nn_args& a, const void* pk, hi
 int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream, int np = 3);
 
 // producers that can leave max |output| behind for the three-MFMA GEMM form (elementwise.hip; amax = nullptr: plain launch)
-int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, hipStream_t stream);
+int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, float* amax_part,
+                        hipStream_t stream);
+int64_t gelu_amax_scratch_elems(int64_t n);
 int launch_bn_relu_bwd_colsum(const float* dR, const float* Hh, float* dH, int ld, int R, int Cc, const float* mean, const float* invstd,
                               const float* scale, const float* shift, const float* gamma, const float* sum_dy, const float* sum_dy_hhat,
                               float inv_rows, const float* roww, float* colsum, float* workspace, uint32_t* amax, hipStream_t stream);
@@ -44,7 +46,7 @@ int launch_edge_attn_fwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, co
                          float* score, float* a, float* alpha, float* aggr, int32_t lda, float* amax_part /* [N] or nullptr */, hipStream_t stream);
 int launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
                          const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ, float* dEkEm, float* ga, float* rs,
-                         float* cls_part, float* amax_part /* [3 N] or nullptr */, hipStream_t stream);
+                         float* cls_part, float* amax_part /* [3 N] or nullptr */, uint32_t* amax_slot, hipStream_t stream);
 int launch_amax_reduce(const float* part, int64_t n, uint32_t* slot, hipStream_t stream);  // max of n non-negative floats -> *slot (elementwise.hip)
 
 #define QAGNN_REQUIRE(cond, code, ...) \

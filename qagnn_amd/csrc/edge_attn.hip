@@ -528,16 +528,26 @@ __global__ __launch_bounds__(1024) void k_cls_reduce(const int* __restrict__ chu
     st4(slices + ((int64_t)c * QAGNN_CLS_SLICES + sl) * DP2 + threadIdx.x * 4, s);
   }
 }
-__global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ slices, float* __restrict__ dEkEm, int lde, int DP2, int C) {
+// amax_part != nullptr: the launch also folds the node-side kernels' per-node maxima (npart non-negative floats) into *amax_slot -- every
+// block a slice, one atomic per block (common.h): the last small kernel of the edge backward carries the reduction instead of a launch of its own
+__global__ __launch_bounds__(256) void k_cls_reduce2(const float* __restrict__ slices, float* __restrict__ dEkEm, int lde, int DP2, int C,
+                                                     const float* __restrict__ amax_part, int npart, uint32_t* __restrict__ amax_slot) {
   const int ncol4 = DP2 >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * ncol4) return;
-  const int c = i / ncol4, col4 = i - c * ncol4;
-  const float* p = slices + (int64_t)c * QAGNN_CLS_SLICES * DP2 + col4 * 4;
-  float4 s = ld4(p);
+  if (i < C * ncol4) {
+    const int c = i / ncol4, col4 = i - c * ncol4;
+    const float* p = slices + (int64_t)c * QAGNN_CLS_SLICES * DP2 + col4 * 4;
+    float4 s = ld4(p);
 #pragma unroll
-  for (int q = 1; q < QAGNN_CLS_SLICES; ++q) s = add4(s, ld4(p + (int64_t)q * DP2));
-  st4(dEkEm + (int64_t)c * lde + col4 * 4, s);
+    for (int q = 1; q < QAGNN_CLS_SLICES; ++q) s = add4(s, ld4(p + (int64_t)q * DP2));
+    st4(dEkEm + (int64_t)c * lde + col4 * 4, s);
+  }
+  if (amax_part) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int k = i; k < npart; k += (int)(gridDim.x * blockDim.x)) m = fmaxf(m, amax_part[k]);
+    block_amax_merge(m, amax_slot, red);
+  }
 }
 
 static int check_common(const qagnn_graph* g, const float* KMQ, int ldk, const float* EkEm, int lde, int HP, const char* who) {
@@ -582,13 +592,14 @@ extern "C" int qagnn_edge_attn_fwd_f32(const qagnn_graph* g, const float* KMQ, i
 extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde,
                                        int32_t HP, float qscale, const float* a, const float* alpha, const float* G, int32_t ldg,
                                        float* dKMQ, float* dEkEm, float* ga, float* rs, float* cls_part, qagnn_stream_t stream_) {
-  return launch_edge_attn_bwd(g, KMQ, ldk, EkEm, lde, HP, qscale, a, alpha, G, ldg, dKMQ, dEkEm, ga, rs, cls_part, nullptr, (hipStream_t)stream_);
+  return launch_edge_attn_bwd(g, KMQ, ldk, EkEm, lde, HP, qscale, a, alpha, G, ldg, dKMQ, dEkEm, ga, rs, cls_part, nullptr, nullptr, (hipStream_t)stream_);
 }
 
-// amax_part != nullptr: [3 N] floats, max |d M row|, |d Q row|, |d K row| per node (the three node-side kernels)
+// amax_part != nullptr: [3 N] floats of scratch for max |d M row|, |d Q row|, |d K row| per node (the three node-side kernels), folded into
+// *amax_slot (max |d K|M|Q|, bit pattern; the caller zeroed it) by the last kernel of the call
 int qagnn::launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
                                 const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ, float* dEkEm, float* ga, float* rs,
-                                float* cls_part, float* amax_part, hipStream_t stream) {
+                                float* cls_part, float* amax_part, uint32_t* amax_slot, hipStream_t stream) {
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_bwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(a && alpha && G && dKMQ && dEkEm && ga && rs && cls_part, QAGNN_EINVAL, "edge_attn_bwd: null pointer");
@@ -616,7 +627,7 @@ int qagnn::launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t 
   k_cls_reduce<<<dim3(g->C, QAGNN_CLS_SLICES), cr_threads, (size_t)P * (DP2 / 4) * sizeof(float4), stream>>>(g->chunkptr, cls_part, slices, DP2,
                                                                                                           g->C, g->n_groups);
   QAGNN_LAUNCH_CHECK("k_cls_reduce");
-  k_cls_reduce2<<<cdiv((int64_t)g->C * (DP2 / 4), 256), 256, 0, stream>>>(slices, dEkEm, lde, DP2, g->C);
+  k_cls_reduce2<<<cdiv((int64_t)g->C * (DP2 / 4), 256), 256, 0, stream>>>(slices, dEkEm, lde, DP2, g->C, amax_slot ? amax_part : nullptr, 3 * g->N, amax_slot);
   QAGNN_LAUNCH_CHECK("k_cls_reduce2");
   return QAGNN_OK;
 }

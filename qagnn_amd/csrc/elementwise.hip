@@ -269,9 +269,10 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float t = tanhf(u);
   return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x2);
 }
-// AMAX: the launch also merges max |out| into *amax.  Such a launch is a grid of at most GD_AMAX_BLOCKS fat blocks walking the tensor
-// with a grid stride (one atomic per block: common.h says why), four float4 per thread in flight.
-constexpr int GD_AMAX_BLOCKS = 2048;
+// AMAX: the launch also leaves max |out| of every block in amax_part[blockIdx.x] (a plain store; launch_amax_reduce folds them).  The
+// kernel keeps its shape -- one float4 per thread, 13 000 blocks at 64 000 rows: it is ALU-bound (the counter hash) and wants every wave
+// slot; two fat-block forms with one atomic per block (1 024 / 2 048 blocks) measured 20.6 -> 28.7 / 35.8 us, the atomics alone ~8 ns each
+// on the kernel's tail (round 6, visits 4 and 10).
 template <bool BWD>
 __device__ __forceinline__ float4 gelu_dropout_val(float4 x, float4 g, int64_t i, float p, uint64_t seed, float inv) {
   float4 o;
@@ -291,36 +292,22 @@ __device__ __forceinline__ float4 gelu_dropout_one(const float* __restrict__ X, 
 template <bool BWD, bool AMAX = false>
 __global__ __launch_bounds__(256) void k_gelu_dropout(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out, int64_t n4,
                                                       float p, uint64_t seed, const unsigned long long* __restrict__ epoch,
-                                                      uint32_t* __restrict__ amax = nullptr) {
+                                                      float* __restrict__ amax_part = nullptr) {
   if (p > 0.f) seed = epoch_seed(seed, epoch);
   const float inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  if constexpr (!AMAX) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    st4(out + i * 4, gelu_dropout_one<BWD>(X, dY, i, p, seed, inv));
-  } else {
-    __shared__ float red[16];
-    float m = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
-      float4 x[4], g[4];  // four float4 per thread in flight (a fat block is a latency chain otherwise: 20.6 -> 28.7 us with one)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + u * stride < n4 ? i0 + u * stride : i0;
-        x[u] = ld4(X + i * 4);
-        g[u] = BWD ? ld4(dY + i * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + u * stride;
-        if (i < n4) {
-          const float4 o = gelu_dropout_val<BWD>(x[u], g[u], i, p, seed, inv);
-          st4(out + i * 4, o);
-          m = fmaxf(m, absmax4(o));
-        }
-      }
-    }
-    block_amax_merge(m, amax, red);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!AMAX && i >= n4) return;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    o = gelu_dropout_one<BWD>(X, dY, i, p, seed, inv);
+    st4(out + i * 4, o);
+  }
+  if constexpr (AMAX) {  // (whole waves: idle lanes carry 0)
+    __shared__ float red[4];
+    const float m = wave_amax_lane63(absmax4(o));
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -580,18 +567,21 @@ extern "C" int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int3
 }
 
 namespace qagnn {
-// dY == nullptr: forward.  amax != nullptr: the launch also merges max |out| into that word (k_gelu_dropout, AMAX)
-int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, hipStream_t stream) {
-  const int grid = cdiv(n / 4, 256), fat = grid < GD_AMAX_BLOCKS ? grid : GD_AMAX_BLOCKS;
+// dY == nullptr: forward.  amax != nullptr: max |out| is merged into that word; amax_part: scratch of gelu_amax_scratch_elems(n) floats
+int64_t gelu_amax_scratch_elems(int64_t n) { return cdiv(n / 4, 256); }
+int launch_gelu_dropout(const float* X, const float* dY, float* out, int64_t n, float p, uint64_t seed, uint32_t* amax, float* amax_part,
+                        hipStream_t stream) {
+  const int grid = cdiv(n / 4, 256);
+  if (amax && !amax_part) { set_error("gelu_dropout: the maximum needs its scratch"); return QAGNN_EINVAL; }
   if (dY) {
-    if (amax) k_gelu_dropout<true, true><<<fat, 256, 0, stream>>>(X, dY, out, n / 4, p, seed, seed_epoch_ptr(), amax);
+    if (amax) k_gelu_dropout<true, true><<<grid, 256, 0, stream>>>(X, dY, out, n / 4, p, seed, seed_epoch_ptr(), amax_part);
     else k_gelu_dropout<true><<<grid, 256, 0, stream>>>(X, dY, out, n / 4, p, seed, seed_epoch_ptr());
   } else {
-    if (amax) k_gelu_dropout<false, true><<<fat, 256, 0, stream>>>(X, nullptr, out, n / 4, p, seed, seed_epoch_ptr(), amax);
+    if (amax) k_gelu_dropout<false, true><<<grid, 256, 0, stream>>>(X, nullptr, out, n / 4, p, seed, seed_epoch_ptr(), amax_part);
     else k_gelu_dropout<false><<<grid, 256, 0, stream>>>(X, nullptr, out, n / 4, p, seed, seed_epoch_ptr());
   }
   QAGNN_LAUNCH_CHECK("k_gelu_dropout");
-  return QAGNN_OK;
+  return amax ? launch_amax_reduce(amax_part, grid, amax, stream) : QAGNN_OK;
 }
 }  // namespace qagnn
 
@@ -599,7 +589,15 @@ extern "C" int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, f
   hipStream_t stream = (hipStream_t)stream_;
   QAGNN_REQUIRE(X && Y && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(Y), QAGNN_EINVAL, "gelu_dropout_fwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_fwd: p=%f", p);
-  return launch_gelu_dropout(X, nullptr, Y, n, p, seed, nullptr, stream);
+  return launch_gelu_dropout(X, nullptr, Y, n, p, seed, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t qagnn_gelu_dropout_amax_scratch_elems(int64_t n) { return gelu_amax_scratch_elems(n); }
+extern "C" int qagnn_gelu_dropout_fwd_amax_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, uint32_t* amax, float* scratch,
+                                               qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(X && Y && amax && scratch && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(Y), QAGNN_EINVAL, "gelu_dropout_fwd_amax: bad args");
+  QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_fwd_amax: p=%f", p);
+  return launch_gelu_dropout(X, nullptr, Y, n, p, seed, amax, scratch, (hipStream_t)stream_);
 }
 
 extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed,
@@ -608,7 +606,7 @@ extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float
   QAGNN_REQUIRE(X && dY && dX && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX), QAGNN_EINVAL,
                 "gelu_dropout_bwd: bad args");
   QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd: p=%f", p);
-  return launch_gelu_dropout(X, dY, dX, n, p, seed, nullptr, stream);
+  return launch_gelu_dropout(X, dY, dX, n, p, seed, nullptr, nullptr, stream);
 }
 
 extern "C" int qagnn_absmax_f32(const float* x, int64_t n, uint32_t* slot, qagnn_stream_t stream_) {

@@ -451,10 +451,14 @@ static hipError_t zero_range(void* p, size_t bytes, hipStream_t stream) {
 #ifdef QAGNN_PREP_MEMSET_NODE  // the faulty form, only to reproduce the fault (tools/build_micro.sh -> scripts/r5_memset_node_fault.sh)
   return hipMemsetAsync(p, 0, bytes, stream);
 #endif
+  // (the callers' layout guarantees both: carve() rounds every array to 4 words and the storage is checked for 16-byte alignment; a layout
+  // change that broke either would leave a tail of stale counters behind, so it fails here instead)
+  if (bytes % 16 != 0 || !aligned16(p)) return hipErrorInvalidValue;
   const int64_t n16 = (int64_t)(bytes / 16);
+  if (n16 == 0) return hipSuccess;  // (nothing launched: nothing to ask hipGetLastError about -- it would report and clear somebody else's error)
   int blocks = (int)((n16 + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  if (n16 > 0) k_zero16<<<blocks, 256, 0, stream>>>((int4*)p, n16);
+  k_zero16<<<blocks, 256, 0, stream>>>((int4*)p, n16);
   return hipGetLastError();
 }
 

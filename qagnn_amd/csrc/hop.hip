@@ -61,15 +61,20 @@ struct HopAmax {
 static bool hop_h2(const qagnn_hop_args* h) { return h->gemm_split == 2 && h->amax != nullptr && h->batch_stats && h->N >= 8192; }
 static HopAmax hop_amax_single(const qagnn_hop_args* h) {
   HopAmax m{hop_h2(h), nullptr, nullptr, nullptr, h->amax};
-  if (m.on) { m.x = h->amax + AM_X; m.s = h->amax + AM_S; m.y = h->amax + AM_Y; }
+  if (m.on) {  // (x_amax / s_amax: words the caller's producers filled; read-only here)
+    m.x = h->x_amax ? const_cast<uint32_t*>(h->x_amax) : h->amax + AM_X;
+    m.s = h->s_amax ? const_cast<uint32_t*>(h->s_amax) : h->amax + AM_S;
+    m.y = h->amax + AM_Y;
+  }
   return m;
 }
 // hop l of a stack: X / S words shared along the chain where the tensors are
 static HopAmax hop_amax_stack(const qagnn_hop_args* hops, int k, int l) {
   HopAmax m = hop_amax_single(&hops[l]);
   if (!m.on) return m;
-  if (l > 0 && hop_h2(&hops[l - 1]) && hops[l].X == hops[l - 1].y && hops[l - 1].apply_act) m.x = hops[l - 1].amax + AM_Y;
-  if (l > 0 && hop_h2(&hops[0]) && hops[l].S == hops[0].S && hops[l].SP == hops[0].SP) m.s = hops[0].amax + AM_S;
+  if (l > 0 && hop_h2(&hops[l - 1]) && hops[l].X == hops[l - 1].y && hops[l - 1].apply_act && !hops[l].x_amax) m.x = hops[l - 1].amax + AM_Y;
+  if (l > 0 && hop_h2(&hops[0]) && hops[l].S == hops[0].S && hops[l].SP == hops[0].SP && !hops[l].s_amax)
+    m.s = hops[0].s_amax ? const_cast<uint32_t*>(hops[0].s_amax) : hops[0].amax + AM_S;
   return m;
 }
 
@@ -89,7 +94,7 @@ static int64_t hop_pack_elems(int DP) { return up4((qagnn_gemm_nn_pack_bytes(3 *
 
 extern "C" int64_t qagnn_hop_fwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP) {
   return up4((int64_t)Ep * 4) + up4(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP)) + hop_pack_elems(DP) +
-         up4((int64_t)N);  // (+ the edge forward's per-node maxima: qagnn_hop_args.amax)
+         up4(max64(N, gelu_amax_scratch_elems((int64_t)N * DP)));  // (+ per-node / per-block maxima: qagnn_hop_args.amax)
 }
 
 // NN product through the kernel family the caller asked for (qagnn_hop_args.gemm_split): the bf16-split kernel takes B in its
@@ -109,7 +114,7 @@ static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready,
   float* crws = w.take(max64(qagnn_colreduce_workspace_elems(N, DP, 1), (int64_t)cdiv(N, 128) * 3 * DP));
   const int64_t pk_elems = hop_pack_elems(DP);
   float* pkws = w.take(pk_elems);
-  float* ampart = w.take(N);
+  float* ampart = w.take(max64(N, gelu_amax_scratch_elems((int64_t)N * DP)));
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_fwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   float* mean = h->stats, *var = h->stats + DP, *invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
 
@@ -167,7 +172,7 @@ static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready,
   HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, pkws, pk_elems, stream));
   if (h->apply_act) {  // X' = dropout(GELU(out))  (:48-49)
     QAGNN_REQUIRE(h->p_drop >= 0.f && h->p_drop < 1.f, QAGNN_EINVAL, "hop_fwd: p=%f", h->p_drop);
-    HOP_TRY(launch_gelu_dropout(h->out, nullptr, h->y, (int64_t)N * DP, h->p_drop, h->seed, am.on ? am.y : nullptr, (hipStream_t)stream));
+    HOP_TRY(launch_gelu_dropout(h->out, nullptr, h->y, (int64_t)N * DP, h->p_drop, h->seed, am.on ? am.y : nullptr, ampart, (hipStream_t)stream));
   }
   return QAGNN_OK;
 }
@@ -176,7 +181,7 @@ extern "C" int qagnn_hop_fwd_f32(const qagnn_hop_args* h, qagnn_stream_t stream)
   QAGNN_REQUIRE(h, QAGNN_EINVAL, "hop_fwd: null argument block");
   const HopAmax am = hop_amax_single(h);
   if (am.on) HOP_TRY(qagnn_zero_words(h->amax, QAGNN_HOP_AMAX_WORDS, stream));
-  return hop_fwd_one(h, am, false, false, stream);
+  return hop_fwd_one(h, am, h->x_amax != nullptr, h->s_amax != nullptr, stream);
 }
 
 extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t DP, int32_t SP, int32_t cls_part_rows) {
@@ -185,7 +190,7 @@ extern "C" int64_t qagnn_hop_bwd_workspace_elems(int32_t N, int32_t Ep, int32_t 
   // two sets of the buffers the weight-gradient stream reads (d out, d h1, d K|M|Q) + what the main stream keeps to itself
   return 2 * (2 * up4((int64_t)N * DP) + up4((int64_t)N * 3 * DP)) + up4((int64_t)N * DP) + up4((int64_t)Ep * 4) + up4((int64_t)N * 4) +
          up4((int64_t)cls_part_rows * 2 * DP) + up4(tn) + up4(qagnn_colreduce_workspace_elems(N, 3 * DP, 4)) + hop_pack_elems(DP) +
-         up4((int64_t)3 * N);  // (+ the edge backward's per-node maxima)
+         up4(max64((int64_t)3 * N, gelu_amax_scratch_elems((int64_t)N * DP)));  // (+ per-node / per-block maxima)
 }
 
 namespace qagnn {
@@ -263,7 +268,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
   float* crws = w.take(qagnn_colreduce_workspace_elems(N, 3 * DP, 4));  // column-reduction partials: main stream only
   const int64_t pk_elems = hop_pack_elems(DP);
   float* pkws = w.take(pk_elems);  // packed B images of the data-gradient products: main stream only
-  float* ampart = w.take((int64_t)3 * N);
+  float* ampart = w.take(max64((int64_t)3 * N, gelu_amax_scratch_elems((int64_t)N * DP)));
   QAGNN_REQUIRE(w.ok(), QAGNN_EINVAL, "hop_bwd: workspace of %lld floats is too small", (long long)h->ws_elems);
   const float* mean = h->batch_stats ? h->stats : h->run_mean_p;
   const float* invstd = h->stats + 2 * DP, *scale = h->stats + 3 * DP, *shift = h->stats + 4 * DP;
@@ -276,7 +281,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
   const bool h2 = am.on && DP > 192 && DP <= 208;
   uint32_t* const w_dout = h2 ? am.own + AM_DOUT : nullptr, *const w_dh1 = h2 ? am.own + AM_DH1 : nullptr, *const w_dkmq = h2 ? am.own + AM_DKMQ : nullptr;
   if (h->apply_act) {
-    HOP_TRY(launch_gelu_dropout(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, w_dout, (hipStream_t)stream));
+    HOP_TRY(launch_gelu_dropout(h->out, h->dy, bufA, (int64_t)N * DP, h->p_drop, h->seed, w_dout, ampart, (hipStream_t)stream));
     dout = bufA;
   } else if (h2) {
     HOP_TRY(qagnn_absmax_f32(dout, (int64_t)N * DP, w_dout, stream));
@@ -311,8 +316,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
   HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, pkws, pk_elems, stream));
   // attention backward
   HOP_TRY(launch_edge_attn_bwd(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs, cls_part,
-                               h2 ? ampart : nullptr, (hipStream_t)stream));
-  if (h2) HOP_TRY(launch_amax_reduce(ampart, (int64_t)3 * N, w_dkmq, (hipStream_t)stream));
+                               h2 ? ampart : nullptr, w_dkmq, (hipStream_t)stream));
   // projection: weight gradients, node-type-table gradient, data gradients
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
   if (SP > 0 && h->dWs_t == h->dWx_t + (int64_t)DP * 3 * DP) {  // the two gradients are one [DP + SP, 3 DP] matrix: one launch

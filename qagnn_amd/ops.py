@@ -549,9 +549,13 @@ def type_indicators(S, ntype, col0, T):
     (41 us + a 19-27 us final stage at 64 000 rows).  The gradient that flows back into S is zeroed at the indicator positions by
     scatter's own backward."""
     assert col0 + T <= S.size(1)
+    word = amax_lookup(S)
     # the kernels clamp a node type outside [0, T) to T - 1 and report it through ERR_WATCH: the indicator must follow the same rule,
     # or an invalid id would land in a later padding column (or past SP) and dTT would silently lose that row's contribution
-    return S.scatter(1, (ntype.clamp(0, T - 1).view(-1, 1) + col0), 1.0)
+    out = S.scatter(1, (ntype.clamp(0, T - 1).view(-1, 1) + col0), 1.0)
+    if word is not None:  # max |.| of the copy = max(max |S|, 1.0): bit patterns of non-negative floats order like integers
+        amax_note(out, torch.clamp(word, min=0x3F800000))
+    return out
 
 
 class SplitColsFn(torch.autograd.Function):
@@ -578,6 +582,34 @@ def split_cols(X, k):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------------------------
+# Operand maxima for the three-MFMA GEMM form (csrc/gemm_nn2.hip), where a tensor is produced by one operator and read by another: the
+# producer leaves max |.| in a 4-word int32 tensor and NOTES it against the tensor object; the consumer (the natively sequenced stack)
+# looks it up and hands the word to the library (qagnn_hop_args.x_amax / s_amax), which then skips its own reduction pass.  An entry is
+# valid for exactly the tensor object it was noted for, at the version it had (an in-place op invalidates it); anything else -- no entry,
+# a dead tensor, a view, a modified tensor -- is a miss, and a miss only costs the reduction pass.
+_AMAX_NOTES = {}
+
+
+def amax_note(t, word):
+    import weakref
+    key = id(t)
+    _AMAX_NOTES[key] = (weakref.ref(t, lambda _r, k=key: _AMAX_NOTES.pop(k, None)), t._version, word)
+    return t
+
+
+def amax_lookup(t):
+    e = _AMAX_NOTES.get(id(t)) if t is not None else None
+    if e is None or e[0]() is not t or t._version != e[1]:
+        return None
+    return e[2]
+
+
+def _wants_amax(K, X):
+    """the provider runs the three-MFMA form and X is large enough for it (the library's own threshold: csrc/hop.hip, hop_h2)"""
+    return getattr(K, 'gemm_split', 1) == 2 and getattr(K, 'name', '') == 'hip' and X.dim() == 2 and X.size(0) >= 8192
+
+
 class GeluDropoutFn(torch.autograd.Function):
     """Y = dropout(gelu_tanh(X), p)   (utils/layers.py:10-14 + F.dropout); the keep mask is regenerated in backward."""
 
@@ -586,7 +618,11 @@ class GeluDropoutFn(torch.autograd.Function):
     def forward(ctx, X, p, seed):
         ctx.save_for_backward(X)
         ctx.p, ctx.seed = p, seed
-        return kernels().gelu_dropout_fwd(X, p, seed)
+        K = kernels()
+        if _wants_amax(K, X):
+            Y, word = K.gelu_dropout_fwd(X, p, seed, amax=True)
+            return amax_note(Y, word)
+        return K.gelu_dropout_fwd(X, p, seed)
 
     @staticmethod
     @_bwd
@@ -928,7 +964,11 @@ class StackFn(torch.autograd.Function):
         K = kernels()
         npk = len(prm) // k
         prms = [prm[l * npk:(l + 1) * npk] for l in range(k)]
-        y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, tab_col)
+        xw, sw = amax_lookup(X), amax_lookup(S)
+        kw = {}
+        if xw is not None or sw is not None:  # (the producers of X / S left their maxima: no reduction pass inside the stack)
+            kw = dict(x_amax=xw, s_amax=sw)
+        y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, tab_col, **kw)
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seeds, k, npk)
         ctx.accX, ctx.tab_col = accX, tab_col
@@ -1075,6 +1115,9 @@ class ConceptInputFn(torch.autograd.Function):
         pre.view(B, n, -1)[:, 0] = ctx_pre
         ctx.save_for_backward(emb_w, rowidx, pre)
         ctx.cfg = (n, p, seed)
+        if _wants_amax(K, pre):
+            Hp, word = K.gelu_dropout_fwd(pre, p, seed, amax=True)
+            return amax_note(Hp, word)
         return K.gelu_dropout_fwd(pre, p, seed)
 
     @staticmethod

@@ -110,8 +110,16 @@ class SplitGradBuckets:
     the transfer overlaps what is left of the backward.  `finish()` -- called where GradBucket.allreduce() would be -- reduces the
     small `late` bucket, waits for the early one and copies both back into the existing p.grad tensors.
 
-    A step that produces no autograd callbacks (a replayed hipGraph) or misses a gradient simply reduces both buckets in finish():
-    the result is the same as GradBucket's in every case (tests/test_parallel_gloo.py)."""
+    A step that produces no autograd callbacks (a replayed hipGraph) or misses a gradient simply reduces both buckets in finish().
+    Two rules keep the ranks in step with each other whatever path each of them took (advisor findings, round 5):
+      * ORDER: every rank issues its collectives early bucket first, late bucket second -- the rank whose hook fired issued `early` inside
+        the backward; a rank whose hook did not fire (a parameter without a gradient on its shard, a replay on that rank only) issues
+        `early` at the top of finish().  A 2.15 M-element all-reduce is never paired with a 0.7 M one.
+      * ONE backward per finish(): the early bucket is packed at the moment its last gradient arrives, so a second backward before
+        finish() (gradient accumulation over micro-batches) would be reduced from a stale snapshot.  The hook raises instead; a loop
+        that accumulates calls `defer()` before its non-final micro-batches (nothing is issued early for those) and lets the last
+        backward -- or finish() -- reduce the accumulated totals.
+    The result equals GradBucket's in every case (tests/test_parallel_gloo.py, incl. a rank that misses an early gradient)."""
 
     def __init__(self, model, early_module, group=None):
         early_ids = {id(p) for p in early_module.parameters() if p.requires_grad}
@@ -120,29 +128,45 @@ class SplitGradBuckets:
         late = [p for p in params if id(p) not in early_ids]
         self.late = GradBucket(late) if late else None
         self.group = group
-        self._seen, self._work, self._packed = 0, None, None
+        self._seen, self._work, self._packed, self._deferred = 0, None, None, False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.early.params]
 
+    def defer(self):
+        """The coming backward is not the last one before finish() (gradient accumulation): issue nothing early for it."""
+        if self._work is not None:
+            raise RuntimeError('SplitGradBuckets.defer(): the early all-reduce of this step is already in flight')
+        self._deferred, self._seen = True, 0
+
+    def arm(self):
+        """The coming backward IS the last one before finish(): its hooks may issue the early all-reduce (the default state)."""
+        self._deferred, self._seen = False, 0
+
     def _on_grad(self, _p):
+        if self._work is not None:
+            raise RuntimeError('SplitGradBuckets: a gradient arrived while the early all-reduce of this step is in flight -- one backward per '
+                               'finish(); call defer() before the non-final backwards of an accumulation loop')
+        if self._deferred:
+            return
         self._seen += 1
-        if self._seen == len(self.early.params) and self._work is None:
+        if self._seen == len(self.early.params):
             b = self.early
             self._packed = [(v, p.grad) for v, p in zip(b.views, b.params)]
             torch._foreach_copy_([v for v, _ in self._packed], [g for _, g in self._packed])
             self._work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        """-> number of elements reduced.  Both buckets are reduced when this returns (on the current stream for RCCL)."""
+        """-> number of elements reduced.  Both buckets are reduced when this returns (on the current stream for RCCL).  Collective
+        order on every rank: early, then late."""
         n = 0
+        if self._work is None:  # no hook fired for every early gradient (hipGraph replay, a missing gradient, defer()): the plain path, FIRST
+            n += self.early.allreduce(self.group)
         if self.late is not None:
             n += self.late.allreduce(self.group)
         if self._work is not None:
             self._work.wait()
             torch._foreach_copy_([g for _, g in self._packed], [v for v, _ in self._packed])
             n += self.early.flat.numel()
-        else:  # no hook fired for every early gradient (hipGraph replay, a frozen tensor): the plain path
-            n += self.early.allreduce(self.group)
-        self._seen, self._work, self._packed = 0, None, None
+        self._seen, self._work, self._packed, self._deferred = 0, None, None, False
         return n
 
     def close(self):

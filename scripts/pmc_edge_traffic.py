@@ -34,7 +34,7 @@ exact_kib = N * DP * 4 / 1024.0
 total = sum(2 * v['FETCH_SIZE'] + v['WRITE_SIZE'] for v in per.values()) * 1024
 total_bwd = sum(2 * v['FETCH_SIZE'] + v['WRITE_SIZE'] for v in per_bwd.values()) * 1024
 print(json.dumps({
-    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` (scripts/gpu_r3.sh pmc)',
+    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` (bench.py's own PMC child run: bench.py --pmc)',
     'units': 'KiB per launch (mean over the launches of the run); FETCH_SIZE is doubled in the totals (gfx950 tallies 128-B reads at 64 B)',
     'calibration': {'kernel': 'k_gelu_dropout<false> (reads and writes N*DP*4 bytes)', 'exact_KiB': round(exact_kib, 1),
                     'FETCH_SIZE_KiB': round(cal_f, 1), 'WRITE_SIZE_KiB': round(cal_w, 1),

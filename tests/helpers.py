@@ -411,7 +411,7 @@ class PreActRecorder:
         if attr == 'stack_fwd':
             def stack_fwd(*a, **kw):
                 y, saved = fn(*a, **kw)
-                if len(saved) in (4, 5) and saved[2].dim() == 4:  # libqagnn_hip: (KMQ, aa, rows [k, 4, N, DP] = aggr | h1 | out | y, stats [k, 5, DP][, amax words])
+                if len(saved) in (4, 5, 7) and saved[2].dim() == 4:  # libqagnn_hip: (KMQ, aa, rows [k, 4, N, DP] = aggr | h1 | out | y, stats [k, 5, DP][, amax words])
                     rows, stats = saved[2], saved[3]
                     for l in range(rows.size(0)):
                         self._keep(rows[l, 1], stats[l, 3], stats[l, 4])

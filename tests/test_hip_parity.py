@@ -185,6 +185,52 @@ def test_oracle_parity_hub_node_and_truncated_graph(train):
     assert max(report.values()) < helpers.MAX_ALLOWED
 
 
+def emb_data_and_cache_output_vs_oracle(device=None):
+    """QAGNN.forward(emb_data=..., cache_output=True) against the oracle (reference modeling_qagnn.py:141, 154, 182-185 and
+    utils/layers.py:596-601: contextualised embeddings replace the table lookup -- `emb_data [B, m, in_dim]`, gathered along dim 1 by
+    concept_ids[:, 1:] - 1 -- and the module keeps concept_ids, adj and pool_attn).  Eval mode (running statistics, no dropout): the
+    logits, the pooling attention and every gradient, incl. the one that flows into emb_data."""
+    device = device or DEVICE
+    case = dict(shape='tiny', nq=2, nc=3, n=37, n_rel=17, std=0.3, train=False, seed=77,
+                cfg=helpers.model_cfg(d=200, k=3, sent_dim=48, n_concept=500, concept_in_dim=32))
+    args, _ = _case_args(case)
+    B, n = case['nq'] * case['nc'], case['n']
+    g = torch.Generator().manual_seed(5)
+    m = 50  # contextualised rows per subgraph; concept ids index them (1-based, slot 0 is the context node)
+    cids = torch.randint(1, m + 1, (B, n), generator=g)
+    emb = torch.randn(B, m, case['cfg']['concept_in_dim'], generator=g)
+    model, omodel = _package_model(case, device), helpers.build_oracle(case)
+    e_dev = emb.detach().clone().to(device).requires_grad_(True)
+    e_ref = emb.detach().clone().requires_grad_(True)
+    dargs = [a.to(device) for a in args]
+    logits, attn = model(dargs[0], cids.to(device), *dargs[2:5], (dargs[5], dargs[6]), emb_data=e_dev, cache_output=True)
+    ologits, oattn = omodel(args[0], cids, *args[2:5], (args[5], args[6]), emb_data=e_ref, cache_output=True)
+    # what cache_output stashes (:182-185)
+    assert torch.equal(model.concept_ids.cpu(), cids) and model.pool_attn is attn and torch.equal(model.adj[0].cpu(), args[5])
+    assert torch.equal(omodel.concept_ids, cids) and omodel.pool_attn is oattn
+    w = torch.linspace(0.5, 1.5, B).view(B, 1)
+    (logits * w.to(device)).sum().backward()
+    (ologits * w).sum().backward()
+    helpers._close(logits.detach().cpu(), ologits.detach(), what='logits (emb_data)', **FWD)
+    helpers._close(attn.detach().cpu(), oattn.detach(), what='pool_attn (emb_data)', **FWD)
+    helpers._close(e_dev.grad.cpu(), e_ref.grad, what='d emb_data', rtol=2e-4, atol=1e-7)
+    ref = {k: p.grad for k, p in omodel.named_parameters() if p.grad is not None}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref) and len(got) >= 40
+    for k, gr in ref.items():
+        if helpers.has_null_gradient(k, False):
+            continue
+        helpers._close(got[k].cpu(), gr, what='grad ' + k, rtol=5e-4, atol=1e-7 + 1e-4 * gr.abs().max().item())
+    # without cache_output nothing is kept from THIS call
+    model.concept_ids = None
+    model(dargs[0], cids.to(device), *dargs[2:5], (dargs[5], dargs[6]), emb_data=e_dev)
+    assert model.concept_ids is None
+
+
+def test_emb_data_and_cache_output():
+    emb_data_and_cache_output_vs_oracle()
+
+
 BIG_TRAIN_CASES = {
     # train-mode fwd+bwd at the largest sizes the CPU oracle handles in seconds (SURVEY 8d), n = 200, d = 200, 5 layers:
     'configs1_csqa_b40': dict(shape='csqa', nq=8, nc=5, n=200, n_rel=17, std=0.6, train=True, seed=41,
@@ -506,6 +552,9 @@ BENCH_WORKLOADS = {
     'configs1_csqa_320': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
     'configs2_obqa_256': dict(nq=64, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
     'configs4_medqa_64': dict(nq=16, nc=4, shape='medqa', n_rel=15, n_etype=34, dim=768, std=0.6),
+    # the regime a fresh training run starts in: the reference's own initialisation (N(0, 0.02) weights, modeling_qagnn.py:127-138) -- near-
+    # uniform attention, tiny activations and gradients (the operand scaling of the three-MFMA GEMM form earns its keep here)
+    'configs1_csqa_320_refinit': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=-0.02),  # (std < 0: absolute, helpers.det_fill_)
 }
 
 
@@ -637,7 +686,7 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize('variant,workload', [('default', 'configs1_csqa_320'), ('composed', 'configs1_csqa_320'), ('poison', 'configs1_csqa_320'),
                                               ('blobs', 'configs1_csqa_320'), ('exact', 'configs1_csqa_320'), ('dropout', 'configs1_csqa_320'),
-                                              ('blobs', 'configs2_obqa_256'), ('blobs', 'configs4_medqa_64')])
+                                              ('blobs', 'configs2_obqa_256'), ('blobs', 'configs4_medqa_64'), ('blobs', 'configs1_csqa_320_refinit')])
 def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch):
     """default: int64 edge lists through the natively sequenced stack (qagnn_stack_{fwd,bwd}_f32; round 6: the path every batch size takes),
     whose large products run in the three-MFMA form and whose weight-gradient stream (qagnn_hop_args.side_stream) lags the data-gradient

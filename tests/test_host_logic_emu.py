@@ -371,6 +371,13 @@ def test_kernel_calls_run_on_the_operands_device(monkeypatch):
     assert p.launch(1) == 7 and seen[-1] == ('ran', 1) and state['cur'] == 0
 
 
+def test_emb_data_and_cache_output_on_cpu():
+    """QAGNN.forward(emb_data=..., cache_output=True) -- contextualised embeddings instead of the entity table, and the three attributes the
+    reference stashes -- through the torch emulation (the `-m gpu` twin: tests/test_hip_parity.py::test_emb_data_and_cache_output)."""
+    import test_hip_parity as T
+    T.emb_data_and_cache_output_vs_oracle(device='cpu')
+
+
 @pytest.mark.parametrize('train', [True, False])
 def test_gpu_parity_harness_on_cpu(train):
     """The oracle-vs-package harness of tests/test_hip_parity.py (forward at FWD, gradients on the float64 yardstick), run here

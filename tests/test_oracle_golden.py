@@ -95,3 +95,34 @@ def test_single_gatconve_layer_matches_reference(case):
     for pname, p in layer.named_parameters():
         if p.grad is not None and not helpers.has_null_gradient(pname, helpers.GOLDEN_CASES[case]['train']):
             helpers.check_stored(fix, 'layergrad::' + pname, p.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('which', ['oracle', 'package'])
+def test_contextualised_embedding_input_matches_the_reference(which):
+    """CustomizedEmbedding.forward(index, contextualized_emb) -- the `emb_data` input of QAGNN.forward -- of the oracle and of the
+    package's layer against vectors from the reference's own class (tests/golden/make_golden_embdata.py; utils/layers.py:596-603)."""
+    import os
+    import numpy as np
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mge', os.path.join(helpers.ROOT, 'tests', 'golden', 'make_golden_embdata.py'))
+    mge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mge)
+    fix = np.load(os.path.join(helpers.ROOT, 'tests', 'golden', 'embdata.npz'))
+    if which == 'oracle':
+        from oracle.qagnn_oracle import CustomizedEmbedding
+    else:
+        from qagnn_amd.layers import CustomizedEmbedding
+    C = mge.CFG
+    for scale in (1.0, 0.5):
+        tag = f's{scale}::'
+        mod = CustomizedEmbedding(C['concept_num'], C['concept_in_dim'], C['concept_out_dim'], scale=scale)
+        with torch.no_grad():
+            mod.cpt_transform.weight.copy_(torch.from_numpy(fix[tag + 'weight']))
+            mod.cpt_transform.bias.copy_(torch.from_numpy(fix[tag + 'bias']))
+        emb, index, w = mge.inputs()
+        emb.requires_grad_(True)
+        y = mod(index, emb)
+        (y * w).sum().backward()
+        for key, got in (('out', y), ('d_emb', emb.grad), ('d_weight', mod.cpt_transform.weight.grad), ('d_bias', mod.cpt_transform.bias.grad)):
+            ref = torch.from_numpy(fix[tag + key])
+            assert (got.detach() - ref).abs().max().item() <= 1e-5 * (ref.abs().max().item() + 1e-6), (which, tag + key)

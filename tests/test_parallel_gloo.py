@@ -111,6 +111,51 @@ def _worker(rank, world, port, q):
             if p.grad is not None:
                 p.grad = saved[k] / world
     assert split.finish() == n3 and all(torch.allclose(p.grad, saved[k] * 1.0) for k, p in model3.named_parameters() if p.grad is not None)
+    # ---- one rank MISSES an early gradient (a parameter its shard does not touch: here frozen for the step on rank 1 only), so its hook
+    #      count never completes and it reduces the early bucket in finish(), while rank 0 issued it from its backward: early must pair with
+    #      early and late with late -- every rank's collective order is early -> late -- and the missing gradient comes back as the sum ----
+    for p in model3.parameters():
+        p.grad = None
+    victim = split.early.params[3]
+    if rank == 1:
+        victim.requires_grad_(False)
+    order, real_allreduce = [], dist.all_reduce
+
+    def spy(t, *a, **kw):
+        order.append(t.numel())
+        return real_allreduce(t, *a, **kw)
+    dist.all_reduce = spy
+    try:
+        _run_question_list(model3, inp, parts[rank], CASE['nq'])
+        assert (split._work is not None) == (rank == 0)
+        split.finish()
+    finally:
+        dist.all_reduce = real_allreduce
+        victim.requires_grad_(True)
+    assert order == [split.early.flat.numel()] + ([split.late.flat.numel()] if split.late is not None else []), order
+    assert victim.grad is not None and all(torch.equal(p.grad, g2[k]) for k, p in model3.named_parameters() if p is not victim and k in g2)
+    # ---- accumulation: a second backward before finish() must not be reduced from a stale snapshot: the hook raises; defer() is the way ----
+    for p in model3.parameters():
+        p.grad = None
+    _run_question_list(model3, inp, parts[rank], CASE['nq'])
+    raised = False
+    try:
+        _run_question_list(model3, inp, parts[rank], CASE['nq'])
+    except RuntimeError as e:
+        raised = 'one backward per finish()' in str(e)
+    assert raised, 'a second backward under an in-flight early all-reduce must raise'
+    split.finish()
+    for p in model3.parameters():
+        p.grad = None
+    split.defer()
+    _run_question_list(model3, inp, parts[rank], CASE['nq'])
+    assert split._work is None
+    split.arm()
+    _run_question_list(model3, inp, parts[rank], CASE['nq'])  # accumulates into p.grad; the hooks fire on the totals
+    assert split._work is not None
+    split.finish()
+    acc = {k: p.grad.clone() for k, p in model3.named_parameters() if p.grad is not None}
+    assert all(torch.allclose(acc[k], 2.0 * g2[k], rtol=1e-5, atol=1e-7) for k in g2), 'two accumulated micro-batches = twice the gradient'
     split.close()
     # ---- BatchNorm running statistics: per-shard after a training forward (different on the two ranks), averaged by
     #      sync_batchnorm_running_stats(); the edge encoder's BatchNorm is one module shared by all layers and must be reduced once ----

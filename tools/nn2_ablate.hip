@@ -1,10 +1,11 @@
-// Timing ablations of k_gemm_nn2 (csrc/gemm_nn2.hip): the kernel is compiled into this program with -DQAGNN_NN2_ABL=<bits> (see the
-// kernel source) and timed alone on the GPU with HIP events on the projection and mlp shapes of the 320-subgraph batch.
-// Numerically wrong for ABL != 0; timing only.  Build: tools/build_micro.sh, run: tools/bin/nn2_ablate_<bits>.
+// Timings of k_gemm_nn2 (csrc/gemm_nn2.hip) alone, HIP events, on the NN shapes of the 320-subgraph batch: the six-MFMA form as the
+// library launches it and the three-MFMA form (4-wave blocks).  With -DQAGNN_NN2_ABL=<bits> (see the kernel source)
+// the 4-wave kernels drop parts of their k-loop: numerically wrong, timing only.  Build: tools/build_micro.sh, run: tools/bin/nn2_ablate_<bits>.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #include "../qagnn_amd/csrc/gemm_nn2.hip"
@@ -60,53 +61,39 @@ int main(int argc, char** argv) {
     a.A2 = A2; a.lda2 = sh.K2; a.K2 = sh.K2;
     a.C = C; a.ldc = sh.No; a.M = M; a.No = sh.No;
     const int nt = sh.No >= 208 ? 13 : 7;
-    {  // B packed once (k_pack_b), then the DMA-fed kernel: pack + product, and the product alone
+    // the operand maxima of the three-MFMA form (rand in [-1, 1))
+    uint32_t* am;
+    CK(hipMalloc(&am, 16));
+    const float one = 1.0f;
+    uint32_t w4[4];
+    for (int i = 0; i < 4; ++i) memcpy(&w4[i], &one, 4);
+    CK(hipMemcpy(am, w4, 16, hipMemcpyHostToDevice));
+    const int NJ = (sh.No + 15) / 16;
+    struct Form { const char* name; int np; int wv; } forms[] = {{"six MFMAs, library's choice", 3, 0}, {"three MFMAs, 4-wave blocks", 2, 4}};
+    for (auto& f : forms) {
       void* ws;
-      const int64_t wsb = qagnn::nn2_pack_bytes(sh.No, sh.K1, sh.K2);
-      CK(hipMalloc(&ws, wsb));
-      const int NJ = (sh.No + 15) / 16;
-      for (int alone = 0; alone < 3; ++alone) {  // 2: the staggered 8-wave block
-        for (int i = 0; i < 3; ++i) qagnn::launch_nn2_packed(nt, a, B1n, sh.K1, B2n, sh.K2, ws, st);
-        CK(hipStreamSynchronize(st));
-        const int reps = 30;
-        CK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) {
-          if (!alone) qagnn::launch_nn2_packed(nt, a, B1n, sh.K1, B2n, sh.K2, ws, st);
-          else if (alone == 2 && nt == 13) qagnn::nn2::launch_nt<13, 0, true, 8>(a, (const float*)ws, NJ, nullptr, 0, st);
-          else if (alone == 2) continue;  // (the staggered block is built for 13 and 8 column tiles)
-          else if (nt == 13) qagnn::nn2::launch_nt<13, 0, true>(a, (const float*)ws, NJ, nullptr, 0, st);
-          else qagnn::nn2::launch_nt<7, 0, true>(a, (const float*)ws, NJ, nullptr, 0, st);
-        }
-        CK(hipEventRecord(e1, st));
-        CK(hipStreamSynchronize(st));
-        float ms;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = ms * 1e3 / reps;
-        printf("  %-22s %s  %8.1f us  %7.1f TFLOP/s fp32-eq\n", sh.name, alone == 2 ? "staggered, product only" : alone ? "packed, product only" : "packed, pack+product", us,
-               2.0 * M * (sh.K1 + sh.K2) * sh.No / us / 1e6);
-      }
-      CK(hipFree(ws));
-    }
-    for (int order = 0; order < 2; ++order) {
-      for (int i = 0; i < 3; ++i) {
-        int rc = order ? qagnn::nn2::launch_nt<13, 1>(a, B1n, sh.K1, B2n, sh.K2, st) : qagnn::nn2::launch_nt<13, 0>(a, B1n, sh.K1, B2n, sh.K2, st);
-        if (nt == 7) rc = order ? qagnn::nn2::launch_nt<7, 1>(a, B1n, sh.K1, B2n, sh.K2, st) : qagnn::nn2::launch_nt<7, 0>(a, B1n, sh.K1, B2n, sh.K2, st);
-        if (rc) return 1;
-      }
+      CK(hipMalloc(&ws, qagnn::nn2_pack_bytes(sh.No, sh.K1, sh.K2, f.np)));
+      qagnn_gemm_nn_args b = a;
+      if (f.np == 2) { b.a_amax1 = am; b.a_amax2 = sh.K2 ? am + 1 : nullptr; }
+      qagnn::launch_nn2_packed(nt, b, B1n, sh.K1, B2n, sh.K2, ws, st, f.np);  // (packs the image)
+      auto run = [&] {
+        if (f.wv == 0) return qagnn::launch_nn2_prepacked(nt, b, ws, st, 3);
+        return nt == 13 ? qagnn::nn2::launch_nt<13, 2, true>(b, (const float*)ws, NJ, nullptr, 0, st) : qagnn::nn2::launch_nt<7, 2, true>(b, (const float*)ws, NJ, nullptr, 0, st);
+      };
+      for (int i = 0; i < 3; ++i) run();
       CK(hipStreamSynchronize(st));
       const int reps = 30;
       CK(hipEventRecord(e0, st));
-      for (int i = 0; i < reps; ++i) {
-        if (nt == 13) order ? qagnn::nn2::launch_nt<13, 1>(a, B1n, sh.K1, B2n, sh.K2, st) : qagnn::nn2::launch_nt<13, 0>(a, B1n, sh.K1, B2n, sh.K2, st);
-        else order ? qagnn::nn2::launch_nt<7, 1>(a, B1n, sh.K1, B2n, sh.K2, st) : qagnn::nn2::launch_nt<7, 0>(a, B1n, sh.K1, B2n, sh.K2, st);
-      }
+      for (int i = 0; i < reps; ++i) run();
       CK(hipEventRecord(e1, st));
       CK(hipStreamSynchronize(st));
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / reps;
-      printf("  %-22s order %d  %8.1f us  %7.1f TFLOP/s fp32-eq\n", sh.name, order, us, 2.0 * M * (sh.K1 + sh.K2) * sh.No / us / 1e6);
+      printf("  %-22s %-30s %8.1f us  %7.1f TFLOP/s fp32-eq\n", sh.name, f.name, us, 2.0 * M * (sh.K1 + sh.K2) * sh.No / us / 1e6);
+      CK(hipFree(ws));
     }
+    CK(hipFree(am));
     CK(hipFree(A1)); CK(hipFree(B1n)); CK(hipFree(C));
     if (A2) CK(hipFree(A2));
     if (B2n) CK(hipFree(B2n));
