@@ -422,6 +422,10 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     timed.active = {'gemm_nn', 'gemm_tn', 'gemm_tn2', 'edge_attn_bwd', 'edge_attn_fwd'}
     overlap, fused, ops.WGRAD_OVERLAP, ops.FUSED_HOP = ops.WGRAD_OVERLAP, ops.FUSED_HOP, False, False
     try:
+        timed.enabled = False
+        run_step()  # (the composed path allocates tensors of its own sizes: the allocator settles outside the brackets)
+        sync()
+        timed.enabled = True
         for _ in range(n_steps):
             run_step()
         sync()
@@ -431,7 +435,33 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn') + timed.total_ms('gemm_tn2')
     flops = timed.work['gemm_nn'] + timed.work['gemm_tn'] + timed.work['gemm_tn2']
     useful = timed.useful['gemm_nn'] + timed.useful['gemm_tn'] + timed.useful['gemm_tn2']
-    return dict(gemm_ms=gemm_ms / n_steps, gemm_flops=flops / n_steps, gemm_useful_flops=useful / n_steps,
+    # The composed pass above runs the SAME products (shapes, FLOPs, launch count) but not always the same kernels: the natively sequenced
+    # stack -- the path the timed regions take -- hands operand maxima from producer to consumer and runs its large products in the
+    # three-MFMA form, which the per-kernel entry points called from Python do not.  So the GEMM time comes from a second pass on the
+    # path that is timed, bracketed inside the library (qagnn_timing_enable: HIP events on the launch stream around every GEMM entry
+    # point, whoever calls it), weight-gradient side stream off like above.
+    composed_gemm_ms = gemm_ms
+    native = None
+    inner = timed._inner
+    if hasattr(inner, 'timing_enable'):
+        overlap, ops.WGRAD_OVERLAP = ops.WGRAD_OVERLAP, False
+        try:
+            run_step()  # (anything keyed on the overlap switch settles outside the brackets)
+            sync()
+            inner.timing_enable(True)
+            for _ in range(n_steps):
+                run_step()
+            sync()
+            native = inner.timing_read()
+        finally:
+            inner.timing_enable(False)
+            ops.WGRAD_OVERLAP = overlap
+        gemm_ms = native['gemm_nn'][0] + native['gemm_tn'][0]
+    return dict(gemm_ms=gemm_ms / n_steps, gemm_ms_composed=composed_gemm_ms / n_steps,
+                gemm_nn_ms=(native['gemm_nn'][0] / n_steps if native else None), gemm_tn_ms=(native['gemm_tn'][0] / n_steps if native else None),
+                native_edge_fwd_ms=(native['edge_attn_fwd'][0] / max(1, native['edge_attn_fwd'][1]) if native else None),
+                native_edge_bwd_ms=(native['edge_attn_bwd'][0] / max(1, native['edge_attn_bwd'][1]) if native else None),
+                gemm_flops=flops / n_steps, gemm_useful_flops=useful / n_steps,
                 gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn']) + len(timed.events['gemm_tn2'])) // n_steps,
                 edge_fwd_ms=timed.mean_ms('edge_attn_fwd')[0], edge_bwd_ms=timed.mean_ms('edge_attn_bwd')[0],
                 n_edge_fwd=timed.mean_ms('edge_attn_fwd')[1], n_edge_bwd=timed.mean_ms('edge_attn_bwd')[1])
@@ -884,22 +914,35 @@ def main():
                                       'achieved_algorithmic': round(alg_bwd / (bwd_ms * 1e-3) / 1e9, 1) if bwd_ms > 0 else 0.0,
                                       'timed_in': 'extra steps after the timed regions, weight-gradient overlap off (see source)'}},
             # the dense side of the step: every GEMM launch, algorithmic FLOPs of the products over their HIP-event time
-            'roofline_mfma': {'bound': 'mfma', 'kernel': 'all GEMM launches of the step (qagnn_gemm_nn_split_f32 / qagnn_gemm_nn_f32 / qagnn_gemm_tn_f32 / qagnn_gemm_tn2_f32)',
+            'roofline_mfma': {'bound': 'mfma', 'kernel': 'all GEMM launches of the step (NN products qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_f32, weight-gradient '
+                                                         'products qagnn_gemm_tn_h2_f32 / qagnn_gemm_tn_f32 / qagnn_gemm_tn2_f32 incl. their chunk sums)',
                               'achieved': round(gemm_tf, 1), 'unit': 'TFLOP/s',
-                              'peak': round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), 'frac': round(gemm_tf / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
-                              'peak_is': 'fp32-equivalent ceiling of the kernels that run: dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per exact 3 x bf16 product',
+                              'peak': round(MFMA_BF16_PEAK_TFLOPS / 3.0, 1), 'frac': round(gemm_tf / (MFMA_BF16_PEAK_TFLOPS / 3.0), 4),
+                              'peak_is': 'fp32-equivalent ceiling of the form the large products run in: dense fp16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product '
+                                         '(scaled two-piece fp16 split); the products without a known operand maximum (input stage, class tables: '
+                                         '~8 % of the FLOPs) run six bf16 MFMAs per product and are held to the same ceiling',
+                              'peak_six_mfma': round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), 'frac_of_six_mfma_peak': round(gemm_tf / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
                               'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'frac_of_fp32_mfma_peak': round(gemm_tf / MFMA_F32_PEAK_TFLOPS, 4),
                               'gflop_per_step': round(gemm_flops / 1e9, 1), 'ms_per_step': round(gemm_ms, 3),
+                              'ms_per_step_nn': round(ins['gemm_nn_ms'], 3) if ins.get('gemm_nn_ms') is not None else None,
+                              'ms_per_step_tn': round(ins['gemm_tn_ms'], 3) if ins.get('gemm_tn_ms') is not None else None,
+                              'ms_per_step_six_mfma_form': round(ins['gemm_ms_composed'], 3),
                               'useful_gflop_per_step': round(ins['gemm_useful_flops'] / 1e9, 1),
                               'achieved_useful': round(ins['gemm_useful_flops'] / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
-                              'frac_useful': round(ins['gemm_useful_flops'] / (gemm_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4) if gemm_ms > 0 else 0.0,
+                              'frac_useful': round(ins['gemm_useful_flops'] / (gemm_ms * 1e-3) / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 3.0), 4) if gemm_ms > 0 else 0.0,
                               'useful_is': 'FLOPs of the same products at the reference\'s tensor widths (d = 200 for the stored 208, K|M|Q 600 for 624, the '
                                            'score embedding 100 for 112): `achieved` counts what the launches execute on head-padded operands',
                               'launches_per_step': ins['gemm_launches'],
-                              'timed_in': f'{GEMM_STEPS} extra steps after the timed regions (HIP events around every launch)',
-                              'note': 'fp32-equivalent FLOPs.  The NN products run as six bf16 MFMAs per exact 3-way operand split (error <= 2^-23 per '
-                                      'product = one fp32 rounding), the weight-gradient (TN) products the same way with the tiles transposed '
-                                      'into LDS; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels for both'},
+                              'timed_in': f'{GEMM_STEPS} extra eager steps after the timed regions on the path the timed regions take (natively sequenced stack), '
+                                          'HIP events on the launch stream around every GEMM entry point INSIDE the library (qagnn_timing_enable), '
+                                          'weight-gradient side stream off; FLOPs and launch count from a composed pass over the same products '
+                                          '(`ms_per_step_six_mfma_form` is that pass: the per-kernel entry points called from Python, every product as six bf16 MFMAs)',
+                              'note': 'fp32-equivalent FLOPs, fp32 storage.  Round 6: every product of the stack whose A operand carries its maximum (left '
+                                      'behind by the kernel that wrote it) runs as THREE fp16 MFMAs on an error-corrected two-piece split with exact '
+                                      'power-of-two operand scales (Ootomo & Yokota 2022): |error| <= 2^-21 sum_k |a_k b_k| + 2^-38 K max|A| max|B col| per '
+                                      'output, below the sqrt(K) 2^-24 accumulation noise of an fp32 dot product at K >= 208 (csrc/gemm_nn2.hip header); '
+                                      'the others as six bf16 MFMAs on the exact 3-way split (<= 2^-23 per product).  QAGNN_GEMM_SPLIT=1 pins the six-MFMA '
+                                      'form everywhere, =0 the fp32-MFMA kernels'},
             'breakdown_ms_per_step': {'edge_fwd_x5': round(fwd_ms * K_LAYERS, 3), 'edge_bwd_x5': round(bwd_ms * K_LAYERS, 3),
                                       'graph_prep': round(prep_ms, 3), 'mfma_gemms': round(gemm_ms, 3)},
         }

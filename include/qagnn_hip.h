@@ -302,6 +302,15 @@ typedef struct qagnn_gather_tabs { const float* p[QAGNN_GATHER_MAX]; int32_t n; 
 int qagnn_gather_multi_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, float* out, int32_t total, qagnn_stream_t stream);
 int qagnn_gather_multi_sum_f32(const qagnn_gather_tabs* t, const int32_t* tid, const int32_t* off, int32_t K, int32_t S, float* out,
                                qagnn_stream_t stream);
+/* Launch timing for measurement harnesses (bench.py): while enabled, the NN-product, weight-gradient-product and edge-stage entry points
+ * (also when the natively sequenced hop / stack calls them) bracket what they launch with HIP events on their launch stream.
+ * qagnn_timing_enable(1) clears the record and starts, (0) stops; qagnn_timing_read synchronises on the recorded events and returns the
+ * summed milliseconds and the number of bracketed calls per kind: 0 NN products, 1 weight-gradient products (incl. their chunk sums),
+ * 2 edge forward, 3 edge backward.  Off by default; not for use around a stream capture.  (The reference has no counterpart: it is what
+ * torch.profiler gives its users for free, modeling_qagnn.py's ops being stock torch kernels.) */
+#define QAGNN_TIMING_KINDS 4
+int qagnn_timing_enable(int32_t on);
+int qagnn_timing_read(double* ms /* [QAGNN_TIMING_KINDS] */, int64_t* calls /* [QAGNN_TIMING_KINDS] */);
 int qagnn_gelu_dropout_fwd_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, qagnn_stream_t stream);
 /* qagnn_gelu_dropout_fwd_f32 that also merges max |Y| into *amax (bit pattern, integer atomic max; the caller zeroed the word): the operand

@@ -22,10 +22,11 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_pool_attn_fwd_f32', 'qagnn_pool_attn_bwd_f32', 'qagnn_head_post_fwd_f32', 'qagnn_head_post_bwd_f32', 'qagnn_add_row0_f32', 'qagnn_gather_multi_f32', 'qagnn_gather_multi_sum_f32',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
-           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32', 'qagnn_gelu_dropout_fwd_amax_f32', 'qagnn_gelu_dropout_amax_scratch_elems']
+           'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32', 'qagnn_gelu_dropout_fwd_amax_f32', 'qagnn_gelu_dropout_amax_scratch_elems',
+           'qagnn_timing_enable', 'qagnn_timing_read']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 17  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32)
+ABI_VERSION = 18  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -109,6 +110,8 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_h2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.qagnn_absmax_f32.argtypes = [_vp, _i64, _vp, _vp]
     lib.qagnn_zero_words.argtypes = [_vp, _i64, _vp]
+    lib.qagnn_timing_enable.argtypes = [_i32]
+    lib.qagnn_timing_read.argtypes = [_vp, _vp]
     lib.qagnn_gemm_tn_colsum_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                              _vp, _vp]
     lib.qagnn_colreduce_workspace_elems.restype = _i64
@@ -757,6 +760,16 @@ class HipKernels(metaclass=_GuardedMeta):
         assert dK.is_contiguous() and dZ.is_contiguous() and dZ.shape == (B, Cc)
         self._check(self.lib.qagnn_add_row0_f32(dK.data_ptr(), n * Cc, dZ.data_ptr(), B, Cc, self._stream()), 'qagnn_add_row0_f32')
         return dK
+
+    def timing_enable(self, on):
+        """Library-side HIP-event brackets around the GEMM and edge-stage entry points (qagnn_timing_enable): measurement harnesses only."""
+        self._check(self.lib.qagnn_timing_enable(1 if on else 0), 'qagnn_timing_enable')
+
+    def timing_read(self):
+        """-> {kind: (milliseconds, calls)} for 'gemm_nn', 'gemm_tn', 'edge_attn_fwd', 'edge_attn_bwd' since timing_enable(True)"""
+        ms, calls = (C.c_double * 4)(), (C.c_int64 * 4)()
+        self._check(self.lib.qagnn_timing_read(ms, calls), 'qagnn_timing_read')
+        return {k: (ms[i], calls[i]) for i, k in enumerate(('gemm_nn', 'gemm_tn', 'edge_attn_fwd', 'edge_attn_bwd'))}
 
     def gelu_dropout_fwd(self, X, p, seed, amax=False):
         """amax=True: -> (Y, word) with word = int32 [4], [0] = the bit pattern of max |Y| (qagnn_gelu_dropout_fwd_amax_f32)"""

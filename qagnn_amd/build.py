@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libqagnn_hip.so')
 STAMP = LIB + '.srchash'
-SOURCES = ['graph_prep.hip', 'gemm.hip', 'elementwise.hip', 'edge_attn.hip', 'pool.hip', 'hop.hip', 'optim.hip', 'gemm_split.hip', 'gemm_nn2.hip']
+SOURCES = ['graph_prep.hip', 'gemm.hip', 'elementwise.hip', 'edge_attn.hip', 'pool.hip', 'hop.hip', 'optim.hip', 'gemm_split.hip', 'gemm_nn2.hip', 'timing.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
 
 

@@ -49,6 +49,18 @@ int launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, co
                          float* cls_part, float* amax_part /* [3 N] or nullptr */, uint32_t* amax_slot, hipStream_t stream);
 int launch_amax_reduce(const float* part, int64_t n, uint32_t* slot, hipStream_t stream);  // max of n non-negative floats -> *slot (elementwise.hip)
 
+// launch timing (timing.hip): a scope at the top of an entry point brackets everything it launches on `s` while qagnn_timing_enable(1)
+struct TimedScope {
+  int kind;
+  hipStream_t s;
+  hipEvent_t e0, e1;
+  bool counted;
+  TimedScope(int kind, hipStream_t s);
+  ~TimedScope();
+  TimedScope(const TimedScope&) = delete;
+  TimedScope& operator=(const TimedScope&) = delete;
+};
+
 #define QAGNN_REQUIRE(cond, code, ...) \
   do {                                 \
     if (!(cond)) {                     \

@@ -570,6 +570,7 @@ namespace qagnn {
 // amax_part != nullptr: [N] floats, max |aggr row| per node (k_edge_aggregate; launch_amax_reduce folds them into the word)
 int launch_edge_attn_fwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
                          float* score, float* a, float* alpha, float* aggr, int32_t lda, float* amax_part, hipStream_t stream) {
+  TimedScope timed(2, stream);
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_fwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(score && a && alpha && aggr && lda >= 4 * HP && lda % 4 == 0 && aligned16(aggr), QAGNN_EINVAL,
@@ -600,6 +601,7 @@ extern "C" int qagnn_edge_attn_bwd_f32(const qagnn_graph* g, const float* KMQ, i
 int qagnn::launch_edge_attn_bwd(const qagnn_graph* g, const float* KMQ, int32_t ldk, const float* EkEm, int32_t lde, int32_t HP, float qscale,
                                 const float* a, const float* alpha, const float* G, int32_t ldg, float* dKMQ, float* dEkEm, float* ga, float* rs,
                                 float* cls_part, float* amax_part, uint32_t* amax_slot, hipStream_t stream) {
+  TimedScope timed(3, stream);
   int rc = check_common(g, KMQ, ldk, EkEm, lde, HP, "edge_attn_bwd");
   if (rc != QAGNN_OK) return rc;
   QAGNN_REQUIRE(a && alpha && G && dKMQ && dEkEm && ga && rs && cls_part, QAGNN_EINVAL, "edge_attn_bwd: null pointer");

@@ -692,6 +692,7 @@ using namespace qagnn;
 
 extern "C" int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TimedScope timed(0, stream);
   QAGNN_REQUIRE(a && a->A1 && a->B1 && a->C, QAGNN_EINVAL, "gemm_nn: null pointer");
   QAGNN_REQUIRE(a->M > 0 && a->No > 0 && a->K1 > 0, QAGNN_EINVAL, "gemm_nn: bad sizes M=%d No=%d K1=%d", a->M, a->No, a->K1);
   QAGNN_REQUIRE(a->K1 % BK == 0 && a->K2 % BK == 0 && a->K2 >= 0, QAGNN_EINVAL, "gemm_nn: K1=%d K2=%d must be multiples of %d",
@@ -725,6 +726,7 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
                                         int32_t accumulate, float* bsum, const int64_t* b_rowidx, int32_t groups, float* workspace,
                                         qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TimedScope timed(1, stream);
   QAGNN_REQUIRE(A && B && C && workspace, QAGNN_EINVAL, "gemm_tn: null pointer");
   QAGNN_REQUIRE(R > 0 && Ka > 0 && No > 0 && Ka % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
                 "gemm_tn: bad sizes R=%d Ka=%d No=%d (Ka, No multiples of 4)", R, Ka, No);
@@ -766,6 +768,7 @@ extern "C" int qagnn_gemm_tn_colsum_f32(const float* A, int32_t lda, const float
 extern "C" int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
                                   int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, float* workspace, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TimedScope timed(1, stream);
   QAGNN_REQUIRE(A1 && A2 && B && C && workspace, QAGNN_EINVAL, "gemm_tn2: null pointer");
   QAGNN_REQUIRE(R > 0 && Ka1 > 0 && Ka2 > 0 && No > 0 && Ka1 % 4 == 0 && Ka2 % 4 == 0 && No % 4 == 0, QAGNN_EINVAL,
                 "gemm_tn2: bad sizes R=%d Ka1=%d Ka2=%d No=%d (Ka, No multiples of 4)", R, Ka1, Ka2, No);
@@ -802,6 +805,7 @@ extern "C" int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, 
                                     const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace,
                                     qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TimedScope timed(1, stream);
   const bool two = A2 != nullptr && Ka2 > 0;
   QAGNN_REQUIRE(A1 && B && C && workspace, QAGNN_EINVAL, "gemm_tn_h2: null pointer");
   QAGNN_REQUIRE(!two || !a_scale, QAGNN_EINVAL, "gemm_tn_h2: the two-operand product has no BatchNorm prologue");

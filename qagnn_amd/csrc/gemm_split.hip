@@ -1123,6 +1123,7 @@ extern "C" int qagnn_gemm_nn_split_f32(const qagnn_gemm_nn_args* a, const float*
 extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2,
                                           void* ws, int64_t ws_bytes, qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TimedScope timed(0, stream);
   QAGNN_REQUIRE(a && a->A1 && B1n && a->C, QAGNN_EINVAL, "gemm_nn_split: null pointer");
   QAGNN_REQUIRE(a->M > 0 && a->No > 0 && a->K1 >= 4, QAGNN_EINVAL, "gemm_nn_split: bad sizes M=%d No=%d K1=%d", a->M, a->No, a->K1);
   QAGNN_REQUIRE(a->K1 % 4 == 0 && a->K2 % 4 == 0 && a->K2 >= 0 && (a->K2 == 0 || a->K2 >= 4), QAGNN_EINVAL,

@@ -366,13 +366,17 @@ def install_keep_masks(omodel, masks, ps):
 #   * check the hidden BatchNorm outputs of EVERY node row of every layer against the HIP values: the root-mean-square deviation of a row,
 #     rms_c(x_oracle[r, c] - x_hip[r, c]), must stay below HIDDEN_RTOL of the row's own scale s(r) = rms_c(x_oracle[r, :]) + 1 (1 = the
 #     scale of a BatchNorm output) -- a forward parity statement on all 64 000 rows of all hops, not only on the logits; measured on
-#     MI355X: <= 3.9e-5 at every site of every workload -- and
+#     MI355X (round 6, three-MFMA GEMM form, profiles/r6_run14_parity_report.txt): <= 3.9e-5 at every site of the three workloads with
+#     the deterministic fill; the reference-initialisation case (N(0, 0.02) weights: a BatchNorm there divides pre-activations of
+#     ~1e-3 by their standard deviation, so forward differences grow ~1.7x per hop) 4.6e-5 at the edge encoder up to 2.7e-4 at hop 4,
+#     and carries its own bar (BENCH_WORKLOADS[..]['hidden_rtol']) -- and
 #   * take the HIP side's 0/1 mask where the two signs differ AND the oracle's own value lies in the rounding band of the kink,
-#     |x_oracle| <= KINK_BAND * s(r) (measured: every element whose sign differed lay within 9e-5 s(r); 30-120 elements per hop, and
+#     |x_oracle| <= KINK_BAND * s(r) (measured: every element whose sign differed lay within 8.9e-5 s(r), 1.4e-4 in the reference-
+#     initialisation case; 30-120 elements per hop, and
 #     one whole edge class = ~9 000 identical rows of the edge encoder).  A sign difference outside the band is counted and fails the test.
 # Every gradient is then held to a fixed bar.
-HIDDEN_RTOL = 5e-4
-KINK_BAND = 5e-4
+HIDDEN_RTOL = 1e-4  # (2.6x the largest measured row deviation)
+KINK_BAND = 2e-4    # (2.2x the farthest aligned element of the deterministic-fill workloads, 1.4x that of the reference-initialisation case)
 
 
 class PreActRecorder:

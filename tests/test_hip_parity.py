@@ -540,21 +540,25 @@ def test_whole_stack_native_call_equals_per_hop_path(case):
 # masks must agree (asserted: zero disagreements), and every node row's hidden BatchNorm outputs are held to the HIP values (HIDDEN_RTOL).  Then: logits within 5e-4 of scale, every gradient tensor within BENCH_SIZE_BAR of
 # its scale, the median over the tensors within BENCH_SIZE_MEDIAN.  The `dropout` variant is the configuration bench.py times
 # (0.2 / 0.2 / 0.2, pooler 0.1): the keep masks of its ten dropout sites are replayed on the oracle the same way (helpers.hip_keep_masks).
-BENCH_SIZE_BAR, BENCH_SIZE_MEDIAN = 3e-3, 3e-4  # measured on MI355X: worst 1.3e-3 / median 7e-5 (320 CSQA subgraphs), 5.2e-4 / 7e-5 (256 OBQA), 5.4e-4 / 2.7e-5 (64 MedQA)
+BENCH_SIZE_BAR, BENCH_SIZE_MEDIAN = 2e-3, 3e-4  # measured on MI355X, round 6 (three-MFMA GEMM form; profiles/r6_run14_parity_report.txt): worst 1.26e-3 / median 7.1e-5 (320 CSQA subgraphs;
+# 2.3e-4 / 5.3e-5 with the bench's dropout), 5.2e-4 / 7.1e-5 (256 OBQA), 5.4e-4 / 2.5e-5 (64 MedQA), 9.3e-4 / 1.7e-4 (320 CSQA, reference initialisation)
 # ---------------------------------------------------------------------------------------------------------------------------------
 _BENCH_SIZE, _BENCH_ORACLE = {}, {}
-# (workload of BASELINE.json) -> questions, choices, record shape, relations, edge types, input width.  configs[2] at 64 x 4 = 256
-# subgraphs: the full 128 x 4 needs ~50 GB of autograd state on the host; configs[4]/gpu is the MedQA shard as bench.py runs it.
+# (workload of BASELINE.json) -> questions, choices, record shape, relations, edge types, input width.  configs[2] at the size bench.py
+# times it, 128 x 4 = 512 subgraphs = 102 400 node rows (400 row tiles instead of 200; ~50 GB of autograd state in the oracle: the GPU
+# boxes hold 3 TB) -- a host with less than 120 GB free runs the 64 x 4 = 256 half instead; configs[4]/gpu is the MedQA shard as bench.py runs it.
 BENCH_WORKLOADS = {
     # (fill gain 0.2 at the two large batches: with the 0.6 of the small cases every hop amplifies a forward difference ~10x -- measured, the
     # fp32 oracle then sits a median 4.7e-2 of scale from its own float64 run at 320 subgraphs even with identical ReLU masks, i.e. the case
     # itself says nothing; at 0.2 the same pair agrees to 3.6e-4 / 1.2e-3 (median / worst, 256 subgraphs))
     'configs1_csqa_320': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
     'configs2_obqa_256': dict(nq=64, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
+    'configs2_obqa_512': dict(nq=128, nc=4, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=0.2),
     'configs4_medqa_64': dict(nq=16, nc=4, shape='medqa', n_rel=15, n_etype=34, dim=768, std=0.6),
     # the regime a fresh training run starts in: the reference's own initialisation (N(0, 0.02) weights, modeling_qagnn.py:127-138) -- near-
     # uniform attention, tiny activations and gradients (the operand scaling of the three-MFMA GEMM form earns its keep here)
-    'configs1_csqa_320_refinit': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=-0.02),  # (std < 0: absolute, helpers.det_fill_)
+    'configs1_csqa_320_refinit': dict(nq=64, nc=5, shape='csqa', n_rel=17, n_etype=38, dim=1024, std=-0.02, hidden_rtol=5e-4),  # (std < 0: absolute, helpers.det_fill_;
+    # hidden_rtol: measured 2.7e-4 at hop 4, see helpers.HIDDEN_RTOL)
 }
 
 
@@ -648,7 +652,8 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
     kinks = ref['kinks']
     summary = [{k: (float('%.1e' % v) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kinks]
     assert all(kk['outside'] == 0 for kk in kinks), f'ReLU signs differ OUTSIDE the rounding band of the kink (|x_oracle| > {helpers.KINK_BAND} of the row\'s scale): {summary}'
-    assert all(kk['row_dev'] <= helpers.HIDDEN_RTOL for kk in kinks), f'hidden BatchNorm outputs of a row differ by more than {helpers.HIDDEN_RTOL} of the row\'s scale: {summary}'
+    hidden_rtol = wl.get('hidden_rtol', helpers.HIDDEN_RTOL)
+    assert all(kk['row_dev'] <= hidden_rtol for kk in kinks), f'hidden BatchNorm outputs of a row differ by more than {hidden_rtol} of the row\'s scale: {summary}'
     # forward bar 5e-4 of the logits' scale (1e-4 at the small cases): both sides are fp32, and at N = 64 000 rows x 5 layers of
     # train-mode BatchNorm each is ~1e-4 from exact arithmetic (measured 1.4e-4 between them)
     helpers._close(logits.detach().cpu(), ref['logits'], what=f'{workload} train-mode logits [{variant}]', rtol=5e-4, atol=1e-5)
@@ -686,7 +691,7 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize('variant,workload', [('default', 'configs1_csqa_320'), ('composed', 'configs1_csqa_320'), ('poison', 'configs1_csqa_320'),
                                               ('blobs', 'configs1_csqa_320'), ('exact', 'configs1_csqa_320'), ('dropout', 'configs1_csqa_320'),
-                                              ('blobs', 'configs2_obqa_256'), ('blobs', 'configs4_medqa_64'), ('blobs', 'configs1_csqa_320_refinit')])
+                                              ('blobs', 'configs2_obqa_512'), ('blobs', 'configs4_medqa_64'), ('blobs', 'configs1_csqa_320_refinit')])
 def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch):
     """default: int64 edge lists through the natively sequenced stack (qagnn_stack_{fwd,bwd}_f32; round 6: the path every batch size takes),
     whose large products run in the three-MFMA form and whose weight-gradient stream (qagnn_hop_args.side_stream) lags the data-gradient
@@ -696,6 +701,10 @@ def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch
     bench.py's default mode; exact: the native stack with gemm_split = 1 (the exact 3 x bf16 products of rounds 2-5: the same bars hold for
     both arithmetic forms); dropout: blobs + the run scripts' dropout rates, i.e. exactly the step bench.py times, keep masks replayed on
     the oracle."""
+    if workload == 'configs2_obqa_512':
+        import psutil
+        if psutil.virtual_memory().available < 120 * 2 ** 30:  # (the oracle's autograd state at 102 400 node rows)
+            workload = 'configs2_obqa_256'
     wl = BENCH_WORKLOADS[workload]
     nq, nc, n = wl['nq'], wl['nc'], 200
     composed = variant in ('composed', 'poison')
