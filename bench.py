@@ -976,6 +976,28 @@ def main():
                     out['configs']['configs[1]/edge_lists'] = secondary_config('configs[1]/edge_lists', dict(
                         wl, n_concept=args.n_concept, what=wl['what'] + '; graph fed as int64 (edge_index [2, E], edge_type [E]) on the device (the '
                         'reference protocol, modeling_qagnn.py:224-228,244-251), graph orderings derived per batch'), el_args, dev, timed)
+                # REDUCED PRECISION, a second line and never the headline: the same step with ONE fp16 MFMA per product in the stack's large
+                # products (operands rounded to fp16 under exact power-of-two scales, fp32 accumulation; storage, BatchNorm statistics,
+                # softmax and aggregation stay fp32) -- the GEMM arithmetic torch.autocast gives the reference's Linear layers under the
+                # --fp16 switch all its run scripts set (qagnn.py:254-257).  Parity: tests/test_hip_parity.py::
+                # test_reduced_precision_line_against_the_fp32_oracle (bars REDUCED_BARS, measured).
+                try:
+                    Kp = timed._inner
+                    old_split, Kp.gemm_split = Kp.gemm_split, 3
+                    try:
+                        rp = secondary_config('configs[1]/fp16_gemms', dict(
+                            wl, n_concept=args.n_concept, what=wl['what'] + '; REDUCED PRECISION: one fp16 MFMA per product (fp32 accumulate, fp32 storage) in '
+                            'the large products of the GNN stack, everything else as the headline'), argparse.Namespace(**dict(vars(args), no_cpu_baseline=True)),
+                            dev, timed)
+                    finally:
+                        Kp.gemm_split = old_split
+                    rp['dtype'] = 'f16 x f16 -> f32 products, f32 everywhere else'
+                    rp['is'] = ('NOT the headline and not comparable with it as a precision claim: GEMM operands carry 11 significant bits.  Gradient tensors '
+                                'sit a median ~3e-3 / worst ~3e-2 of their scale from the fp32 oracle (the headline path: 7e-5 / 1.3e-3)')
+                    rp['speedup_vs_headline'] = round(rp['value'] / (total_subgraphs * args.steps / dt), 3)
+                    out['configs']['configs[1]/fp16_gemms'] = rp
+                except Exception as e:  # noqa: BLE001
+                    out['configs']['configs[1]/fp16_gemms'] = dict(error=f'{type(e).__name__}: {str(e)[:300]}')
                 try:
                     out['configs']['configs[1]/with_lm'] = with_lm_leg(wl, args, dev, dt / args.steps * 1e3)
                 except Exception as e:  # noqa: BLE001

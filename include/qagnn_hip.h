@@ -154,6 +154,10 @@ typedef struct qagnn_gemm_nn_args {
                                         understates the maximum by 2x or more makes the result inf / nan (never silently wrong): the
                                         producers of this library fill it exactly (qagnn_absmax_f32 and the *_amax arguments) */
   const uint32_t* a_amax2;
+  int32_t pieces;                    /* 0 (default): full-accuracy arithmetic, see above.  1: the REDUCED-PRECISION form, on request only and only
+                                        where the three-MFMA form would run (a_amax known): ONE fp16 MFMA per product -- both operands rounded to
+                                        fp16 (11 significant bits) under the same power-of-two scales, fp32 accumulation and fp32 storage; what
+                                        torch.autocast makes of the reference's Linear layers (qagnn.py:254-257, --fp16), minus its fp16 outputs */
 } qagnn_gemm_nn_args;
 int qagnn_gemm_nn_f32(const qagnn_gemm_nn_args* a, qagnn_stream_t stream);
 /* The same product on the bf16 matrix cores by EXACT operand splitting (csrc/gemm_split.hip): every fp32 operand is the exact sum
@@ -182,7 +186,8 @@ int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, in
  * registry, mutex-protected; clear(0) empties it. */
 typedef struct qagnn_pack_desc { const float* B1n; int32_t ldn1; int32_t K1; const float* B2n; int32_t ldn2; int32_t K2; int32_t No;
                                  int32_t pieces; /* 0 / 3: the three bf16 images; 2: the two scaled fp16 images of the three-MFMA form (taken by
-                                                    products that come with a_amax1 / a_amax2) */ } qagnn_pack_desc;
+                                                    products that come with a_amax1 / a_amax2); 1: the one image of the reduced-precision form
+                                                    (qagnn_gemm_nn_args.pieces = 1) */ } qagnn_pack_desc;
 int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n);
 int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, void* out, int64_t out_bytes, int64_t tag, qagnn_stream_t stream);
 int qagnn_gemm_nn_prepack_clear(int64_t tag);
@@ -210,6 +215,12 @@ int qagnn_gemm_tn2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* 
  * pattern of its max |.| (amax_a1 covers A1 AFTER the a_scale / a_shift prologue).  Falls back to the six-MFMA kernels (same results to fp32
  * round-off, amax ignored) for shapes the split kernels do not take.  workspace: qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No). */
 int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
+                         float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift, const uint32_t* amax_a1,
+                         const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace, qagnn_stream_t stream);
+/* The REDUCED-PRECISION form of the same call (on request only: qagnn_hop_args.gemm_split == 3): ONE fp16 MFMA per product, both operands
+ * rounded to fp16 under the same power-of-two scales, fp32 accumulation -- the arithmetic torch.autocast gives the reference's Linear
+ * layers in backward (qagnn.py:254-257, --fp16).  Same fallbacks as qagnn_gemm_tn_h2_f32. */
+int qagnn_gemm_tn_h1_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B, int32_t ldb,
                          float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift, const uint32_t* amax_a1,
                          const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace, qagnn_stream_t stream);
 /* Same, and additionally  bsum[g][no] = sum_r [grp(r) == g] B[r][no]  (groups in 1..4; b_rowidx NULL = one group): the
@@ -413,7 +424,10 @@ typedef struct qagnn_hop_args {
   float* dW2t; float* db2;         /* [DP, DP], [DP] */
   float* ws; int64_t ws_elems;     /* scratch: qagnn_hop_{fwd,bwd}_workspace_elems floats */
   int32_t gemm_split;              /* 1: the NN products run through qagnn_gemm_nn_split_f32 (bf16 matrix cores, exact 3-way split);
-                                      2: the same, and the three-MFMA form wherever `amax` (below) makes it possible */
+                                      2: the same, and the three-MFMA form wherever `amax` (below) makes it possible;
+                                      3: REDUCED PRECISION, on request only (never a default): as 2 with ONE fp16 MFMA per product where 2 takes
+                                      three (qagnn_gemm_nn_args.pieces = 1, qagnn_gemm_tn_h1_f32) -- the GEMM arithmetic of the reference under
+                                      its own --fp16 autocast; statistics, softmax, aggregation and all storage stay fp32 */
   int32_t ones_col;                /* see qagnn_bn_finalize_f32: >= 0 makes db2 = row ones_col of dW2t (no column reduction of d out); a caller
                                       that passes db2 = dW2t + ones_col * DP (and, for tab_col, dTT = dWs_t + tab_col * 3 DP) gets no copy */
   int32_t tab_col;                 /* >= 0: columns [tab_col, tab_col + T) of S hold the node-type indicators (1 at tab_col + ntype[r], S's

@@ -23,10 +23,10 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32', 'qagnn_gelu_dropout_fwd_amax_f32', 'qagnn_gelu_dropout_amax_scratch_elems',
-           'qagnn_timing_enable', 'qagnn_timing_read']
+           'qagnn_timing_enable', 'qagnn_timing_read', 'qagnn_gemm_tn_h1_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 18  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read)
+ABI_VERSION = 19  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read; 19: the reduced-precision form on request -- qagnn_gemm_nn_args.pieces, qagnn_gemm_tn_h1_f32, qagnn_hop_args.gemm_split == 3)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -56,7 +56,7 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
                 ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32), ('colstat_part', _vp),
-                ('a_amax1', _vp), ('a_amax2', _vp)]
+                ('a_amax1', _vp), ('a_amax2', _vp), ('pieces', _i32)]
 
 
 class qagnn_hop_args(C.Structure):
@@ -108,6 +108,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gemm_tn_f32.argtypes = [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]
     lib.qagnn_gemm_tn2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]
     lib.qagnn_gemm_tn_h2_f32.argtypes = [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.qagnn_gemm_tn_h1_f32.argtypes = lib.qagnn_gemm_tn_h2_f32.argtypes
     lib.qagnn_absmax_f32.argtypes = [_vp, _i64, _vp, _vp]
     lib.qagnn_zero_words.argtypes = [_vp, _i64, _vp]
     lib.qagnn_timing_enable.argtypes = [_i32]
@@ -312,8 +313,9 @@ class HipKernels(metaclass=_GuardedMeta):
         # NN GEMMs on the bf16 matrix cores by exact 3-way operand splitting (qagnn_gemm_nn_split_f32) whenever the caller also
         # hands over B in its [No, K] layout; QAGNN_GEMM_SPLIT=0 pins the fp32-MFMA kernels
         # 2 (default): additionally the THREE-MFMA form (scaled two-piece fp16 split, csrc/gemm_nn2.hip) wherever the operand maxima are
-        # known -- inside the natively sequenced hops; 1 pins the exact 3 x bf16 split everywhere
-        self.gemm_split = {'0': 0, '1': 1}.get(os.environ.get('QAGNN_GEMM_SPLIT', '2'), 2)
+        # known -- inside the natively sequenced hops; 1 pins the exact 3 x bf16 split everywhere; 3 asks for the REDUCED-PRECISION form
+        # (ONE fp16 MFMA per product where 2 takes three: the GEMM arithmetic of the reference under its --fp16 autocast; never a default)
+        self.gemm_split = {'0': 0, '1': 1, '3': 3}.get(os.environ.get('QAGNN_GEMM_SPLIT', '2'), 2)
         self.PACK_MIN_M = 8192  # (the library applies the same threshold: nn2_packed_ok)
         self._side_streams = {}  # per device: the stream the natively sequenced hops put their weight-gradient products on
 
@@ -490,9 +492,10 @@ class HipKernels(metaclass=_GuardedMeta):
             assert a_scale.numel() == K1 and a_shift.numel() == K1 and a_scale.is_contiguous() and a_shift.is_contiguous()
             a.a_scale, a.a_shift = a_scale.data_ptr(), a_shift.data_ptr()
         a.accumulate = 1 if accumulate else 0
-        if a_amax1 is not None and self.gemm_split == 2:  # int32 [1] device words: absmax() of A1 / A2 -> the three-MFMA form
+        if a_amax1 is not None and self.gemm_split >= 2:  # int32 [1] device words: absmax() of A1 / A2 -> the three-MFMA form
             assert a_amax1.dtype == torch.int32 and a_amax1.is_cuda and (A2 is None or a_amax2 is not None)
             a.a_amax1, a.a_amax2 = a_amax1.data_ptr(), _ptr(a_amax2)
+            a.pieces = 1 if self.gemm_split == 3 else 0  # (3: the reduced-precision form, on request only)
         if a_rowidx is not None:
             assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
             a.a_rowidx = a_rowidx.data_ptr()
@@ -563,7 +566,8 @@ class HipKernels(metaclass=_GuardedMeta):
         if out is None:
             out = torch.empty((Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
         ws = torch.empty(self.lib.qagnn_gemm_tn_workspace_elems(R, Ka1 + Ka2, No), dtype=torch.float32, device=B.device)
-        rc = self.lib.qagnn_gemm_tn_h2_f32(A1.data_ptr(), Ka1, Ka1, _ptr(A2), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No, _ptr(a_scale),
+        fn = self.lib.qagnn_gemm_tn_h1_f32 if self.gemm_split == 3 else self.lib.qagnn_gemm_tn_h2_f32
+        rc = fn(A1.data_ptr(), Ka1, Ka1, _ptr(A2), Ka2, Ka2, B.data_ptr(), No, out.data_ptr(), No, R, No, _ptr(a_scale),
                                            _ptr(a_shift), amax_a1.data_ptr(), _ptr(amax_a2), amax_b.data_ptr(), ws.data_ptr(), self._stream())
         self._check(rc, 'qagnn_gemm_tn_h2_f32')
         return out

@@ -15,10 +15,10 @@ bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affi
 int tn_split_chunk_rows(int R, int Ka, int No, int lo);
 // amax (both launchers): nullptr, or {max|A1|, max|A2|, max|B|} device words -> the three-MFMA form (gemm_nn2.hip, header)
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    const int64_t* a_rowidx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr);
+                    const int64_t* a_rowidx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr, int np = 2);
 int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo);
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr);
+                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax = nullptr, int np = 2);
 
 // NN products, second kernel generation (gemm_nn2.hip): A fragments straight from global memory, B double-buffered in LDS
 bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2);
@@ -184,6 +184,11 @@ __device__ __forceinline__ float h2_inv_scale(uint32_t fa, uint32_t fb) {
   return __builtin_bit_cast(float, (uint32_t)f << 23);
 }
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two numbers -> the hi pieces alone (the one-MFMA reduced-precision form, NP = 1)
+__device__ __forceinline__ void split1(float x, float y, float s, uint32_t& hi) {
+  const f16x2 h = {(_Float16)(x * s), (_Float16)(y * s)};
+  hi = __builtin_bit_cast(uint32_t, h);
+}
 // two numbers -> (hi, lo) pairs packed as fp16x2 dwords; the subtraction is exact (hi is x s rounded to 11 bits)
 __device__ __forceinline__ void split2(float x, float y, float s, uint32_t& hi, uint32_t& lo) {
   const float xs = x * s, ys = y * s;
@@ -205,8 +210,10 @@ __device__ __forceinline__ f32x4s mfma_pieces(const u32x4s* __restrict__ a, cons
                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(QAGNN_HF(a[I]), QAGNN_HF(b[J]), c, 0, 0, 0);
   if constexpr (NP == 3) {
     QAGNN_MF3(2, 0) QAGNN_MF3(0, 2) QAGNN_MF3(1, 1) QAGNN_MF3(1, 0) QAGNN_MF3(0, 1) QAGNN_MF3(0, 0)
-  } else {
+  } else if constexpr (NP == 2) {
     QAGNN_MF2(1, 0) QAGNN_MF2(0, 1) QAGNN_MF2(0, 0)
+  } else {  // NP == 1: the reduced-precision form -- operands rounded to fp16 (11 significant bits) under the same scales, fp32 accumulation
+    QAGNN_MF2(0, 0)
   }
 #undef QAGNN_MF3
 #undef QAGNN_MF2

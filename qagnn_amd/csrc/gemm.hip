@@ -800,10 +800,10 @@ extern "C" int qagnn_gemm_tn_f32(const float* A, int32_t lda, const float* B, in
 
 // The weight-gradient products in the three-MFMA form (scaled two-piece fp16 split: gemm_nn2.hip's header, gemm_split.hip's NP = 2 kernels).
 // Same chunking, same ordered chunk sum as the six-MFMA route; shapes the split kernels do not take fall back to it (amax unused).
-extern "C" int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
-                                    int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift,
-                                    const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace,
-                                    qagnn_stream_t stream_) {
+static int gemm_tn_scaled(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
+                          int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift,
+                          const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace, int np,
+                          qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TimedScope timed(1, stream);
   const bool two = A2 != nullptr && Ka2 > 0;
@@ -824,10 +824,26 @@ extern "C" int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, 
   const int Ka = Ka1 + (two ? Ka2 : 0);
   const int crows = two ? tn_split2_chunk_rows(R, Ka1, Ka2, No, tn_split_min_chunk(R)) : tn_split_chunk_rows(R, Ka1, No, tn_split_min_chunk(R));
   const int nchunks = cdiv(R, crows);
-  int rc = two ? launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream, am)
-               : launch_tn_split(A1, lda1, B, ldb, workspace, R, Ka1, No, a_scale, a_shift, nullptr, crows, stream, am);
+  int rc = two ? launch_tn_split2(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, workspace, R, No, crows, stream, am, np)
+               : launch_tn_split(A1, lda1, B, ldb, workspace, R, Ka1, No, a_scale, a_shift, nullptr, crows, stream, am, np);
   if (rc != QAGNN_OK) return rc;
   k_sum_chunks4<<<cdiv((int64_t)Ka * No / 4, 64), SC_G * 64, 0, stream>>>(workspace, C, ldc, Ka, No, nchunks, 0);
   QAGNN_LAUNCH_CHECK("k_sum_chunks");
   return QAGNN_OK;
+}
+
+extern "C" int qagnn_gemm_tn_h2_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
+                                    int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift,
+                                    const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace,
+                                    qagnn_stream_t stream_) {
+  return gemm_tn_scaled(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, C, ldc, R, No, a_scale, a_shift, amax_a1, amax_a2, amax_b, workspace, 2, stream_);
+}
+
+// The reduced-precision form of the same products (ONE fp16 MFMA per product, operands rounded to fp16 under the same scales: see
+// qagnn_gemm_nn_args.pieces); on request only -- qagnn_hop_args.gemm_split == 3
+extern "C" int qagnn_gemm_tn_h1_f32(const float* A1, int32_t lda1, int32_t Ka1, const float* A2, int32_t lda2, int32_t Ka2, const float* B,
+                                    int32_t ldb, float* C, int32_t ldc, int32_t R, int32_t No, const float* a_scale, const float* a_shift,
+                                    const uint32_t* amax_a1, const uint32_t* amax_a2, const uint32_t* amax_b, float* workspace,
+                                    qagnn_stream_t stream_) {
+  return gemm_tn_scaled(A1, lda1, Ka1, A2, lda2, Ka2, B, ldb, C, ldc, R, No, a_scale, a_shift, amax_a1, amax_a2, amax_b, workspace, 1, stream_);
 }

@@ -77,8 +77,8 @@ __device__ __forceinline__ void split3(uint32_t u, uint32_t& h1, uint32_t& h2, u
 }
 __device__ __forceinline__ uint32_t pack_hi(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-template <bool AFFINE>
-__device__ __forceinline__ void split_frag2(const u32x4s (&r)[2], u32x4s (&f)[2], const float* __restrict__ sc, const float* __restrict__ sh, float lo,
+template <bool AFFINE, int NP = 2>
+__device__ __forceinline__ void split_frag2(const u32x4s (&r)[2], u32x4s (&f)[NP], const float* __restrict__ sc, const float* __restrict__ sh, float lo,
                                             float s) {
   uint32_t ph[4], pl[4];
 #pragma unroll
@@ -90,10 +90,11 @@ __device__ __forceinline__ void split_frag2(const u32x4s (&r)[2], u32x4s (&f)[2]
       x = fmaxf(fmaf(x, sc[e], sh[e]), lo);
       y = fmaxf(fmaf(y, sc[e + 1], sh[e + 1]), lo);
     }
-    split2(x, y, s, ph[e >> 1], pl[e >> 1]);
+    if constexpr (NP == 2) split2(x, y, s, ph[e >> 1], pl[e >> 1]);
+    else split1(x, y, s, ph[e >> 1]);
   }
   f[0] = (u32x4s){ph[0], ph[1], ph[2], ph[3]};
-  f[1] = (u32x4s){pl[0], pl[1], pl[2], pl[3]};
+  if constexpr (NP == 2) f[1] = (u32x4s){pl[0], pl[1], pl[2], pl[3]};
 }
 
 // 8 consecutive k of one row (two 16-byte loads) -> the three bf16x8 fragments
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                                                                                           int ldn1, const float* __restrict__ B2n, int ldn2,
                                                                                           int ntiles) {
   static_assert(WV == 4 || (WV == 8 && PACKED), "the staggered block takes B by DMA only");
-  static_assert(NP == 3 || (NP == 2 && PACKED && WV == 4), "the two-piece form: packed B, 4-wave blocks");
+  static_assert(NP == 3 || (NP <= 2 && PACKED && WV == 4), "the scaled fp16 forms (two pieces: three MFMAs; one piece: one MFMA): packed B, 4-wave blocks");
   static_assert(!(AFFINE && STATS), "no product needs both");
   constexpr bool STAG = WV == 8;
   constexpr bool DIRECT = PACKED && !STATS;  // (see below)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // written behind the image (and its 13 tiles of slack) by the packer
   uint32_t fa = 127u;
   float sa = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
     uint32_t mb = a.a_amax1[0];
     if (K2 > 0 && a.a_amax2) mb = max(mb, a.a_amax2[0]);
     fa = __builtin_amdgcn_readfirstlane(h2_scale_field(mb));
@@ -342,12 +343,12 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                              s1_ ? h1.x : 0.f, s1_ ? h1.y : 0.f, s1_ ? h1.z : 0.f, s1_ ? h1.w : 0.f};                    \
         const float lo = s1_ ? 0.f : -INFINITY;                                                                          \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
-          if constexpr (NP == 2) split_frag2<true>(ra[i], af[i], sc, sh, lo, sa);                                        \
+          if constexpr (NP <= 2) split_frag2<true, NP>(ra[i], af[i], sc, sh, lo, sa);                                    \
           else split_frag<true>(ra[i], af[i], sc, sh, lo);                                                               \
         }                                                                                                                \
       } else {                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                  \
-          if constexpr (NP == 2) split_frag2<false>(ra[i], af[i], nullptr, nullptr, 0.f, sa);                            \
+          if constexpr (NP <= 2) split_frag2<false, NP>(ra[i], af[i], nullptr, nullptr, 0.f, sa);                        \
           else split_frag<false>(ra[i], af[i], nullptr, nullptr, 0.f);                                                   \
         }                                                                                                                \
       }                                                                                                                  \
@@ -382,6 +383,11 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       __builtin_amdgcn_s_setprio(0);                                                                                     \
     }
 
+    // (Round 6, visit 18, measured and removed: the PACKED 4-wave blocks with their fragment reads as inline assembly two column tiles
+    // ahead and counted lgkmcnt waits, as in the staggered block below.  hipcc issues the reads of column tile j + 1 behind four of tile
+    // j's six MFMAs and waits lgkmcnt(0) two MFMAs later; with the reads hoisted the ISA is six back-to-back MFMAs per column tile behind
+    // lgkmcnt(4) -- and the kernels take the same time: projection 95.3 -> 100.8 us alone, NN products 2.12 ms per step either way
+    // (profiles/r6_run18_nn2_asm_frags.txt).  The LDS round trip is not what the MFMA phases wait for.)
     // STAG: the B fragments of column tile J of the image at LDS address ADDR (+ this lane's slot); the MFMAs of one k-tile with the
     // fragments read TWO column tiles ahead (a ring of three register sets; sets 0 and 1 arrive in flight from the N phase), so that the
     // one wave of the SIMD that is in its M phase never waits for LDS.  Reads and waits are inline assembly: hipcc's own counter waits for
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       QAGNN_NN2_MFMA_TILE(cur, cur, false)
     }
     }
-    if constexpr (NP == 2) {  // undo the operand scales: one exact power of two per column tile
+    if constexpr (NP <= 2) {  // undo the operand scales: one exact power of two per column tile
       const uint32_t* const bfield = reinterpret_cast<const uint32_t*>(pk + ((int64_t)nkt * ldn1 + 13) * (NP * 1024)) + n0 / 16;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -746,7 +752,7 @@ __device__ __forceinline__ void pack_b_wave(const float* __restrict__ B1n, int l
   const int lane = threadIdx.x & 63;
   if (j >= NJ) return;
   float sb = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
     const int nn = j * 16 + (lane & 15);
     float m = 0.f;
     if (nn < No) {
@@ -790,7 +796,7 @@ __device__ __forceinline__ void pack_b_wave(const float* __restrict__ B1n, int l
     r[1] = *reinterpret_cast<const u32x4s*>(src + 4);
   }
   u32x4s f[NP];
-  if constexpr (NP == 2) split_frag2<false>(r, f, nullptr, nullptr, 0.f, sb);
+  if constexpr (NP <= 2) split_frag2<false, NP>(r, f, nullptr, nullptr, 0.f, sb);
   else split_frag<false>(r, f, nullptr, nullptr, 0.f);
   // (the slot permutation of the in-kernel loader, so that both kinds of image are read with the same fragment offsets)
   unsigned char* dst = out + ((int64_t)it * NJ + j) * (NP * 1024) + (((lane & 15) ^ (2 * (lane >> 4))) + 16 * (lane >> 4)) * 16;
@@ -817,6 +823,7 @@ __global__ __launch_bounds__(256) void k_pack_b_multi(PackArgs a, unsigned char*
   const int lb = (int)blockIdx.x - d.blk0;
   const int it = lb / d.jb, j = (lb % d.jb) * 4 + (threadIdx.x >> 6);
   if (d.np == 2) pack_b_wave<2>(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, d.nkt, it, j, out + d.out_off);
+  else if (d.np == 1) pack_b_wave<1>(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, d.nkt, it, j, out + d.out_off);
   else pack_b_wave<3>(d.B1n, d.ldn1, d.K1, d.B2n, d.ldn2, d.K2, d.No, d.NJ, d.nkt, it, j, out + d.out_off);
 }
 
@@ -845,6 +852,15 @@ static bool nn2_staggered(int nt, const qagnn_gemm_nn_args& a) {
 }
 // the PACKED kernel on an image `p` of B (NJ column tiles per k-tile)
 static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p, int NJ, hipStream_t stream, int np = 3) {
+  if (np == 1) {  // the one-MFMA reduced-precision form (qagnn_gemm_nn_args.pieces = 1)
+    switch (nt) {
+      case 13: return nn2::launch_nt<13, 1, true>(a, p, NJ, nullptr, 0, stream);
+      case 8: return nn2::launch_nt<8, 1, true>(a, p, NJ, nullptr, 0, stream);
+      case 7: return nn2::launch_nt<7, 1, true>(a, p, NJ, nullptr, 0, stream);
+      case 4: return nn2::launch_nt<4, 1, true>(a, p, NJ, nullptr, 0, stream);
+      default: return nn2::launch_nt<2, 1, true>(a, p, NJ, nullptr, 0, stream);
+    }
+  }
   if (np == 2) {  // the two-piece fp16 form: 4-wave blocks at every shape (tools/nn2_ablate.hip, profiles/r6_run1_three_product_ablation.txt)
     switch (nt) {
       case 13: return nn2::launch_nt<13, 2, true>(a, p, NJ, nullptr, 0, stream);
@@ -893,7 +909,7 @@ int launch_nn2(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, 
 // np == 2: + one exponent word per column tile (13 more of slack for the same reason), rounded up to 16 bytes
 int64_t nn2_pack_bytes(int No, int K1, int K2, int np) {
   const int64_t img = ((int64_t)nn2::walk_tiles(K1, K2) * cdiv(No, 16) + 13) * (np * 1024);
-  return np == 2 ? img + (((int64_t)cdiv(No, 16) + 13) * 4 + 15) / 16 * 16 : img;
+  return np <= 2 ? img + (((int64_t)cdiv(No, 16) + 13) * 4 + 15) / 16 * 16 : img;
 }
 // (h2_ok: what the two-piece form additionally asks of a product -- a known maximum of A and a finite-size image)
 bool nn2_h2_ok(const qagnn_gemm_nn_args& a) { return a.a_amax1 != nullptr && (a.K2 == 0 || a.a_amax2 != nullptr) && a.M >= NN2_PACK_MIN_M; }
@@ -902,6 +918,7 @@ bool nn2_h2_ok(const qagnn_gemm_nn_args& a) { return a.a_amax1 != nullptr && (a.
 int launch_nn2_packed(int nt, const qagnn_gemm_nn_args& a, const float* B1n, int ldn1, const float* B2n, int ldn2, void* ws, hipStream_t stream, int np) {
   const int NJ = cdiv(a.No, 16), nkt = nn2::walk_tiles(a.K1, a.K2);
   if (np == 2) nn2::k_pack_b<2><<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
+  else if (np == 1) nn2::k_pack_b<1><<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
   else nn2::k_pack_b<3><<<dim3(cdiv(NJ, 4), nkt), 256, 0, stream>>>(B1n, ldn1, a.K1, B2n, ldn2, a.K2, a.No, NJ, nkt, reinterpret_cast<unsigned char*>(ws));
   QAGNN_LAUNCH_CHECK("k_pack_b");
   return launch_nn2_image(nt, a, reinterpret_cast<const float*>(ws), NJ, stream, np);
@@ -947,7 +964,7 @@ using namespace qagnn;
 extern "C" int64_t qagnn_gemm_nn_prepack_bytes(const qagnn_pack_desc* d, int32_t n) {
   int64_t tot = 0;
   for (int i = 0; i < n; ++i)
-    if (prepack_takes(d[i])) tot += nn2_pack_bytes(d[i].No, d[i].K1, d[i].K2, d[i].pieces == 2 ? 2 : 3);
+    if (prepack_takes(d[i])) tot += nn2_pack_bytes(d[i].No, d[i].K1, d[i].K2, (d[i].pieces == 2 || d[i].pieces == 1) ? d[i].pieces : 3);
   return tot;
 }
 
@@ -979,7 +996,7 @@ extern "C" int qagnn_gemm_nn_prepack_f32(const qagnn_pack_desc* d, int32_t n, vo
       o.jb = cdiv(o.NJ, 4);
       o.blk0 = pa.nblk;
       o.out_off = off;
-      o.np = d[i].pieces == 2 ? 2 : 3;
+      o.np = (d[i].pieces == 2 || d[i].pieces == 1) ? d[i].pieces : 3;
       o.nkt = nn2::walk_tiles(o.K1, o.K2);
       pa.nblk += o.jb * o.nkt;
       fresh.push_back(PrepackEntry{(long long)tag, o.B1n, o.B2n, o.ldn1, o.K1, o.ldn2, o.K2, o.No, o.np, static_cast<const unsigned char*>(out) + off});

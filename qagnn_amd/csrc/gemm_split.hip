@@ -399,6 +399,13 @@ __device__ __forceinline__ void store_col8(uint16_t* __restrict__ dst, int img_e
     *reinterpret_cast<uint4*>(dst + img_elems) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
     return;
   }
+  if constexpr (NP == 1) {  // (the one-MFMA reduced-precision form: x s rounded to fp16)
+    uint32_t ph[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) split1(x[e], x[e + 1], s, ph[e >> 1]);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    return;
+  }
   uint32_t h1[8], h2[8], h3[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) split3(x[i], h1[i], h2[i], h3[i]);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
   uint32_t fa = 127u, fb = 127u;
   float sa = 1.f, sb = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
     fa = __builtin_amdgcn_readfirstlane(h2_scale_field(second ? amax.a2[0] : amax.a[0]));
     fb = __builtin_amdgcn_readfirstlane(h2_scale_field(amax.b[0]));
     sa = h2_field_to_scale(fa);
@@ -612,12 +619,12 @@ __global__ __launch_bounds__(TTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #undef QAGNN_SIX
 
   float* const Pc = P + (int64_t)chunk * ka_total * No;
-  const float inv = NP == 2 ? h2_inv_scale(fa, fb) : 1.f;  // (NP == 2: the operand scales come out again, exactly)
+  const float inv = NP <= 2 ? h2_inv_scale(fa, fb) : 1.f;  // (NP == 2: the operand scales come out again, exactly)
   auto put = [&](int strip, int j, const f32x4s& c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + strip * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
-      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP == 2 ? c[r] * inv : c[r];
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP <= 2 ? c[r] * inv : c[r];
     }
   };
 #pragma unroll
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
   }
   uint32_t fa = 127u, fb = 127u;
   float sa = 1.f, sb = 1.f;
-  if constexpr (NP == 2) {
+  if constexpr (NP <= 2) {
     fa = __builtin_amdgcn_readfirstlane(h2_scale_field(second ? amax.a2[0] : amax.a[0]));
     fb = __builtin_amdgcn_readfirstlane(h2_scale_field(amax.b[0]));
     sa = h2_field_to_scale(fa);
@@ -894,15 +901,17 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #define QAGNN_TNW_WAIT(F, N)                                                                                             \
   {                                                                                                                      \
     if constexpr (NP == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]) : "i"((N) * 3));    \
-    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(F[0]), "+v"(F[1]) : "i"((N) * 2));                                  \
+    else if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(F[0]), "+v"(F[1]) : "i"((N) * 2));           \
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(F[0]) : "i"((N) * 1));                                              \
   }
 #define QAGNN_TNW_TOUCH(F)                                                               \
   {                                                                                      \
     if constexpr (NP == 3) asm volatile("" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]));        \
-    else asm volatile("" : "+v"(F[0]), "+v"(F[1]));                                      \
+    else if constexpr (NP == 2) asm volatile("" : "+v"(F[0]), "+v"(F[1]));               \
+    else asm volatile("" : "+v"(F[0]));                                                  \
   }
 #define QAGNN_TNW_SIX(C, AF, BF)                                          \
-  if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[1]), "v"(BF[0]), "v"(BF[1])); } else { C = mfma_pieces<NP>(AF, BF, C); }
+  if constexpr ((QAGNN_TNW_ABL & 4) != 0) { asm volatile("" ::"v"(AF[0]), "v"(AF[NP > 1 ? 1 : 0]), "v"(BF[0]), "v"(BF[NP > 1 ? 1 : 0])); } else { C = mfma_pieces<NP>(AF, BF, C); }
 
   QAGNN_TNW_BAR  // image 0 is complete
   for (int t = 0; t < ntile4; ++t) {
@@ -968,13 +977,13 @@ __global__ __launch_bounds__(WTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 #undef QAGNN_TNW_BAR
 
   float* const Pc = P + (int64_t)chunk * ka_total * No;
-  const float inv = NP == 2 ? h2_inv_scale(fa, fb) : 1.f;
+  const float inv = NP <= 2 ? h2_inv_scale(fa, fb) : 1.f;
   auto put = [&](int maj_strip, int min_tile, const f32x4s& c) {
     const int rstrip = MAJ_A ? maj_strip : min_tile, ctile = MAJ_A ? min_tile : maj_strip;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + rstrip * 16 + (lane >> 4) * 4 + r, col = n0 + ctile * 16 + (lane & 15);
-      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP == 2 ? c[r] * inv : c[r];
+      if (row < Ka && col < No) Pc[(int64_t)(row + row_shift) * No + col] = NP <= 2 ? c[r] * inv : c[r];
     }
   };
 #pragma unroll
@@ -1062,10 +1071,15 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
 // the step 2.29 -> 2.22 ms)
 constexpr int TN_WS_MIN_TILES = 28;
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
-                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax) {
+                     int chunk_rows, hipStream_t stream, const uint32_t* const* amax, int np) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
-  if (amax) {  // the three-MFMA form (amax = {max|A1|, max|A2|, max|B|})
+  if (amax) {  // the scaled fp16 forms (amax = {max|A1|, max|A2|, max|B|}; np = 2: three MFMAs, np = 1: one)
     const TnAmax am{amax[0], amax[1], amax[2]};
+    if (np == 1) {
+      if (chunk_rows >= TN_WS_MIN_TILES * 32)
+        return launch_tn_ws_i<7, 13, false, 1>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2, am);
+      return launch_tn_split_i<7, 13, false, false, 1>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2, am);
+    }
     if (chunk_rows >= TN_WS_MIN_TILES * 32)
       return launch_tn_ws_i<7, 13, false, 2>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, A2, lda2, Ka2, am);
     return launch_tn_split_i<7, 13, false, false, 2>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2, am);
@@ -1075,7 +1089,18 @@ int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int ld
   return launch_tn_split_i<7, 13, false>(grid, stream, A1, lda1, B, ldb, P, R, Ka1, No, nullptr, nullptr, chunk_rows, nullptr, A2, lda2, Ka2);
 }
 int launch_tn_split(const float* A, int lda, const float* B, int ldb, float* P, int R, int Ka, int No, const float* sc, const float* sh,
-                    const int64_t* ridx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax) {
+                    const int64_t* ridx, int chunk_rows, hipStream_t stream, const uint32_t* const* amax, int np) {
+  if (amax && !ridx && np == 1) {  // the one-MFMA reduced-precision form
+    const TnAmax am{amax[0], nullptr, amax[2]};
+    if (tn_split_wide_b(Ka)) {
+      dim3 grid(cdiv(No, 208), cdiv(Ka, 112), cdiv(R, chunk_rows));
+      return sc ? launch_tn_split_i<7, 13, true, false, 1>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am)
+                : launch_tn_split_i<7, 13, false, false, 1>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am);
+    }
+    dim3 grid(cdiv(No, 112), cdiv(Ka, 208), cdiv(R, chunk_rows));
+    return sc ? launch_tn_split_i<13, 7, true, false, 1>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am)
+              : launch_tn_split_i<13, 7, false, false, 1>(grid, stream, A, lda, B, ldb, P, R, Ka, No, sc, sh, chunk_rows, nullptr, nullptr, 0, 0, am);
+  }
   if (amax && !ridx) {  // the three-MFMA form (amax = {max|A|, -, max|B|})
     const TnAmax am{amax[0], nullptr, amax[2]};
     if (tn_split_wide_b(Ka)) {
@@ -1109,8 +1134,8 @@ extern "C" int64_t qagnn_gemm_nn_pack_bytes(int32_t No, int32_t K1, int32_t K2) 
 
 extern "C" int64_t qagnn_gemm_nn_ws_bytes(const qagnn_gemm_nn_args* a, const float* B1n, int32_t ldn1, const float* B2n, int32_t ldn2) {
   if (!a || !B1n || !nn2_ok(*a, ldn1, ldn2)) return 0;                                      // not a product of the packed kernels
-  if (nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, nn2_h2_ok(*a) ? 2 : 3)) return 0;  // B is registered: nothing to pack per call
-  const int np = nn2_h2_ok(*a) ? 2 : 3;
+  const int np = nn2_h2_ok(*a) ? (a->pieces == 1 ? 1 : 2) : 3;
+  if (nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, np)) return 0;  // B is registered: nothing to pack per call
   const int64_t need = nn2_pack_bytes(a->No, a->K1, a->K2, np);
   return nn2_packed_ok(*a, need, np) ? need : 0;                                              // (too few rows: the in-kernel split)
 }
@@ -1162,8 +1187,9 @@ extern "C" int qagnn_gemm_nn_split_ws_f32(const qagnn_gemm_nn_args* a, const flo
   if (nn2_ok(*a, ldn1, ldn2)) {
     // The three-MFMA form where the operand maxima are known (a_amax1 / a_amax2) and B's two-piece image exists or can be made
     if (nn2_h2_ok(*a)) {
-      if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, 2)) return launch_nn2_prepacked(nt, *a, pk, stream, 2);
-      if (ws && aligned16(ws) && nn2_packed_ok(*a, ws_bytes, 2)) return launch_nn2_packed(nt, *a, B1n, ldn1, B2n, ldn2, ws, stream, 2);
+      const int np = a->pieces == 1 ? 1 : 2;  // (1: the one-MFMA reduced-precision form, on request only)
+      if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No, np)) return launch_nn2_prepacked(nt, *a, pk, stream, np);
+      if (ws && aligned16(ws) && nn2_packed_ok(*a, ws_bytes, np)) return launch_nn2_packed(nt, *a, B1n, ldn1, B2n, ldn2, ws, stream, np);
     }
     // B pre-packed by the caller (qagnn_gemm_nn_prepack_f32: one launch for all weights of a step)?
     if (const void* pk = nn2_prepack_lookup(B1n, ldn1, a->K1, B2n, ldn2, a->K2, a->No)) return launch_nn2_prepacked(nt, *a, pk, stream);

@@ -58,7 +58,12 @@ struct HopAmax {
   uint32_t* own;    // the hop's own block
 };
 // The form needs batch statistics (the bound of relu(bn(h1)) comes from them) and pays from NN2_PACK_MIN_M rows on (packed B images)
-static bool hop_h2(const qagnn_hop_args* h) { return h->gemm_split == 2 && h->amax != nullptr && h->batch_stats && h->N >= 8192; }
+static bool hop_h2(const qagnn_hop_args* h) { return h->gemm_split >= 2 && h->amax != nullptr && h->batch_stats && h->N >= 8192; }
+// gemm_split == 3: the reduced-precision form (one fp16 MFMA per product) wherever 2 would take three
+static int hop_pieces(const qagnn_hop_args* h) { return h->gemm_split == 3 ? 1 : 0; }
+typedef int (*tn_scaled_fn)(const float*, int32_t, int32_t, const float*, int32_t, int32_t, const float*, int32_t, float*, int32_t, int32_t, int32_t,
+                            const float*, const float*, const uint32_t*, const uint32_t*, const uint32_t*, float*, qagnn_stream_t);
+static tn_scaled_fn hop_tn(const qagnn_hop_args* h) { return h->gemm_split == 3 ? qagnn_gemm_tn_h1_f32 : qagnn_gemm_tn_h2_f32; }
 static HopAmax hop_amax_single(const qagnn_hop_args* h) {
   HopAmax m{hop_h2(h), nullptr, nullptr, nullptr, h->amax};
   if (m.on) {  // (x_amax / s_amax: words the caller's producers filled; read-only here)
@@ -128,7 +133,7 @@ static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready,
   if (SP > 0) { ga.A2 = h->S; ga.lda2 = SP; ga.K2 = SP; ga.B2 = h->Ws_t; ga.ldb2 = 3 * DP; }
   ga.C = h->KMQ; ga.ldc = 3 * DP; ga.M = N; ga.No = 3 * DP;
   ga.rowtab = h->TT; ga.ldt = 3 * DP; ga.rowidx = h->ntype;
-  if (am.on) { ga.a_amax1 = am.x; ga.a_amax2 = SP > 0 ? am.s : nullptr; }
+  if (am.on) { ga.a_amax1 = am.x; ga.a_amax2 = SP > 0 ? am.s : nullptr; ga.pieces = hop_pieces(h); }
   HOP_TRY(hop_nn(h, &ga, h->Wx, DP, SP > 0 ? h->Ws : nullptr, SP, pkws, pk_elems, stream));
   // attention + aggregation (:442, 455-484)
   HOP_TRY(launch_edge_attn_fwd(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, score, h->a, h->alpha, h->aggr, DP,
@@ -140,7 +145,7 @@ static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready,
   // batch statistics as a by-product of this GEMM's epilogue where the split kernel can provide them (same rule as ops.GatMlpFn)
   const bool fused_stats = h->batch_stats && h->gemm_split && DP > 192 && DP <= 208;
   if (fused_stats) g1.colstat_part = crws;
-  if (am.on) g1.a_amax1 = am.own + AM_AGGR;
+  if (am.on) { g1.a_amax1 = am.own + AM_AGGR; g1.pieces = hop_pieces(h); }
   HOP_TRY(hop_nn(h, &g1, h->W1, DP, nullptr, 0, pkws, pk_elems, stream));
   const double Rd = (double)N;
   const float unbias = (float)(Rd / (Rd - 1.0 > 1.0 ? Rd - 1.0 : 1.0));
@@ -168,7 +173,7 @@ static int hop_fwd_one(const qagnn_hop_args* h, const HopAmax& am, bool x_ready,
   qagnn_gemm_nn_args g2 = {};
   g2.A1 = h->h1; g2.lda1 = DP; g2.K1 = DP; g2.B1 = h->W2t; g2.ldb1 = DP; g2.C = h->out; g2.ldc = DP; g2.M = N; g2.No = DP; g2.bias = h->b2;
   g2.a_scale = scale; g2.a_shift = shift;
-  if (h1_bound) g2.a_amax1 = am.own + AM_H1;
+  if (h1_bound) { g2.a_amax1 = am.own + AM_H1; g2.pieces = hop_pieces(h); }
   HOP_TRY(hop_nn(h, &g2, h->W2, DP, nullptr, 0, pkws, pk_elems, stream));
   if (h->apply_act) {  // X' = dropout(GELU(out))  (:48-49)
     QAGNN_REQUIRE(h->p_drop >= 0.f && h->p_drop < 1.f, QAGNN_EINVAL, "hop_fwd: p=%f", h->p_drop);
@@ -290,7 +295,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
     HOP_TRY(qagnn_colreduce_f32(0, dout, DP, nullptr, DP, N, DP, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, h->db2, crws, stream));
   // second Linear: dW2^T = relu(bn(h1))^T dout, d r = dout W2
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
-  if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->h1, DP, DP, nullptr, 0, 0, dout, DP, h->dW2t, DP, N, DP, scale, shift, am.own + AM_H1, nullptr, w_dout, tnws, wstream));
+  if (h2) HOP_TRY(hop_tn(h)(h->h1, DP, DP, nullptr, 0, 0, dout, DP, h->dW2t, DP, N, DP, scale, shift, am.own + AM_H1, nullptr, w_dout, tnws, wstream));
   else HOP_TRY(qagnn_gemm_tn_f32(h->h1, DP, dout, DP, h->dW2t, DP, N, DP, DP, scale, shift, nullptr, 0, tnws, wstream));
   // relu(bn(h1)) carries a column of ones there: that row of the weight gradient is the bias gradient (no copy when the caller's db2 IS
   // that row)
@@ -300,7 +305,7 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
   }
   qagnn_gemm_nn_args gr = {};
   gr.A1 = dout; gr.lda1 = DP; gr.K1 = DP; gr.B1 = h->W2; gr.ldb1 = DP; gr.C = bufB; gr.ldc = DP; gr.M = N; gr.No = DP;
-  gr.a_amax1 = w_dout;
+  gr.a_amax1 = w_dout; gr.pieces = hop_pieces(h);
   HOP_TRY(hop_nn(h, &gr, h->W2t, DP, nullptr, 0, pkws, pk_elems, stream));
   // BatchNorm + ReLU backward: dbn[0] = d beta, dbn[1] = d gamma, then d h1
   HOP_TRY(qagnn_colreduce_f32(2, bufB, DP, h->h1, DP, N, DP, nullptr, 1, mean, invstd, scale, shift, nullptr, 1.0f, h->dbn, crws, stream));
@@ -308,11 +313,11 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
                                     h->batch_stats ? (float)(1.0 / (double)N) : 0.f, nullptr, h->db1, crws, w_dh1, (hipStream_t)stream));
   // first Linear (db1 = colsum(d h1) came out of the pass above)
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
-  if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->aggr, DP, DP, nullptr, 0, 0, bufC, DP, h->dW1t, DP, N, DP, nullptr, nullptr, am.own + AM_AGGR, nullptr, w_dh1, tnws, wstream));
+  if (h2) HOP_TRY(hop_tn(h)(h->aggr, DP, DP, nullptr, 0, 0, bufC, DP, h->dW1t, DP, N, DP, nullptr, nullptr, am.own + AM_AGGR, nullptr, w_dh1, tnws, wstream));
   else HOP_TRY(qagnn_gemm_tn_f32(h->aggr, DP, bufC, DP, h->dW1t, DP, N, DP, DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
   qagnn_gemm_nn_args gg = {};
   gg.A1 = bufC; gg.lda1 = DP; gg.K1 = DP; gg.B1 = h->W1; gg.ldb1 = DP; gg.C = bufB; gg.ldc = DP; gg.M = N; gg.No = DP;
-  gg.a_amax1 = w_dh1;
+  gg.a_amax1 = w_dh1; gg.pieces = hop_pieces(h);
   HOP_TRY(hop_nn(h, &gg, h->W1t, DP, nullptr, 0, pkws, pk_elems, stream));
   // attention backward
   HOP_TRY(launch_edge_attn_bwd(h->g, h->KMQ, 3 * DP, h->EkEm, 2 * DP, h->HP, h->qscale, h->a, h->alpha, bufB, DP, dKMQ, h->dEkEm, gab, rs, cls_part,
@@ -320,12 +325,12 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
   // projection: weight gradients, node-type-table gradient, data gradients
   if (ss->side) HOP_TRY(stream_after(ss->side, ss->main, ss->take()));
   if (SP > 0 && h->dWs_t == h->dWx_t + (int64_t)DP * 3 * DP) {  // the two gradients are one [DP + SP, 3 DP] matrix: one launch
-    if (h2) HOP_TRY(qagnn_gemm_tn_h2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, am.s, w_dkmq, tnws, wstream));
+    if (h2) HOP_TRY(hop_tn(h)(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, am.s, w_dkmq, tnws, wstream));
     else HOP_TRY(qagnn_gemm_tn2_f32(h->X, DP, DP, h->S, SP, SP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, tnws, wstream));
   } else if (h2) {
-    HOP_TRY(qagnn_gemm_tn_h2_f32(h->X, DP, DP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, nullptr, w_dkmq, tnws, wstream));
+    HOP_TRY(hop_tn(h)(h->X, DP, DP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.x, nullptr, w_dkmq, tnws, wstream));
     if (SP > 0)
-      HOP_TRY(qagnn_gemm_tn_h2_f32(h->S, SP, SP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.s, nullptr, w_dkmq, tnws, wstream));
+      HOP_TRY(hop_tn(h)(h->S, SP, SP, nullptr, 0, 0, dKMQ, 3 * DP, h->dWs_t, 3 * DP, N, 3 * DP, nullptr, nullptr, am.s, nullptr, w_dkmq, tnws, wstream));
   } else {
     HOP_TRY(qagnn_gemm_tn_f32(h->X, DP, dKMQ, 3 * DP, h->dWx_t, 3 * DP, N, DP, 3 * DP, nullptr, nullptr, nullptr, 0, tnws, wstream));
     if (SP > 0)
@@ -352,14 +357,14 @@ static int hop_bwd_one(const qagnn_hop_args* h, const HopAmax& am, SideSync* ss,
     qagnn_gemm_nn_args gx = {};
     gx.A1 = dKMQ; gx.lda1 = 3 * DP; gx.K1 = 3 * DP; gx.B1 = h->Wx; gx.ldb1 = DP; gx.C = h->dX; gx.ldc = DP; gx.M = N; gx.No = DP;
     gx.accumulate = h->accumulate_dX;
-    gx.a_amax1 = w_dkmq;
+    gx.a_amax1 = w_dkmq; gx.pieces = hop_pieces(h);
     HOP_TRY(hop_nn(h, &gx, h->Wx_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   if (SP > 0 && h->dS) {
     qagnn_gemm_nn_args gs = {};
     gs.A1 = dKMQ; gs.lda1 = 3 * DP; gs.K1 = 3 * DP; gs.B1 = h->Ws; gs.ldb1 = SP; gs.C = h->dS; gs.ldc = SP; gs.M = N; gs.No = SP;
     gs.accumulate = h->accumulate_dS;
-    gs.a_amax1 = w_dkmq;
+    gs.a_amax1 = w_dkmq; gs.pieces = hop_pieces(h);
     HOP_TRY(hop_nn(h, &gs, h->Ws_t, 3 * DP, nullptr, 0, pkws, pk_elems, stream));
   }
   return QAGNN_OK;

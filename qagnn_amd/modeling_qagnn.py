@@ -449,7 +449,8 @@ class QAGNN_Message_Passing(nn.Module):
         Kp = ops.kernels()
         stack_native = self.k > 0 and ops.use_fused_hop(bs * n) and hasattr(Kp, 'stack_fwd') and ops.FUSED_STACK
         bn0 = self.gnn_layers[0].mlp[1] if self.k > 0 else None
-        pieces = 2 if (stack_native and getattr(Kp, 'gemm_split', 1) == 2 and (self.training or not bn0.track_running_stats)) else 3
+        pieces = ({2: 2, 3: 1}[Kp.gemm_split] if (stack_native and getattr(Kp, 'gemm_split', 1) >= 2 and (self.training or not bn0.track_running_stats))
+                  else 3)  # (3 -> one image: the reduced-precision form, on request only)
         pairs = []
         for pk in per_layer:
             pairs += [(pk[1], pk[3], pieces), (pk[0], None, pieces), (pk[2], None, pieces), (pk[9], None, pieces), (pk[8], None, pieces),

@@ -607,7 +607,7 @@ def amax_lookup(t):
 
 def _wants_amax(K, X):
     """the provider runs the three-MFMA form and X is large enough for it (the library's own threshold: csrc/hop.hip, hop_h2)"""
-    return getattr(K, 'gemm_split', 1) == 2 and getattr(K, 'name', '') == 'hip' and X.dim() == 2 and X.size(0) >= 8192
+    return getattr(K, 'gemm_split', 1) >= 2 and getattr(K, 'name', '') == 'hip' and X.dim() == 2 and X.size(0) >= 8192
 
 
 class GeluDropoutFn(torch.autograd.Function):

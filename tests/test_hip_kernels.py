@@ -1009,6 +1009,69 @@ def test_gemm_tn_three_mfma_form(R, Ka1, Ka2, No, kind):
     assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
 
 
+# ---- the REDUCED-PRECISION form (gemm_split = 3, on request only: ONE fp16 MFMA per product, csrc/gemm_nn2.hip / qagnn_gemm_nn_args.pieces) ---
+# Both operands are rounded to fp16 under their power-of-two scales: a relative 2^-11 each, i.e. 2^-10 per term (+ the fp32 accumulation and
+# the same absolute floor as the three-MFMA form).  The bound is asserted, and so is that the form really ran (the error exceeds what the
+# three-MFMA form could have made).
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K1,K2,No', [(64000, 208, 112, 624), (20000, 208, 0, 208), (9000, 624, 0, 208)])
+@pytest.mark.parametrize('kind', ['plain', 'tiny', 'spread'])
+def test_gemm_nn_reduced_precision_form(M, K1, K2, No, kind, monkeypatch):
+    g = torch.Generator().manual_seed(M + K1 + No + 1)
+    A1, B1 = _ranged(g, M, K1, kind), torch.randn(K1, No, generator=g) * torch.pow(10.0, -3 * torch.rand(1, No, generator=g))
+    A2 = _ranged(g, M, K2, 'plain' if kind == 'spread' else kind) if K2 else None
+    B2 = torch.randn(K2, No, generator=g) if K2 else None
+    K = hip()
+    monkeypatch.setattr(K, 'gemm_split', 3)
+    cu = lambda t: None if t is None else t.cuda()  # noqa: E731
+    am1, am2 = K.absmax(cu(A1)), (K.absmax(cu(A2)) if K2 else None)
+    got = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), B1n=cu(B1.t().contiguous()), B2n=cu(B2.t().contiguous()) if K2 else None,
+                    a_amax1=am1, a_amax2=am2).cpu()
+    ref = A1.double() @ B1.double() + (A2.double() @ B2.double() if K2 else 0.0)
+    sab = A1.abs().double() @ B1.abs().double() + (A2.abs().double() @ B2.abs().double() if K2 else 0.0)
+    amax = max(A1.abs().max().item(), A2.abs().max().item() if K2 else 0.0)
+    bcol = B1.abs().max(0).values.double() if not K2 else torch.maximum(B1.abs().max(0).values, B2.abs().max(0).values).double()
+    bound = 1.05 * 2.0 ** -10 * sab + 2.0 ** -38 * (K1 + K2) * amax * bcol + 1e-30
+    err = (got.double() - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+    monkeypatch.setattr(K, 'gemm_split', 2)
+    full = K.gemm_nn(cu(A1), cu(B1), cu(A2), cu(B2), B1n=cu(B1.t().contiguous()), B2n=cu(B2.t().contiguous()) if K2 else None,
+                     a_amax1=am1, a_amax2=am2).cpu()
+    assert err.max().item() > 8 * (full.double() - ref).abs().max().item(), 'the reduced-precision form did not run (its error is that of the three-MFMA form)'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Ka1,Ka2,No', [(64000, 208, 112, 624), (64000, 208, 0, 208), (5000, 112, 0, 624)])
+@pytest.mark.parametrize('kind', ['plain', 'tiny', 'affine'])
+def test_gemm_tn_reduced_precision_form(R, Ka1, Ka2, No, kind, monkeypatch):
+    if kind == 'affine' and Ka2:
+        pytest.skip('no prologue on the two-operand product')
+    g = torch.Generator().manual_seed(R + Ka1 + Ka2 + No + 1)
+    k0 = 'plain' if kind == 'affine' else kind
+    A1, B = _ranged(g, R, Ka1, k0), _ranged(g, R, No, 'tiny' if kind == 'tiny' else 'plain')
+    A2 = _ranged(g, R, Ka2, 'plain') if Ka2 else None
+    kw = dict(a_scale=torch.randn(Ka1, generator=g), a_shift=torch.randn(Ka1, generator=g)) if kind == 'affine' else {}
+    A1e = torch.relu(A1 * kw['a_scale'] + kw['a_shift']) if kind == 'affine' else A1
+    K = hip()
+    monkeypatch.setattr(K, 'gemm_split', 3)
+    cu = lambda t: None if t is None else t.cuda()  # noqa: E731
+    got = K.gemm_tn_h2(cu(A1), cu(B), K.absmax(cu(A1e.contiguous())), K.absmax(cu(B)), A2=cu(A2), amax_a2=K.absmax(cu(A2)) if Ka2 else None,
+                       **{k: cu(v) for k, v in kw.items()}).cpu()
+    A = A1e if not Ka2 else torch.cat([A1e, A2], 1)
+    ref = A.double().t() @ B.double()
+    sab = A.abs().double().t() @ B.abs().double()
+    arow = torch.cat([torch.full((Ka1,), A1e.abs().max().item()), torch.full((Ka2,), A2.abs().max().item() if Ka2 else 0.0)]).double()
+    bound = 1.05 * 2.0 ** -10 * sab + 2.0 ** -38 * R * arow[:, None] * B.abs().max().item() + 1e-30
+    err = (got.double() - ref).abs()
+    assert torch.isfinite(got).all()
+    assert bool((err <= bound).all()), f'max err {err.max().item():.3e}, worst bound ratio {(err / bound).max().item():.2f}'
+    monkeypatch.setattr(K, 'gemm_split', 2)
+    full = K.gemm_tn_h2(cu(A1), cu(B), K.absmax(cu(A1e.contiguous())), K.absmax(cu(B)), A2=cu(A2), amax_a2=K.absmax(cu(A2)) if Ka2 else None,
+                        **{k: cu(v) for k, v in kw.items()}).cpu()
+    assert err.max().item() > 8 * (full.double() - ref).abs().max().item(), 'the reduced-precision form did not run'
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['big', 'big_pad'])
 def test_native_hop_in_the_three_mfma_form(name, monkeypatch):

@@ -616,8 +616,10 @@ def _bench_size_oracle(case, pre, dropout, seeds):
     return _BENCH_ORACLE[key]
 
 
-def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
-    """One train step of the package at a bench-size workload against the oracle with aligned ReLU kinks -> report dict."""
+def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None, bars=None):
+    """One train step of the package at a bench-size workload against the oracle with aligned ReLU kinks -> report dict.
+    bars: overrides of the fixed bars (dict: bar, median, hidden_rtol, logits_rtol) -- the reduced-precision variant only."""
+    bars = bars or {}
     from qagnn_amd import modeling_qagnn as MQ
     device = device or DEVICE
     case = _bench_size_case(workload, B_override)
@@ -652,11 +654,11 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
     kinks = ref['kinks']
     summary = [{k: (float('%.1e' % v) if isinstance(v, float) else v) for k, v in kk.items()} for kk in kinks]
     assert all(kk['outside'] == 0 for kk in kinks), f'ReLU signs differ OUTSIDE the rounding band of the kink (|x_oracle| > {helpers.KINK_BAND} of the row\'s scale): {summary}'
-    hidden_rtol = wl.get('hidden_rtol', helpers.HIDDEN_RTOL)
+    hidden_rtol = bars.get('hidden_rtol', wl.get('hidden_rtol', helpers.HIDDEN_RTOL))
     assert all(kk['row_dev'] <= hidden_rtol for kk in kinks), f'hidden BatchNorm outputs of a row differ by more than {hidden_rtol} of the row\'s scale: {summary}'
     # forward bar 5e-4 of the logits' scale (1e-4 at the small cases): both sides are fp32, and at N = 64 000 rows x 5 layers of
     # train-mode BatchNorm each is ~1e-4 from exact arithmetic (measured 1.4e-4 between them)
-    helpers._close(logits.detach().cpu(), ref['logits'], what=f'{workload} train-mode logits [{variant}]', rtol=5e-4, atol=1e-5)
+    helpers._close(logits.detach().cpu(), ref['logits'], what=f'{workload} train-mode logits [{variant}]', rtol=bars.get('logits_rtol', 5e-4), atol=1e-5)
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     assert set(grads) == set(ref['grads'])
     rel, fails = {}, []
@@ -668,8 +670,8 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
             continue
         scale = gref.abs().max().item()
         rel[k] = (grads[k].cpu() - gref).abs().max().item() / (scale + 1e-30)
-        if rel[k] > BENCH_SIZE_BAR:
-            fails.append(f'{k}: {rel[k]:.2e} of scale (bar {BENCH_SIZE_BAR:.1e})')
+        if rel[k] > bars.get('bar', BENCH_SIZE_BAR):
+            fails.append(f'{k}: {rel[k]:.2e} of scale (bar {bars.get("bar", BENCH_SIZE_BAR):.1e})')
     rs = sorted(rel.values())
     worst = max(rel, key=rel.get)
     line = (f'bench-size {workload} train [{variant}] vs fp32 oracle (ReLU kinks aligned): {len(rs)} tensors, worst {rel[worst]:.3e} of scale ({worst}), '
@@ -682,9 +684,9 @@ def bench_size_step_vs_oracle(variant, workload, device=None, B_override=None):
         with open(helpers.REPORT, 'a') as f:
             f.write(line + '\n')
     assert len(rs) >= 60 and not fails, (fails[:10], line)
-    assert rs[len(rs) // 2] <= BENCH_SIZE_MEDIAN, line
+    assert rs[len(rs) // 2] <= bars.get('median', BENCH_SIZE_MEDIAN), line
     for bname, b in model.named_buffers():
-        helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=5e-4, atol=1e-6, what='buffer ' + bname)  # the forward bar: statistics of activations that agree to ~1e-4
+        helpers._close(b.detach().cpu().float(), ref['bufs'][bname].float(), rtol=bars.get('logits_rtol', 5e-4), atol=1e-6, what='buffer ' + bname)  # the forward bar: statistics of activations that agree to ~1e-4
     return dict(rel=rel, kinks=kinks, line=line)
 
 
@@ -720,6 +722,26 @@ def test_bench_size_train_step_matches_the_oracle(variant, workload, monkeypatch
     bench_size_step_vs_oracle(variant, workload)
     if composed:
         assert ops._WgradQueue.n_deferred - deferred0 >= 20, 'the weight-gradient GEMMs were not deferred: not the composed path + overlap'
+
+
+# The REDUCED-PRECISION line of bench.py (`configs[1]/fp16_gemms`, QAGNN_GEMM_SPLIT=3 -- never the headline): ONE fp16 MFMA per product in the
+# stack's large products, operands rounded to fp16 (11 significant bits) under exact power-of-two scales, fp32 accumulation, fp32 storage,
+# fp32 statistics / softmax / aggregation: the GEMM arithmetic torch.autocast gives the reference's Linear layers under its --fp16 switch
+# (qagnn.py:254-257).  Held to the fp32 ORACLE -- the same one as the full-precision path, ReLU kinks aligned the same way -- at bars that
+# say what the rounding costs (measured on MI355X, profiles/r6_run16_reduced_precision_parity.txt; ~2x measured).  The band of the kink
+# alignment widens with the forward error (a hidden BatchNorm output now differs by ~1e-3 of its row's scale instead of ~3e-5).
+REDUCED_BARS = dict(bar=3.5e-2, median=7e-3, hidden_rtol=4e-3, logits_rtol=1e-2, kink_band=1.5e-2)  # measured: worst 1.62e-2, median 3.3e-3, rows 1.8e-3, farthest aligned element 7.3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_reduced_precision_line_against_the_fp32_oracle(monkeypatch):
+    monkeypatch.setattr(ops.kernels(), 'gemm_split', 3)
+    monkeypatch.setattr(helpers, 'KINK_BAND', REDUCED_BARS['kink_band'])
+    res = bench_size_step_vs_oracle('blobs', 'configs1_csqa_320', bars=REDUCED_BARS)
+    rs = sorted(res['rel'].values())
+    # ... and it is the reduced form that ran: its gradients sit visibly farther from the oracle than the full-precision path's (worst 1.3e-3)
+    assert rs[len(rs) // 2] > 3e-4, res['line']
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -69,15 +69,18 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 4; ++i) memcpy(&w4[i], &one, 4);
     CK(hipMemcpy(am, w4, 16, hipMemcpyHostToDevice));
     const int NJ = (sh.No + 15) / 16;
-    struct Form { const char* name; int np; int wv; } forms[] = {{"six MFMAs, library's choice", 3, 0}, {"three MFMAs, 4-wave blocks", 2, 4}};
+    struct Form { const char* name; int np; int wv; } forms[] = {{"six MFMAs, library's choice", 3, 0}, {"three MFMAs, 4-wave blocks", 2, 4},
+                                                          {"one MFMA (reduced precision)", 1, 4}};
     for (auto& f : forms) {
       void* ws;
       CK(hipMalloc(&ws, qagnn::nn2_pack_bytes(sh.No, sh.K1, sh.K2, f.np)));
       qagnn_gemm_nn_args b = a;
-      if (f.np == 2) { b.a_amax1 = am; b.a_amax2 = sh.K2 ? am + 1 : nullptr; }
+      if (f.np <= 2) { b.a_amax1 = am; b.a_amax2 = sh.K2 ? am + 1 : nullptr; }
       qagnn::launch_nn2_packed(nt, b, B1n, sh.K1, B2n, sh.K2, ws, st, f.np);  // (packs the image)
       auto run = [&] {
         if (f.wv == 0) return qagnn::launch_nn2_prepacked(nt, b, ws, st, 3);
+        if (f.np == 1)
+          return nt == 13 ? qagnn::nn2::launch_nt<13, 1, true>(b, (const float*)ws, NJ, nullptr, 0, st) : qagnn::nn2::launch_nt<7, 1, true>(b, (const float*)ws, NJ, nullptr, 0, st);
         return nt == 13 ? qagnn::nn2::launch_nt<13, 2, true>(b, (const float*)ws, NJ, nullptr, 0, st) : qagnn::nn2::launch_nt<7, 2, true>(b, (const float*)ws, NJ, nullptr, 0, st);
       };
       for (int i = 0; i < 3; ++i) run();
