@@ -1017,6 +1017,8 @@ def test_gemm_tn_three_mfma_form(R, Ka1, Ka2, No, kind):
 @pytest.mark.parametrize('M,K1,K2,No', [(64000, 208, 112, 624), (20000, 208, 0, 208), (9000, 624, 0, 208)])
 @pytest.mark.parametrize('kind', ['plain', 'tiny', 'spread'])
 def test_gemm_nn_reduced_precision_form(M, K1, K2, No, kind, monkeypatch):
+    if os.environ.get('QAGNN_GEMM_SPLIT') == '0':
+        pytest.skip('the fp32-MFMA family is pinned (test_gemm_kernel_families): no scaled fp16 form to ask for')
     g = torch.Generator().manual_seed(M + K1 + No + 1)
     A1, B1 = _ranged(g, M, K1, kind), torch.randn(K1, No, generator=g) * torch.pow(10.0, -3 * torch.rand(1, No, generator=g))
     A2 = _ranged(g, M, K2, 'plain' if kind == 'spread' else kind) if K2 else None
@@ -1045,6 +1047,8 @@ def test_gemm_nn_reduced_precision_form(M, K1, K2, No, kind, monkeypatch):
 @pytest.mark.parametrize('R,Ka1,Ka2,No', [(64000, 208, 112, 624), (64000, 208, 0, 208), (5000, 112, 0, 624)])
 @pytest.mark.parametrize('kind', ['plain', 'tiny', 'affine'])
 def test_gemm_tn_reduced_precision_form(R, Ka1, Ka2, No, kind, monkeypatch):
+    if os.environ.get('QAGNN_GEMM_SPLIT') == '0':
+        pytest.skip('the fp32-MFMA family is pinned (test_gemm_kernel_families): no scaled fp16 form to ask for')
     if kind == 'affine' and Ka2:
         pytest.skip('no prologue on the two-operand product')
     g = torch.Generator().manual_seed(R + Ka1 + Ka2 + No + 1)
