@@ -1047,6 +1047,7 @@ bool tn_split_ok(int R, int Ka, int No, int lda, int ldb, bool gather, bool affi
   return v != 0 && Ka >= 64 && No >= 104 && R >= 1024 && big < (int64_t)0x7FFFFFFF;  // 32-bit buffer offsets
 }
 static bool tn_split_wide_b(int Ka) { return Ka <= 112; }  // (KT, NT) = (7, 13), else (13, 7)
+constexpr int TN_WS_MIN_TILES_C = 28;  // (= TN_WS_MIN_TILES below: chunks of that many k-tiles and more run k_gemm_tn_ws)
 // rows per split-K chunk: two blocks per CU, a multiple of the 32-row k-tile, never below `lo` (the workspace's sizing)
 int tn_split_chunk_rows(int R, int Ka, int No, int lo) {
   const int ac = tn_split_wide_b(Ka) ? 112 : 208, bc = tn_split_wide_b(Ka) ? 208 : 112;
@@ -1059,9 +1060,18 @@ int tn_split_chunk_rows(int R, int Ka, int No, int lo) {
 // [A1 | A2]^T B in one launch: 112-row output tiles (the (7, 13) shape) over A1's columns, then over A2's
 int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
   const int blocks_per_chunk = cdiv(No, 208) * (cdiv(Ka1, 112) + cdiv(Ka2, 112));
+  const int lo32 = (lo + TKR - 1) / TKR * TKR;
+#ifndef QAGNN_TN_WS_TWO_ROUNDS
+  // Long products run k_gemm_tn_ws, ONE 8-wave block per CU: chunks sized for one block per CU (28 chunks of 72 k-tiles at 64 000 rows
+  // instead of 56 of 36) halve the partial sums that are written and summed again and the uncovered first loads / last stores per CU
+  {
+    const int target1 = split_num_cus() / blocks_per_chunk;
+    const int rows1 = (cdiv(R, target1 > 0 ? target1 : 1) + TKR - 1) / TKR * TKR;
+    if (rows1 >= 2 * TN_WS_MIN_TILES_C * TKR) return rows1 > lo32 ? rows1 : lo32;
+  }
+#endif
   const int target = 2 * split_num_cus() / blocks_per_chunk;
   const int rows = (cdiv(R, target > 0 ? target : 1) + TKR - 1) / TKR * TKR;
-  const int lo32 = (lo + TKR - 1) / TKR * TKR;
   return rows > lo32 ? rows : lo32;
 }
 // k_gemm_tn_ws serves the two-operand product [X | S]^T dKMQ where its chunks are long (36 k-tiles per block at 64 000 rows: 201 -> 171 us).
@@ -1069,7 +1079,7 @@ int tn_split2_chunk_rows(int R, int Ka1, int Ka2, int No, int lo) {
 // 112 x 624 72 -> 74 -- one block per CU leaves a block's first loads and its partial-sum stores uncovered, which only a long chunk
 // amortises; at the 2-tile chunks of a 10-subgraph batch it took 29 us against the 4-wave kernel's ~14 (profiles/r5_run5_tn_ws_min_tiles_ab_b10.txt:
 // the step 2.29 -> 2.22 ms)
-constexpr int TN_WS_MIN_TILES = 28;
+constexpr int TN_WS_MIN_TILES = TN_WS_MIN_TILES_C;
 int launch_tn_split2(const float* A1, int lda1, int Ka1, const float* A2, int lda2, int Ka2, const float* B, int ldb, float* P, int R, int No,
                      int chunk_rows, hipStream_t stream, const uint32_t* const* amax, int np) {
   dim3 grid(cdiv(No, 208), cdiv(Ka1, 112) + cdiv(Ka2, 112), cdiv(R, chunk_rows));
