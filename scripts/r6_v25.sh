@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > gpurun_out/r6_v25_tests.txt
+tail -3 gpurun_out/r6_v25_tests.txt | cut -c1-200
+timeout 1200 python bench.py > gpurun_out/r6_v25_bench.json 2> gpurun_out/r6_v25_bench.err; tail -2 gpurun_out/r6_v25_bench.err | cut -c1-300
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6_v25_bench.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['repeat_ms_per_step'], d.get('breakdown_ms_per_step'), d['small_batch']['ms_per_step'])
+print({k:(v.get('value'), v.get('ms_per_step')) for k,v in d['configs'].items()})
+r=d['roofline']; print(r['frac'], r['avg_launch_ms'], r['traffic'], r['backward']['avg_launch_ms'], r['backward'].get('traffic_over_compulsory'))
+m=d['roofline_mfma']; print(m['achieved'], m['frac'], m['ms_per_step'], m['ms_per_step_nn'], m['ms_per_step_tn'], m['ms_per_step_six_mfma_form'])
+print(d['optimizer']['reference_operating_point']['ms_per_optimizer_step'], d['cpu_baseline']['value'], d['speedup_vs_cpu_baseline_same_batch'])
+PY
+python __graft_entry__.py smoke 2>&1 | tail -1
