@@ -191,6 +191,10 @@ def _tn2_flops(A1, A2, B, **kw):
     return 2.0 * B.size(0) * (A1.size(1) + A2.size(1)) * B.size(1)
 
 
+def _tnh2_flops(A1, B, amax_a1, amax_b, A2=None, **kw):  # (the output layer's weight gradient where every operand carries its maximum)
+    return 2.0 * B.size(0) * (A1.size(1) + (A2.size(1) if A2 is not None else 0)) * B.size(1)
+
+
 # The operands the kernels see are head-padded: d = 200 is stored as DP = 208 (4 heads x 52), K|M|Q as 624 for 600, the score
 # embedding S as 112 columns for d/2 = 100 (+ 4 node-type indicator columns that exist for a by-product gradient, + padding).
 # `_dense` maps an operand width back to the width of the reference's tensor, so that the USEFUL FLOPs of a product -- the ones the
@@ -219,7 +223,12 @@ def _tn2_useful(A1, A2, B, **kw):
     return 2.0 * B.size(0) * (_dense(A1.size(1)) + _dense(A2.size(1))) * _dense(B.size(1))
 
 
-TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn', 'gemm_tn2']
+def _tnh2_useful(A1, B, amax_a1, amax_b, A2=None, **kw):
+    return 2.0 * B.size(0) * (_dense(A1.size(1)) + (_dense(A2.size(1)) if A2 is not None else 0)) * _dense(B.size(1))
+
+
+GEMM_KEYS = ('gemm_nn', 'gemm_tn', 'gemm_tn2', 'gemm_tn_h2')
+TIMED = ['edge_attn_fwd', 'edge_attn_bwd', 'graph_prep', 'graph_from_blobs', 'gemm_nn', 'gemm_tn', 'gemm_tn2', 'gemm_tn_h2']
 
 
 class Comm:
@@ -419,7 +428,7 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     off (both hide kernels from the events: see main()).  Returns per-step numbers."""
     timed.reset()
     timed.enabled = True
-    timed.active = {'gemm_nn', 'gemm_tn', 'gemm_tn2', 'edge_attn_bwd', 'edge_attn_fwd'}
+    timed.active = {'gemm_nn', 'gemm_tn', 'gemm_tn2', 'gemm_tn_h2', 'edge_attn_bwd', 'edge_attn_fwd'}
     overlap, fused, ops.WGRAD_OVERLAP, ops.FUSED_HOP = ops.WGRAD_OVERLAP, ops.FUSED_HOP, False, False
     try:
         timed.enabled = False
@@ -432,9 +441,9 @@ def instrumented_pass(run_step, timed, sync, n_steps):
     finally:
         ops.WGRAD_OVERLAP, ops.FUSED_HOP = overlap, fused
         timed.enabled = False
-    gemm_ms = timed.total_ms('gemm_nn') + timed.total_ms('gemm_tn') + timed.total_ms('gemm_tn2')
-    flops = timed.work['gemm_nn'] + timed.work['gemm_tn'] + timed.work['gemm_tn2']
-    useful = timed.useful['gemm_nn'] + timed.useful['gemm_tn'] + timed.useful['gemm_tn2']
+    gemm_ms = sum(timed.total_ms(k) for k in GEMM_KEYS)
+    flops = sum(timed.work[k] for k in GEMM_KEYS)
+    useful = sum(timed.useful[k] for k in GEMM_KEYS)
     # The composed pass above runs the SAME products (shapes, FLOPs, launch count) but not always the same kernels: the natively sequenced
     # stack -- the path the timed regions take -- hands operand maxima from producer to consumer and runs its large products in the
     # three-MFMA form, which the per-kernel entry points called from Python do not.  So the GEMM time comes from a second pass on the
@@ -462,7 +471,7 @@ def instrumented_pass(run_step, timed, sync, n_steps):
                 native_edge_fwd_ms=(native['edge_attn_fwd'][0] / max(1, native['edge_attn_fwd'][1]) if native else None),
                 native_edge_bwd_ms=(native['edge_attn_bwd'][0] / max(1, native['edge_attn_bwd'][1]) if native else None),
                 gemm_flops=flops / n_steps, gemm_useful_flops=useful / n_steps,
-                gemm_launches=(len(timed.events['gemm_nn']) + len(timed.events['gemm_tn']) + len(timed.events['gemm_tn2'])) // n_steps,
+                gemm_launches=sum(len(timed.events[k]) for k in GEMM_KEYS) // n_steps,
                 edge_fwd_ms=timed.mean_ms('edge_attn_fwd')[0], edge_bwd_ms=timed.mean_ms('edge_attn_bwd')[0],
                 n_edge_fwd=timed.mean_ms('edge_attn_fwd')[1], n_edge_bwd=timed.mean_ms('edge_attn_bwd')[1])
 
@@ -784,8 +793,8 @@ def main():
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     comm = Comm(params, world, assignment=assignment, model=model, overlap=args.comm_overlap)
-    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops},
-                         useful={'gemm_nn': _nn_useful, 'gemm_tn': _tn_useful, 'gemm_tn2': _tn2_useful})
+    timed = TimedKernels(ops.kernels(), TIMED, work={'gemm_nn': _nn_flops, 'gemm_tn': _tn_flops, 'gemm_tn2': _tn2_flops, 'gemm_tn_h2': _tnh2_flops},
+                         useful={'gemm_nn': _nn_useful, 'gemm_tn': _tn_useful, 'gemm_tn2': _tn2_useful, 'gemm_tn_h2': _tnh2_useful})
     ops.set_kernels(timed)
     run, run_eager, gs = make_runner(model, b, nc, loss_weight, params, comm, args.graphs)
     headline_choice = make_runner.last_choice

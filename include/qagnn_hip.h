@@ -329,6 +329,10 @@ int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64
 int64_t qagnn_gelu_dropout_amax_scratch_elems(int64_t n);
 int qagnn_gelu_dropout_fwd_amax_f32(const float* X, float* Y, int64_t n, float p, uint64_t seed, uint32_t* amax,
                                     float* scratch /* qagnn_gelu_dropout_amax_scratch_elems(n) floats */, qagnn_stream_t stream);
+/* likewise the backward pass, which leaves max |dX| (the B operand of the weight-gradient product and the A operand of the data-gradient
+ * products of the Linear in front of the GELU: modeling_qagnn.py:92-93 behind Vh / Vx) */
+int qagnn_gelu_dropout_bwd_amax_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, uint32_t* amax,
+                                    float* scratch, qagnn_stream_t stream);
 /* qagnn_bn_relu_bwd_f32 with the column sums of its OUTPUT as a by-product (the bias gradient of the Linear in front of the
  * BatchNorm): one pass instead of an elementwise pass + a column-reduction pass; sums bit-identical to qagnn_colreduce_f32
  * mode 0 on the output.  workspace: qagnn_colreduce_workspace_elems(R, Cc, 1) floats.  (The same fusion for the GELU + dropout

@@ -23,10 +23,10 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_edge_attn_fwd_f32', 'qagnn_edge_attn_bwd_f32',
            'qagnn_hop_fwd_workspace_elems', 'qagnn_hop_bwd_workspace_elems', 'qagnn_hop_fwd_f32', 'qagnn_hop_bwd_f32',
            'qagnn_stack_fwd_f32', 'qagnn_stack_bwd_f32', 'qagnn_absmax_f32', 'qagnn_zero_words', 'qagnn_gemm_tn_h2_f32', 'qagnn_gelu_dropout_fwd_amax_f32', 'qagnn_gelu_dropout_amax_scratch_elems',
-           'qagnn_timing_enable', 'qagnn_timing_read', 'qagnn_gemm_tn_h1_f32']
+           'qagnn_timing_enable', 'qagnn_timing_read', 'qagnn_gemm_tn_h1_f32', 'qagnn_gelu_dropout_bwd_amax_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 19  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read; 19: the reduced-precision form on request -- qagnn_gemm_nn_args.pieces, qagnn_gemm_tn_h1_f32, qagnn_hop_args.gemm_split == 3)
+ABI_VERSION = 20  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read; 19: the reduced-precision form on request -- qagnn_gemm_nn_args.pieces, qagnn_gemm_tn_h1_f32, qagnn_hop_args.gemm_split == 3; 20: qagnn_gelu_dropout_bwd_amax_f32)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -124,6 +124,7 @@ def load_library(path=LIB_PATH):
     lib.qagnn_gelu_dropout_fwd_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_bwd_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp]
     lib.qagnn_gelu_dropout_fwd_amax_f32.argtypes = [_vp, _vp, _i64, _f32, _u64, _vp, _vp, _vp]
+    lib.qagnn_gelu_dropout_bwd_amax_f32.argtypes = [_vp, _vp, _vp, _i64, _f32, _u64, _vp, _vp, _vp]
     lib.qagnn_gelu_dropout_amax_scratch_elems.restype = _i64
     lib.qagnn_gelu_dropout_amax_scratch_elems.argtypes = [_i64]
     lib.qagnn_sin_basis_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
@@ -790,9 +791,17 @@ class HipKernels(metaclass=_GuardedMeta):
                                                         self._stream()), 'qagnn_gelu_dropout_fwd_f32')
         return Y
 
-    def gelu_dropout_bwd(self, X, dY, p, seed):
+    def gelu_dropout_bwd(self, X, dY, p, seed, amax=False):
+        """amax=True: -> (dX, word) with word = int32 [4], [0] = the bit pattern of max |dX| (qagnn_gelu_dropout_bwd_amax_f32)"""
         assert X.is_contiguous() and dY.is_contiguous()
         dX = torch.empty_like(X)
+        if amax:
+            word = torch.empty(4, dtype=torch.int32, device=X.device)
+            self._check(self.lib.qagnn_zero_words(word.data_ptr(), 4, self._stream()), 'qagnn_zero_words')
+            scratch = torch.empty(self.lib.qagnn_gelu_dropout_amax_scratch_elems(X.numel()), dtype=torch.float32, device=X.device)
+            self._check(self.lib.qagnn_gelu_dropout_bwd_amax_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), X.numel(), float(p), int(seed),
+                                                                 word.data_ptr(), scratch.data_ptr(), self._stream()), 'qagnn_gelu_dropout_bwd_amax_f32')
+            return dX, word
         self._check(self.lib.qagnn_gelu_dropout_bwd_f32(X.data_ptr(), dY.data_ptr(), dX.data_ptr(), X.numel(), float(p),
                                                         int(seed), self._stream()), 'qagnn_gelu_dropout_bwd_f32')
         return dX

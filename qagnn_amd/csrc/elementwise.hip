@@ -600,6 +600,16 @@ extern "C" int qagnn_gelu_dropout_fwd_amax_f32(const float* X, float* Y, int64_t
   return launch_gelu_dropout(X, nullptr, Y, n, p, seed, amax, scratch, (hipStream_t)stream_);
 }
 
+// the backward pass that leaves max |dX| behind (a consumer of dX in the three-MFMA form: the weight-gradient and data-gradient products of the
+// Linear in front of the GELU); same scratch as the forward form
+extern "C" int qagnn_gelu_dropout_bwd_amax_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed, uint32_t* amax,
+                                               float* scratch, qagnn_stream_t stream_) {
+  QAGNN_REQUIRE(X && dY && dX && amax && scratch && n > 0 && n % 4 == 0 && aligned16(X) && aligned16(dY) && aligned16(dX), QAGNN_EINVAL,
+                "gelu_dropout_bwd_amax: bad args");
+  QAGNN_REQUIRE(p >= 0.f && p < 1.f, QAGNN_EINVAL, "gelu_dropout_bwd_amax: p=%f", p);
+  return launch_gelu_dropout(X, dY, dX, n, p, seed, amax, scratch, (hipStream_t)stream_);
+}
+
 extern "C" int qagnn_gelu_dropout_bwd_f32(const float* X, const float* dY, float* dX, int64_t n, float p, uint64_t seed,
                                           qagnn_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -455,7 +455,7 @@ class QAGNN_Message_Passing(nn.Module):
         for pk in per_layer:
             pairs += [(pk[1], pk[3], pieces), (pk[0], None, pieces), (pk[2], None, pieces), (pk[9], None, pieces), (pk[8], None, pieces),
                       (pk[14], None, pieces), (pk[13], None, pieces)]
-        pairs += [(Vh, Vx), (Vh_t, None), (Vx_t, None), (Wes, None)]
+        pairs += [(Vh, Vx, pieces), (Vh_t, None, pieces), (Vx_t, None, pieces), (Wes, None)]
         ops.prepack_weights(self, pairs, bs * n)
         # Every weight operand below comes straight out of pack_all (GatherPlan), whose backward is the only reader of its
         # gradient: the operators may queue their weight-gradient GEMMs and run them under the edge backward kernels.

@@ -451,7 +451,14 @@ class LinearNNFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, A1, B1t, B1, A2, B2t, B2, bias, rowtab, rowidx, acc, tabcol=-1):
         K = kernels()
-        C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx, B1n=B1, B2n=B2)
+        # operand maxima left by the producers of A1 / A2 (amax_note): the product then runs in the three-MFMA form, and so do its
+        # data-gradient and weight-gradient products when the incoming gradient carries its maximum too
+        am1, am2 = (amax_lookup(A1), amax_lookup(A2)) if _wants_amax(K, A1) else (None, None)
+        if am1 is None or (A2 is not None and am2 is None):
+            am1 = am2 = None
+        kw = dict(a_amax1=am1, a_amax2=am2) if am1 is not None else {}
+        C = K.gemm_nn(A1, B1t, A2, B2t, bias=bias, rowtab=rowtab, rowidx=rowidx, B1n=B1, B2n=B2, **kw)
+        ctx.am = (am1, am2)
         ctx.save_for_backward(A1, B1, A2, B2, rowidx, B1t, B2t)
         ctx.has = (bias is not None, rowtab is not None, rowtab.size(0) if rowtab is not None else 0)
         # tabcol >= 0: columns [tabcol, tabcol + G) of A2 hold the indicators of rowidx (see type_indicators): the row-table gradient
@@ -466,18 +473,23 @@ class LinearNNFn(torch.autograd.Function):
     def backward(ctx, dC):
         K = kernels()
         A1, B1, A2, B2, rowidx, B1t, B2t = ctx.saved_tensors
-        dC = dC.contiguous()
+        amc = amax_lookup(dC) if _wants_amax(K, dC) else None  # (max |dC| from dC's producer, e.g. GeluDropoutFn.backward)
+        if not dC.is_contiguous():
+            dC, amc = dC.contiguous(), None
         need = ctx.needs_input_grad
         has_bias, has_tab, G = ctx.has
         dbias = drowtab = None
         want_tab, want_bias = has_tab and need[7], has_bias and need[6]
+        am1, am2 = getattr(ctx, 'am', (None, None))
+        nn_kw = dict(a_amax1=amc) if amc is not None else {}
+        tn_h2 = amc is not None and am1 is not None and (A2 is None or am2 is not None)
         if ctx.defer:  # weight gradients queued for the next edge backward (see defer_wgrads)
             jobs, dB1t, dB2t = [], None, None
             if need[1] and A2 is not None and need[4]:
                 # both weight gradients share dC: ONE split-K launch and one chunk sum into one [K1 + K2, No] buffer (qagnn_gemm_tn2_f32)
                 joint = _wg_empty(dC, (A1.size(1) + A2.size(1), dC.size(1)))
                 dB1t, dB2t = joint[:A1.size(1)], joint[A1.size(1):]
-                jobs.append(lambda: K.gemm_tn2(A1, A2, dC, out=joint))
+                jobs.append((lambda: K.gemm_tn_h2(A1, dC, am1, amc, A2=A2, amax_a2=am2, out=joint)) if tn_h2 else (lambda: K.gemm_tn2(A1, A2, dC, out=joint)))
             else:
                 if need[1]:
                     dB1t = _wg_empty(dC, (A1.size(1), dC.size(1)))
@@ -502,12 +514,14 @@ class LinearNNFn(torch.autograd.Function):
                 if acc1 is None and A2 is None and dC.size(0) <= 2048 and dC.size(1) >= 512 and dC.size(0) % 4 == 0:
                     dA1 = K.gemm_tn(dC.t().contiguous(), B1)  # few rows, long reduction: see below
                 else:
-                    dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t))
+                    dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t, **nn_kw))
             if A2 is not None and need[3]:
-                dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
+                dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t, **nn_kw))
             return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
         cs = None
-        joint = K.gemm_tn2(A1, A2, dC) if (need[1] and A2 is not None and need[4]) else None  # (see the deferred path)
+        joint = None
+        if need[1] and A2 is not None and need[4]:  # (see the deferred path)
+            joint = K.gemm_tn_h2(A1, dC, am1, amc, A2=A2, amax_a2=am2) if tn_h2 else K.gemm_tn2(A1, A2, dC)
         dB1t = joint[:A1.size(1)] if joint is not None else (K.gemm_tn(A1, dC) if need[1] else None)
         tab_from_wgrad = want_tab and not want_bias and ctx.tabcol >= 0 and A2 is not None and need[4]
         if (want_tab or want_bias) and not tab_from_wgrad:
@@ -530,10 +544,10 @@ class LinearNNFn(torch.autograd.Function):
             # after the other; the split-K weight-gradient kernel computes the same product as (dC^T)^T B1 in parallel chunks
             dA1 = K.gemm_tn(dC.t().contiguous(), B1)
         else:
-            dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t)) if need[0] else None
+            dA1 = _acc_grad(acc1, last1, lambda out, accu: K.gemm_nn(dC, B1, out=out, accumulate=accu, B1n=B1t, **nn_kw)) if need[0] else None
         dA2 = None
         if A2 is not None and need[3]:
-            dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t))
+            dA2 = _acc_grad(acc2, last2, lambda out, accu: K.gemm_nn(dC, B2, out=out, accumulate=accu, B1n=B2t, **nn_kw))
         return dA1, dB1t, None, dA2, dB2t, None, dbias, drowtab, None, None, None
 
 
@@ -628,7 +642,11 @@ class GeluDropoutFn(torch.autograd.Function):
     @_bwd
     def backward(ctx, dY):
         (X,) = ctx.saved_tensors
-        return kernels().gelu_dropout_bwd(X, dY.contiguous(), ctx.p, ctx.seed), None, None
+        K = kernels()
+        if _wants_amax(K, X):  # (max |dX| rides on the pass: the Linear in front of this GELU runs its backward products in the three-MFMA form)
+            dX, word = K.gelu_dropout_bwd(X, dY.contiguous(), ctx.p, ctx.seed, amax=True)
+            return amax_note(dX, word), None, None
+        return K.gelu_dropout_bwd(X, dY.contiguous(), ctx.p, ctx.seed), None, None
 
 
 _seed_counter = [0]
@@ -969,6 +987,8 @@ class StackFn(torch.autograd.Function):
         if xw is not None or sw is not None:  # (the producers of X / S left their maxima: no reduction pass inside the stack)
             kw = dict(x_amax=xw, s_amax=sw)
         y, saved = K.stack_fwd(graph, HP, qscale, X, S, ntype, prms, batch_stats, eps, p, seeds, runnings, tab_col, **kw)
+        if len(saved) > 4 and _wants_amax(K, X) and batch_stats:  # (the library's own condition for the form: csrc/hop.hip, hop_h2)
+            amax_note(y, saved[4][k - 1, 4:5])  # max |y| of the last hop (AM_Y), left by its GELU / dropout pass
         ctx.save_for_backward(X, S, ntype, *prm, *saved)
         ctx.cfg = (graph, HP, qscale, batch_stats, eps, p, seeds, k, npk)
         ctx.accX, ctx.tab_col = accX, tab_col
