@@ -154,6 +154,10 @@ typedef struct qagnn_gemm_nn_args {
                                         understates the maximum by 2x or more makes the result inf / nan (never silently wrong): the
                                         producers of this library fill it exactly (qagnn_absmax_f32 and the *_amax arguments) */
   const uint32_t* a_amax2;
+  int64_t a_rows;                    /* with a_rowidx: the number of rows of A1's storage (the entity table), or 0 = unknown.  Known and below
+                                        2 GB, a gathered product of qagnn_gemm_nn_split*_f32 takes the second-generation kernels (and, with
+                                        a_amax1 = the bit pattern of an upper bound of max |table| -- the table is frozen, one reduction when it
+                                        is loaded --, the three-MFMA form) instead of the first-generation gather kernel */
   int32_t pieces;                    /* 0 (default): full-accuracy arithmetic, see above.  1: the REDUCED-PRECISION form, on request only and only
                                         where the three-MFMA form would run (a_amax known): ONE fp16 MFMA per product -- both operands rounded to
                                         fp16 (11 significant bits) under the same power-of-two scales, fp32 accumulation and fp32 storage; what

@@ -26,7 +26,7 @@ EXPORTS = ['qagnn_last_error', 'qagnn_abi_version', 'qagnn_graph_storage_elems',
            'qagnn_timing_enable', 'qagnn_timing_read', 'qagnn_gemm_tn_h1_f32', 'qagnn_gelu_dropout_bwd_amax_f32']
 
 CLS_SLICES = 4  # QAGNN_CLS_SLICES
-ABI_VERSION = 20  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read; 19: the reduced-precision form on request -- qagnn_gemm_nn_args.pieces, qagnn_gemm_tn_h1_f32, qagnn_hop_args.gemm_split == 3; 20: qagnn_gelu_dropout_bwd_amax_f32)
+ABI_VERSION = 21  # bumped when the ABI of include/qagnn_hip.h changes (2: qagnn_graph.tgt_t; 3: (group, class) class order; 4: qagnn_hop_args.accumulate_dX; 5: qagnn_graph_from_blobs; 6: qagnn_edge_attn_fwd_lds_f32 replaces the first LDS kernel; 7: qagnn_graph.pk_s / pk_t / sub_ncls / sub_cls; 8: qagnn_hop_args.gemm_split; 9: qagnn_stack_{fwd,bwd}_f32; 10: qagnn_node_prep_f32 checks the concept ids; 11: qagnn_graph_from_blobs takes an edge CAPACITY, seed epoch, column statistics in the GEMM epilogue, LDS-resident edge forward removed; 12: qagnn_hop_args.side_stream, two buffer sets in the backward workspace; 13: qagnn_gemm_tn2_f32; 14: qagnn_gemm_nn_split_ws_f32 / qagnn_gemm_nn_pack_bytes, hop workspaces carry the pack buffer, qagnn_gemm_nn_prepack_{bytes,f32,clear}; 15: qagnn_head_post_{fwd,bwd}_f32, qagnn_add_row0_f32, qagnn_gather_multi{,_sum}_f32; 16: qagnn_gemm_nn_ws_bytes; 17: the three-MFMA GEMM form -- qagnn_gemm_nn_args.a_amax1 / a_amax2, qagnn_pack_desc.pieces, qagnn_hop_args.amax, qagnn_absmax_f32, qagnn_zero_words, qagnn_gemm_tn_h2_f32; 18: qagnn_hop_args.x_amax / s_amax, qagnn_gelu_dropout_fwd_amax_f32, qagnn_timing_enable / qagnn_timing_read; 19: the reduced-precision form on request -- qagnn_gemm_nn_args.pieces, qagnn_gemm_tn_h1_f32, qagnn_hop_args.gemm_split == 3; 20: qagnn_gelu_dropout_bwd_amax_f32; 21: qagnn_gemm_nn_args.a_rows)
 
 _i32, _i64, _f32, _u64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 
@@ -56,7 +56,7 @@ class qagnn_gemm_nn_args(C.Structure):
                 ('C', _vp), ('ldc', _i32), ('M', _i32), ('No', _i32),
                 ('bias', _vp), ('rowtab', _vp), ('ldt', _i32), ('rowidx', _vp),
                 ('a_scale', _vp), ('a_shift', _vp), ('accumulate', _i32), ('a_rowidx', _vp), ('xcd_remap', _i32), ('colstat_part', _vp),
-                ('a_amax1', _vp), ('a_amax2', _vp), ('pieces', _i32)]
+                ('a_amax1', _vp), ('a_amax2', _vp), ('a_rows', _i64), ('pieces', _i32)]
 
 
 class qagnn_hop_args(C.Structure):
@@ -500,6 +500,7 @@ class HipKernels(metaclass=_GuardedMeta):
         if a_rowidx is not None:
             assert a_rowidx.dtype == torch.long and a_rowidx.is_contiguous() and a_rowidx.is_cuda
             a.a_rowidx = a_rowidx.data_ptr()
+            a.a_rows = A1.size(0)  # (the table's extent: lets the gathered product take the second-generation kernels)
         part = None
         if colstats:
             assert self.colstats_supported(M, K1, No) and B1n is not None and A2 is None and rowtab is None and a_scale is None and a_rowidx is None \

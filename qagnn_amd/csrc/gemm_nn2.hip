@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int KA = (K1 + 31) & ~31;
 
   // all four operands through buffer descriptors (built once, wave-uniform); a null second segment gets an empty range
-  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A1), 0, M * a.lda1 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A1), 0, (a.a_rowidx ? (int)a.a_rows : M) * a.lda1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A2), 0, K2 > 0 ? M * a.lda2 * 4 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B1n), 0, No * ldn1 * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B2n), 0, K2 > 0 ? No * ldn2 * 4 : 0, 0x00020000);
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(WV * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     n0 = (tile % ncb) * BN;                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                      \
       const int row = m0 + w * 32 + i * 16 + (lane & 15);                                                                \
-      arow1[i] = row < M ? (uint32_t)row * (uint32_t)a.lda1 * 4u + (uint32_t)ac * 32u : OOB;                             \
+      /* (a_rowidx: row m of A1 is table row a_rowidx[m], negative = a zero row -- nn2_ok: the table lies below 2 GB) */   \
+      const int64_t grow = (a.a_rowidx && row < M) ? a.a_rowidx[row] : (int64_t)row;                                     \
+      arow1[i] = (row < M && grow >= 0) ? (uint32_t)grow * (uint32_t)a.lda1 * 4u + (uint32_t)ac * 32u : OOB;             \
       arow2[i] = row < M ? (uint32_t)row * (uint32_t)a.lda2 * 4u + (uint32_t)ac * 32u : OOB;                             \
     }                                                                                                                    \
   }
@@ -886,7 +888,8 @@ static int launch_nn2_image(int nt, const qagnn_gemm_nn_args& a, const float* p,
 // what the second-generation kernel takes: no fused row gather, 32-bit operand offsets, segments that are multiples of 8
 bool nn2_ok(const qagnn_gemm_nn_args& a, int ldn1, int ldn2) {
   const int64_t lim = (int64_t)0x7FFFFFFF;
-  if (a.a_rowidx) return false;
+  // (a gathered A1: the table's extent must be known and addressable with the kernels' 32-bit offsets; one segment)
+  if (a.a_rowidx && !(a.a_rows > 0 && a.a_rows * (int64_t)a.lda1 * 4 < lim && a.K2 == 0)) return false;
   if (a.K1 % 8 != 0 || a.K2 % 8 != 0) return false;
   if ((int64_t)a.M * a.lda1 * 4 >= lim || (int64_t)a.No * ldn1 * 4 >= lim || (int64_t)a.M * a.ldc * 4 >= lim) return false;
   if (a.K2 > 0 && ((int64_t)a.M * a.lda2 * 4 >= lim || (int64_t)a.No * ldn2 * 4 >= lim)) return false;

@@ -518,7 +518,7 @@ static int class_pass(qagnn_graph* g, int32_t* hist, int32_t* gc_cnt, int32_t* g
 }
 
 extern "C" const char* qagnn_last_error(void) { return g_err; }
-extern "C" int qagnn_abi_version(void) { return 20; }
+extern "C" int qagnn_abi_version(void) { return 21; }
 
 extern "C" int64_t qagnn_graph_storage_elems(int32_t N, int32_t E, int32_t R, int32_t T) {
   const int64_t Ep = (int64_t)E + N, C = (int64_t)R * T * T + T;

@@ -1116,6 +1116,27 @@ def pool_attention_supported(nh, width, n):
     return lim is not None and nh <= lim[0] and width <= lim[1] and width % 4 == 0 and n <= lim[2]
 
 
+_TABLE_AMAX = {}
+
+
+def table_amax(K, table):
+    """max |.| of a FROZEN entity table as the device word the three-MFMA GEMM form wants (an upper bound of the maximum over any batch's
+    gathered rows): one reduction pass per table and version, cached -- the first call must not fall inside a stream capture (GraphedStep's
+    warm-up steps are eager).  None where the form does not apply (table not 16-byte / 4-element aligned, provider without the form)."""
+    if not (getattr(K, 'gemm_split', 1) >= 2 and getattr(K, 'name', '') == 'hip') or table.requires_grad or table.numel() % 4 != 0 \
+            or table.data_ptr() % 16 != 0 or not table.is_contiguous():
+        return None
+    key = (table.data_ptr(), table._version, table.numel())
+    w = _TABLE_AMAX.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if len(_TABLE_AMAX) > 8:
+            _TABLE_AMAX.clear()
+        w = _TABLE_AMAX[key] = K.absmax(table.detach().view(-1))
+    return w
+
+
 class ConceptInputFn(torch.autograd.Function):
     """Node features entering the GNN, fused (reference modeling_qagnn.py:153-156 + utils/layers.py:604-605):
 
@@ -1130,7 +1151,10 @@ class ConceptInputFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, emb_w, rowidx, Wc_t, bc, ctx_pre, n, p, seed, Wc=None):
         K = kernels()
-        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx, B1n=Wc if Wc is not None else Wc_t.t().contiguous())
+        # (the frozen table's maximum: the gathered product then runs in the three-MFMA form like the stack's -- csrc/gemm_nn2.hip)
+        tam = table_amax(K, emb_w) if rowidx.numel() >= 8192 else None
+        pre = K.gemm_nn(emb_w, Wc_t, bias=bc, a_rowidx=rowidx, B1n=Wc if Wc is not None else Wc_t.t().contiguous(),
+                        **(dict(a_amax1=tam) if tam is not None else {}))
         B = ctx_pre.size(0)
         pre.view(B, n, -1)[:, 0] = ctx_pre
         ctx.save_for_backward(emb_w, rowidx, pre)

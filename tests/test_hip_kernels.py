@@ -296,6 +296,15 @@ def test_gemm_with_fused_row_gather(M, V, K, No):
     ref = Ag @ B.double() + bias.double()
     err = (got.double() - ref).abs()
     assert bool((err <= _bound(Ag.abs(), B.abs().double()) + 4 * EPS * ref.abs()).all()), err.max().item()
+    if M >= 8192 and K_.gemm_split >= 2:
+        # the same gathered product in the three-MFMA form: the table's own maximum as the operand word (an upper bound of the maximum over
+        # the gathered rows -- what ops.table_amax hands over for a frozen entity table); round 6: second-generation kernels with the gather
+        got3 = K_.gemm_nn(table.cuda(), B.cuda(), bias=bias.cuda(), a_rowidx=idx.cuda(), B1n=B.t().contiguous().cuda(),
+                          a_amax1=K_.absmax(table.cuda().view(-1))).cpu()
+        err3 = (got3.double() - ref).abs()
+        bound3 = 12 * EPS * (Ag.abs() @ B.abs().double()) + 2.0 ** -38 * K * table.abs().max().item() * B.abs().max(0).values.double() + 4 * EPS * ref.abs()
+        assert bool((err3 <= bound3).all()), (err3.max().item(), (err3 / bound3).max().item())
+        assert not torch.equal(got3, got)
     got = K_.gemm_tn(table.cuda(), dC.cuda(), a_rowidx=idx.cuda()).cpu()
     ref = Ag.t() @ dC.double()
     err = (got.double() - ref).abs()
