@@ -27,8 +27,14 @@ Extra objects on the JSON line:
                profiles/pmc_edge_fwd.json is then quoted and labelled as such).  The ALGORITHMIC figure of SURVEY.md 8(d)
                (E'*2410 + N*800: every per-edge row gather priced as memory traffic) is reported next to it as
                `algorithmic_bytes_per_launch` / `achieved_algorithmic`; L1/L2 serve the re-reads, so it is not an HBM fraction.
-  roofline_mfma  all GEMM launches of a step against BOTH ceilings: the fp32-input MFMA peak (157.3 TFLOP/s) and the
-               fp32-equivalent ceiling of the exact 3 x bf16 split the kernels actually run (2500 / 6 = 417 TFLOP/s).
+  roofline_mfma  all GEMM launches of a step, timed ON THE PATH THAT RUNS (HIP events inside the library around every GEMM entry point:
+               qagnn_timing_enable; the natively sequenced stack is invisible from Python), against the fp32-equivalent ceiling of the
+               form the large products run in -- three fp16 MFMAs per product on an error-corrected two-piece split: 2500 / 3 =
+               833 TFLOP/s -- with the six-MFMA ceiling (417), the fp32-input MFMA peak (157.3) and the time of the same products in the
+               exact six-MFMA form (`ms_per_step_six_mfma_form`) beside it.
+  configs[1]/fp16_gemms   REDUCED PRECISION, labelled, never the headline: the same step with ONE fp16 MFMA per product (operands rounded
+               to fp16 under exact power-of-two scales, fp32 accumulation and storage) -- the GEMM arithmetic of the reference under the
+               --fp16 autocast of its run scripts (qagnn.py:254-257).  Parity bars: tests/test_hip_parity.py::REDUCED_BARS.
   configs      the other single-GPU configurations of BASELINE.json on the same line: configs[0] (B = 5, n = 100, e = 800),
                configs[2] (OpenBookQA 128 x 4 = 512 subgraphs), the per-GPU MedQA-USMLE shard of configs[4] (16 questions x 4 =
                64 subgraphs, 34 relations, ~3 k-edge graphs, no node scores, 768-d SapBERT table): value, ms_per_step, the
