@@ -19,3 +19,5 @@ hipcc --offload-arch=gfx950 -O3 -o bin/cu_census cu_census.hip
 hipcc --offload-arch=gfx950 -O3 -o bin/simd_probe simd_probe.hip
 # round 5: the library with the graph preparation's zero fill as a hipMemsetAsync node (the faulty form: scripts/r5_memset_node_fault.sh)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DQAGNN_PREP_MEMSET_NODE -I../include -o bin/libqagnn_hip_memset_node.so $SRC
+# round 6: phase ablation of the three-MFMA / one-MFMA forms of k_gemm_nn2 (profiles/r6_run17_nn2_ablation.txt): bits as above
+for v in 0 1 2 4 16 32 64 33 35 39 96 103; do hipcc --offload-arch=gfx950 -O3 -std=c++17 $INC -DQAGNN_NN2_ABL=$v -o bin/nn2_r6_abl$v nn2_ablate.hip; done
