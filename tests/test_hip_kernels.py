@@ -920,6 +920,34 @@ def _ranged(g, rows, cols, kind):
 
 
 @pytest.mark.gpu
+def test_library_side_launch_timing():
+    """qagnn_timing_enable / qagnn_timing_read (csrc/timing.hip): the brackets bench.py's roofline_mfma rests on.  Off: nothing is recorded;
+    on: one record per GEMM / edge-stage entry point, of the right kind, with a plausible duration; an entry point that falls back to another
+    one (qagnn_gemm_tn_h2_f32 -> qagnn_gemm_tn_f32 on a shape the split kernels decline) is counted once; enable(True) clears the record."""
+    K = hip()
+    g = torch.Generator().manual_seed(3)
+    A, B = torch.randn(20000, 208, generator=g).cuda(), torch.randn(208, 208, generator=g).cuda()
+    K.timing_enable(False)
+    K.gemm_nn(A, B, B1n=B.t().contiguous())
+    K.timing_enable(True)
+    assert all(c == 0 for _, c in K.timing_read().values())
+    K.gemm_nn(A, B, B1n=B.t().contiguous())
+    K.gemm_nn(A, B)                                   # (the fp32-MFMA entry point)
+    K.gemm_tn(A, A)
+    small = torch.randn(300, 40, generator=g).cuda()  # a shape the split kernels do not take: h2 -> tn2 / tn fallbacks, ONE record
+    K.gemm_tn_h2(small, small, K.absmax(small.view(-1)), K.absmax(small.view(-1)))
+    torch.cuda.synchronize()
+    r = K.timing_read()
+    K.timing_enable(False)
+    assert r['gemm_nn'][1] == 2 and r['gemm_tn'][1] == 2 and r['edge_attn_fwd'][1] == 0 and r['edge_attn_bwd'][1] == 0, r
+    assert 0.005 < r['gemm_nn'][0] < 5.0 and 0.005 < r['gemm_tn'][0] < 5.0, r
+    K.gemm_nn(A, B, B1n=B.t().contiguous())           # off again: not recorded
+    K.timing_enable(True)
+    assert all(c == 0 for _, c in K.timing_read().values())
+    K.timing_enable(False)
+
+
+@pytest.mark.gpu
 def test_absmax_is_exact():
     K = hip()
     g = torch.Generator().manual_seed(5)
